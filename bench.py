@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: elements/sec assembling the global stiffness matrix K, 3-D Hex8 linear elasticity.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = one numeric assembly pass (CsrAssembler::assemble semantics: K written into a pre-built CSR
+pattern; benches/assembly.rs:126-145 times the same call) over a synthetic structured mesh that is
+already resident in HBM.  N = 1: BASELINE's north-star point, Hex8 elasticity on the 216^3 unit box
+(10 077 696 elements).  N > 1: weak scaling, the global mesh is 216 x 216 x (216 N) cells cut into N
+z-slabs, one per rank (see fenris_amd/distributed.py); value = all elements of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(E, N, s, n, d, nnz, uses_u=False):
+    """connectivity as i32 + each vertex once + (u) + each value written once + each column
+    index read once (i32) + row offsets."""
+    return E * n * 4 + N * d * 8 + (s * N * 8 if uses_u else 0) + nnz * 8 + nnz * 4 + (s * N + 1) * 8
+
+
+def cpu_baseline(cells, threads):
+    """The oracle (restatement of fenris's CPU path, NOT the Rust binary) timed on the host cores."""
+    import numpy as np
+
+    from oracle import oracle
+
+    v, c = oracle.unit_box_hex_mesh(cells)
+    w, p = oracle.hexahedron_gauss(2)
+    asm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, v, c, w, p,
+                                  params=oracle.lame_from_young_poisson(1e6, 0.2))
+    ro, ci = oracle.pattern_for(asm)
+    colors = oracle.color_nodes(asm)
+    vals = np.zeros(len(ci))
+    t0 = time.perf_counter()
+    st, _ = oracle.par_assemble_into_csr(asm, colors, ro, ci, vals, num_threads=threads)
+    t_par = time.perf_counter() - t0
+    assert st == 0
+    vals[:] = 0
+    t0 = time.perf_counter()
+    st, _ = oracle.assemble_into_csr(asm, ro, ci, vals)
+    t_ser = time.perf_counter() - t0
+    assert st == 0
+    E = len(c)
+    return {"value": E / t_par, "unit": "elements/s", "cores": threads, "kind": "port",
+            "serial_value": E / t_ser,
+            "sample": f"Hex8 linear elasticity {cells}^3 = {E} elements, coloured parallel assembly "
+                      f"(CsrParAssembler restatement, {threads} OpenMP threads, {t_par:.1f} s) and serial "
+                      f"({t_ser:.1f} s); restatement of fenris CPU path, not the Rust binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=216, help="cells per unit box edge (216 = north-star point)")
+    ap.add_argument("--scatter", default="gather", choices=["gather", "atomic", "colored"])
+    ap.add_argument("--operator", default="elasticity", choices=["elasticity", "poisson"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=56)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fenris_amd as fa
+    from fenris_amd import quadrature
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic input: this rank's slab of the 216 x 216 x (216 world) box
+    cells = args.cells
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = fa.Engine(local_rank, stream=stream)
+    if world == 1:
+        mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
+        exchange = None
+    else:
+        from fenris_amd import distributed as fd
+
+        mesh, exchange = fd.make_slab_problem(cells, rank, world)
+    weights, points = quadrature.tensor.hexahedron_gauss(2)
+    qtable = fa.UniformQuadratureTable.from_points_and_weights(points, weights)
+    if args.operator == "elasticity":
+        lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
+        qtable = qtable.with_uniform_data(lame)
+        op, s = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), 3
+    else:
+        op, s = fa.LaplaceOperator(), 1
+    asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(op)
+           .with_quadrature_table(qtable).with_u(None).build())
+    t0 = time.perf_counter()
+    nnz = eng.build_pattern()
+    t_pattern = time.perf_counter() - t0
+    E, N = mesh.num_elements(), mesh.num_nodes()
+    values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
+    if args.scatter == "colored":
+        eng.color()
+    flags |= fa.ASSEMBLE_OVERWRITE
+    if exchange is not None:
+        exchange.bind(eng, values)
+
+    def step():
+        eng.assemble_matrix_async(values, flags)
+        if exchange is not None:
+            exchange.run()
+
+    for _ in range(args.warmup):
+        step()
+    eng.poll_status()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        eng.assemble_matrix_async(values, flags)
+        b.record()
+        if exchange is not None:
+            exchange.run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.poll_status()
+    kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e_t = torch.tensor([float(E)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e_t, op=dist.ReduceOp.SUM)
+        total_elements = float(e_t.item())
+    else:
+        total_elements = float(E)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_elements * args.steps / elapsed
+        abytes = algorithmic_bytes(E, N, s, 8, 3, nnz)
+        achieved = abytes / (kernel_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "elements/sec assembling global stiffness K, 3D Hex8 elasticity" if s == 3 else
+                      "elements/sec assembling global stiffness K, 3D Hex8 Poisson",
+            "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Hex8 {'linear elasticity' if s == 3 else 'Poisson'} stiffness assembly, "
+                                   f"structured {cells}x{cells}x{cells * world} unit-cell box "
+                                   f"({int(total_elements)} elements), hexahedron_gauss(2), "
+                                   f"YoungPoisson(1e6, 0.2), u = 0, CSR pattern pre-built, values overwritten",
+                       "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
+                       "partition": "single" if world == 1 else f"{world} z-slabs, interface rows exchanged",
+                       "pattern_build_s": t_pattern},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                         "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
+                         "kernel_min_ms": kernel_ms[0], "algorithmic_bytes_per_launch": abytes,
+                         "bytes_per_element": abytes / E},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(args.cpu_cells, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

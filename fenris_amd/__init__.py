@@ -1,0 +1,17 @@
+"""fenris_amd -- MI355X-native FEM assembly engine behind fenris's element-assembler interface.
+
+Python host layer over the C ABI of libfenris_hip.so (include/fenris_hip.h).  Only the hot path of
+fenris -- global stiffness / residual assembly -- lives here; see DESIGN.md.
+"""
+from . import _ffi, assembly, mesh, operators, quadrature
+from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
+                   SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, FenrisError, SingularJacobianError)
+from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler,
+                       ElementEllipticAssemblerBuilder, Engine, MockElementAssembler, UniformQuadratureTable,
+                       VectorAssembler, VectorParAssembler, apply_homogeneous_dirichlet_bc_csr,
+                       apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes)
+from .mesh import Mesh, hex27_mesh_from_hex8, procedural
+from .operators import (LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
+                        NeoHookeanMaterial, StVKMaterial, YoungPoisson)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

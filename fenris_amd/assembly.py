@@ -1,0 +1,460 @@
+"""Global / local assembly: host mirror of src/assembly/{local,global}.rs over the C ABI.
+
+Names and call shapes follow the reference so that tests read like the reference's own tests:
+
+    quadrature = UniformQuadratureTable.from_points_and_weights(points, weights)
+    assembler = (ElementEllipticAssemblerBuilder()
+                 .with_finite_element_space(mesh).with_operator(LaplaceOperator())
+                 .with_quadrature_table(quadrature).with_u(u).build())
+    a_global = CsrAssembler().assemble(assembler)                  # examples/poisson2d.rs:33-60
+    colors = color_nodes(mesh); CsrParAssembler().assemble(colors, assembler)
+
+All numerics run in libfenris_hip.so on the GPU; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (ASSEMBLE_OVERWRITE, SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER, FenrisError,
+                   SingularJacobianError)
+from .mesh import Mesh
+
+
+# ------------------------------------------------------------------------------------------ engine
+class Engine:
+    """Owns one fh_ctx (one device, one stream)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _ffi.lib()
+        self._h = self._lib.fh_create(device)
+        if not self._h:
+            raise FenrisError(_ffi.FH_HIP_ERROR, f"cannot create a context on HIP device {device} (no GPU?)")
+        self.device = device
+        if stream is not None:
+            self._check(self._lib.fh_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, failed=None):
+        if rc == _ffi.FH_OK:
+            return
+        msg = (self._lib.fh_last_error(self._h) or b"").decode()
+        if rc == _ffi.FH_SINGULAR_JACOBIAN:
+            raise SingularJacobianError(msg, int(failed.value) if failed is not None else -1)
+        raise FenrisError(rc, msg)
+
+    # inputs
+    def set_mesh(self, mesh: Mesh):
+        self._mesh = mesh  # keep the host arrays alive
+        self._check(self._lib.fh_set_mesh(self._h, mesh.elem_kind, _ffi.fp(mesh.vertices), mesh.num_nodes(),
+                                          _ffi.up(mesh.connectivity), mesh.num_elements()))
+
+    def set_connectivity_ragged(self, sdim, num_nodes, elem_offsets, elem_nodes):
+        eo, en = _ffi.as_u64(elem_offsets), _ffi.as_u64(elem_nodes)
+        en_p = en if len(en) else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.fh_set_connectivity_ragged(self._h, sdim, num_nodes, _ffi.up(eo), _ffi.up(en_p), len(eo) - 1))
+
+    def set_operator(self, op_kind):
+        self._check(self._lib.fh_set_operator(self._h, op_kind))
+
+    def set_quadrature_uniform(self, weights, points, params=None):
+        w, p = _ffi.as_f64(weights), _ffi.as_f64(points)
+        q = None if params is None else _ffi.as_f64(params)
+        self._check(self._lib.fh_set_quadrature_uniform(self._h, _ffi.fp(w), _ffi.fp(p), len(w), _ffi.fp(q)))
+
+    def set_u(self, u):
+        if u is None:
+            self._check(self._lib.fh_set_u(self._h, None))
+        elif _is_torch(u):
+            self._check(self._lib.fh_set_u_dev(self._h, C.c_void_p(u.data_ptr())))
+        else:
+            self._check(self._lib.fh_set_u(self._h, _ffi.fp(_ffi.as_f64(u))))
+
+    # queries
+    def solution_dim(self):
+        return int(self._lib.fh_solution_dim(self._h))
+
+    def num_elements(self):
+        return int(self._lib.fh_num_elements(self._h))
+
+    def num_nodes(self):
+        return int(self._lib.fh_num_nodes(self._h))
+
+    def num_rows(self):
+        return int(self._lib.fh_num_rows(self._h))
+
+    def nnz(self):
+        return int(self._lib.fh_nnz(self._h))
+
+    def last_kernel_name(self):
+        return (self._lib.fh_last_kernel_name(self._h) or b"").decode()
+
+    def synchronize(self):
+        self._check(self._lib.fh_synchronize(self._h))
+
+    # pattern
+    def pattern(self, want_cols=True):
+        R = self.num_rows()
+        ro = np.zeros(R + 1, dtype=np.uint64)
+        nnz = C.c_uint64()
+        self._check(self._lib.fh_pattern(self._h, _ffi.up(ro), C.byref(nnz)))
+        if not want_cols:
+            return ro, None
+        ci = np.zeros(max(int(nnz.value), 1), dtype=np.uint64)
+        self._check(self._lib.fh_pattern_cols(self._h, _ffi.up(ci)))
+        return ro, ci[: int(nnz.value)]
+
+    def build_pattern(self):
+        nnz = C.c_uint64()
+        self._check(self._lib.fh_pattern(self._h, None, C.byref(nnz)))
+        return int(nnz.value)
+
+    def pattern_dev(self, row_offsets_t=None, col_indices_t=None):
+        self._check(self._lib.fh_pattern_dev(self._h, _ptr(row_offsets_t), _ptr(col_indices_t)))
+
+    # colouring
+    def color(self):
+        E = self.num_elements()
+        nc = C.c_uint64()
+        co = np.zeros(E + 2, dtype=np.uint64)
+        lab = np.zeros(max(E, 1), dtype=np.uint64)
+        self._check(self._lib.fh_color(self._h, C.byref(nc), _ffi.up(co), _ffi.up(lab)))
+        return DisjointSubsetsColors(co[: nc.value + 1].copy(), lab[:E].copy())
+
+    def set_colors(self, colors: "DisjointSubsetsColors"):
+        co, lab = _ffi.as_u64(colors.color_offsets), _ffi.as_u64(colors.labels)
+        lab_p = lab if len(lab) else np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.fh_set_colors(self._h, len(co) - 1, _ffi.up(co), _ffi.up(lab_p)))
+
+    # numeric
+    def assemble_matrix(self, values, flags=SCATTER_ATOMIC):
+        failed = C.c_uint64(0)
+        if _is_torch(values):
+            rc = self._lib.fh_assemble_matrix_dev(self._h, C.c_void_p(values.data_ptr()), flags, C.byref(failed))
+        else:
+            assert values.dtype == np.float64 and values.flags.c_contiguous
+            rc = self._lib.fh_assemble_matrix(self._h, _ffi.fp(values), flags, C.byref(failed))
+        self._check(rc, failed)
+
+    def assemble_matrix_async(self, values_t, flags):
+        self._check(self._lib.fh_assemble_matrix_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags))
+
+    def poll_status(self):
+        failed = C.c_uint64(0)
+        self._check(self._lib.fh_poll_status(self._h, C.byref(failed)), failed)
+
+    def assemble_vector(self, out):
+        failed = C.c_uint64(0)
+        if _is_torch(out):
+            rc = self._lib.fh_assemble_vector_dev(self._h, C.c_void_p(out.data_ptr()), C.byref(failed))
+        else:
+            rc = self._lib.fh_assemble_vector(self._h, _ffi.fp(out), C.byref(failed))
+        self._check(rc, failed)
+
+    def assemble_scalar(self):
+        out, failed = C.c_double(), C.c_uint64(0)
+        self._check(self._lib.fh_assemble_scalar(self._h, C.byref(out), C.byref(failed)), failed)
+        return out.value
+
+    def element_matrices(self, first, count):
+        s, n = self.solution_dim(), _ffi.ELEM_NODES[self._mesh.elem_kind]
+        ld = s * n
+        out = np.zeros((count, ld, ld))
+        self._check(self._lib.fh_assemble_element_matrices(self._h, first, count, _ffi.fp(out)))
+        return out.transpose(0, 2, 1).copy()  # column-major blocks -> [e][row][col]
+
+    def apply_dirichlet_csr_dev(self, values_t, nodes):
+        nodes = _ffi.as_u64(nodes)
+        self._check(self._lib.fh_apply_dirichlet_csr_dev(self._h, C.c_void_p(values_t.data_ptr()), _ffi.up(nodes), len(nodes)))
+
+    def apply_dirichlet_rhs_dev(self, rhs_t, nodes):
+        nodes = _ffi.as_u64(nodes)
+        self._check(self._lib.fh_apply_dirichlet_rhs_dev(self._h, C.c_void_p(rhs_t.data_ptr()), _ffi.up(nodes), len(nodes)))
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "device")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------ tables
+class UniformQuadratureTable:
+    """src/assembly/local/quadrature_table.rs:213-298"""
+
+    def __init__(self, points, weights, data=None):
+        self.points = _ffi.as_f64(points)
+        self.weights = _ffi.as_f64(weights)
+        self.data = data  # nq x 2 (mu, lambda) or None
+
+    @classmethod
+    def from_points_and_weights(cls, points, weights):
+        """NOTE the argument order (points, weights) -- a rule is (weights, points); quadrature_table.rs:232"""
+        return cls(points, weights)
+
+    @classmethod
+    def from_quadrature(cls, rule):
+        weights, points = rule
+        return cls(points, weights)
+
+    def with_uniform_data(self, data):
+        """quadrature_table.rs:264-266"""
+        pair = data.as_pair() if hasattr(data, "as_pair") else tuple(data)
+        return UniformQuadratureTable(self.points, self.weights, np.tile(np.asarray(pair, dtype=np.float64), (len(self.weights), 1)))
+
+    def with_data(self, data):
+        """quadrature_table.rs:252-262: one Parameters value per quadrature point"""
+        arr = np.array([d.as_pair() if hasattr(d, "as_pair") else tuple(d) for d in data], dtype=np.float64)
+        assert arr.shape == (len(self.weights), 2)
+        return UniformQuadratureTable(self.points, self.weights, arr)
+
+
+@dataclass
+class DisjointSubsetsColors:
+    """Vec<DisjointSubsets> (fenris-paradis/src/lib.rs:171-181) flattened: elements of colour c are
+    labels[color_offsets[c]:color_offsets[c+1]] in ascending order."""
+    color_offsets: np.ndarray
+    labels: np.ndarray
+
+    def __len__(self):
+        return len(self.color_offsets) - 1
+
+    def color(self, c):
+        return self.labels[int(self.color_offsets[c]): int(self.color_offsets[c + 1])]
+
+
+class CsrMatrix:
+    """nalgebra_sparse::CsrMatrix triple (row_offsets, col_indices, values); values may be numpy or a
+    torch tensor on the engine's device."""
+
+    def __init__(self, row_offsets, col_indices, values):
+        self.row_offsets, self.col_indices, self.values = row_offsets, col_indices, values
+
+    def nnz(self):
+        return len(self.values)
+
+    def nrows(self):
+        return len(self.row_offsets) - 1
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+
+        v = self.values.cpu().numpy() if _is_torch(self.values) else self.values
+        n = self.nrows()
+        return sp.csr_matrix((v, self.col_indices.astype(np.int64), self.row_offsets.astype(np.int64)), shape=(n, n))
+
+
+# ------------------------------------------------------------------------------------------ local
+class ElementEllipticAssemblerBuilder:
+    """src/assembly/local/elliptic.rs:63-150"""
+
+    def __init__(self, engine: Optional[Engine] = None):
+        self._engine, self._space, self._op, self._qtable, self._u, self._has_u = engine, None, None, None, None, False
+
+    @classmethod
+    def new(cls, engine: Optional[Engine] = None):
+        return cls(engine)
+
+    def with_finite_element_space(self, space: Mesh):
+        self._space = space
+        return self
+
+    def with_operator(self, op):
+        self._op = op
+        return self
+
+    def with_quadrature_table(self, qtable: UniformQuadratureTable):
+        self._qtable = qtable
+        return self
+
+    def with_u(self, u):
+        self._u, self._has_u = u, True
+        return self
+
+    def build(self) -> "ElementEllipticAssembler":
+        if self._space is None or self._op is None or self._qtable is None or not self._has_u:
+            raise ValueError("builder incomplete: space, operator, quadrature table and u are all required")
+        return ElementEllipticAssembler(self._engine or Engine(), self._space, self._op, self._qtable, self._u)
+
+
+class ElementEllipticAssembler:
+    """ElementEllipticAssembler<Mesh, Op, UniformQuadratureTable> (elliptic.rs:152-340), device resident."""
+
+    def __init__(self, engine, space, op, qtable, u):
+        self.engine, self.space, self.op, self.qtable = engine, space, op, qtable
+        engine.set_mesh(space)
+        engine.set_operator(op.op_kind)
+        s = engine.solution_dim()
+        if u is not None and not _is_torch(u):
+            u = _ffi.as_f64(u)
+            if len(u) != s * space.num_nodes():
+                raise ValueError("Local element dofs (u) dimension mismatch")  # elliptic.rs:385-389
+        engine.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
+        engine.set_u(u)
+
+    # ElementConnectivityAssembler (src/assembly/local.rs:18-47)
+    def solution_dim(self):
+        return self.engine.solution_dim()
+
+    def num_elements(self):
+        return self.engine.num_elements()
+
+    def num_nodes(self):
+        return self.engine.num_nodes()
+
+    def element_node_count(self, _element_index):
+        return _ffi.ELEM_NODES[self.space.elem_kind]
+
+    def populate_element_nodes(self, output, element_index):
+        output[:] = self.space.connectivity[element_index]
+
+    # ElementMatrixAssembler::assemble_element_matrix_into (local.rs:78)
+    def assemble_element_matrix(self, element_index):
+        return self.engine.element_matrices(element_index, 1)[0]
+
+    def with_u(self, u):
+        self.engine.set_u(u)
+        return self
+
+
+class MockElementAssembler:
+    """Generic ElementConnectivityAssembler with ragged node lists
+    (tests/unit_tests/assembly/global.rs MockElementAssembler)."""
+
+    def __init__(self, solution_dim, num_nodes, element_connectivities, engine: Optional[Engine] = None):
+        self.engine = engine or Engine()
+        offs = np.cumsum([0] + [len(c) for c in element_connectivities]).astype(np.uint64)
+        nodes = np.array([x for c in element_connectivities for x in c], dtype=np.uint64)
+        self.engine.set_connectivity_ragged(solution_dim, num_nodes, offs, nodes)
+
+
+# ------------------------------------------------------------------------------------------ global
+class CsrAssembler:
+    """src/assembly/global.rs:24-183.  ``scatter`` picks the device strategy (default: atomic adds)."""
+
+    def __init__(self, scatter=SCATTER_ATOMIC):
+        self.scatter = scatter
+
+    def assemble_pattern(self, element_assembler):
+        """global.rs:65-120 -> (row_offsets, col_indices) as uint64 arrays"""
+        return element_assembler.engine.pattern()
+
+    def assemble(self, element_assembler, device_values=False):
+        """global.rs:124-131"""
+        eng = element_assembler.engine
+        ro, ci = eng.pattern()
+        if device_values:
+            import torch
+
+            values = torch.zeros(len(ci), dtype=torch.float64, device=f"cuda:{eng.device}")
+        else:
+            values = np.zeros(len(ci))
+        csr = CsrMatrix(ro, ci, values)
+        self.assemble_into_csr(csr, element_assembler)
+        return csr
+
+    def assemble_into_csr(self, csr: CsrMatrix, element_assembler):
+        """global.rs:133-182: accumulates into csr.values"""
+        eng = element_assembler.engine
+        if eng.nnz() == 0 and len(csr.values):
+            eng.build_pattern()
+        if len(csr.values) != eng.nnz():
+            raise ValueError("CSR matrix does not have the pattern of this element assembler")
+        flags = self.scatter
+        if flags == SCATTER_COLORED:
+            eng.color()
+        eng.assemble_matrix(csr.values, flags)
+
+
+class CsrParAssembler:
+    """src/assembly/global.rs:185-377: colour-by-colour scatter without atomics."""
+
+    def assemble_pattern(self, element_assembler):
+        return element_assembler.engine.pattern()
+
+    def assemble(self, colors: DisjointSubsetsColors, element_assembler):
+        eng = element_assembler.engine
+        ro, ci = eng.pattern()
+        csr = CsrMatrix(ro, ci, np.zeros(len(ci)))
+        self.assemble_into_csr(csr, colors, element_assembler)
+        return csr
+
+    def assemble_into_csr(self, csr: CsrMatrix, colors: DisjointSubsetsColors, element_assembler):
+        eng = element_assembler.engine
+        if len(csr.values) != eng.nnz():
+            raise ValueError("CSR matrix does not have the pattern of this element assembler")
+        eng.set_colors(colors)
+        eng.assemble_matrix(csr.values, SCATTER_COLORED)
+
+
+class VectorAssembler:
+    """src/assembly/global.rs:569-616"""
+
+    def assemble_vector(self, element_assembler):
+        out = np.zeros(element_assembler.solution_dim() * element_assembler.num_nodes())
+        self.assemble_vector_into(out, element_assembler)
+        return out
+
+    def assemble_vector_into(self, output, element_assembler):
+        n = element_assembler.solution_dim() * element_assembler.num_nodes()
+        if (output.numel() if _is_torch(output) else len(output)) != n:
+            raise ValueError("Output dimensions mismatch")  # global.rs:592
+        element_assembler.engine.assemble_vector(output)
+
+
+class VectorParAssembler(VectorAssembler):
+    """src/assembly/global.rs:618-686 (colours are not needed on the device: atomic adds)"""
+
+    def assemble_vector(self, colors, element_assembler):  # noqa: D401 - signature of the reference
+        return VectorAssembler.assemble_vector(self, element_assembler)
+
+
+def assemble_scalar(element_assembler):
+    """global.rs:697-711"""
+    return element_assembler.engine.assemble_scalar()
+
+
+def color_nodes(mesh_or_assembler, engine: Optional[Engine] = None) -> DisjointSubsetsColors:
+    """global.rs:540-551 + sequential_greedy_coloring (fenris-paradis/src/coloring.rs:6-70)"""
+    if hasattr(mesh_or_assembler, "engine"):
+        return mesh_or_assembler.engine.color()
+    eng = engine or Engine()
+    eng.set_mesh(mesh_or_assembler)
+    return eng.color()
+
+
+def apply_homogeneous_dirichlet_bc_csr(csr: CsrMatrix, nodes, solution_dim, element_assembler):
+    """global.rs:379-451 on device-resident values"""
+    assert solution_dim == element_assembler.solution_dim()
+    eng = element_assembler.engine
+    if _is_torch(csr.values):
+        eng.apply_dirichlet_csr_dev(csr.values, nodes)
+    else:
+        import torch
+
+        t = torch.from_numpy(csr.values).to(f"cuda:{eng.device}")
+        eng.apply_dirichlet_csr_dev(t, nodes)
+        csr.values[:] = t.cpu().numpy()
+
+
+def apply_homogeneous_dirichlet_bc_rhs(rhs, nodes, solution_dim):
+    """global.rs:479-495 (host arrays: trivial)"""
+    nodes = np.asarray(nodes, dtype=np.int64)
+    for i in range(solution_dim):
+        rhs[solution_dim * nodes + i] = 0.0

@@ -1,0 +1,771 @@
+// Numeric assembly kernels (matrix / vector / scalar) for gfx950.
+//
+// One workgroup = one "work unit":
+//   element-centric modes (ATOMIC, COLORED, DUMP): `epb` consecutive elements (of a colour list);
+//   GATHER (owner-computes): a contiguous range of nodes whose CSR row blocks the workgroup owns.
+// Every unit runs the same phases, separated by workgroup barriers:
+//   A  stage the unit's unique elements: connectivity, vertex coordinates (and u) -> LDS
+//   B  one lane per (element, quadrature point): Jacobian, inverse, |det| w, physical gradients and the
+//      operator's per-point coefficients -> LDS   (restates src/assembly/local/elliptic.rs:398-422)
+//   C  one lane per (node pair): sum over quadrature points of the operator contraction
+//      (operators.rs:146-189, fenris-solid lib.rs:349-392) -> s x s block, then scatter:
+//        ATOMIC  : fp64 atomics on the CSR values          COLORED : plain read-modify-write
+//        GATHER  : ds_add_f64 into the row accumulators held in LDS, laid out exactly like the CSR rows
+//   D  (GATHER) stream the finished rows to HBM once, coalesced.
+// The block of a pair (I <= J) is always computed with roles (a = grad phi_I, b = grad phi_J) and the
+// (J, I) block is its transpose -- the same values clone_upper_to_lower produces (src/util.rs:38-51).
+#pragma once
+#include "device_common.hpp"
+
+namespace fenris_hip {
+
+// ------------------------------------------------------------------------------------------ LDS carve
+struct Layout {
+    int o_gref, o_ggeom, o_qw, o_qpar, o_X, o_U, o_QP, o_ACC, n_doubles;
+    int o_uniq, o_cn, o_ent, o_entnode, o_entu, o_rank, o_slot, o_ncols, o_noff, o_n2eoff, n_ints;
+    int qpd;  // doubles per (element, quadrature point)
+    __host__ __device__ size_t bytes() const { return sizeof(double) * (size_t)n_doubles + sizeof(int) * (size_t)n_ints; }
+};
+
+enum { WHAT_MATRIX = 0, WHAT_VECTOR = 1, WHAT_SCALAR = 2 };
+
+template <int EK, int OP, int WHAT>
+__host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int nb_max, bool gather, int mb = 0) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    Layout L;
+    int o = 0;
+    L.o_gref = o;  o += nq * E::N * E::D;
+    L.o_ggeom = o; o += nq * E::NG * E::D;
+    L.o_qw = o;    o += nq;
+    L.o_qpar = o;  o += 2 * nq;
+    L.o_X = o;     o += ub * E::NG * E::D;
+    L.o_U = o;     o += ub * E::N * O::S;
+    if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + O::NCOEF;
+    else if (WHAT == WHAT_VECTOR) L.qpd = E::N * E::D + O::S * E::D;
+    else L.qpd = 1;
+    L.o_QP = o;    o += ub * nq * L.qpd;
+    L.o_ACC = o;   o += gather ? acc_max : 0;
+    L.n_doubles = o;
+    int i = 0;
+    L.o_uniq = i;    i += gather ? mb : ub;   // gather: all unique elements of an entry batch
+    L.o_cn = i;      i += ub * E::N;
+    L.o_ent = i;     i += gather ? mb : 0;
+    L.o_entnode = i; i += gather ? mb : 0;
+    L.o_entu = i;    i += gather ? mb : 0;
+    L.o_rank = i;    i += gather ? mb : 0;
+    L.o_slot = i;    i += gather ? mb : 0;
+    L.o_ncols = i;   i += gather ? acc_max / (O::S * O::S) : 0;
+    L.o_noff = i;    i += gather ? nb_max + 1 : 0;
+    L.o_n2eoff = i;  i += gather ? nb_max + 1 : 0;
+    L.n_ints = i + 4;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------ small dense
+template <int D> __device__ __forceinline__ double det_small(const double (&m)[D][D]);
+template <> __device__ __forceinline__ double det_small<2>(const double (&m)[2][2]) {
+    return m[0][0] * m[1][1] - m[1][0] * m[0][1];
+}
+template <> __device__ __forceinline__ double det_small<3>(const double (&m)[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) - m[0][1] * (m[1][0] * m[2][2] - m[2][0] * m[1][2]) +
+           m[0][2] * (m[1][0] * m[2][1] - m[2][0] * m[1][1]);
+}
+// inverse by cofactors / det (what nalgebra's try_inverse does for 2x2 / 3x3)
+__device__ __forceinline__ void inv_small(const double (&m)[2][2], double det, double (&o)[2][2]) {
+    const double r = 1.0 / det;
+    o[0][0] = m[1][1] * r;  o[0][1] = -m[0][1] * r;
+    o[1][0] = -m[1][0] * r; o[1][1] = m[0][0] * r;
+}
+__device__ __forceinline__ void inv_small(const double (&m)[3][3], double det, double (&o)[3][3]) {
+    const double r = 1.0 / det;
+    o[0][0] = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * r;
+    o[0][1] = (m[0][2] * m[2][1] - m[2][2] * m[0][1]) * r;
+    o[0][2] = (m[0][1] * m[1][2] - m[1][1] * m[0][2]) * r;
+    o[1][0] = -(m[1][0] * m[2][2] - m[2][0] * m[1][2]) * r;
+    o[1][1] = (m[0][0] * m[2][2] - m[2][0] * m[0][2]) * r;
+    o[1][2] = (m[0][2] * m[1][0] - m[1][2] * m[0][0]) * r;
+    o[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * r;
+    o[2][1] = (m[0][1] * m[2][0] - m[2][1] * m[0][0]) * r;
+    o[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * r;
+}
+
+// ------------------------------------------------------------------------------------------ phase B
+// One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
+template <int EK, int OP, int WHAT>
+__device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
+                                         long long elem) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
+    const double* X = lds + L.o_X + u * NG * D;
+    const double* gg = lds + L.o_ggeom + q * NG * D;
+    const double* gr = lds + L.o_gref + q * N * D;
+    double* qp = lds + L.o_QP + (size_t)(u * a.nq + q) * L.qpd;
+    (void)lds_i;
+
+    // J = X G^T  (hexahedron.rs:101-107): J[i][j] = sum_g x_g[i] dN_g/dxi_j
+    double J[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) J[i][j] = 0.0;
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) J[i][j] = fma(X[g * D + i], gg[g * D + j], J[i][j]);
+    const double detJ = det_small<D>(J);
+    double Ji[D][D];
+    if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
+        report_singular(a.status, elem);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Ji[i][j] = 0.0;
+    } else {
+        inv_small(J, detJ, Ji);
+    }
+    const double s = lds[L.o_qw + q] * fabs(detJ);  // scale = w |det J| (elliptic.rs:422)
+
+    // physical gradients g_n = J^{-T} grad_ref_n ; optionally grad u = sum_n g_n u_n^T  (d x s)
+    constexpr bool want_u = O::NEEDS_U || WHAT != WHAT_MATRIX;
+    double gu[D][S];
+    if (want_u) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) gu[i][k] = 0.0;
+    }
+    const double* Ue = lds + L.o_U + u * N * S;
+    double* gout = qp;  // first node-vector block: physical gradients
+    for (int n = 0; n < N; ++n) {
+        double g[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t = fma(Ji[k][i], gr[n * D + k], t);
+            g[i] = t;
+        }
+        if (WHAT != WHAT_SCALAR) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) gout[n * D + i] = g[i];
+        }
+        if (want_u) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < S; ++k) gu[i][k] = fma(g[i], Ue[n * S + k], gu[i][k]);
+        }
+    }
+    double mu = 0.0, lambda = 0.0;
+    if (OP != FH_LAPLACE) {
+        mu = lds[L.o_qpar + 2 * q];
+        lambda = lds[L.o_qpar + 2 * q + 1];
+    }
+
+    // deformation gradient F = I + (grad u)^T  (fenris-solid/src/lib.rs:20-29)
+    double F[D][D];
+    if (S == D && want_u) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) F[i][j] = (i == j ? 1.0 : 0.0) + gu[j][i % S];
+    }
+
+    if (WHAT == WHAT_MATRIX) {
+        double* coef = qp + O::NVEC * N * D;
+        if (OP == FH_LAPLACE) {
+            coef[0] = s;
+        } else if (OP == FH_LINEAR_ELASTIC) {
+            coef[0] = s * mu;
+            coef[1] = s * lambda;
+        } else if (OP == FH_NEO_HOOKEAN) {
+            // materials.rs:287-315: J <= 0 => all-NaN block
+            const double Jd = det_small<D>(F);
+            double Fi[D][D];
+            double c_l, c_a, c_m;
+            if (Jd <= 0.0) {
+                c_l = c_a = c_m = __builtin_nan("");
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Fi[i][j] = 0.0;
+            } else {
+                inv_small(F, Jd, Fi);
+                const double alpha = -mu + lambda * log(Jd);
+                c_l = s * lambda; c_a = s * alpha; c_m = s * mu;
+            }
+            coef[0] = c_l; coef[1] = c_a; coef[2] = c_m;
+            double* at = qp + N * D;  // F^{-T} g_n
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(Fi[k][i], gout[n * D + k], t);
+                    at[n * D + i] = t;
+                }
+        } else {  // StVK, materials.rs:417-438
+            double Eg[D][D];  // Green strain (F^T F - I)/2
+            double trE = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[k][i], F[k][j], t);
+                    Eg[i][j] = (t - (i == j ? 1.0 : 0.0)) * 0.5;
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) trE += Eg[i][i];
+            coef[0] = s * 2.0 * mu;
+            coef[1] = s * lambda * trE;
+            coef[2] = s * mu;
+            coef[3] = s * lambda;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[i][k], F[j][k], t);
+                    coef[4 + i * D + j] = t;  // F F^T
+                }
+            double* fg = qp + N * D;       // F g_n
+            double* eg = qp + 2 * N * D;   // E g_n
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0, t2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        t = fma(F[i][k], gout[n * D + k], t);
+                        t2 = fma(Eg[i][k], gout[n * D + k], t2);
+                    }
+                    fg[n * D + i] = t;
+                    eg[n * D + i] = t2;
+                }
+        }
+    } else {
+        // stress P (s x d), scaled by s, for the residual; energy density for the scalar path
+        double P[S][D];
+        double psi = 0.0;
+        if (OP == FH_LAPLACE) {
+            // g^T = (grad u)^T (laplace.rs:52-56); psi = 1/2 |grad u|^2 (laplace.rs:35-37)
+#pragma unroll
+            for (int k = 0; k < D; ++k) { P[0][k] = gu[k][0]; psi = fma(gu[k][0], gu[k][0], psi); }
+            psi *= 0.5;
+        } else if (OP == FH_LINEAR_ELASTIC) {
+            // eps = sym(F) - I formed from F like the reference does (materials.rs:71-79)
+            double eps[D][D];
+            double tr = 0.0, ee = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    eps[i][j] = (F[j][i] + F[i][j]) * 0.5 - (i == j ? 1.0 : 0.0);
+                    ee = fma(eps[i][j], eps[i][j], ee);
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) tr += eps[i][i];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) P[i % S][j] = eps[i][j] * 2.0 * mu + (i == j ? lambda * tr : 0.0);
+            psi = mu * ee + 0.5 * lambda * (tr * tr);
+        } else if (OP == FH_NEO_HOOKEAN) {
+            const double Jd = det_small<D>(F);
+            if (Jd <= 0.0) {  // materials.rs:271-274
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) P[i % S][j] = __builtin_nan("");
+            } else {
+                double Fi[D][D];
+                inv_small(F, Jd, Fi);
+                const double c = -mu + lambda * log(Jd);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) P[i % S][j] = Fi[j][i] * c + F[i][j] * mu;
+            }
+            if (WHAT == WHAT_SCALAR) {
+                // materials.rs:249-262 with log_det_F of du_dX = (grad u)^T (logdet.rs:17-86)
+                double U[D][D];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) U[i][j] = gu[j][i % S];
+                double gamma;
+                if (D == 2) {
+                    gamma = U[0][0] * U[1][1] + U[0][0] + U[1][1] - U[0][1] * U[1][0];
+                } else {
+                    const double u11 = U[0][0], u22 = U[1][1], u33 = U[2 % D][2 % D];
+                    const double aa = 1.0 + u11, e2 = 1.0 + u22, i2 = 1.0 + u33;
+                    const double b = U[0][1], c = U[0][2 % D], d2 = U[1][0], f = U[1][2 % D], g = U[2 % D][0], h = U[2 % D][1];
+                    gamma = u11 * u22 * u33 + u11 * u22 + u11 * u33 + u22 * u33 + u11 + u22 + u33 + b * f * g + c * d2 * h -
+                            c * e2 * g - b * d2 * i2 - aa * f * h;
+                }
+                if (gamma > -1.0) {
+                    const double logJ = log1p(gamma);
+                    double trU = 0.0, nn = 0.0;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        trU += U[i][i];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) nn = fma(U[i][j], U[i][j], nn);
+                    }
+                    psi = mu * (trU + 0.5 * nn) - mu * logJ + (0.5 * lambda) * (logJ * logJ);
+                } else {
+                    psi = __builtin_inf();
+                }
+            }
+        } else {  // StVK: P = F E 2 mu + F lambda tr E ; psi = mu E:E + lambda/2 tr^2
+            double Eg[D][D];
+            double trE = 0.0, ee = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[k][i], F[k][j], t);
+                    Eg[i][j] = (t - (i == j ? 1.0 : 0.0)) * 0.5;
+                    ee = fma(Eg[i][j], Eg[i][j], ee);
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) trE += Eg[i][i];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[i][k], Eg[k][j], t);
+                    P[i % S][j] = t * 2.0 * mu + F[i][j] * lambda * trE;
+                }
+            psi = mu * ee + 0.5 * lambda * (trE * trE);
+        }
+        if (WHAT == WHAT_VECTOR) {
+            double* sp = qp + N * D;
+#pragma unroll
+            for (int i = 0; i < S; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) sp[i * D + k] = s * P[i][k];
+        } else {
+            qp[0] = s * psi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ phase C
+// s x s block K_e[(I,.),(J,.)] for I <= J: sum over quadrature points of scale * C(grad u; g_I, g_J).
+template <int EK, int OP>
+__device__ __forceinline__ void pair_block(const Layout& L, const double* lds, int nq, int u, int I, int J,
+                                           double (&blk)[OpT<OP, ElemT<EK>::D>::S][OpT<OP, ElemT<EK>::D>::S]) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S;
+    const double* qp = lds + L.o_QP + (size_t)u * nq * L.qpd;
+    if (OP == FH_LAPLACE) {
+        double k = 0.0;
+        for (int q = 0; q < nq; ++q, qp += L.qpd) {
+            const double* a = qp + I * D;
+            const double* b = qp + J * D;
+            double dt = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) dt = fma(a[i], b[i], dt);
+            k = fma(qp[N * D], dt, k);
+        }
+        blk[0][0] = k;
+    } else if (OP == FH_LINEAR_ELASTIC) {
+        // C = mu [(a.b) I + b a^T] + lambda a b^T (materials.rs:108-118), per-point coefficients:
+        // M1 = sum (s mu a) b^T, M2 = sum (s lambda a) b^T  =>  block = tr(M1) I + M1^T + M2
+        double M1[D][D], M2[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) { M1[i][j] = 0.0; M2[i][j] = 0.0; }
+        for (int q = 0; q < nq; ++q, qp += L.qpd) {
+            const double* a = qp + I * D;
+            const double* b = qp + J * D;
+            const double cm = qp[N * D], cl = qp[N * D + 1];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double am = cm * a[i], al = cl * a[i];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    M1[i][j] = fma(am, b[j], M1[i][j]);
+                    M2[i][j] = fma(al, b[j], M2[i][j]);
+                }
+            }
+        }
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) tr += M1[i][i];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) blk[i % S][j % S] = (i == j ? tr : 0.0) + M1[j][i] + M2[i][j];
+    } else if (OP == FH_NEO_HOOKEAN) {
+        // lambda (F^-T a)(F^-T b)^T - alpha (F^-T b)(F^-T a)^T + mu (a.b) I   (materials.rs:302-313)
+        double B[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) B[i][j] = 0.0;
+        for (int q = 0; q < nq; ++q, qp += L.qpd) {
+            const double* a = qp + I * D;
+            const double* b = qp + J * D;
+            const double* ta = qp + N * D + I * D;
+            const double* tb = qp + N * D + J * D;
+            const double* c = qp + 2 * N * D;
+            double dt = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) dt = fma(a[i], b[i], dt);
+            const double diag = c[2] * dt;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double tl = c[0] * ta[i], tal = c[1] * tb[i];
+#pragma unroll
+                for (int j = 0; j < D; ++j) B[i][j] += tl * tb[j] - tal * ta[j] + (i == j ? diag : 0.0 * diag);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) blk[i % S][j % S] = B[i][j];
+    } else {  // StVK (materials.rs:417-438)
+        double B[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) B[i][j] = 0.0;
+        for (int q = 0; q < nq; ++q, qp += L.qpd) {
+            const double* a = qp + I * D;
+            const double* b = qp + J * D;
+            const double* fa = qp + N * D + I * D;
+            const double* fb = qp + N * D + J * D;
+            const double* eb = qp + 2 * N * D + J * D;
+            const double* c = qp + 3 * N * D;
+            double ab = 0.0, aeb = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) { ab = fma(a[i], b[i], ab); aeb = fma(a[i], eb[i], aeb); }
+            const double diag = c[0] * aeb + c[1] * ab;
+            const double mab = c[2] * ab;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    B[i][j] += (i == j ? diag : 0.0) + c[2] * fb[i] * fa[j] + c[3] * fa[i] * fb[j] + mab * c[4 + i * D + j];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) blk[i % S][j % S] = B[i][j];
+    }
+    if (I == J) {  // scalar-level mirror inside the diagonal block (util.rs:46-50)
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (i > j) blk[i][j] = blk[j][i];
+    }
+}
+
+// position of column node j inside the (ascending) neighbour list of a row node
+__device__ __forceinline__ int find_col(const unsigned* cols, int cnt, unsigned j) {
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cols[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int find_col_lds(const int* cols, int cnt, int j) {
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cols[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int MODE> __device__ __forceinline__ void add_value(double* p, double v) {
+    if (MODE == MODE_ATOMIC) atomic_add_f64(p, v);
+    else *p += v;  // colours are disjoint: plain read-modify-write (paradis lib.rs:258-278)
+}
+
+// stage tables shared by all phases
+template <int EK>
+__device__ __forceinline__ void stage_tables(const KArgs& a, const Layout& L, double* lds) {
+    using E = ElemT<EK>;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < a.nq * E::N * E::D; i += nt) lds[L.o_gref + i] = a.gref[i];
+    for (int i = tid; i < a.nq * E::NG * E::D; i += nt) lds[L.o_ggeom + i] = a.ggeom[i];
+    for (int i = tid; i < a.nq; i += nt) lds[L.o_qw + i] = a.qw[i];
+    for (int i = tid; i < 2 * a.nq; i += nt) lds[L.o_qpar + i] = a.qparams ? a.qparams[i] : 0.0;
+}
+
+// stage connectivity, vertices and u of the U unique elements listed in lds_i[o_uniq..]
+template <int EK, int S>
+__device__ __forceinline__ void stage_elements(const KArgs& a, const Layout& L, double* lds, int* lds_i, int U, bool need_u,
+                                               int ubase = 0) {
+    using E = ElemT<EK>;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < U * E::N; i += nt) {
+        const int u = i / E::N, n = i % E::N;
+        lds_i[L.o_cn + i] = a.conn[(size_t)lds_i[L.o_uniq + ubase + u] * E::N + n];
+    }
+    __syncthreads();
+    for (int i = tid; i < U * E::NG * E::D; i += nt) {
+        const int u = i / (E::NG * E::D), r = i % (E::NG * E::D), g = r / E::D, c = r % E::D;
+        lds[L.o_X + i] = a.verts[(size_t)lds_i[L.o_cn + u * E::N + g] * E::D + c];
+    }
+    if (need_u) {
+        for (int i = tid; i < U * E::N * S; i += nt) {
+            const int u = i / (E::N * S), r = i % (E::N * S), n = r / S, c = r % S;
+            lds[L.o_U + i] = a.u ? a.u[(size_t)lds_i[L.o_cn + u * E::N + n] * S + c] : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// triangular pair index p -> (I <= J), p = J (J+1)/2 + I
+__device__ __forceinline__ void unpack_pair(int p, int& I, int& J) {
+    int j = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((j + 1) * (j + 2) / 2 <= p) ++j;
+    while (j * (j + 1) / 2 > p) --j;
+    J = j;
+    I = p - j * (j + 1) / 2;
+}
+
+// ============================================================================================ matrix
+template <int EK, int OP, int MODE>
+__global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S;
+    (void)D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool GATHER = (MODE == MODE_GATHER);
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, GATHER, a.mb);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    stage_tables<EK>(a, L, lds);
+
+    if (!GATHER) {
+        // ---- element-centric unit: elements [e0, e0 + U) of the (colour) list
+        const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
+        const int U = (int)min((long long)a.epb, a.work_end - w0);
+        for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = a.labels ? (int)a.labels[w0 + i] : (int)(w0 + i);
+        __syncthreads();
+        stage_elements<EK, S>(a, L, lds, lds_i, U, O::NEEDS_U);
+        for (int i = tid; i < U * a.nq; i += nt)
+            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+        __syncthreads();
+        constexpr int NP = N * (N + 1) / 2;
+        for (int it = tid; it < U * NP; it += nt) {
+            const int u = it / NP;
+            int I, J;
+            unpack_pair(it % NP, I, J);
+            double blk[S][S];
+            pair_block<EK, OP>(L, lds, a.nq, u, I, J, blk);
+            if (MODE == MODE_DUMP) {
+                // K_e column-major (s n) x (s n), both triangles
+                double* ke = a.ke_out + (size_t)(w0 - a.work_begin + u) * (S * N) * (S * N);
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int j = 0; j < S; ++j) {
+                        ke[(size_t)(S * J + j) * (S * N) + (S * I + i)] = blk[i][j];
+                        ke[(size_t)(S * I + i) * (S * N) + (S * J + j)] = blk[i][j];
+                    }
+            } else {
+                const unsigned ni = (unsigned)lds_i[L.o_cn + u * N + I], nj = (unsigned)lds_i[L.o_cn + u * N + J];
+                {
+                    const unsigned r0 = a.noff[ni], cnt = a.noff[ni + 1] - r0;
+                    const int pos = find_col(a.ncols + r0, (int)cnt, nj);
+                    double* base = a.vals + (size_t)S * S * r0 + (size_t)S * pos;
+#pragma unroll
+                    for (int i = 0; i < S; ++i)
+#pragma unroll
+                        for (int j = 0; j < S; ++j) add_value<MODE>(base + (size_t)i * S * cnt + j, blk[i][j]);
+                }
+                if (I != J) {
+                    const unsigned r0 = a.noff[nj], cnt = a.noff[nj + 1] - r0;
+                    const int pos = find_col(a.ncols + r0, (int)cnt, ni);
+                    double* base = a.vals + (size_t)S * S * r0 + (size_t)S * pos;
+#pragma unroll
+                    for (int j = 0; j < S; ++j)
+#pragma unroll
+                        for (int i = 0; i < S; ++i) add_value<MODE>(base + (size_t)j * S * cnt + i, blk[i][j]);
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- owner-computes unit: nodes [i0, i1)
+    const int i0 = (int)a.blk_off[blockIdx.x], i1 = (int)a.blk_off[blockIdx.x + 1];
+    const int nb = i1 - i0;
+    for (int i = tid; i <= nb; i += nt) {
+        lds_i[L.o_noff + i] = (int)a.noff[i0 + i];
+        lds_i[L.o_n2eoff + i] = (int)a.n2e_off[i0 + i];
+    }
+    __syncthreads();
+    const int r0 = lds_i[L.o_noff], r1 = lds_i[L.o_noff + nb];
+    const int nacc = S * S * (r1 - r0);
+    double* acc = lds + L.o_ACC;
+    for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
+    for (int i = tid; i < r1 - r0; i += nt) lds_i[L.o_ncols + i] = (int)a.ncols[r0 + i];
+    const int k0 = lds_i[L.o_n2eoff], k1 = lds_i[L.o_n2eoff + nb];
+    __syncthreads();
+
+    for (int kb = k0; kb < k1; kb += a.mb) {
+        const int m = min(a.mb, k1 - kb);
+        // phase A: entries (node, element, local index) of this batch; dedupe elements
+        for (int t = tid; t < m; t += nt) {
+            lds_i[L.o_ent + t] = (int)a.n2e[kb + t];
+            int lo = 0, hi = nb;  // owning node: last i with n2e_off[i] <= kb + t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (lds_i[L.o_n2eoff + mid] <= kb + t) lo = mid; else hi = mid;
+            }
+            lds_i[L.o_entnode + t] = lo;
+        }
+        __syncthreads();
+        // first occurrence of each element (entries are few: O(m^2) scan in LDS)
+        for (int t = tid; t < m; t += nt) {
+            const int e = lds_i[L.o_ent + t] / N;
+            int first = t;
+            for (int x = 0; x < t; ++x)
+                if (lds_i[L.o_ent + x] / N == e) { first = x; break; }
+            lds_i[L.o_entu + t] = first;
+        }
+        __syncthreads();
+        // rank the first occurrences -> unique element list; entries then point at their unique slot
+        int U = 0;
+        for (int t = tid; t < m; t += nt) {
+            if (lds_i[L.o_entu + t] == t) {
+                int rank = 0;
+                for (int x = 0; x < t; ++x) rank += (lds_i[L.o_entu + x] == x);
+                lds_i[L.o_uniq + rank] = lds_i[L.o_ent + t] / N;
+                lds_i[L.o_rank + t] = rank;
+            }
+        }
+        for (int x = 0; x < m; ++x) U += (lds_i[L.o_entu + x] == x);
+        __syncthreads();
+        for (int t = tid; t < m; t += nt) lds_i[L.o_slot + t] = lds_i[L.o_rank + lds_i[L.o_entu + t]];
+        __syncthreads();
+        for (int c0 = 0; c0 < U; c0 += a.ub) {
+            const int Uc = min(a.ub, U - c0);
+            stage_elements<EK, S>(a, L, lds, lds_i, Uc, O::NEEDS_U, c0);
+            // phase B
+            for (int i = tid; i < Uc * a.nq; i += nt)
+                prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + c0 + i / a.nq]);
+            __syncthreads();
+            // phase C: one lane per (entry, other local node)
+            for (int it = tid; it < m * N; it += nt) {
+                const int t = it / N, Jn = it % N;
+                const int an = lds_i[L.o_ent + t] % N;
+                const int u = lds_i[L.o_slot + t] - c0;
+                if (u < 0 || u >= Uc) continue;
+                const int il = lds_i[L.o_entnode + t];
+                const int nj = lds_i[L.o_cn + u * N + Jn];
+                double blk[S][S];
+                const bool swap = an > Jn;
+                pair_block<EK, OP>(L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
+                const int rb = lds_i[L.o_noff + il] - r0, cnt = lds_i[L.o_noff + il + 1] - lds_i[L.o_noff + il];
+                const int pos = find_col_lds(lds_i + L.o_ncols + rb, cnt, nj);
+                double* base = acc + S * S * rb + S * pos;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int j = 0; j < S; ++j) atomic_add_f64(base + i * S * cnt + j, swap ? blk[j][i] : blk[i][j]);
+            }
+            __syncthreads();
+        }
+    }
+    // phase D: rows [S i0, S i1) are contiguous in the CSR values
+    double* out = a.vals + (size_t)S * S * r0;
+    if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
+    else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
+}
+
+// ============================================================================================ vector
+// f_I = sum_q s P g_I  (elliptic.rs:457-531), scattered with fp64 atomics into out[s node + i]
+template <int EK, int OP>
+__global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout L = make_layout<EK, OP, WHAT_VECTOR>(a.nq, a.ub, 0, 0, false);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    stage_tables<EK>(a, L, lds);
+    const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
+    const int U = (int)min((long long)a.epb, a.work_end - w0);
+    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
+    __syncthreads();
+    stage_elements<EK, S>(a, L, lds, lds_i, U, true);
+    for (int i = tid; i < U * a.nq; i += nt)
+        prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+    __syncthreads();
+    for (int it = tid; it < U * N; it += nt) {
+        const int u = it / N, I = it % N;
+        double f[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) f[i] = 0.0;
+        const double* qp = lds + L.o_QP + (size_t)u * a.nq * L.qpd;
+        for (int q = 0; q < a.nq; ++q, qp += L.qpd) {
+            const double* g = qp + I * D;
+            const double* sp = qp + N * D;
+#pragma unroll
+            for (int i = 0; i < S; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) f[i] = fma(sp[i * D + k], g[k], f[i]);
+        }
+        const int node = lds_i[L.o_cn + u * N + I];
+#pragma unroll
+        for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node * S + i, f[i]);
+    }
+}
+
+// ============================================================================================ scalar
+template <int EK, int OP>
+__global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int S = O::S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout L = make_layout<EK, OP, WHAT_SCALAR>(a.nq, a.ub, 0, 0, false);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    stage_tables<EK>(a, L, lds);
+    const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
+    const int U = (int)min((long long)a.epb, a.work_end - w0);
+    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
+    __syncthreads();
+    stage_elements<EK, S>(a, L, lds, lds_i, U, true);
+    for (int i = tid; i < U * a.nq; i += nt)
+        prologue<EK, OP, WHAT_SCALAR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+    __syncthreads();
+    // per-element energies in element order, then one partial per block (summed on the host in block
+    // order => deterministic)
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < U * a.nq; ++i) tot += lds[L.o_QP + i];
+        a.scalar_out[blockIdx.x] = tot;
+    }
+}
+
+}  // namespace fenris_hip

@@ -1,0 +1,97 @@
+// Shared device-side definitions of the assembly engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fenris_hip.h"
+
+namespace fenris_hip {
+
+// ------------------------------------------------------------------------------------ element traits
+// D = geometry/reference dim, N = nodes, NG = nodes of the geometry map (Hex27 is sub-parametric: its
+// Jacobian is the trilinear map of its first 8 nodes, src/element/hexahedron.rs:324-326).
+template <int EK> struct ElemT;
+template <> struct ElemT<FH_QUAD4> { static constexpr int D = 2, N = 4, NG = 4; };
+template <> struct ElemT<FH_HEX8>  { static constexpr int D = 3, N = 8, NG = 8; };
+template <> struct ElemT<FH_TET4>  { static constexpr int D = 3, N = 4, NG = 4; };
+template <> struct ElemT<FH_HEX27> { static constexpr int D = 3, N = 27, NG = 8; };
+template <> struct ElemT<FH_TRI3>  { static constexpr int D = 2, N = 3, NG = 3; };
+
+// ------------------------------------------------------------------------------------ operator traits
+// Per (element, quadrature point) the prologue leaves in LDS:  NVEC vectors per node (physical
+// gradient g_n; for NeoHookean also F^{-T} g_n; for StVK also F g_n and E g_n) and NCOEF scalars.
+template <int OP, int D> struct OpT;
+template <int D> struct OpT<FH_LAPLACE, D> {
+    static constexpr int S = 1, NVEC = 1, NCOEF = 1;  // [s]
+    static constexpr bool NEEDS_U = false;
+};
+template <int D> struct OpT<FH_LINEAR_ELASTIC, D> {
+    static constexpr int S = D, NVEC = 1, NCOEF = 2;  // [s*mu, s*lambda]
+    static constexpr bool NEEDS_U = false;
+};
+template <int D> struct OpT<FH_NEO_HOOKEAN, D> {
+    static constexpr int S = D, NVEC = 2, NCOEF = 3;  // [s*lambda, s*alpha, s*mu]
+    static constexpr bool NEEDS_U = true;
+};
+template <int D> struct OpT<FH_STVK, D> {
+    static constexpr int S = D, NVEC = 3, NCOEF = 4 + D * D;  // [2 s mu, s lambda trE, s mu, s lambda, F F^T]
+    static constexpr bool NEEDS_U = true;
+};
+
+enum { MODE_ATOMIC = 0, MODE_COLORED = 1, MODE_GATHER = 2, MODE_DUMP = 3 };
+
+// status words in device memory
+struct DevStatus {
+    int singular;                    // set to 1 if any Jacobian determinant was exactly zero
+    int pad;
+    unsigned long long failed_elem;  // lowest failing element (atomicMin)
+};
+
+// kernel arguments (plain struct, passed by value)
+struct KArgs {
+    // mesh
+    const double* verts;   // N x D
+    const int* conn;       // E x n
+    long long num_elements;
+    int num_nodes;
+    // quadrature tables (device)
+    int nq;
+    const double* qw;      // nq
+    const double* gref;    // nq x N x D   reference gradients of the element basis
+    const double* ggeom;   // nq x NG x D  reference gradients of the geometry map
+    const double* qparams; // nq x 2 (mu, lambda) or null
+    const double* u;       // S x N or null
+    // node-level pattern
+    const unsigned* noff;     // N+1
+    const unsigned* ncols;    // nnz_n
+    const unsigned* n2e_off;  // N+1
+    const unsigned* n2e;      // E*n entries e*n+a, ascending per node
+    // output
+    double* vals;
+    double* vec_out;
+    double* scalar_out;
+    double* ke_out;
+    int overwrite;
+    DevStatus* status;
+    // element-centric work description
+    const unsigned* labels;  // element list (colour) or null for identity
+    long long work_begin, work_end;
+    int epb;                 // elements per block
+    // gather work description
+    const unsigned* blk_off; // node block boundaries, nblk+1
+    int nblk;
+    int ub;                  // max unique elements staged at a time
+    int mb;                  // max (node, element) entries per batch (gather)
+    int acc_max;             // doubles reserved for row accumulators
+    int nb_max;              // max nodes per block
+};
+
+__device__ __forceinline__ void report_singular(DevStatus* st, long long e) {
+    st->singular = 1;
+    atomicMin(&st->failed_elem, static_cast<unsigned long long>(e));
+}
+
+// hardware fp64 atomic add (global_atomic_add_f64 / ds_add_f64); never a CAS loop
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+}  // namespace fenris_hip

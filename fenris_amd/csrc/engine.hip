@@ -1,0 +1,1024 @@
+// fenris_hip engine: context, device memory, pattern build, dispatch of the assembly kernels and
+// the C ABI declared in include/fenris_hip.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fenris_hip.h"
+#include "assemble_kernels.hpp"
+#include "device_common.hpp"
+#include "host_inputs.hpp"
+#include "pattern_kernels.hpp"
+
+using namespace fenris_hip;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small RAII device buffer
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+// reference gradient tables (host): product-side evaluation of the shape-function gradients.
+// Node sign tables and 1-D factors: SURVEY Appendix A.1/A.2 (src/element.rs:244-298,
+// hexahedron.rs:49-58, 229-264, quadrilateral.rs:84-99, tetrahedron.rs:561-568, triangle.rs:82-89).
+const double HEX_SIGN[27][3] = {
+    {-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1},
+    {0, -1, -1}, {-1, 0, -1}, {-1, -1, 0}, {1, 0, -1}, {1, -1, 0}, {0, 1, -1}, {1, 1, 0}, {-1, 1, 0},
+    {0, -1, 1}, {-1, 0, 1}, {1, 0, 1}, {0, 1, 1},
+    {0, 0, -1}, {0, -1, 0}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+const double QUAD_SIGN[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+
+inline double lin(double al, double x) { return (1.0 + al * x) / 2.0; }
+inline double dlin(double al) { return al / 2.0; }
+inline double quad(double al, double x) { const double a2 = al * al; return (3.0 / 2.0 * a2 - 1.0) * (x * x) + 0.5 * al * x + 1.0 - a2; }
+inline double dquad(double al, double x) { const double a2 = al * al; return 2.0 * (3.0 / 2.0 * a2 - 1.0) * x + 0.5 * al; }
+
+// out: n x d (node-major, AoS per node)
+void ref_gradients(int kind, const double* xi, double* out) {
+    switch (kind) {
+        case FH_QUAD4:
+            for (int n = 0; n < 4; ++n) {
+                const double al = QUAD_SIGN[n][0], be = QUAD_SIGN[n][1];
+                out[2 * n] = al * (1.0 + be * xi[1]) / 4.0;
+                out[2 * n + 1] = be * (1.0 + al * xi[0]) / 4.0;
+            }
+            break;
+        case FH_HEX8:
+            for (int n = 0; n < 8; ++n) {
+                const double* s = HEX_SIGN[n];
+                out[3 * n] = dlin(s[0]) * lin(s[1], xi[1]) * lin(s[2], xi[2]);
+                out[3 * n + 1] = lin(s[0], xi[0]) * dlin(s[1]) * lin(s[2], xi[2]);
+                out[3 * n + 2] = lin(s[0], xi[0]) * lin(s[1], xi[1]) * dlin(s[2]);
+            }
+            break;
+        case FH_HEX27:
+            for (int n = 0; n < 27; ++n) {
+                const double* s = HEX_SIGN[n];
+                out[3 * n] = dquad(s[0], xi[0]) * quad(s[1], xi[1]) * quad(s[2], xi[2]);
+                out[3 * n + 1] = quad(s[0], xi[0]) * dquad(s[1], xi[1]) * quad(s[2], xi[2]);
+                out[3 * n + 2] = quad(s[0], xi[0]) * quad(s[1], xi[1]) * dquad(s[2], xi[2]);
+            }
+            break;
+        case FH_TET4: {
+            static const double G[12] = {-0.5, -0.5, -0.5, 0.5, 0, 0, 0, 0.5, 0, 0, 0, 0.5};
+            std::memcpy(out, G, sizeof G);
+            break;
+        }
+        case FH_TRI3: {
+            static const double G[6] = {-0.5, -0.5, 0.5, 0, 0, 0.5};
+            std::memcpy(out, G, sizeof G);
+            break;
+        }
+    }
+}
+
+struct ElemInfo { int d, n, ng, geom_kind; };
+bool elem_info(int kind, ElemInfo& e) {
+    switch (kind) {
+        case FH_QUAD4: e = {2, 4, 4, FH_QUAD4}; return true;
+        case FH_HEX8: e = {3, 8, 8, FH_HEX8}; return true;
+        case FH_TET4: e = {3, 4, 4, FH_TET4}; return true;
+        case FH_HEX27: e = {3, 27, 8, FH_HEX8}; return true;
+        case FH_TRI3: e = {2, 3, 3, FH_TRI3}; return true;
+        default: return false;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct fh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string last_kernel;
+
+    // mesh
+    bool has_mesh = false, ragged = false;
+    int elem_kind = -1;
+    ElemInfo ei{};
+    uint64_t N = 0, E = 0;
+    DevBuf<double> verts;
+    DevBuf<int> conn;           // flat node list
+    DevBuf<unsigned> eoff, k2e; // ragged only
+    uint64_t flat_len = 0;
+    std::vector<uint64_t> h_eoff, h_nodes;  // host copy of the connectivity (colouring)
+    bool has_host_conn = false;
+    // operator / quadrature / u
+    int op = -1;
+    uint64_t sdim_ragged = 1;
+    int nq = 0;
+    DevBuf<double> qw, gref, ggeom, qparams, u;
+    bool has_params = false, has_u = false;
+    std::vector<double> h_points;
+    // pattern
+    bool has_pattern = false;
+    DevBuf<unsigned> noff, ncols, n2e_off, n2e;
+    uint64_t nnz_nodes = 0;
+    std::vector<unsigned> h_noff, h_n2e_off;  // host copies (gather block partition)
+    // gather partition
+    DevBuf<unsigned> blk_off;
+    int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0;
+    bool has_partition = false;
+    // colours
+    bool has_colors = false;
+    std::vector<uint64_t> color_offsets;
+    DevBuf<unsigned> labels;
+    // status
+    DevBuf<DevStatus> status;
+    DevBuf<double> scratch;
+
+    int S() const {
+        if (ragged) return (int)sdim_ragged;
+        if (op < 0) return 0;
+        return op == FH_LAPLACE ? 1 : ei.d;
+    }
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+    int hip_fail(hipError_t e, const char* what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return FH_HIP_ERROR;
+    }
+};
+
+#define HIP_TRY(ctx, expr)                                        \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return (ctx)->hip_fail(_e, #expr);  \
+    } while (0)
+
+namespace {
+
+int grid_for(long long n, int block, int cap = 256 * 32) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void invalidate_pattern(fh_ctx* c) {
+    c->has_pattern = false;
+    c->has_partition = false;
+    c->has_colors = false;
+    c->nnz_nodes = 0;
+}
+
+// ---------------------------------------------------------------------------------- pattern build
+int build_pattern(fh_ctx* c) {
+    if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_pattern: no mesh/connectivity set");
+    if (c->S() <= 0) return c->fail(FH_INVALID_STATE, "fh_pattern: no operator set (solution dim unknown)");
+    if (c->has_pattern) return FH_OK;
+    const int N = (int)c->N;
+    hipStream_t st = c->stream;
+    ConnView cv{c->conn.p, c->ragged ? c->eoff.p : nullptr, c->ragged ? c->k2e.p : nullptr, c->ei.n, (long long)c->flat_len};
+    DevBuf<unsigned> deg, cursor, cnt;
+    DevBuf<int> flags;
+    HIP_TRY(c, deg.alloc((size_t)N + 1));
+    HIP_TRY(c, cursor.alloc((size_t)N + 1));
+    HIP_TRY(c, cnt.alloc((size_t)N + 1));
+    HIP_TRY(c, flags.alloc(2));
+    HIP_TRY(c, c->n2e_off.alloc((size_t)N + 1));
+    HIP_TRY(c, c->noff.alloc((size_t)N + 1));
+    HIP_TRY(c, hipMemsetAsync(deg.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(int) * 2, st));
+    if (c->flat_len > 0)
+        hipLaunchKernelGGL(k_count_degree, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, deg.p, N, flags.p);
+    // exclusive scan over N+1 entries (last = total)
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg.p, c->n2e_off.p, N + 1, st));
+    DevBuf<char> tmp;
+    HIP_TRY(c, tmp.alloc(tmp_bytes + 16));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, deg.p, c->n2e_off.p, N + 1, st));
+    HIP_TRY(c, c->n2e.alloc((size_t)c->flat_len + 1));
+    if (c->flat_len > 0) {
+        hipLaunchKernelGGL(k_fill_n2e, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, c->n2e_off.p, cursor.p,
+                           c->n2e.p, N);
+        hipLaunchKernelGGL(k_sort_n2e, dim3(grid_for(N, 256, 1 << 30)), dim3(256), 0, st, c->n2e_off.p, c->n2e.p, N);
+    }
+    if (N > 0) {
+        const int g = std::min(N, 256 * 64);
+        hipLaunchKernelGGL(k_node_neighbors<false>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, cnt.p, nullptr,
+                           nullptr, flags.p + 1);
+    }
+    size_t tmp2 = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, cnt.p, c->noff.p, N + 1, st));
+    if (tmp2 > tmp_bytes) { HIP_TRY(c, tmp.alloc(tmp2 + 16)); }
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp2, cnt.p, c->noff.p, N + 1, st));
+    c->h_noff.assign((size_t)N + 1, 0);
+    c->h_n2e_off.assign((size_t)N + 1, 0);
+    int h_flags[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(c->h_noff.data(), c->noff.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_n2e_off.data(), c->n2e_off.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
+    if (h_flags[1]) return c->fail(FH_UNSUPPORTED, "a node has more than 4096 candidate neighbours");
+    c->nnz_nodes = c->h_noff[N];
+    if (c->nnz_nodes >= (1ull << 32) - 1) return c->fail(FH_UNSUPPORTED, "node-level nnz exceeds 2^32");
+    HIP_TRY(c, c->ncols.alloc((size_t)c->nnz_nodes + 1));
+    if (N > 0) {
+        const int g = std::min(N, 256 * 64);
+        hipLaunchKernelGGL(k_node_neighbors<true>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, nullptr, c->noff.p,
+                           c->ncols.p, flags.p + 1);
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    c->has_pattern = true;
+    c->has_partition = false;
+    return FH_OK;
+}
+
+// ---------------------------------------------------------------------------------- kernel dispatch
+template <int EK, int OP>
+int launch_matrix(fh_ctx* c, KArgs& a, int mode, size_t lds_bytes, int grid) {
+    hipStream_t st = c->stream;
+#define FH_LAUNCH(M)                                                                                              \
+    do {                                                                                                          \
+        auto kern = k_assemble_matrix<EK, OP, M>;                                                                 \
+        if (lds_bytes > 48 * 1024)                                                                                \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds_bytes));                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);                                        \
+    } while (0)
+    switch (mode) {
+        case MODE_ATOMIC: FH_LAUNCH(MODE_ATOMIC); break;
+        case MODE_COLORED: FH_LAUNCH(MODE_COLORED); break;
+        case MODE_GATHER: FH_LAUNCH(MODE_GATHER); break;
+        case MODE_DUMP: FH_LAUNCH(MODE_DUMP); break;
+        default: return c->fail(FH_BAD_ARGUMENT, "bad scatter mode");
+    }
+#undef FH_LAUNCH
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int EK, int OP>
+size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb) {
+    switch (what) {
+        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb).bytes();
+        case WHAT_VECTOR: return make_layout<EK, OP, WHAT_VECTOR>(nq, ub, acc, nb, gather, mb).bytes();
+        default: return make_layout<EK, OP, WHAT_SCALAR>(nq, ub, acc, nb, gather, mb).bytes();
+    }
+}
+
+// dispatch over (element kind, operator kind) -> template instantiation
+#define FH_FOR_ELEM_OP(EKV, OPV, CALL)                                             \
+    switch (EKV) {                                                                 \
+        case FH_QUAD4: FH_FOR_OP(FH_QUAD4, OPV, CALL); break;                      \
+        case FH_HEX8: FH_FOR_OP(FH_HEX8, OPV, CALL); break;                        \
+        case FH_TET4: FH_FOR_OP(FH_TET4, OPV, CALL); break;                        \
+        case FH_HEX27: FH_FOR_OP(FH_HEX27, OPV, CALL); break;                      \
+        case FH_TRI3: FH_FOR_OP(FH_TRI3, OPV, CALL); break;                        \
+        default: break;                                                            \
+    }
+#define FH_FOR_OP(EKC, OPV, CALL)                                   \
+    switch (OPV) {                                                  \
+        case FH_LAPLACE: CALL(EKC, FH_LAPLACE); break;              \
+        case FH_LINEAR_ELASTIC: CALL(EKC, FH_LINEAR_ELASTIC); break;\
+        case FH_NEO_HOOKEAN: CALL(EKC, FH_NEO_HOOKEAN); break;      \
+        case FH_STVK: CALL(EKC, FH_STVK); break;                    \
+        default: break;                                             \
+    }
+
+size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0) {
+    size_t r = 0;
+#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb)
+    FH_FOR_ELEM_OP(ek, op, CALL)
+#undef CALL
+    return r;
+}
+
+constexpr size_t LDS_TARGET = 64 * 1024;   // two workgroups per CU
+constexpr size_t LDS_LIMIT = 160 * 1024;   // hardware limit per workgroup
+
+int check_ready(fh_ctx* c, const char* who, bool need_pattern) {
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, std::string(who) + ": no finite element mesh set");
+    if (c->op < 0) return c->fail(FH_INVALID_STATE, std::string(who) + ": no operator set");
+    if (c->nq <= 0) return c->fail(FH_INVALID_STATE, std::string(who) + ": no quadrature table set");
+    if (c->op != FH_LAPLACE && !c->has_params)
+        return c->fail(FH_INVALID_STATE, std::string(who) + ": operator needs per-point parameters (mu, lambda)");
+    if (need_pattern && !c->has_pattern) return c->fail(FH_INVALID_STATE, std::string(who) + ": call fh_pattern first");
+    return FH_OK;
+}
+
+void fill_common(fh_ctx* c, KArgs& a) {
+    std::memset(&a, 0, sizeof a);
+    a.verts = c->verts.p;
+    a.conn = c->conn.p;
+    a.num_elements = (long long)c->E;
+    a.num_nodes = (int)c->N;
+    a.nq = c->nq;
+    a.qw = c->qw.p;
+    a.gref = c->gref.p;
+    a.ggeom = c->ggeom.p;
+    a.qparams = c->has_params ? c->qparams.p : nullptr;
+    a.u = c->has_u ? c->u.p : nullptr;
+    a.noff = c->noff.p;
+    a.ncols = c->ncols.p;
+    a.n2e_off = c->n2e_off.p;
+    a.n2e = c->n2e.p;
+    a.status = c->status.p;
+}
+
+int reset_status(fh_ctx* c) {
+    if (!c->status.p) HIP_TRY(c, c->status.alloc(1));
+    DevStatus s{0, 0, ~0ull};
+    HIP_TRY(c, hipMemcpyAsync(c->status.p, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    return FH_OK;
+}
+
+int read_status(fh_ctx* c, uint64_t* failed) {
+    DevStatus s{};
+    HIP_TRY(c, hipMemcpyAsync(&s, c->status.p, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (s.singular) {
+        if (failed) *failed = s.failed_elem;
+        return c->fail(FH_SINGULAR_JACOBIAN, "Singular element Jacobian encountered");
+    }
+    return FH_OK;
+}
+
+// choose elements-per-block for the element-centric kernels so the LDS footprint stays <= target
+int choose_epb(fh_ctx* c, int what) {
+    int best = 1;
+    for (int epb = 1; epb <= 64; ++epb) {
+        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false);
+        if (b <= LDS_TARGET) best = epb; else break;
+    }
+    return best;
+}
+
+// greedy partition of the node range into owner blocks (gather mode)
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
+int build_partition(fh_ctx* c) {
+    if (c->has_partition) return FH_OK;
+    const int S = c->S();
+    const int N = (int)c->N;
+    unsigned max_row = 0;
+    for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+    // nodes per block (tunable), entry capacity per batch, accumulator budget
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 8)));
+    const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
+    const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 78) * 1024;
+    // accumulators: nb_target typical rows, but at least the largest single row block
+    long long sum_rows = 0;
+    for (int i = 0; i < N; ++i) sum_rows += c->h_noff[i + 1] - c->h_noff[i];
+    const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
+    int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
+    int ub = 0;
+    for (int t = 1; t <= mb; ++t) {
+        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, t, acc, 64, true, mb);
+        if (b <= lds_target) ub = t; else break;
+    }
+    if (ub == 0) {
+        ub = 1;
+        if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, 1, acc, 64, true, mb) > LDS_LIMIT)
+            return c->fail(FH_UNSUPPORTED, "gather mode: a row block does not fit in LDS; use FH_SCATTER_ATOMIC");
+    }
+    std::vector<unsigned> blk;
+    blk.push_back(0);
+    int i0 = 0;
+    while (i0 < N) {
+        int i1 = i0 + 1;
+        while (i1 < N && i1 - i0 < nb_target) {
+            const long long rows = (long long)c->h_noff[i1 + 1] - c->h_noff[i0];
+            const long long ents = (long long)c->h_n2e_off[i1 + 1] - c->h_n2e_off[i0];
+            if (S * S * rows > acc || ents > mb) break;
+            ++i1;
+        }
+        blk.push_back((unsigned)i1);
+        i0 = i1;
+    }
+    c->nblk = (int)blk.size() - 1;
+    HIP_TRY(c, c->blk_off.alloc(blk.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, blk.data(), sizeof(unsigned) * blk.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->g_ub = ub;
+    c->g_mb = mb;
+    c->g_acc = acc;
+    c->g_nb = 64;
+    c->has_partition = true;
+    return FH_OK;
+}
+
+int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    const int mode = flags & FH_SCATTER_MASK;
+    const int overwrite = (flags & FH_ASSEMBLE_OVERWRITE) ? 1 : 0;
+    rc = reset_status(c);
+    if (rc) return rc;
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    a.vals = values_dev;
+    a.overwrite = overwrite;
+    const uint64_t nnz = (uint64_t)c->S() * c->S() * c->nnz_nodes;
+    if (mode == FH_SCATTER_GATHER) {
+        rc = build_partition(c);
+        if (rc) return rc;
+        a.blk_off = c->blk_off.p;
+        a.nblk = c->nblk;
+        a.ub = c->g_ub;
+        a.mb = c->g_mb;
+        a.acc_max = c->g_acc;
+        a.nb_max = c->g_nb;
+        const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb);
+        c->last_kernel = "k_assemble_matrix<gather>";
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_GATHER, lds, c->nblk)
+        FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+        return rc;
+    }
+    if (overwrite) HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * nnz, c->stream));
+    a.epb = choose_epb(c, WHAT_MATRIX);
+    a.ub = a.epb;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    if (mode == FH_SCATTER_ATOMIC) {
+        a.work_begin = 0;
+        a.work_end = (long long)c->E;
+        const int grid = (int)((c->E + a.epb - 1) / a.epb);
+        c->last_kernel = "k_assemble_matrix<atomic>";
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_ATOMIC, lds, grid)
+        FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+        return rc;
+    }
+    if (mode == FH_SCATTER_COLORED) {
+        if (!c->has_colors) return c->fail(FH_INVALID_STATE, "FH_SCATTER_COLORED: call fh_color or fh_set_colors first");
+        a.labels = c->labels.p;
+        c->last_kernel = "k_assemble_matrix<colored>";
+        for (size_t col = 0; col + 1 < c->color_offsets.size(); ++col) {
+            a.work_begin = (long long)c->color_offsets[col];
+            a.work_end = (long long)c->color_offsets[col + 1];
+            const long long cntc = a.work_end - a.work_begin;
+            if (cntc <= 0) continue;
+            const int grid = (int)((cntc + a.epb - 1) / a.epb);
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_COLORED, lds, grid)
+            FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+            if (rc) return rc;
+        }
+        return FH_OK;
+    }
+    return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: unknown scatter mode");
+}
+
+}  // namespace
+
+template <int EK, int OP>
+static int launch_vector(fh_ctx* c, KArgs& a, size_t lds, int grid) {
+    auto kern = k_assemble_vector<EK, OP>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+template <int EK, int OP>
+static int launch_scalar(fh_ctx* c, KArgs& a, size_t lds, int grid) {
+    auto kern = k_assemble_scalar<EK, OP>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int fh_abi_version(void) { return FH_ABI_VERSION; }
+
+fh_ctx* fh_create(int device_id) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    fh_ctx* c = new fh_ctx();
+    c->device = device_id;
+    if (c->status.alloc(1) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+
+void fh_destroy(fh_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+const char* fh_last_error(const fh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* fh_last_kernel_name(const fh_ctx* c) { return c ? c->last_kernel.c_str() : ""; }
+
+int fh_set_stream(fh_ctx* c, void* s) {
+    if (!c) return FH_BAD_ARGUMENT;
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return FH_OK;
+}
+int fh_synchronize(fh_ctx* c) {
+    if (!c) return FH_BAD_ARGUMENT;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+uint64_t fh_solution_dim(const fh_ctx* c) { return c ? (uint64_t)c->S() : 0; }
+uint64_t fh_num_elements(const fh_ctx* c) { return c ? c->E : 0; }
+uint64_t fh_num_nodes(const fh_ctx* c) { return c ? c->N : 0; }
+uint64_t fh_num_rows(const fh_ctx* c) { return c ? (uint64_t)c->S() * c->N : 0; }
+uint64_t fh_nnz(const fh_ctx* c) { return (c && c->has_pattern) ? (uint64_t)c->S() * c->S() * c->nnz_nodes : 0; }
+
+static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
+    ElemInfo ei;
+    if (!elem_info(elem_kind, ei)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh: unknown element kind");
+    if (N >= (1ull << 31)) return c->fail(FH_UNSUPPORTED, "fh_set_mesh: num_vertices must be < 2^31");
+    if (E * (uint64_t)ei.n >= (1ull << 32)) return c->fail(FH_UNSUPPORTED, "fh_set_mesh: num_elements * n must be < 2^32");
+    HIP_TRY(c, hipSetDevice(c->device));
+    invalidate_pattern(c);
+    c->has_mesh = false;
+    c->ragged = false;
+    c->elem_kind = elem_kind;
+    c->ei = ei;
+    c->N = N;
+    c->E = E;
+    c->flat_len = E * (uint64_t)ei.n;
+    c->has_u = false;
+    c->nq = 0;  // reference gradient tables depend on the element kind
+    HIP_TRY(c, c->verts.alloc((size_t)N * ei.d));
+    HIP_TRY(c, c->conn.alloc((size_t)c->flat_len));
+    return FH_OK;
+}
+
+static int narrow_conn(fh_ctx* c, const unsigned long long* conn_dev) {
+    DevBuf<int> bad;
+    HIP_TRY(c, bad.alloc(1));
+    HIP_TRY(c, hipMemsetAsync(bad.p, 0, sizeof(int), c->stream));
+    if (c->flat_len)
+        hipLaunchKernelGGL(k_narrow_connectivity, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, c->stream, conn_dev,
+                           c->conn.p, (long long)c->flat_len, (int)c->N, bad.p);
+    int h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh: connectivity refers to a vertex index >= num_vertices");
+    return FH_OK;
+}
+
+int fh_set_mesh(fh_ctx* c, int elem_kind, const double* vertices, uint64_t N, const uint64_t* connectivity, uint64_t E) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if ((N && !vertices) || (E && !connectivity)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh: null pointer");
+    int rc = set_mesh_common(c, elem_kind, N, E);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->verts.p, vertices, sizeof(double) * N * c->ei.d, hipMemcpyHostToDevice, c->stream));
+    DevBuf<unsigned long long> tmp;
+    HIP_TRY(c, tmp.alloc((size_t)c->flat_len));
+    HIP_TRY(c, hipMemcpyAsync(tmp.p, connectivity, sizeof(uint64_t) * c->flat_len, hipMemcpyHostToDevice, c->stream));
+    rc = narrow_conn(c, tmp.p);
+    if (rc) return rc;
+    // host copy for the (host-side, reference-identical) greedy colouring
+    c->h_nodes.assign(connectivity, connectivity + c->flat_len);
+    c->h_eoff.clear();
+    c->has_host_conn = true;
+    c->has_mesh = true;
+    return FH_OK;
+}
+
+int fh_set_mesh_dev(fh_ctx* c, int elem_kind, const double* vertices_dev, uint64_t N, const uint64_t* conn_dev, uint64_t E) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if ((N && !vertices_dev) || (E && !conn_dev)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh_dev: null pointer");
+    int rc = set_mesh_common(c, elem_kind, N, E);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->verts.p, vertices_dev, sizeof(double) * N * c->ei.d, hipMemcpyDeviceToDevice, c->stream));
+    rc = narrow_conn(c, reinterpret_cast<const unsigned long long*>(conn_dev));
+    if (rc) return rc;
+    c->h_nodes.clear();
+    c->has_host_conn = false;
+    c->has_mesh = true;
+    return FH_OK;
+}
+
+int fh_update_vertices(fh_ctx* c, const double* vertices) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_update_vertices: no mesh");
+    if (!vertices) return c->fail(FH_BAD_ARGUMENT, "fh_update_vertices: null pointer");
+    HIP_TRY(c, hipMemcpyAsync(c->verts.p, vertices, sizeof(double) * c->N * c->ei.d, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint64_t* eoff, const uint64_t* nodes, uint64_t E) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!eoff || sdim == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_connectivity_ragged: bad argument");
+    const uint64_t total = eoff[E];
+    if (total && !nodes) return c->fail(FH_BAD_ARGUMENT, "fh_set_connectivity_ragged: null node list");
+    if (N >= (1ull << 31) || total >= (1ull << 32)) return c->fail(FH_UNSUPPORTED, "connectivity too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    invalidate_pattern(c);
+    c->has_mesh = false;
+    c->ragged = true;
+    c->elem_kind = -1;
+    c->ei = ElemInfo{0, 0, 0, -1};
+    c->N = N;
+    c->E = E;
+    c->flat_len = total;
+    c->sdim_ragged = sdim;
+    std::vector<int> h_nodes(total ? total : 1, 0);
+    std::vector<unsigned> h_off(E + 1), h_k2e(total ? total : 1, 0);
+    for (uint64_t e = 0; e <= E; ++e) {
+        if (e && eoff[e] < eoff[e - 1]) return c->fail(FH_BAD_ARGUMENT, "element offsets must be non-decreasing");
+        h_off[e] = (unsigned)eoff[e];
+    }
+    for (uint64_t e = 0; e < E; ++e)
+        for (uint64_t k = eoff[e]; k < eoff[e + 1]; ++k) {
+            if (nodes[k] >= N) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
+            h_nodes[k] = (int)nodes[k];
+            h_k2e[k] = (unsigned)e;
+        }
+    HIP_TRY(c, c->conn.alloc(h_nodes.size()));
+    HIP_TRY(c, c->eoff.alloc(h_off.size()));
+    HIP_TRY(c, c->k2e.alloc(h_k2e.size()));
+    HIP_TRY(c, hipMemcpy(c->conn.p, h_nodes.data(), sizeof(int) * h_nodes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->eoff.p, h_off.data(), sizeof(unsigned) * h_off.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->k2e.p, h_k2e.data(), sizeof(unsigned) * h_k2e.size(), hipMemcpyHostToDevice));
+    c->h_eoff.assign(eoff, eoff + E + 1);
+    c->h_nodes.assign(nodes, nodes + total);
+    c->has_host_conn = true;
+    c->has_mesh = true;
+    return FH_OK;
+}
+
+int fh_set_operator(fh_ctx* c, int op_kind) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (op_kind < FH_LAPLACE || op_kind > FH_STVK) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
+    if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
+    const int old_s = c->S();
+    c->op = op_kind;
+    if (c->S() != old_s) { c->has_u = false; c->has_partition = false; }
+    return FH_OK;
+}
+
+int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uint32_t nq, const double* params) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_uniform: set the mesh first");
+    if (!w || !pts || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform: bad argument");
+    const ElemInfo& ei = c->ei;
+    std::vector<double> gref((size_t)nq * ei.n * ei.d), ggeom((size_t)nq * ei.ng * ei.d);
+    for (uint32_t q = 0; q < nq; ++q) {
+        ref_gradients(c->elem_kind, pts + (size_t)q * ei.d, gref.data() + (size_t)q * ei.n * ei.d);
+        ref_gradients(ei.geom_kind, pts + (size_t)q * ei.d, ggeom.data() + (size_t)q * ei.ng * ei.d);
+    }
+    HIP_TRY(c, c->qw.alloc(nq));
+    HIP_TRY(c, c->gref.alloc(gref.size()));
+    HIP_TRY(c, c->ggeom.alloc(ggeom.size()));
+    HIP_TRY(c, c->qparams.alloc(2 * (size_t)nq));
+    HIP_TRY(c, hipMemcpy(c->qw.p, w, sizeof(double) * nq, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->gref.p, gref.data(), sizeof(double) * gref.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ggeom.p, ggeom.data(), sizeof(double) * ggeom.size(), hipMemcpyHostToDevice));
+    c->has_params = params != nullptr;
+    if (params) HIP_TRY(c, hipMemcpy(c->qparams.p, params, sizeof(double) * 2 * nq, hipMemcpyHostToDevice));
+    c->h_points.assign(pts, pts + (size_t)nq * ei.d);
+    c->nq = (int)nq;
+    c->has_partition = false;
+    return FH_OK;
+}
+
+static int set_u_common(fh_ctx* c, const double* u, hipMemcpyKind kind) {
+    if (!c->has_mesh || c->ragged || c->op < 0) return c->fail(FH_INVALID_STATE, "fh_set_u: set mesh and operator first");
+    if (!u) { c->has_u = false; return FH_OK; }
+    const size_t len = (size_t)c->S() * c->N;
+    if (c->u.n < len) HIP_TRY(c, c->u.alloc(len));
+    HIP_TRY(c, hipMemcpyAsync(c->u.p, u, sizeof(double) * len, kind, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->has_u = true;
+    return FH_OK;
+}
+int fh_set_u(fh_ctx* c, const double* u) { return c ? set_u_common(c, u, hipMemcpyHostToDevice) : FH_BAD_ARGUMENT; }
+int fh_set_u_dev(fh_ctx* c, const double* u) { return c ? set_u_common(c, u, hipMemcpyDeviceToDevice) : FH_BAD_ARGUMENT; }
+
+// ---- pattern
+int fh_pattern_dev(fh_ctx* c, uint64_t* row_offsets_dev, uint64_t* col_indices_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_pattern_dev: call fh_pattern first");
+    const int S = c->S(), N = (int)c->N;
+    if (row_offsets_dev)
+        hipLaunchKernelGGL(k_expand_row_offsets, dim3(grid_for((long long)N * S + 1, 256, 1 << 30)), dim3(256), 0, c->stream,
+                           c->noff.p, N, S, reinterpret_cast<unsigned long long*>(row_offsets_dev));
+    if (col_indices_dev && c->nnz_nodes)
+        hipLaunchKernelGGL(k_expand_col_indices, dim3(grid_for((long long)c->nnz_nodes, 256)), dim3(256), 0, c->stream, c->noff.p,
+                           c->ncols.p, N, S, reinterpret_cast<unsigned long long*>(col_indices_dev));
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+int fh_pattern(fh_ctx* c, uint64_t* row_offsets, uint64_t* nnz_out) {
+    if (!c) return FH_BAD_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = build_pattern(c);
+    if (rc) return rc;
+    const uint64_t S = (uint64_t)c->S();
+    if (nnz_out) *nnz_out = S * S * c->nnz_nodes;
+    if (row_offsets) {  // cheap on the host from the node-level offsets
+        uint64_t r = 0;
+        for (uint64_t i = 0; i < c->N; ++i) {
+            const uint64_t cnt = c->h_noff[i + 1] - c->h_noff[i];
+            for (uint64_t t = 0; t < S; ++t) row_offsets[r++] = S * S * c->h_noff[i] + t * S * cnt;
+        }
+        row_offsets[r] = S * S * c->nnz_nodes;
+    }
+    return FH_OK;
+}
+
+int fh_pattern_cols(fh_ctx* c, uint64_t* col_indices) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_pattern_cols: call fh_pattern first");
+    const uint64_t nnz = fh_nnz(c);
+    if (nnz == 0) return FH_OK;
+    if (!col_indices) return c->fail(FH_BAD_ARGUMENT, "fh_pattern_cols: null pointer");
+    DevBuf<unsigned long long> tmp;
+    HIP_TRY(c, tmp.alloc((size_t)nnz));
+    int rc = fh_pattern_dev(c, nullptr, reinterpret_cast<uint64_t*>(tmp.p));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(col_indices, tmp.p, sizeof(uint64_t) * nnz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+// ---- colouring
+static int upload_colors(fh_ctx* c, const std::vector<uint64_t>& offs, const std::vector<uint64_t>& labels) {
+    std::vector<unsigned> l32(labels.size() ? labels.size() : 1, 0);
+    for (size_t i = 0; i < labels.size(); ++i) l32[i] = (unsigned)labels[i];
+    HIP_TRY(c, c->labels.alloc(l32.size()));
+    HIP_TRY(c, hipMemcpy(c->labels.p, l32.data(), sizeof(unsigned) * l32.size(), hipMemcpyHostToDevice));
+    c->color_offsets = offs;
+    c->has_colors = true;
+    return FH_OK;
+}
+
+int fh_color(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_color: no connectivity set");
+    if (!c->has_host_conn) {  // mesh was given as device pointers: fetch the connectivity once
+        std::vector<int> tmp(c->flat_len ? c->flat_len : 1);
+        HIP_TRY(c, hipMemcpy(tmp.data(), c->conn.p, sizeof(int) * c->flat_len, hipMemcpyDeviceToHost));
+        c->h_nodes.assign(tmp.begin(), tmp.begin() + c->flat_len);
+        c->h_eoff.clear();
+        c->has_host_conn = true;
+    }
+    std::vector<uint64_t> eoff_fixed;
+    const uint64_t* eoff = c->h_eoff.data();
+    if (!c->ragged) {
+        eoff_fixed.resize(c->E + 1);
+        for (uint64_t e = 0; e <= c->E; ++e) eoff_fixed[e] = e * (uint64_t)c->ei.n;
+        eoff = eoff_fixed.data();
+    }
+    std::vector<uint64_t> offs, lab;
+    static const uint64_t zero = 0;
+    greedy_coloring(c->E, eoff, c->h_nodes.empty() ? &zero : c->h_nodes.data(), offs, lab);
+    if (num_colors) *num_colors = offs.size() - 1;
+    if (color_offsets) std::copy(offs.begin(), offs.end(), color_offsets);
+    if (labels) std::copy(lab.begin(), lab.end(), labels);
+    return upload_colors(c, offs, lab);
+}
+
+int fh_set_colors(fh_ctx* c, uint64_t num_colors, const uint64_t* color_offsets, const uint64_t* labels) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_set_colors: no connectivity set");
+    if (!color_offsets || (!labels && c->E)) return c->fail(FH_BAD_ARGUMENT, "fh_set_colors: null pointer");
+    if (color_offsets[0] != 0 || color_offsets[num_colors] != c->E)
+        return c->fail(FH_BAD_ARGUMENT, "fh_set_colors: offsets must cover all elements");
+    std::vector<uint64_t> offs(color_offsets, color_offsets + num_colors + 1), lab(labels, labels + c->E);
+    for (uint64_t e : lab)
+        if (e >= c->E) return c->fail(FH_BAD_ARGUMENT, "fh_set_colors: label out of range");
+    return upload_colors(c, offs, lab);
+}
+
+// ---- numeric assembly
+int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
+    if (!c) return FH_BAD_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return assemble_matrix_enqueue(c, values_dev, flags);
+}
+
+int fh_poll_status(fh_ctx* c, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    return read_status(c, failed);
+}
+
+int fh_assemble_matrix_dev(fh_ctx* c, double* values_dev, int flags, uint64_t* failed) {
+    int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);
+    if (rc) return rc;
+    return read_status(c, failed);
+}
+
+int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    const uint64_t nnz = fh_nnz(c);
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc((size_t)nnz));
+    if (!(flags & FH_ASSEMBLE_OVERWRITE))
+        HIP_TRY(c, hipMemcpyAsync(d.p, values, sizeof(double) * nnz, hipMemcpyHostToDevice, c->stream));
+    rc = fh_assemble_matrix_dev(c, d.p, flags, failed);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(values, d.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, double* ke_out) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_element_matrices", false);
+    if (rc) return rc;
+    if (first + count > c->E || (count && !ke_out)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
+    if (count == 0) return FH_OK;
+    rc = reset_status(c);
+    if (rc) return rc;
+    const size_t ld = (size_t)c->S() * c->ei.n;
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc(ld * ld * count));
+    KArgs a;
+    fill_common(c, a);
+    a.ke_out = d.p;
+    a.work_begin = (long long)first;
+    a.work_end = (long long)(first + count);
+    a.epb = choose_epb(c, WHAT_MATRIX);
+    a.ub = a.epb;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    const int grid = (int)((count + a.epb - 1) / a.epb);
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_DUMP, lds, grid)
+    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(ke_out, d.p, sizeof(double) * ld * ld * count, hipMemcpyDeviceToHost, c->stream));
+    return read_status(c, nullptr);
+}
+
+int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_vector", false);
+    if (rc) return rc;
+    if (!out_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_vector: out is null");
+    rc = reset_status(c);
+    if (rc) return rc;
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    a.vec_out = out_dev;
+    a.work_begin = 0;
+    a.work_end = (long long)c->E;
+    a.epb = choose_epb(c, WHAT_VECTOR);
+    a.ub = a.epb;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_VECTOR, c->nq, a.ub, 0, 0, false);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    const int grid = (int)((c->E + a.epb - 1) / a.epb);
+#define CALL(EKC, OPC) rc = launch_vector<EKC, OPC>(c, a, lds, grid)
+    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+    if (rc) return rc;
+    return read_status(c, failed);
+}
+
+int fh_assemble_vector(fh_ctx* c, double* out, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_vector", false);
+    if (rc) return rc;
+    if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_vector: out is null");
+    const size_t len = (size_t)c->S() * c->N;
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc(len));
+    HIP_TRY(c, hipMemcpyAsync(d.p, out, sizeof(double) * len, hipMemcpyHostToDevice, c->stream));
+    rc = fh_assemble_vector_dev(c, d.p, failed);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, d.p, sizeof(double) * len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_scalar", false);
+    if (rc) return rc;
+    if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_scalar: out is null");
+    rc = reset_status(c);
+    if (rc) return rc;
+    *out = 0.0;
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    a.work_begin = 0;
+    a.work_end = (long long)c->E;
+    a.epb = 1;  // one partial per element, summed in element order on the host (global.rs:703-709)
+    a.ub = 1;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_SCALAR, c->nq, a.ub, 0, 0, false);
+    const int grid = (int)c->E;
+    DevBuf<double> partial;
+    HIP_TRY(c, partial.alloc((size_t)grid));
+    a.scalar_out = partial.p;
+#define CALL(EKC, OPC) rc = launch_scalar<EKC, OPC>(c, a, lds, grid)
+    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+    if (rc) return rc;
+    std::vector<double> h((size_t)grid);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), partial.p, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream));
+    rc = read_status(c, failed);
+    if (rc) return rc;
+    double tot = 0.0;
+    for (double v : h) tot += v;
+    *out = tot;
+    return FH_OK;
+}
+
+// ---- Dirichlet helpers
+int fh_apply_dirichlet_csr_dev(fh_ctx* c, double* values_dev, const uint64_t* nodes, uint64_t n) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_apply_dirichlet_csr_dev: call fh_pattern first");
+    if (!values_dev || (n && !nodes)) return c->fail(FH_BAD_ARGUMENT, "fh_apply_dirichlet_csr_dev: null pointer");
+    const int S = c->S(), N = (int)c->N;
+    std::vector<unsigned char> member((size_t)N + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (nodes[i] >= c->N) return c->fail(FH_BAD_ARGUMENT, "Dirichlet node out of range");
+        member[nodes[i]] = 1;
+    }
+    DevBuf<unsigned char> dm;
+    DevBuf<unsigned long long> first;
+    DevBuf<double> scale;
+    HIP_TRY(c, dm.alloc(member.size()));
+    HIP_TRY(c, first.alloc(1));
+    HIP_TRY(c, scale.alloc(1));
+    HIP_TRY(c, hipMemcpyAsync(dm.p, member.data(), member.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(first.p, 0xff, sizeof(unsigned long long), c->stream));
+    const long long R = (long long)N * S;
+    hipLaunchKernelGGL(k_first_nonzero_diag, dim3(grid_for(R, 256, 1 << 30)), dim3(256), 0, c->stream, c->noff.p, c->ncols.p, N, S,
+                       values_dev, first.p, (double*)nullptr);
+    hipLaunchKernelGGL(k_first_nonzero_diag, dim3(1), dim3(64), 0, c->stream, c->noff.p, c->ncols.p, N, S, values_dev, first.p,
+                       scale.p);
+    double h_scale = 1.0;
+    HIP_TRY(c, hipMemcpyAsync(&h_scale, scale.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->nnz_nodes)
+        hipLaunchKernelGGL(k_dirichlet_rows, dim3(grid_for((long long)c->nnz_nodes, 256)), dim3(256), 0, c->stream, c->noff.p,
+                           c->ncols.p, N, S, dm.p, values_dev, h_scale);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+int fh_apply_dirichlet_rhs_dev(fh_ctx* c, double* rhs_dev, const uint64_t* nodes, uint64_t n) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!rhs_dev || (n && !nodes)) return c->fail(FH_BAD_ARGUMENT, "fh_apply_dirichlet_rhs_dev: null pointer");
+    if (n == 0) return FH_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (nodes[i] >= c->N) return c->fail(FH_BAD_ARGUMENT, "Dirichlet node out of range");
+    const int S = c->S();
+    DevBuf<unsigned long long> dn;
+    HIP_TRY(c, dn.alloc((size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(dn.p, nodes, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_dirichlet_rhs, dim3(grid_for((long long)n * S, 256, 1 << 30)), dim3(256), 0, c->stream, rhs_dev, dn.p,
+                       (long long)n, S);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,439 @@
+// Host-side input generators of the engine: quadrature rules, structured mesh generators, Hex8->Hex27
+// conversion, Lame conversion and the reference-identical greedy colouring.  Pure C++ (no device code);
+// everything here reproduces the *orderings* of the reference bit-exactly, because CSR index parity
+// depends on them.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fenris_hip.h"
+#include "host_inputs.hpp"
+
+namespace fenris_hip {
+
+// ---------------------------------------------------------------------------------------- quadrature
+// Gauss-Legendre by Newton iteration on P_n, following fenris-quadrature/src/univariate.rs:13-118:
+// three-term recurrence for (P_n, P_{n-1}), derivative n (x P_n - P_{n-1}) / (x^2 - 1), start value
+// cos(pi (i + 3/4) / (n + 1/2)), stop when |dx| <= 1e-15, weights 2 / ((1 - x^2) P_n'(x)^2); the first
+// ceil(n/2) roots are the positive ones in descending order, the rest are mirrored.
+static inline void legendre_pair(unsigned n, double x, double& pn, double& dpn) {
+    double cur = 1.0, prev = 0.0;
+    for (unsigned m = 1; m <= n; ++m) {
+        const double mm = static_cast<double>(m);
+        const double prev2 = prev;
+        prev = cur;
+        cur = ((2.0 * mm - 1.0) * x * prev - (mm - 1.0) * prev2) / mm;
+    }
+    pn = cur;
+    dpn = static_cast<double>(n) * (x * cur - prev) / (x * x - 1.0);
+}
+
+bool gauss_rule(unsigned n, std::vector<double>& w, std::vector<double>& x) {
+    if (n == 0) return false;
+    w.assign(n, 0.0);
+    x.assign(n, 0.0);
+    const unsigned half = (n + 1) / 2;
+    for (unsigned i = 0; i < half; ++i) {
+        double xi = std::cos(M_PI * (static_cast<double>(i) + 0.75) / (static_cast<double>(n) + 0.5));
+        double p, dp;
+        legendre_pair(n, xi, p, dp);
+        while (true) {
+            const double step = -p / dp;
+            xi += step;
+            legendre_pair(n, xi, p, dp);
+            if (std::fabs(step) <= 1e-15) break;
+        }
+        x[i] = xi;
+        w[i] = 2.0 / ((1.0 - xi * xi) * dp * dp);
+    }
+    for (unsigned i = half; i < n; ++i) {
+        x[i] = -x[n - 1 - i];
+        w[i] = w[n - 1 - i];
+    }
+    return true;
+}
+
+// Tensor rules: first coordinate outermost, last innermost, w = wx*wy(*wz)  (tensor.rs:13-55)
+bool tensor_rule(unsigned dim, unsigned n, double* w_out, double* p_out) {
+    std::vector<double> w, x;
+    if (!gauss_rule(n, w, x)) return false;
+    size_t k = 0;
+    if (dim == 2) {
+        for (unsigned a = 0; a < n; ++a)
+            for (unsigned b = 0; b < n; ++b, ++k) {
+                w_out[k] = w[a] * w[b];
+                p_out[2 * k] = x[a];
+                p_out[2 * k + 1] = x[b];
+            }
+    } else {
+        for (unsigned a = 0; a < n; ++a)
+            for (unsigned b = 0; b < n; ++b)
+                for (unsigned c = 0; c < n; ++c, ++k) {
+                    w_out[k] = w[a] * w[b] * w[c];
+                    p_out[3 * k] = x[a];
+                    p_out[3 * k + 1] = x[b];
+                    p_out[3 * k + 2] = x[c];
+                }
+    }
+    return true;
+}
+
+// Witherden-Vincent tables as decimal strings, converted with strtod like Rust's str::parse::<f64>
+// (polyquad-parse/src/lib.rs:48-51).  Row = coordinates..., weight.
+struct TableRule { unsigned strength, npts; const char* const* rows; };
+static const char* const TET_1[] = {"-0.5", "-0.5", "-0.5", "1.3333333333333333333333333333333333333"};
+#define A2 "-0.72360679774997896964091736687312762354"
+#define B2 "0.17082039324993690892275210061938287063"
+#define W2 "0.33333333333333333333333333333333333333"
+static const char* const TET_2[] = {A2, A2, B2, W2, A2, B2, A2, W2, B2, A2, A2, W2, A2, A2, A2, W2};
+#define A3 "-0.34367339496723662642072827083693243093"
+#define B3 "-0.9689798150982901207378151874892027072"
+#define W3A "0.18162379004944980942342872025562069427"
+#define C3 "-0.78390550020314279176487322158837338344"
+#define D3 "0.35171650060942837529461966476512015033"
+#define W3B "0.15170954328388352390990461307771263906"
+static const char* const TET_3[] = {A3, A3, B3, W3A, A3, B3, A3, W3A, B3, A3, A3, W3A, A3, A3, A3, W3A,
+                                    C3, C3, D3, W3B, C3, D3, C3, W3B, D3, C3, C3, W3B, C3, C3, C3, W3B};
+static const TableRule TET_RULES[] = {{1, 1, TET_1}, {2, 4, TET_2}, {3, 8, TET_3}};
+#define T13 "-0.33333333333333333333333333333333333333"
+static const char* const TRI_1[] = {T13, T13, "2"};
+#define T23 "-0.66666666666666666666666666666666666667"
+#define T13P "0.33333333333333333333333333333333333333"
+#define T23P "0.66666666666666666666666666666666666667"
+static const char* const TRI_2[] = {T23, T13P, T23P, T13P, T23, T23P, T23, T23, T23P};
+static const TableRule TRI_RULES[] = {{1, 1, TRI_1}, {2, 3, TRI_2}};
+
+// select_minimum (fenris-quadrature/build.rs:172-194): smallest tabulated strength >= requested
+template <size_t K>
+static int table_rule(const TableRule (&rules)[K], unsigned dim, unsigned strength, double* w, double* p,
+                      uint32_t* npts) {
+    for (const TableRule& r : rules) {
+        if (r.strength < strength) continue;
+        for (unsigned i = 0; i < r.npts; ++i) {
+            for (unsigned c = 0; c < dim; ++c) p[dim * i + c] = std::strtod(r.rows[(dim + 1) * i + c], nullptr);
+            w[i] = std::strtod(r.rows[(dim + 1) * i + dim], nullptr);
+        }
+        *npts = r.npts;
+        return FH_OK;
+    }
+    return FH_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------- meshes
+// Structured generators; vertex and cell orders follow src/mesh/procedural.rs (A.6 of the survey).
+void quad_mesh_sizes(uint64_t ux, uint64_t uy, uint64_t cpu, uint64_t& nv, uint64_t& nc) {
+    if (!ux || !uy || !cpu) { nv = nc = 0; return; }
+    nv = (ux * cpu + 1) * (uy * cpu + 1);
+    nc = ux * cpu * uy * cpu;
+}
+
+void quad_mesh_fill(double unit, uint64_t ux, uint64_t uy, uint64_t cpu, const double tl[2], double* v,
+                    uint64_t* c) {
+    const double h = unit / static_cast<double>(cpu);
+    const uint64_t nx = ux * cpu, ny = uy * cpu, stride = nx + 1;
+    for (uint64_t j = 0; j <= ny; ++j)
+        for (uint64_t i = 0; i <= nx; ++i) {
+            double* out = v + 2 * (stride * j + i);
+            out[0] = tl[0] + static_cast<double>(i) * h;
+            out[1] = tl[1] + (-static_cast<double>(j)) * h;
+        }
+    for (uint64_t j = 0; j < ny; ++j)
+        for (uint64_t i = 0; i < nx; ++i) {
+            uint64_t* q = c + 4 * (nx * j + i);
+            q[0] = stride * (j + 1) + i;
+            q[1] = stride * (j + 1) + i + 1;
+            q[2] = stride * j + i + 1;
+            q[3] = stride * j + i;
+        }
+}
+
+void hex_mesh_sizes(uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, uint64_t& nv, uint64_t& nc) {
+    if (!ux || !uy || !cpu) { nv = nc = 0; return; }  // procedural.rs:236 (units_z is not checked there)
+    nv = (ux * cpu + 1) * (uy * cpu + 1) * (uz * cpu + 1);
+    nc = ux * cpu * uy * cpu * uz * cpu;
+}
+
+void hex_mesh_fill(double unit, uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, double* v, uint64_t* c) {
+    const double h = unit / static_cast<double>(cpu);
+    const uint64_t nx = ux * cpu, ny = uy * cpu, nz = uz * cpu;
+    const uint64_t sx = nx + 1, sxy = (nx + 1) * (ny + 1);
+    if (v) {
+        double* out = v;
+        for (uint64_t k = 0; k <= nz; ++k)
+            for (uint64_t j = 0; j <= ny; ++j)
+                for (uint64_t i = 0; i <= nx; ++i, out += 3) {
+                    out[0] = static_cast<double>(i) * h;
+                    out[1] = static_cast<double>(j) * h;
+                    out[2] = static_cast<double>(k) * h;
+                }
+    }
+    if (c) {
+        // local corner (di,dj,dk) per Hex8 node: (0,0,0),(1,0,0),(1,1,0),(0,1,0),(0,0,1),(1,0,1),(1,1,1),(0,1,1)
+        static const uint64_t CORNER[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0},
+                                              {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+        uint64_t* out = c;
+        for (uint64_t k = 0; k < nz; ++k)
+            for (uint64_t j = 0; j < ny; ++j)
+                for (uint64_t i = 0; i < nx; ++i, out += 8)
+                    for (int a = 0; a < 8; ++a)
+                        out[a] = sxy * (k + CORNER[a][2]) + sx * (j + CORNER[a][1]) + (i + CORNER[a][0]);
+    }
+}
+
+// BCC tetrahedral mesh (procedural.rs:286-403): lattice vertices, then cell centres; for every cell and
+// axis: 4 tets around the centre-centre edge towards the +axis neighbour, and a 2-tet pyramid on each
+// boundary face with the diagonal alternating by (i+j+k) % 2.
+void tet_mesh_sizes(uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, uint64_t& nv, uint64_t& nc) {
+    if (!ux || !uy || !uz || !cpu) { nv = nc = 0; return; }
+    const uint64_t cx = ux * cpu, cy = uy * cpu, cz = uz * cpu;
+    nv = (cx + 1) * (cy + 1) * (cz + 1) + cx * cy * cz;
+    nc = 4 * ((cx - 1) * cy * cz + cx * (cy - 1) * cz + cx * cy * (cz - 1)) + 4 * (cy * cz + cx * cz + cx * cy);
+}
+
+void tet_mesh_fill(double unit, uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, double* v, uint64_t* c) {
+    const double h = unit / static_cast<double>(cpu);
+    const uint64_t cells[3] = {ux * cpu, uy * cpu, uz * cpu};
+    const uint64_t vx = cells[0] + 1, vy = cells[1] + 1, vz = cells[2] + 1;
+    const uint64_t centre0 = vx * vy * vz;
+    double* out = v;
+    for (uint64_t k = 0; k < vz; ++k)
+        for (uint64_t j = 0; j < vy; ++j)
+            for (uint64_t i = 0; i < vx; ++i, out += 3) {
+                out[0] = h * static_cast<double>(i);
+                out[1] = h * static_cast<double>(j);
+                out[2] = h * static_cast<double>(k);
+            }
+    for (uint64_t k = 0; k < cells[2]; ++k)
+        for (uint64_t j = 0; j < cells[1]; ++j)
+            for (uint64_t i = 0; i < cells[0]; ++i, out += 3) {
+                out[0] = h * (0.5 + static_cast<double>(i));
+                out[1] = h * (0.5 + static_cast<double>(j));
+                out[2] = h * (0.5 + static_cast<double>(k));
+            }
+    auto vid = [&](const std::array<int64_t, 3>& p) {
+        return (vx * vy) * static_cast<uint64_t>(p[2]) + vx * static_cast<uint64_t>(p[1]) + static_cast<uint64_t>(p[0]);
+    };
+    auto cid = [&](uint64_t i, uint64_t j, uint64_t k) { return (cells[0] * cells[1]) * k + cells[0] * j + i + centre0; };
+    // corners of the face shared with the +axis neighbour, as offsets from (i,j,k)
+    static const int64_t FACE[3][4][3] = {{{1, 0, 1}, {1, 1, 1}, {1, 1, 0}, {1, 0, 0}},
+                                          {{0, 1, 0}, {1, 1, 0}, {1, 1, 1}, {0, 1, 1}},
+                                          {{0, 1, 1}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}}};
+    uint64_t* t = c;
+    auto emit = [&](uint64_t a, uint64_t b, uint64_t cc, uint64_t d) { t[0] = a; t[1] = b; t[2] = cc; t[3] = d; t += 4; };
+    for (uint64_t k = 0; k < cells[2]; ++k)
+        for (uint64_t j = 0; j < cells[1]; ++j)
+            for (uint64_t i = 0; i < cells[0]; ++i) {
+                const uint64_t ijk[3] = {i, j, k};
+                for (int axis = 0; axis < 3; ++axis) {
+                    std::array<std::array<int64_t, 3>, 4> f;
+                    for (int q = 0; q < 4; ++q)
+                        for (int r = 0; r < 3; ++r) f[q][r] = FACE[axis][q][r] + static_cast<int64_t>(ijk[r]);
+                    if (ijk[axis] + 1 < cells[axis]) {
+                        const uint64_t c1 = cid(i, j, k);
+                        const uint64_t c2 = cid(i + (axis == 0), j + (axis == 1), k + (axis == 2));
+                        for (int q = 0; q < 4; ++q) emit(c1, c2, vid(f[(q + 1) & 3]), vid(f[q]));
+                    }
+                    for (int positive = 0; positive < 2; ++positive) {
+                        if (positive == 0 && ijk[axis] != 0) continue;
+                        if (positive == 1 && ijk[axis] + 1 != cells[axis]) continue;
+                        auto g = f;
+                        if (!positive) {
+                            std::reverse(g.begin(), g.end());
+                            for (auto& p : g) p[axis] -= 1;
+                        }
+                        const uint64_t a = vid(g[0]), b = vid(g[1]), cc = vid(g[2]), d = vid(g[3]);
+                        const uint64_t ctr = cid(i, j, k);
+                        if ((i + j + k) % 2 == 0) { emit(a, b, cc, ctr); emit(a, cc, d, ctr); }
+                        else { emit(a, b, d, ctr); emit(b, cc, d, ctr); }
+                    }
+                }
+            }
+}
+
+// Hex8 -> Hex27 (mesh_convert.rs:85-166 + 227-330): per element 8 corners, 12 edge midpoints
+// (lerp 0.5), 6 face points and the centre through the trilinear map; global numbering = first
+// occurrence while sweeping elements in order, local nodes 0..26 in order, keyed by the sorted set of
+// parent vertices.
+static inline double trilinear_shape(int node, const double xi[3]) {
+    static const double SGN[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1},
+                                     {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+    return ((1.0 + SGN[node][0] * xi[0]) / 2.0) * ((1.0 + SGN[node][1] * xi[1]) / 2.0) * ((1.0 + SGN[node][2] * xi[2]) / 2.0);
+}
+
+struct ParentKey {
+    std::array<uint64_t, 8> p;
+    bool operator==(const ParentKey& o) const { return p == o.p; }
+};
+struct ParentKeyHash {
+    size_t operator()(const ParentKey& k) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (uint64_t x : k.p) { h ^= x + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); }
+        return static_cast<size_t>(h);
+    }
+};
+
+void hex8_to_hex27(const double* verts, const uint64_t* hex8, uint64_t ncells, double* out_v, uint64_t* out_nv,
+                   uint64_t* out_c) {
+    static const int EDGE[12][2] = {{0, 1}, {0, 3}, {0, 4}, {1, 2}, {1, 5}, {2, 3}, {2, 6}, {3, 7}, {4, 5}, {4, 7}, {5, 6}, {6, 7}};
+    static const int FACE[6][4] = {{0, 1, 2, 3}, {0, 1, 4, 5}, {0, 3, 4, 7}, {1, 2, 5, 6}, {2, 3, 6, 7}, {4, 5, 6, 7}};
+    static const double FACE_XI[7][3] = {{0, 0, -1}, {0, -1, 0}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+    const uint64_t NONE = ~0ull;
+    std::unordered_map<ParentKey, uint64_t, ParentKeyHash> label;
+    label.reserve(static_cast<size_t>(ncells) * 10);
+    uint64_t next = 0;
+    for (uint64_t e = 0; e < ncells; ++e) {
+        const uint64_t* g = hex8 + 8 * e;
+        double X[8][3];
+        for (int a = 0; a < 8; ++a)
+            for (int r = 0; r < 3; ++r) X[a][r] = verts[3 * g[a] + r];
+        double pos[27][3];
+        ParentKey key[27];
+        for (auto& k : key) k.p.fill(NONE);
+        for (int a = 0; a < 8; ++a) {
+            std::memcpy(pos[a], X[a], sizeof(double) * 3);
+            key[a].p[0] = g[a];
+        }
+        for (int m = 0; m < 12; ++m) {
+            const int b = EDGE[m][0], en = EDGE[m][1];
+            // nalgebra lerp: res = t * rhs + (1 - t) * self
+            for (int r = 0; r < 3; ++r) pos[8 + m][r] = 0.5 * X[en][r] + (1.0 - 0.5) * X[b][r];
+            key[8 + m].p[0] = g[b];
+            key[8 + m].p[1] = g[en];
+        }
+        for (int f = 0; f < 7; ++f) {
+            double N[8];
+            for (int a = 0; a < 8; ++a) N[a] = trilinear_shape(a, FACE_XI[f]);
+            for (int r = 0; r < 3; ++r) {
+                double s = X[0][r] * N[0];
+                for (int a = 1; a < 8; ++a) s = s + X[a][r] * N[a];
+                pos[20 + f][r] = s;
+            }
+            if (f < 6) for (int q = 0; q < 4; ++q) key[20 + f].p[q] = g[FACE[f][q]];
+            else for (int q = 0; q < 8; ++q) key[26].p[q] = g[q];
+        }
+        for (int a = 0; a < 27; ++a) {
+            std::sort(key[a].p.begin(), key[a].p.end());  // NONE sorts last: padding stays at the end
+            auto it = label.find(key[a]);
+            if (it == label.end()) {
+                label.emplace(key[a], next);
+                std::memcpy(out_v + 3 * next, pos[a], sizeof(double) * 3);
+                out_c[27 * e + a] = next++;
+            } else {
+                out_c[27 * e + a] = it->second;
+            }
+        }
+    }
+    *out_nv = next;
+}
+
+// ---------------------------------------------------------------------------------------- colouring
+// sequential_greedy_coloring (fenris-paradis/src/coloring.rs:6-70): repeated passes over the still
+// uncoloured elements in ascending order; an element joins the current colour iff none of its nodes
+// already carries the current colour stamp; stamps are updated immediately.
+void greedy_coloring(uint64_t E, const uint64_t* offs, const uint64_t* nodes, std::vector<uint64_t>& color_offsets,
+                     std::vector<uint64_t>& labels) {
+    uint64_t max_node = 0;
+    for (uint64_t i = 0; i < offs[E]; ++i) max_node = std::max(max_node, nodes[i]);
+    std::vector<int32_t> stamp(static_cast<size_t>(max_node) + 1, -1);
+    std::vector<uint64_t> todo(E), later;
+    for (uint64_t e = 0; e < E; ++e) todo[e] = e;
+    labels.clear();
+    labels.reserve(E);
+    color_offsets.assign(1, 0);
+    for (int32_t color = 0; !todo.empty(); ++color) {
+        later.clear();
+        for (uint64_t e : todo) {
+            bool blocked = false;
+            for (uint64_t k = offs[e]; k < offs[e + 1] && !blocked; ++k) blocked = (stamp[nodes[k]] == color);
+            if (blocked) { later.push_back(e); continue; }
+            for (uint64_t k = offs[e]; k < offs[e + 1]; ++k) stamp[nodes[k]] = color;
+            labels.push_back(e);
+        }
+        color_offsets.push_back(labels.size());
+        todo.swap(later);
+    }
+}
+
+}  // namespace fenris_hip
+
+// ------------------------------------------------------------------------------------------- C ABI
+using namespace fenris_hip;
+
+extern "C" {
+
+int fh_gauss(uint32_t n, double* w, double* x) {
+    std::vector<double> ww, xx;
+    if (!w || !x || !gauss_rule(n, ww, xx)) return FH_BAD_ARGUMENT;
+    std::copy(ww.begin(), ww.end(), w);
+    std::copy(xx.begin(), xx.end(), x);
+    return FH_OK;
+}
+int fh_quadrilateral_gauss(uint32_t n, double* w, double* p) {
+    return (w && p && tensor_rule(2, n, w, p)) ? FH_OK : FH_BAD_ARGUMENT;
+}
+int fh_hexahedron_gauss(uint32_t n, double* w, double* p) {
+    return (w && p && tensor_rule(3, n, w, p)) ? FH_OK : FH_BAD_ARGUMENT;
+}
+int fh_tetrahedron_rule(uint32_t strength, double* w, double* p, uint32_t* np) {
+    if (!w || !p || !np) return FH_BAD_ARGUMENT;
+    return table_rule(TET_RULES, 3, strength, w, p, np);
+}
+int fh_triangle_rule(uint32_t strength, double* w, double* p, uint32_t* np) {
+    if (!w || !p || !np) return FH_BAD_ARGUMENT;
+    return table_rule(TRI_RULES, 2, strength, w, p, np);
+}
+
+int fh_quad_mesh_2d(double unit, uint64_t ux, uint64_t uy, uint64_t cpu, const double tl[2], double* v, uint64_t* c,
+                    uint64_t* nv, uint64_t* nc) {
+    uint64_t a, b;
+    quad_mesh_sizes(ux, uy, cpu, a, b);
+    if (nv) *nv = a;
+    if (nc) *nc = b;
+    if (v && c && a) {
+        if (!tl) return FH_BAD_ARGUMENT;
+        quad_mesh_fill(unit, ux, uy, cpu, tl, v, c);
+    }
+    return FH_OK;
+}
+int fh_hex_mesh(double unit, uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, double* v, uint64_t* c, uint64_t* nv,
+                uint64_t* nc) {
+    uint64_t a, b;
+    hex_mesh_sizes(ux, uy, uz, cpu, a, b);
+    if (nv) *nv = a;
+    if (nc) *nc = b;
+    if ((v || c) && a) hex_mesh_fill(unit, ux, uy, uz, cpu, v, c);
+    return FH_OK;
+}
+int fh_tet_mesh(double unit, uint64_t ux, uint64_t uy, uint64_t uz, uint64_t cpu, double* v, uint64_t* c, uint64_t* nv,
+                uint64_t* nc) {
+    uint64_t a, b;
+    tet_mesh_sizes(ux, uy, uz, cpu, a, b);
+    if (nv) *nv = a;
+    if (nc) *nc = b;
+    if (v && c && a) tet_mesh_fill(unit, ux, uy, uz, cpu, v, c);
+    return FH_OK;
+}
+int fh_hex8_to_hex27(const double* v, uint64_t nv, const uint64_t* hex8, uint64_t ncells, double* out_v, uint64_t* out_nv,
+                     uint64_t* out_c) {
+    if (!v || !hex8 || !out_v || !out_nv || !out_c) return FH_BAD_ARGUMENT;
+    for (uint64_t i = 0; i < 8 * ncells; ++i)
+        if (hex8[i] >= nv) return FH_BAD_ARGUMENT;
+    hex8_to_hex27(v, hex8, ncells, out_v, out_nv, out_c);
+    return FH_OK;
+}
+int fh_lame_from_young_poisson(double young, double poisson, double* mu, double* lambda) {
+    if (!mu || !lambda) return FH_BAD_ARGUMENT;
+    // fenris-solid/src/materials.rs:36-42
+    const double m = 0.5 * young / (1.0 + poisson);
+    *mu = m;
+    *lambda = 2.0 * m * poisson / (1.0 - 2.0 * poisson);
+    return FH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Integer kernels: node->element adjacency, node-level sparsity pattern, CSR expansion.
+// Replaces CsrAssembler::assemble_pattern / CsrParAssembler::assemble_pattern
+// (src/assembly/global.rs:65-120, 206-297): the per-node FxHashSet + sort becomes
+// "gather candidates of the adjacent elements, bitonic-sort in LDS, unique".
+// The output is unique given the connectivity, hence bit-identical to the reference.
+#pragma once
+#include "device_common.hpp"
+
+namespace fenris_hip {
+
+// connectivity view that covers both fixed-n meshes (eoff == null, nodes[e*n + a]) and ragged lists
+struct ConnView {
+    const int* nodes;       // flat node list
+    const unsigned* eoff;   // E+1 offsets or null
+    const unsigned* k2e;    // flat index -> element (ragged only)
+    int n;                  // nodes per element when eoff == null
+    long long total;        // flat length
+    __device__ __forceinline__ void elem_range(unsigned e, unsigned& b, unsigned& en) const {
+        if (eoff) { b = eoff[e]; en = eoff[e + 1]; } else { b = e * (unsigned)n; en = b + (unsigned)n; }
+    }
+    __device__ __forceinline__ unsigned elem_of(unsigned k) const { return eoff ? k2e[k] : k / (unsigned)n; }
+};
+
+__global__ void k_count_degree(ConnView c, unsigned* deg, int num_nodes, int* bad) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
+        const int node = c.nodes[k];
+        if (node < 0 || node >= num_nodes) { *bad = 1; continue; }
+        atomicAdd(&deg[node], 1u);
+    }
+}
+
+__global__ void k_fill_n2e(ConnView c, const unsigned* n2e_off, unsigned* cursor, unsigned* n2e, int num_nodes) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
+        const int node = c.nodes[k];
+        if (node < 0 || node >= num_nodes) continue;
+        const unsigned p = atomicAdd(&cursor[node], 1u);
+        n2e[n2e_off[node] + p] = (unsigned)k;
+    }
+}
+
+// per node: ascending flat index == ascending (element, local index): deterministic adjacency
+__global__ void k_sort_n2e(const unsigned* n2e_off, unsigned* n2e, int num_nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_nodes) return;
+    const unsigned b = n2e_off[i], en = n2e_off[i + 1];
+    for (unsigned x = b + 1; x < en; ++x) {
+        const unsigned v = n2e[x];
+        unsigned y = x;
+        while (y > b && n2e[y - 1] > v) { n2e[y] = n2e[y - 1]; --y; }
+        n2e[y] = v;
+    }
+}
+
+// One wave per node: candidates = all nodes of all adjacent elements; sort + unique in LDS.
+// FILL == false: cnt[node] = number of distinct neighbours; FILL == true: write them at noff[node].
+constexpr int NEIGH_CAP = 4096;
+template <bool FILL>
+__global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigned* n2e_off, const unsigned* n2e, int num_nodes,
+                                                       unsigned* cnt, const unsigned* noff, unsigned* ncols, int* overflow) {
+    __shared__ unsigned buf[NEIGH_CAP];
+    const int lane = threadIdx.x;
+    for (int node = blockIdx.x; node < num_nodes; node += gridDim.x) {
+        const unsigned b = n2e_off[node], en = n2e_off[node + 1];
+        // collect candidates; consecutive entries of the same element (degenerate elements) are skipped
+        __syncthreads();
+        unsigned C = 0;
+        unsigned prev_e = 0xffffffffu;
+        for (unsigned x = b; x < en; ++x) {  // uniform loop
+            const unsigned e = c.elem_of(n2e[x]);
+            if (e == prev_e) continue;
+            prev_e = e;
+            unsigned eb, ee;
+            c.elem_range(e, eb, ee);
+            for (unsigned k = eb + lane; k < ee; k += 64)
+                if (C + (k - eb) < NEIGH_CAP) buf[C + (k - eb)] = (unsigned)c.nodes[k];
+            C += ee - eb;
+        }
+        if (C > NEIGH_CAP) {
+            if (lane == 0) { *overflow = 1; if (!FILL) cnt[node] = 0; }
+            __syncthreads();
+            continue;
+        }
+        unsigned P = 64;
+        while (P < C) P <<= 1;
+        for (unsigned k = C + lane; k < P; k += 64) buf[k] = 0xffffffffu;
+        __syncthreads();
+        // bitonic sort, ascending
+        for (unsigned size = 2; size <= P; size <<= 1)
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                for (unsigned t = lane; t < (P >> 1); t += 64) {
+                    const unsigned lo = 2 * t - (t & (stride - 1));
+                    const unsigned hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned x = buf[lo], y = buf[hi];
+                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+                }
+                __syncthreads();
+            }
+        // unique: element k is kept iff k == 0 or differs from its predecessor; rank by wave scan
+        unsigned base = 0;
+        for (unsigned k0 = 0; k0 < C; k0 += 64) {
+            const unsigned k = k0 + lane;
+            const bool keep = (k < C) && (k == 0 || buf[k] != buf[k - 1]);
+            const unsigned long long mask = __ballot(keep);
+            if (FILL && keep) {
+                const unsigned r = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                ncols[noff[node] + r] = buf[k];
+            }
+            base += (unsigned)__popcll(mask);
+        }
+        if (!FILL && lane == 0) cnt[node] = base;
+        __syncthreads();
+    }
+}
+
+// scalar CSR row offsets: rows s*i + r  (global.rs:83-93)
+__global__ void k_expand_row_offsets(const unsigned* noff, int num_nodes, int S, unsigned long long* row_offsets) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long R = (long long)num_nodes * S;
+    if (t > R) return;
+    if (t == R) { row_offsets[R] = (unsigned long long)S * S * noff[num_nodes]; return; }
+    const int i = (int)(t / S), r = (int)(t % S);
+    const unsigned long long cnt = noff[i + 1] - noff[i];
+    row_offsets[t] = (unsigned long long)S * S * noff[i] + (unsigned long long)r * S * cnt;
+}
+
+// scalar CSR column indices: s*j + c, sdim identical rows per node (global.rs:97-110)
+__global__ void k_expand_col_indices(const unsigned* noff, const unsigned* ncols, int num_nodes, int S,
+                                     unsigned long long* col_indices) {
+    const long long nnzn = noff[num_nodes];
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nnzn; t += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = num_nodes;  // last i with noff[i] <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)noff[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int i = lo;
+        const unsigned long long cnt = noff[i + 1] - noff[i];
+        const unsigned long long k = (unsigned long long)t - noff[i];
+        const unsigned long long j = ncols[t];
+        unsigned long long* base = col_indices + (unsigned long long)S * S * noff[i] + (unsigned long long)S * k;
+        for (int r = 0; r < S; ++r)
+            for (int cc = 0; cc < S; ++cc) base[(unsigned long long)r * S * cnt + cc] = (unsigned long long)S * j + cc;
+    }
+}
+
+__global__ void k_narrow_connectivity(const unsigned long long* in, int* out, long long total, int num_nodes, int* bad) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < total; k += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long v = in[k];
+        if (v >= (unsigned long long)num_nodes) { *bad = 1; out[k] = 0; } else out[k] = (int)v;
+    }
+}
+
+// apply_homogeneous_dirichlet_bc_csr (global.rs:379-451) on node-level structure:
+// pass 1 marks Dirichlet rows/cols, pass 2 rewrites values.  member[] has one byte per node.
+__global__ void k_dirichlet_rows(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const unsigned char* member,
+                                 double* vals, double scale) {
+    const long long nnzn = noff[num_nodes];
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nnzn; t += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = num_nodes;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)noff[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int i = lo;
+        const unsigned j = ncols[t];
+        const bool ri = member[i], cj = member[j];
+        if (!ri && !cj) continue;
+        const unsigned long long cnt = noff[i + 1] - noff[i];
+        double* base = vals + (unsigned long long)S * S * noff[i] + (unsigned long long)S * ((unsigned long long)t - noff[i]);
+        for (int r = 0; r < S; ++r)
+            for (int c = 0; c < S; ++c)
+                base[(unsigned long long)r * S * cnt + c] = (ri && (unsigned)i == j && r == c) ? scale : 0.0;
+    }
+}
+
+__global__ void k_dirichlet_rhs(double* rhs, const unsigned long long* nodes, long long n, int S) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= n * S) return;
+    rhs[nodes[t / S] * S + (t % S)] = 0.0;
+}
+
+// first non-zero diagonal entry in row order (global.rs:387-395).
+// pass 1 (out == null): atomicMin of the first scalar row whose diagonal is non-zero;
+// pass 2 (out != null): thread 0 writes |diag| of row *first.
+__device__ __forceinline__ double diag_value(const unsigned* noff, const unsigned* ncols, int S, const double* vals, long long t) {
+    const int i = (int)(t / S), r = (int)(t % S);
+    const unsigned b = noff[i], cnt = noff[i + 1] - b;
+    for (unsigned k = 0; k < cnt; ++k)
+        if (ncols[b + k] == (unsigned)i)
+            return vals[(unsigned long long)S * S * b + (unsigned long long)r * S * cnt + (unsigned long long)S * k + r];
+    return 0.0;
+}
+__global__ void k_first_nonzero_diag(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const double* vals,
+                                     unsigned long long* first, double* out) {
+    if (out) {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            *out = (*first == ~0ull) ? 1.0 : fabs(diag_value(noff, ncols, S, vals, (long long)*first));
+        return;
+    }
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= (long long)num_nodes * S) return;
+    if (diag_value(noff, ncols, S, vals, t) != 0.0) atomicMin(first, (unsigned long long)t);
+}
+
+}  // namespace fenris_hip

@@ -1,0 +1,96 @@
+"""Mesh container and procedural generators: host mirror of src/mesh.rs and src/mesh/procedural.rs."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+
+
+@dataclass
+class Mesh:
+    """Mesh<f64, D, C> (src/mesh.rs:23-40): ``vertices`` N x D float64, ``connectivity`` E x n uint64."""
+    vertices: np.ndarray
+    connectivity: np.ndarray
+    elem_kind: int
+
+    def __post_init__(self):
+        d, n = _ffi.ELEM_DIM[self.elem_kind], _ffi.ELEM_NODES[self.elem_kind]
+        self.vertices = _ffi.as_f64(self.vertices).reshape(-1, d)
+        self.connectivity = _ffi.as_u64(self.connectivity).reshape(-1, n)
+
+    @classmethod
+    def from_vertices_and_connectivity(cls, vertices, connectivity, elem_kind):
+        return cls(vertices, connectivity, elem_kind)
+
+    def num_elements(self):
+        return len(self.connectivity)
+
+    def num_nodes(self):
+        return len(self.vertices)
+
+
+def _gen(fn, d, n, kind, *args):
+    nv, nc = C.c_uint64(), C.c_uint64()
+    rc = fn(*args, None, None, C.byref(nv), C.byref(nc))
+    if rc:
+        raise _ffi.FenrisError(rc, "mesh generator")
+    v = np.zeros((nv.value, d))
+    c = np.zeros((nc.value, n), dtype=np.uint64)
+    if nv.value:
+        rc = fn(*args, _ffi.fp(v), _ffi.up(c), C.byref(nv), C.byref(nc))
+        if rc:
+            raise _ffi.FenrisError(rc, "mesh generator")
+    return Mesh(v, c, kind)
+
+
+class procedural:
+    @staticmethod
+    def create_rectangular_uniform_quad_mesh_2d(unit_length, units_x, units_y, cells_per_unit, top_left):
+        """src/mesh/procedural.rs:46-93"""
+        tl = _ffi.as_f64(top_left)
+        return _gen(_ffi.lib().fh_quad_mesh_2d, 2, 4, _ffi.QUAD4, float(unit_length), units_x, units_y, cells_per_unit,
+                    _ffi.fp(tl))
+
+    @staticmethod
+    def create_unit_square_uniform_quad_mesh_2d(cells_per_dim):
+        """procedural.rs:15-20"""
+        return procedural.create_rectangular_uniform_quad_mesh_2d(1.0, 1, 1, cells_per_dim, (0.0, 1.0))
+
+    @staticmethod
+    def create_rectangular_uniform_hex_mesh(unit_length, units_x, units_y, units_z, cells_per_unit):
+        """procedural.rs:216-277"""
+        return _gen(_ffi.lib().fh_hex_mesh, 3, 8, _ffi.HEX8, float(unit_length), units_x, units_y, units_z,
+                    cells_per_unit)
+
+    @staticmethod
+    def create_unit_box_uniform_hex_mesh_3d(cells_per_dim):
+        """procedural.rs:30-35"""
+        return procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells_per_dim)
+
+    @staticmethod
+    def create_rectangular_uniform_tet_mesh(unit_length, units_x, units_y, units_z, cells_per_unit):
+        """procedural.rs:286-403 (BCC lattice)"""
+        return _gen(_ffi.lib().fh_tet_mesh, 3, 4, _ffi.TET4, float(unit_length), units_x, units_y, units_z,
+                    cells_per_unit)
+
+    @staticmethod
+    def create_unit_box_uniform_tet_mesh_3d(cells_per_dim):
+        """procedural.rs:37-42"""
+        return procedural.create_rectangular_uniform_tet_mesh(1.0, 1, 1, 1, cells_per_dim)
+
+
+def hex27_mesh_from_hex8(mesh: Mesh) -> Mesh:
+    """Hex27Mesh::from(&hex8_mesh) (src/mesh_convert.rs:85-166, 227-330)."""
+    assert mesh.elem_kind == _ffi.HEX8
+    E = mesh.num_elements()
+    out_v = np.zeros((max(27 * E, 1), 3))
+    out_c = np.zeros((E, 27), dtype=np.uint64)
+    nv = C.c_uint64()
+    rc = _ffi.lib().fh_hex8_to_hex27(_ffi.fp(mesh.vertices), mesh.num_nodes(), _ffi.up(mesh.connectivity), E,
+                                     _ffi.fp(out_v), C.byref(nv), _ffi.up(out_c))
+    if rc:
+        raise _ffi.FenrisError(rc, "hex8_to_hex27")
+    return Mesh(out_v[: nv.value].copy(), out_c, _ffi.HEX27)

@@ -1,0 +1,64 @@
+"""Operators and materials: host mirror of src/assembly/operators/laplace.rs and fenris-solid."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+from . import _ffi
+
+
+class LaplaceOperator:
+    """src/assembly/operators/laplace.rs:13-73 (SolutionDim = 1, Parameters = ())"""
+    op_kind = _ffi.LAPLACE
+
+
+@dataclass(frozen=True)
+class LameParameters:
+    """fenris-solid/src/materials.rs:8-12"""
+    mu: float = 0.0
+    lambda_: float = 0.0
+
+    @classmethod
+    def from_young_poisson(cls, yp: "YoungPoisson"):
+        """impl From<YoungPoisson> for LameParameters (materials.rs:31-43)"""
+        mu, lam = C.c_double(), C.c_double()
+        _ffi.lib().fh_lame_from_young_poisson(yp.young, yp.poisson, C.byref(mu), C.byref(lam))
+        return cls(mu.value, lam.value)
+
+    def as_pair(self):
+        return (self.mu, self.lambda_)
+
+
+@dataclass(frozen=True)
+class YoungPoisson:
+    """materials.rs:25-29"""
+    young: float
+    poisson: float
+
+
+class LinearElasticMaterial:
+    """materials.rs:66-123"""
+    op_kind = _ffi.LINEAR_ELASTIC
+
+
+class NeoHookeanMaterial:
+    """materials.rs:225-353"""
+    op_kind = _ffi.NEO_HOOKEAN
+
+
+class StVKMaterial:
+    """materials.rs:370-469"""
+    op_kind = _ffi.STVK
+
+
+class MaterialEllipticOperator:
+    """fenris-solid/src/lib.rs:412-508: turns a hyperelastic material into an elliptic operator
+    (SolutionDim = GeometryDim, Parameters = LameParameters)."""
+
+    def __init__(self, material):
+        self.material = material
+        self.op_kind = material.op_kind
+
+    @classmethod
+    def new(cls, material):
+        return cls(material)

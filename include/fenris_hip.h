@@ -1,0 +1,185 @@
+/*
+ * fenris_hip.h -- C ABI of the MI355X-native FEM assembly engine (libfenris_hip.so).
+ *
+ * This is the drop-in boundary for fenris's global stiffness / residual assembly path: every entry
+ * point names the reference interface it replaces (paths relative to the fenris checkout).  The
+ * reference's plugin point is the Element*Assembler trait family (src/assembly/local.rs:18-149)
+ * consumed by CsrAssembler / CsrParAssembler / VectorAssembler (src/assembly/global.rs); arbitrary
+ * Rust element assemblers cannot run on a GPU, so the engine implements the closed family the
+ * reference ships -- ElementEllipticAssembler<Mesh<C>, Op, UniformQuadratureTable>
+ * (src/assembly/local/elliptic.rs:152-340) -- selected through plain descriptors.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `usize` of the reference is uint64_t; all reals are f64.
+ *   - vertices are AoS [x,y(,z)] (Vec<OPoint<f64,D>>, src/mesh.rs:23-40); connectivity is E x n
+ *     uint64_t (Vec<[usize; n]>, src/connectivity.rs:606-607) -- both are zero-copy views of the
+ *     reference's own storage.
+ *   - dof numbering: s*node + component (src/assembly/global.rs:163-164); CSR as in nalgebra-sparse
+ *     (row_offsets[R+1], col_indices[nnz] ascending per row, values[nnz]).
+ *   - pointers are HOST pointers unless the function name ends in _dev (then: device pointers valid on
+ *     the context's device; the call is enqueued on the context's stream and returns after enqueueing
+ *     unless it has a host out-parameter, in which case it synchronises the stream).
+ *   - every function returns an int32 status; nothing aborts.  fh_last_error() gives the message.
+ *   - a context is bound to one device and one host thread at a time (thread-compatible, like
+ *     CsrAssembler which is !Sync, src/assembly/global.rs:27-31).
+ */
+#ifndef FENRIS_HIP_H
+#define FENRIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_ABI_VERSION 1
+
+/* status codes.  FH_SINGULAR_JACOBIAN is the reference's only runtime error on the path:
+ * eyre!("Singular element Jacobian encountered"), src/assembly/local/elliptic.rs:401-404. */
+enum {
+    FH_OK = 0,
+    FH_SINGULAR_JACOBIAN = 1,
+    FH_BAD_ARGUMENT = 2,
+    FH_HIP_ERROR = 3,
+    FH_INVALID_STATE = 5,     /* e.g. assemble before pattern, operator/element dimension mismatch */
+    FH_UNSUPPORTED = 6
+};
+
+/* element kinds: Quad4d2Element (src/element/quadrilateral.rs:70-142), Hex8Element
+ * (src/element/hexahedron.rs:34-117), Tet4Element (src/element/tetrahedron.rs:543-608),
+ * Hex27Element (hexahedron.rs:157-335), Tri3d2Element (src/element/triangle.rs:63-110) */
+enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4 };
+
+/* operator kinds: LaplaceOperator (src/assembly/operators/laplace.rs), MaterialEllipticOperator over
+ * LinearElasticMaterial / NeoHookeanMaterial / StVKMaterial (fenris-solid/src/lib.rs:412-508,
+ * fenris-solid/src/materials.rs:83-123, 236-353, 392-469) */
+enum { FH_LAPLACE = 0, FH_LINEAR_ELASTIC = 1, FH_NEO_HOOKEAN = 2, FH_STVK = 3 };
+
+/* how K_e contributions reach the CSR values (flags argument of fh_assemble_matrix*):
+ *   FH_SCATTER_ATOMIC  : element-parallel, fp64 atomic adds (replaces the rayon colour loop)
+ *   FH_SCATTER_COLORED : one launch per colour, plain read-modify-write -- CsrParAssembler semantics
+ *                        (src/assembly/global.rs:314-376); needs fh_color() or fh_set_colors()
+ *   FH_SCATTER_GATHER  : owner-computes: each CSR row block is produced by one workgroup from all
+ *                        elements adjacent to its node and written once, coalesced; no atomics on HBM
+ * OR-in FH_ASSEMBLE_OVERWRITE to store K instead of accumulating into the existing values
+ * (= CsrAssembler::assemble, global.rs:124-131, without the explicit zero fill). */
+enum { FH_SCATTER_ATOMIC = 0, FH_SCATTER_COLORED = 1, FH_SCATTER_GATHER = 2, FH_SCATTER_MASK = 0xff };
+enum { FH_ASSEMBLE_OVERWRITE = 0x100 };
+
+typedef struct fh_ctx fh_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+fh_ctx* fh_create(int device_id);               /* NULL if the device cannot be initialised */
+void fh_destroy(fh_ctx*);
+const char* fh_last_error(const fh_ctx*);
+int fh_abi_version(void);
+/* hipStream_t to launch on (NULL = default stream).  Not owned. */
+int fh_set_stream(fh_ctx*, void* hip_stream);
+int fh_synchronize(fh_ctx*);
+
+/* ---- inputs -------------------------------------------------------------------------------- */
+/* Mesh<f64, D, C>: replaces passing &Mesh to ElementEllipticAssemblerBuilder::with_finite_element_space
+ * (src/assembly/local/elliptic.rs:86-97).  Data is copied to the device (connectivity narrowed to i32;
+ * num_vertices must be < 2^31).  Invalidates pattern, colours and u. */
+int fh_set_mesh(fh_ctx*, int elem_kind, const double* vertices, uint64_t num_vertices,
+                const uint64_t* connectivity, uint64_t num_elements);
+int fh_set_mesh_dev(fh_ctx*, int elem_kind, const double* vertices_dev, uint64_t num_vertices,
+                    const uint64_t* connectivity_dev, uint64_t num_elements);
+/* only the vertex coordinates change (e.g. moving mesh); pattern stays valid */
+int fh_update_vertices(fh_ctx*, const double* vertices);
+/* Generic ElementConnectivityAssembler with ragged element node lists (src/assembly/local.rs:18-47),
+ * e.g. the mock connectivities of tests/unit_tests/assembly/global.rs:70-142.  Only fh_pattern*,
+ * fh_color work on such a context.  elem_offsets has num_elements+1 entries. */
+int fh_set_connectivity_ragged(fh_ctx*, uint64_t solution_dim, uint64_t num_nodes, const uint64_t* elem_offsets,
+                               const uint64_t* elem_nodes, uint64_t num_elements);
+/* Operator: replaces .with_operator(&op) (elliptic.rs:99-108).  Solution dim s = 1 for Laplace, D else. */
+int fh_set_operator(fh_ctx*, int op_kind);
+/* UniformQuadratureTable::from_points_and_weights(points, weights).with_data / with_uniform_data
+ * (src/assembly/local/quadrature_table.rs:213-298).  params: nq x 2 doubles (LameParameters{mu,lambda}
+ * per point, fenris-solid/src/materials.rs:8-12) or NULL for operators without parameters. */
+int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* points, uint32_t nq,
+                              const double* params);
+/* .with_u(&u) (elliptic.rs:123-137); u has s*N entries; NULL = zeros */
+int fh_set_u(fh_ctx*, const double* u);
+int fh_set_u_dev(fh_ctx*, const double* u_dev);
+
+/* ---- queries (ElementConnectivityAssembler, src/assembly/local.rs:18-27) ---------------------- */
+uint64_t fh_solution_dim(const fh_ctx*);
+uint64_t fh_num_elements(const fh_ctx*);
+uint64_t fh_num_nodes(const fh_ctx*);
+uint64_t fh_num_rows(const fh_ctx*);   /* s*N */
+uint64_t fh_nnz(const fh_ctx*);        /* 0 before fh_pattern */
+
+/* ---- sparsity pattern: CsrAssembler::assemble_pattern / CsrParAssembler::assemble_pattern
+ *      (src/assembly/global.rs:65-120, 206-297); bit-identical output ---------------------------- */
+/* builds the pattern on the device; row_offsets (R+1 entries) may be NULL; nnz_out may be NULL */
+int fh_pattern(fh_ctx*, uint64_t* row_offsets, uint64_t* nnz_out);
+int fh_pattern_cols(fh_ctx*, uint64_t* col_indices /* nnz */);
+/* device outputs; either may be NULL.  Requires a prior fh_pattern(). */
+int fh_pattern_dev(fh_ctx*, uint64_t* row_offsets_dev, uint64_t* col_indices_dev);
+
+/* ---- colouring: color_nodes + sequential_greedy_coloring (src/assembly/global.rs:540-551,
+ *      fenris-paradis/src/coloring.rs:6-70); reference-identical ----------------------------------- */
+/* color_offsets: capacity num_elements+2 (or NULL); labels: num_elements entries (or NULL):
+ * elements of colour c are labels[color_offsets[c] .. color_offsets[c+1]) in ascending order */
+int fh_color(fh_ctx*, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels);
+/* reuse a colouring computed elsewhere (colours are serialisable in the reference, paradis lib.rs:170) */
+int fh_set_colors(fh_ctx*, uint64_t num_colors, const uint64_t* color_offsets, const uint64_t* labels);
+
+/* ---- numeric assembly ------------------------------------------------------------------------ */
+/* CsrAssembler::assemble_into_csr / CsrParAssembler::assemble_into_csr (global.rs:133-182, 314-376):
+ * values (nnz doubles, layout of the fh_pattern CSR) are ACCUMULATED into unless FH_ASSEMBLE_OVERWRITE.
+ * On FH_SINGULAR_JACOBIAN *failed_element is the lowest failing element index (may be NULL) and the
+ * values are unspecified (the reference aborts at the first failing element). */
+int fh_assemble_matrix(fh_ctx*, double* values, int flags, uint64_t* failed_element);
+int fh_assemble_matrix_dev(fh_ctx*, double* values_dev, int flags, uint64_t* failed_element);
+/* same, but only enqueues; check the status later with fh_poll_status (no host sync; for timing loops) */
+int fh_assemble_matrix_async_dev(fh_ctx*, double* values_dev, int flags);
+int fh_poll_status(fh_ctx*, uint64_t* failed_element);
+/* VectorAssembler::assemble_vector_into / VectorParAssembler (global.rs:582-608, 643-685) with
+ * assemble_element_elliptic_vector (elliptic.rs:457-531): out (s*N) is accumulated into. */
+int fh_assemble_vector(fh_ctx*, double* out, uint64_t* failed_element);
+int fh_assemble_vector_dev(fh_ctx*, double* out_dev, uint64_t* failed_element);
+/* assemble_scalar (global.rs:697-711) with compute_element_elliptic_energy (elliptic.rs:551-605) */
+int fh_assemble_scalar(fh_ctx*, double* out, uint64_t* failed_element);
+/* single element matrix, (s n)^2 column-major: ElementMatrixAssembler::assemble_element_matrix_into
+ * (src/assembly/local.rs:78, elliptic.rs:299-340) -- for unit tests of the element kernels */
+int fh_assemble_element_matrices(fh_ctx*, uint64_t first_element, uint64_t count, double* ke_out);
+
+/* ---- post-assembly helpers (callers of the path) ------------------------------------------------ */
+/* apply_homogeneous_dirichlet_bc_csr / _rhs (global.rs:379-451, 479-495) on device-resident CSR */
+int fh_apply_dirichlet_csr_dev(fh_ctx*, double* values_dev, const uint64_t* nodes, uint64_t num_nodes);
+int fh_apply_dirichlet_rhs_dev(fh_ctx*, double* rhs_dev, const uint64_t* nodes, uint64_t num_nodes);
+
+/* ---- host-side input generators (no device needed) -------------------------------------------- */
+/* fenris-quadrature/src/univariate.rs:66-118, tensor.rs:13-55 */
+int fh_gauss(uint32_t n, double* weights, double* points);
+int fh_quadrilateral_gauss(uint32_t n, double* weights, double* points);
+int fh_hexahedron_gauss(uint32_t n, double* weights, double* points);
+/* polyquad tables (fenris-quadrature/rules/polyquad/expanded/{tet,tri}); returns FH_UNSUPPORTED for
+ * strengths that are not tabulated here; *num_points receives the rule size */
+int fh_tetrahedron_rule(uint32_t strength, double* weights, double* points, uint32_t* num_points);
+int fh_triangle_rule(uint32_t strength, double* weights, double* points, uint32_t* num_points);
+/* src/mesh/procedural.rs:46-93, 216-277, 286-403.  Sizes first (vertices/cells may be NULL). */
+int fh_quad_mesh_2d(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t cells_per_unit,
+                    const double top_left[2], double* vertices, uint64_t* connectivity,
+                    uint64_t* num_vertices, uint64_t* num_cells);
+int fh_hex_mesh(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t units_z, uint64_t cells_per_unit,
+                double* vertices, uint64_t* connectivity, uint64_t* num_vertices, uint64_t* num_cells);
+int fh_tet_mesh(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t units_z, uint64_t cells_per_unit,
+                double* vertices, uint64_t* connectivity, uint64_t* num_vertices, uint64_t* num_cells);
+/* Hex27Mesh::from(&hex8_mesh) (src/mesh_convert.rs:85-166, 227-330).  out_vertices capacity
+ * 27*num_cells*3 doubles, out_connectivity 27*num_cells. */
+int fh_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64_t* hex8, uint64_t num_cells,
+                     double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
+/* LameParameters::from(YoungPoisson) (fenris-solid/src/materials.rs:31-43) */
+int fh_lame_from_young_poisson(double young, double poisson, double* mu, double* lambda);
+
+/* ---- introspection for benchmarks --------------------------------------------------------------- */
+/* name of the device kernel the last fh_assemble_matrix* call launched (for rocprof matching) */
+const char* fh_last_kernel_name(const fh_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FENRIS_HIP_H */

@@ -1,0 +1,413 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar: row offsets / column indices bit-exact; values |K_gpu - K_oracle| <= 1e-12 max|K|;
+NaN positions coincide for NeoHookean with J <= 0.
+"""
+import numpy as np
+import pytest
+
+import fenris_amd as fa
+from fenris_amd import quadrature
+from conftest import load_golden_mesh
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+LAME = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2)) if True else None
+
+OPS = {
+    "LAPLACE": lambda: fa.LaplaceOperator(),
+    "LINEAR_ELASTIC": lambda: fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
+    "NEO_HOOKEAN": lambda: fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()),
+    "STVK": lambda: fa.MaterialEllipticOperator(fa.StVKMaterial()),
+}
+KIND = {"QUAD4": fa.QUAD4, "HEX8": fa.HEX8, "TET4": fa.TET4, "HEX27": fa.HEX27, "TRI3": fa.TRI3}
+
+
+@pytest.fixture(scope="module")
+def engine():
+    eng = fa.Engine(0)
+    yield eng
+    eng.close()
+
+
+def _rule(kind):
+    if kind == "QUAD4":
+        return quadrature.tensor.quadrilateral_gauss(2)
+    if kind == "HEX8":
+        return quadrature.tensor.hexahedron_gauss(2)
+    if kind == "HEX27":
+        return quadrature.tensor.hexahedron_gauss(3)
+    if kind == "TET4":
+        return quadrature.total_order.tetrahedron(2)
+    return quadrature.total_order.triangle(2)
+
+
+def _mesh(kind, distort=True, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "QUAD4":
+        m = fa.procedural.create_unit_square_uniform_quad_mesh_2d(5)
+    elif kind == "HEX8":
+        m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, 4)
+    elif kind == "HEX27":
+        m = fa.hex27_mesh_from_hex8(fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, 2))
+    elif kind == "TET4":
+        m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
+    else:
+        v, c = load_golden_mesh("square_quad4_79")
+        tri = np.concatenate([c[:, [0, 1, 2]], c[:, [0, 2, 3]]])
+        return fa.Mesh(v, tri, fa.TRI3)
+    if distort:
+        h = 1.0 / (5 if kind == "QUAD4" else 4)
+        m = fa.Mesh(m.vertices + rng.uniform(-0.12 * h, 0.12 * h, m.vertices.shape), m.connectivity, m.elem_kind)
+    return m
+
+
+def _pair(engine, oracle, kind, op, mesh=None, u_scale=0.02, seed=1, params=None):
+    """Build the GPU assembler and the oracle assembler on identical inputs."""
+    mesh = mesh or _mesh(kind)
+    w, p = _rule(kind)
+    d = mesh.vertices.shape[1]
+    s = 1 if op == "LAPLACE" else d
+    rng = np.random.default_rng(seed)
+    u = u_scale * rng.standard_normal(s * mesh.num_nodes())
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if op != "LAPLACE":
+        if params is None:
+            qt = qt.with_uniform_data(LAME)
+            oparams = LAME.as_pair()
+        else:
+            qt = qt.with_data([fa.LameParameters(*x) for x in params])
+            oparams = np.asarray(params)
+    else:
+        oparams = None
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(OPS[op]())
+           .with_quadrature_table(qt).with_u(u).build())
+    ref = oracle.ElementAssembler(KIND[kind], getattr(oracle, op), mesh.vertices, mesh.connectivity, w, p,
+                                  params=oparams, u=u)
+    return asm, ref
+
+
+# ------------------------------------------------------------------------------------ pattern
+MOCK = [[0, 1, 2], [2, 3], [], [3, 4, 4, 4, 4, 4, 4]]
+
+
+def test_pattern_kats(engine):
+    # tests/unit_tests/assembly/global.rs:70-142 (identical numbers in the parallel variant :144-216)
+    ro, ci = fa.CsrAssembler().assemble_pattern(fa.MockElementAssembler(1, 0, [[]], engine))
+    assert ro.tolist() == [0] and ci.tolist() == []
+    ro, ci = fa.CsrAssembler().assemble_pattern(fa.MockElementAssembler(2, 5, [[]], engine))
+    assert ro.tolist() == [0] * 11 and ci.tolist() == []
+    ro, ci = fa.CsrAssembler().assemble_pattern(fa.MockElementAssembler(1, 6, MOCK, engine))
+    assert ro.tolist() == [0, 3, 6, 10, 13, 15, 15]
+    assert ci.tolist() == [0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 2, 3, 4, 3, 4]
+    ro, ci = fa.CsrParAssembler().assemble_pattern(fa.MockElementAssembler(2, 6, MOCK, engine))
+    assert ro.tolist() == [0, 6, 12, 18, 24, 32, 40, 46, 52, 56, 60, 60, 60]
+    assert ci.tolist() == [
+        0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1,
+        2, 3, 4, 5, 6, 7, 4, 5, 6, 7, 8, 9, 4, 5, 6, 7, 8, 9, 6, 7, 8, 9, 6, 7, 8, 9]
+
+
+def test_pattern_rejects_out_of_range_nodes(engine):
+    with pytest.raises(fa.FenrisError):
+        fa.MockElementAssembler(1, 3, [[0, 5]], engine)
+
+
+@pytest.mark.parametrize("kind,op", [("HEX8", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("TET4", "LINEAR_ELASTIC"),
+                                     ("QUAD4", "LAPLACE"), ("QUAD4", "LINEAR_ELASTIC"), ("HEX27", "NEO_HOOKEAN"),
+                                     ("TRI3", "LAPLACE")])
+def test_pattern_matches_oracle_bit_exact(engine, oracle, kind, op):
+    asm, ref = _pair(engine, oracle, kind, op)
+    ro, ci = fa.CsrAssembler().assemble_pattern(asm)
+    oro, oci = oracle.pattern_for(ref)
+    assert ro.dtype == np.uint64 and np.array_equal(ro, oro) and np.array_equal(ci, oci)
+
+
+def test_pattern_unstructured_fixtures(engine, oracle):
+    # the reference's own unstructured meshes (tests/unit_tests/io/snapshots)
+    for name, kind, op in (("sphere_tet4_593", "TET4", "LINEAR_ELASTIC"), ("cube_hex27_8", "HEX27", "LAPLACE"),
+                           ("square_quad4_79", "QUAD4", "LAPLACE")):
+        v, c = load_golden_mesh(name)
+        asm, ref = _pair(engine, oracle, kind, op, mesh=fa.Mesh(v, c, KIND[kind]))
+        ro, ci = asm.engine.pattern()
+        oro, oci = oracle.pattern_for(ref)
+        assert np.array_equal(ro, oro) and np.array_equal(ci, oci)
+
+
+def test_pattern_device_arrays(engine, oracle):
+    import torch
+
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    nnz = asm.engine.build_pattern()
+    ro = torch.zeros(asm.engine.num_rows() + 1, dtype=torch.int64, device="cuda")
+    ci = torch.zeros(nnz, dtype=torch.int64, device="cuda")
+    asm.engine.pattern_dev(ro, ci)
+    asm.engine.synchronize()
+    oro, oci = oracle.pattern_for(ref)
+    assert np.array_equal(ro.cpu().numpy().astype(np.uint64), oro)
+    assert np.array_equal(ci.cpu().numpy().astype(np.uint64), oci)
+
+
+# ------------------------------------------------------------------------------------ colouring
+@pytest.mark.parametrize("kind", ["HEX8", "TET4", "QUAD4"])
+def test_coloring_identical_to_reference_algorithm(engine, oracle, kind):
+    asm, ref = _pair(engine, oracle, kind, "LAPLACE")
+    colors = fa.color_nodes(asm)
+    co, labels = oracle.color_nodes(ref)
+    assert np.array_equal(colors.color_offsets, co) and np.array_equal(colors.labels, labels)
+    if kind == "HEX8":
+        assert len(colors) == 8
+
+
+def test_coloring_ragged(engine, oracle):
+    mock = fa.MockElementAssembler(1, 6, MOCK, engine)
+    colors = mock.engine.color()
+    offs = np.cumsum([0] + [len(c) for c in MOCK]).astype(np.uint64)
+    nodes = np.array([x for c in MOCK for x in c], dtype=np.uint64)
+    co, labels = oracle.color_elements(offs, nodes)
+    assert np.array_equal(colors.color_offsets, co) and np.array_equal(colors.labels, labels)
+
+
+# ------------------------------------------------------------------------------------ element matrices
+@pytest.mark.parametrize("kind", ["QUAD4", "HEX8", "TET4", "HEX27", "TRI3"])
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK"])
+def test_element_matrices_match_oracle(engine, oracle, kind, op):
+    asm, ref = _pair(engine, oracle, kind, op)
+    E = asm.num_elements()
+    ke = asm.engine.element_matrices(0, E)
+    for e in range(E):
+        st, oke = ref.element_matrix(e)
+        assert st == 0
+        assert np.abs(ke[e] - oke).max() <= TOL * np.abs(oke).max(), (e, np.abs(ke[e] - oke).max() / np.abs(oke).max())
+        assert np.array_equal(ke[e], ke[e].T)
+
+
+def test_quad4_reference_element_kat(engine):
+    # tests/unit_tests/assembly.rs:159-162
+    mesh = fa.Mesh(np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float), np.array([[0, 1, 2, 3]]), fa.QUAD4)
+    w, p = quadrature.tensor.quadrilateral_gauss(2)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w)).with_u(np.zeros(4)).build())
+    expected = np.array([[2 / 3, -1 / 6, -1 / 3, -1 / 6], [-1 / 6, 2 / 3, -1 / 6, -1 / 3],
+                         [-1 / 3, -1 / 6, 2 / 3, -1 / 6], [-1 / 6, -1 / 3, -1 / 6, 2 / 3]])
+    assert np.allclose(asm.assemble_element_matrix(0), expected, rtol=0, atol=1e-15)
+
+
+def test_per_point_parameters(engine, oracle):
+    params = [(1e6 * (1 + 0.1 * q), 2e5 * (1 + 0.05 * q)) for q in range(8)]
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", params=params)
+    ke = asm.engine.element_matrices(0, 4)
+    for e in range(4):
+        _, oke = ref.element_matrix(e)
+        assert np.abs(ke[e] - oke).max() <= TOL * np.abs(oke).max()
+
+
+# ------------------------------------------------------------------------------------ global matrix
+@pytest.mark.parametrize("scatter", [fa.SCATTER_ATOMIC, fa.SCATTER_COLORED, fa.SCATTER_GATHER])
+@pytest.mark.parametrize("kind,op", [("HEX8", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("HEX8", "NEO_HOOKEAN"),
+                                     ("TET4", "LAPLACE"), ("TET4", "LINEAR_ELASTIC"), ("TET4", "STVK"),
+                                     ("QUAD4", "LAPLACE"), ("QUAD4", "LINEAR_ELASTIC"),
+                                     ("HEX27", "LAPLACE"), ("HEX27", "NEO_HOOKEAN"), ("TRI3", "LINEAR_ELASTIC")])
+def test_global_matrix_matches_oracle(engine, oracle, kind, op, scatter):
+    asm, ref = _pair(engine, oracle, kind, op)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(scatter).assemble(asm)
+    assert np.array_equal(k.row_offsets, oro) and np.array_equal(k.col_indices, oci)
+    err = np.abs(k.values - ovals).max() / np.abs(ovals).max()
+    assert err <= TOL, err
+
+
+def test_unstructured_sphere_tet4(engine, oracle):
+    v, c = load_golden_mesh("sphere_tet4_593")
+    mesh = fa.Mesh(v, c, fa.TET4)
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_COLORED, fa.SCATTER_GATHER):
+        asm, ref = _pair(engine, oracle, "TET4", "LINEAR_ELASTIC", mesh=mesh)
+        st, _, oro, oci, ovals = oracle.assemble(ref)
+        k = fa.CsrAssembler(scatter).assemble(asm)
+        assert np.array_equal(k.col_indices, oci)
+        assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+
+
+def test_par_assembler_with_reference_colors(engine, oracle):
+    # tests/convergence_tests/poisson_mms_common.rs:115-121: serial == coloured
+    asm, ref = _pair(engine, oracle, "HEX8", "LAPLACE")
+    colors = fa.color_nodes(asm)
+    a = fa.CsrAssembler().assemble(asm)
+    b = fa.CsrParAssembler().assemble(colors, asm)
+    assert np.abs(a.values - b.values).max() <= 8 * np.finfo(float).eps * np.abs(a.values).max()
+
+
+@pytest.mark.parametrize("scatter", [fa.SCATTER_ATOMIC, fa.SCATTER_COLORED, fa.SCATTER_GATHER])
+def test_assemble_into_accumulates_and_overwrite(engine, oracle, scatter):
+    # global.rs:133-182: assemble_into_csr adds to the existing values
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    k = fa.CsrAssembler(scatter).assemble(asm)
+    base = k.values.copy()
+    fa.CsrAssembler(scatter).assemble_into_csr(k, asm)
+    assert np.abs(k.values - 2 * base).max() <= 4e-16 * np.abs(base).max() * 4
+    k.values[:] = 123.0
+    if scatter == fa.SCATTER_COLORED:
+        asm.engine.color()
+    asm.engine.assemble_matrix(k.values, scatter | fa.ASSEMBLE_OVERWRITE)
+    assert np.abs(k.values - base).max() <= 4e-16 * np.abs(base).max() * 4
+
+
+def test_device_resident_values(engine, oracle):
+    import torch
+
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm, device_values=True)
+    assert isinstance(k.values, torch.Tensor) and k.values.is_cuda
+    assert np.abs(k.values.cpu().numpy() - ovals).max() <= TOL * np.abs(ovals).max()
+
+
+def test_repeated_runs_agree(engine, oracle):
+    # race-detection analogue of fenris-paradis/test_sanitized.sh: repeated runs and all three scatter
+    # strategies agree to rounding
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    runs = [fa.CsrAssembler(s).assemble(asm).values for s in (0, 0, 1, 2, 2)]
+    scale = np.abs(runs[0]).max()
+    for r in runs[1:]:
+        assert np.abs(r - runs[0]).max() <= 16 * np.finfo(float).eps * scale
+
+
+# ------------------------------------------------------------------------------------ errors / NaN semantics
+def test_singular_jacobian_reports_lowest_element(engine):
+    mesh = _mesh("HEX8", distort=False)
+    v = mesh.vertices.copy()
+    c = mesh.connectivity
+    for e in (17, 5):  # collapse two elements to a point -> det == 0 exactly
+        v[c[e].astype(int)] = v[int(c[e][0])]
+    bad = fa.Mesh(v, c, fa.HEX8)
+    w, p = _rule("HEX8")
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(bad).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w)).with_u(np.zeros(len(v))).build())
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_GATHER):
+        with pytest.raises(fa.SingularJacobianError) as ei:
+            fa.CsrAssembler(scatter).assemble(asm)
+        assert "Singular element Jacobian encountered" in str(ei.value)
+        assert ei.value.element <= 5
+
+
+def test_neo_hookean_inverted_element_nan_positions(engine, oracle):
+    # fenris-solid/src/materials.rs:298-300: J <= 0 => all-NaN blocks, not an error
+    mesh = _mesh("HEX8", distort=False)
+    rng = np.random.default_rng(3)
+    u = 0.01 * rng.standard_normal(3 * mesh.num_nodes())
+    nodes = mesh.connectivity[10].astype(int)
+    centre = mesh.vertices[nodes].mean(axis=0)
+    for n in nodes:  # reflect element 10 through its centre: F = -I there, det F < 0
+        u[3 * n: 3 * n + 3] = -2.2 * (mesh.vertices[n] - centre)
+    w, p = _rule("HEX8")
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(LAME)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh)
+           .with_operator(OPS["NEO_HOOKEAN"]()).with_quadrature_table(qt).with_u(u).build())
+    ref = oracle.ElementAssembler(oracle.HEX8, oracle.NEO_HOOKEAN, mesh.vertices, mesh.connectivity, w, p,
+                                  params=LAME.as_pair(), u=u)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0 and np.isnan(ovals).any() and not np.isnan(ovals).all()
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_GATHER):
+        k = fa.CsrAssembler(scatter).assemble(asm)
+        assert np.array_equal(np.isnan(k.values), np.isnan(ovals))
+        ok = ~np.isnan(ovals)
+        assert np.abs(k.values[ok] - ovals[ok]).max() <= TOL * np.abs(ovals[ok]).max()
+
+
+# ------------------------------------------------------------------------------------ vector / scalar
+@pytest.mark.parametrize("kind,op", [("HEX8", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("HEX8", "NEO_HOOKEAN"),
+                                     ("HEX8", "STVK"), ("TET4", "NEO_HOOKEAN"), ("QUAD4", "LINEAR_ELASTIC"),
+                                     ("HEX27", "NEO_HOOKEAN"), ("TRI3", "LAPLACE")])
+def test_vector_and_scalar_match_oracle(engine, oracle, kind, op):
+    asm, ref = _pair(engine, oracle, kind, op)
+    f = fa.VectorAssembler().assemble_vector(asm)
+    st, _, of = oracle.assemble_vector(ref)
+    assert st == 0
+    assert np.abs(f - of).max() <= TOL * np.abs(of).max()
+    e = fa.assemble_scalar(asm)
+    st, _, oe = oracle.assemble_scalar(ref)
+    assert e == pytest.approx(oe, rel=1e-12)
+    # accumulation semantics (global.rs:582-608)
+    out = f.copy()
+    fa.VectorAssembler().assemble_vector_into(out, asm)
+    assert np.abs(out - 2 * f).max() <= 1e-15 * np.abs(f).max() * 8
+
+
+def test_residual_is_K_times_u_for_linear_operators(engine, oracle):
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", u_scale=1e-3)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm).to_scipy()
+    f = fa.VectorAssembler().assemble_vector(asm)
+    assert np.abs(f - k @ ref.u).max() <= 1e-11 * np.abs(f).max()
+
+
+# ------------------------------------------------------------------------------------ Dirichlet helper
+def test_dirichlet_on_device_matches_oracle(engine, oracle):
+    import torch
+
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm, device_values=True)
+    bc = np.where(np.abs(asm.space.vertices - 0.5).max(axis=1) > 0.4)[0]
+    fa.apply_homogeneous_dirichlet_bc_csr(k, bc, 3, asm)
+    ov = ovals.copy()
+    oracle.apply_homogeneous_dirichlet_bc_csr(oro, oci, ov, bc, 3)
+    got = k.values.cpu().numpy()
+    assert np.abs(got - ov).max() <= TOL * np.abs(ov).max()
+    assert np.array_equal(got == 0.0, ov == 0.0)
+
+
+# ------------------------------------------------------------------------------------ full size properties
+@pytest.mark.parametrize("cells,op", [(128, "LAPLACE"), (216, "LINEAR_ELASTIC")])
+def test_full_size_properties(engine, oracle, cells, op):
+    """BASELINE.json configs C2 (Hex8 128^3 Poisson) and NS (Hex8 216^3 elasticity) at full size, checked
+    through size-independent properties: (1) constant fields are in the null space (row sums vanish per
+    component), (2) owner-computes and atomic scatter agree, (3) an interior row block equals the centre
+    row block of a 3^3 oracle mesh with the same cell size (translation invariance), (4) pattern counts
+    match the closed forms of SURVEY 8 (nnz = s^2 (3m+1)^3)."""
+    import torch
+
+    mesh = fa.procedural.create_unit_box_uniform_hex_mesh_3d(cells)
+    w, p = _rule("HEX8")
+    s = 1 if op == "LAPLACE" else 3
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if s == 3:
+        qt = qt.with_uniform_data(LAME)
+    eng = fa.Engine(0)
+    asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(OPS[op]())
+           .with_quadrature_table(qt).with_u(None).build())
+    nnz = eng.build_pattern()
+    assert nnz == s * s * (3 * cells + 1) ** 3
+    ro, _ = eng.pattern(want_cols=False)
+    vals = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    eng.assemble_matrix(vals, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    scale = float(vals.abs().max())
+    # (1) row sums per column component
+    ro_t = torch.from_numpy(ro.astype(np.int64)).cuda()
+    R = len(ro) - 1
+    lengths = ro_t[1:] - ro_t[:-1]
+    row_id = torch.repeat_interleave(torch.arange(R, device="cuda"), lengths)
+    local = torch.arange(nnz, device="cuda") - ro_t[row_id]
+    for comp in range(s):
+        sums = torch.zeros(R, dtype=torch.float64, device="cuda").index_add_(0, row_id, vals * (local % s == comp))
+        assert float(sums.abs().max()) <= 1e-10 * scale
+    del row_id, local, lengths
+    # (2) atomic scatter on the same pattern
+    vals2 = torch.zeros_like(vals)
+    eng.assemble_matrix(vals2, fa.SCATTER_ATOMIC)
+    assert float((vals - vals2).abs().max()) <= 1e-13 * scale
+    del vals2
+    # (3) interior row block against the oracle on a 3x3x3 mesh of equal cell size
+    h = 1.0 / cells
+    small = fa.procedural.create_rectangular_uniform_hex_mesh(3 * h, 1, 1, 1, 3)
+    ref = oracle.ElementAssembler(oracle.HEX8, getattr(oracle, op), small.vertices, small.connectivity, w, p,
+                                  params=None if s == 1 else LAME.as_pair())
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    centre = 1 + 4 * 1 + 16 * 1
+    oblock = ovals[int(oro[s * centre]): int(oro[s * centre + s - 1 + 1])]
+    nv = cells + 1
+    node = (cells // 2) + nv * (cells // 3) + nv * nv * (cells // 2 + 3)
+    block = vals[int(ro[s * node]): int(ro[s * node + s])].cpu().numpy()
+    assert block.shape == oblock.shape
+    assert np.abs(block - oblock).max() <= 1e-11 * np.abs(oblock).max()
+    eng.close()

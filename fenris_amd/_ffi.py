@@ -100,6 +100,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). fenris_amd has no CPU fallback.")
+        # torch ships its own HIP runtime; it must be the one already loaded when libfenris_hip.so is
+        # bound, so that torch tensors, streams and this library share a single runtime instance.
+        import torch  # noqa: F401
+
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)  # AttributeError if the ABI symbol is missing

@@ -22,7 +22,7 @@ namespace fenris_hip {
 // ------------------------------------------------------------------------------------------ LDS carve
 struct Layout {
     int o_gref, o_ggeom, o_qw, o_qpar, o_X, o_U, o_QP, o_ACC, n_doubles;
-    int o_uniq, o_cn, o_ent, o_entnode, o_entu, o_rank, o_slot, o_ncols, o_noff, o_n2eoff, n_ints;
+    int o_uniq, o_cn, o_ent, o_ncols, o_noff, n_ints;
     int qpd;  // doubles per (element, quadrature point)
     __host__ __device__ size_t bytes() const { return sizeof(double) * (size_t)n_doubles + sizeof(int) * (size_t)n_ints; }
 };
@@ -51,13 +51,8 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.o_uniq = i;    i += gather ? mb : ub;   // gather: all unique elements of an entry batch
     L.o_cn = i;      i += ub * E::N;
     L.o_ent = i;     i += gather ? mb : 0;
-    L.o_entnode = i; i += gather ? mb : 0;
-    L.o_entu = i;    i += gather ? mb : 0;
-    L.o_rank = i;    i += gather ? mb : 0;
-    L.o_slot = i;    i += gather ? mb : 0;
     L.o_ncols = i;   i += gather ? acc_max / (O::S * O::S) : 0;
     L.o_noff = i;    i += gather ? nb_max + 1 : 0;
-    L.o_n2eoff = i;  i += gather ? nb_max + 1 : 0;
     L.n_ints = i + 4;
     return L;
 }
@@ -513,12 +508,12 @@ __device__ __forceinline__ void stage_tables(const KArgs& a, const Layout& L, do
 // stage connectivity, vertices and u of the U unique elements listed in lds_i[o_uniq..]
 template <int EK, int S>
 __device__ __forceinline__ void stage_elements(const KArgs& a, const Layout& L, double* lds, int* lds_i, int U, bool need_u,
-                                               int ubase = 0) {
+                                               const int* uniq) {
     using E = ElemT<EK>;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < U * E::N; i += nt) {
         const int u = i / E::N, n = i % E::N;
-        lds_i[L.o_cn + i] = a.conn[(size_t)lds_i[L.o_uniq + ubase + u] * E::N + n];
+        lds_i[L.o_cn + i] = a.conn[(size_t)uniq[u] * E::N + n];
     }
     __syncthreads();
     for (int i = tid; i < U * E::NG * E::D; i += nt) {
@@ -565,7 +560,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
         const int U = (int)min((long long)a.epb, a.work_end - w0);
         for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = a.labels ? (int)a.labels[w0 + i] : (int)(w0 + i);
         __syncthreads();
-        stage_elements<EK, S>(a, L, lds, lds_i, U, O::NEEDS_U);
+        stage_elements<EK, S>(a, L, lds, lds_i, U, O::NEEDS_U, lds_i + L.o_uniq);
         for (int i = tid; i < U * a.nq; i += nt)
             prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
         __syncthreads();
@@ -611,91 +606,122 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
         return;
     }
 
-    // ---- owner-computes unit: nodes [i0, i1)
-    const int i0 = (int)a.blk_off[blockIdx.x], i1 = (int)a.blk_off[blockIdx.x + 1];
-    const int nb = i1 - i0;
-    for (int i = tid; i <= nb; i += nt) {
-        lds_i[L.o_noff + i] = (int)a.noff[i0 + i];
-        lds_i[L.o_n2eoff + i] = (int)a.n2e_off[i0 + i];
-    }
-    __syncthreads();
-    const int r0 = lds_i[L.o_noff], r1 = lds_i[L.o_noff + nb];
-    const int nacc = S * S * (r1 - r0);
+    // ---- owner-computes unit: nodes [i0, i0 + nb) described by the precomputed block tables
+    const GatherHdr hdr = a.gt_hdr[blockIdx.x];
+    const int i0 = hdr.i0, nb = hdr.nb, r0 = hdr.r0, nrow = hdr.nrow, k0 = hdr.k0, m = hdr.m, U = hdr.U;
+    const int nacc = S * S * nrow;
     double* acc = lds + L.o_ACC;
+    for (int i = tid; i <= nb; i += nt) lds_i[L.o_noff + i] = (int)a.noff[i0 + i];
+    for (int i = tid; i < nrow; i += nt) lds_i[L.o_ncols + i] = (int)a.ncols[r0 + i];
+    const bool ent_in_lds = m <= a.mb;  // U <= m, so the unique list fits whenever the entries do
+    if (ent_in_lds)
+        for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)a.gt_elems[hdr.u_off + i];
+    const int* uniq = ent_in_lds ? lds_i + L.o_uniq : reinterpret_cast<const int*>(a.gt_elems + hdr.u_off);
+    if (ent_in_lds)
+        for (int i = tid; i < m; i += nt) lds_i[L.o_ent + i] = (int)a.gt_ent[k0 + i];
     for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
-    for (int i = tid; i < r1 - r0; i += nt) lds_i[L.o_ncols + i] = (int)a.ncols[r0 + i];
-    const int k0 = lds_i[L.o_n2eoff], k1 = lds_i[L.o_n2eoff + nb];
     __syncthreads();
 
-    for (int kb = k0; kb < k1; kb += a.mb) {
-        const int m = min(a.mb, k1 - kb);
-        // phase A: entries (node, element, local index) of this batch; dedupe elements
-        for (int t = tid; t < m; t += nt) {
-            lds_i[L.o_ent + t] = (int)a.n2e[kb + t];
-            int lo = 0, hi = nb;  // owning node: last i with n2e_off[i] <= kb + t
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (lds_i[L.o_n2eoff + mid] <= kb + t) lo = mid; else hi = mid;
-            }
-            lds_i[L.o_entnode + t] = lo;
-        }
+    for (int c0 = 0; c0 < U; c0 += a.ub) {
+        const int Uc = min(a.ub, U - c0);
+        stage_elements<EK, S>(a, L, lds, lds_i, Uc, O::NEEDS_U, uniq + c0);
+        // phase B
+        for (int i = tid; i < Uc * a.nq; i += nt)
+            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, uniq[c0 + i / a.nq]);
         __syncthreads();
-        // first occurrence of each element (entries are few: O(m^2) scan in LDS)
-        for (int t = tid; t < m; t += nt) {
-            const int e = lds_i[L.o_ent + t] / N;
-            int first = t;
-            for (int x = 0; x < t; ++x)
-                if (lds_i[L.o_ent + x] / N == e) { first = x; break; }
-            lds_i[L.o_entu + t] = first;
-        }
-        __syncthreads();
-        // rank the first occurrences -> unique element list; entries then point at their unique slot
-        int U = 0;
-        for (int t = tid; t < m; t += nt) {
-            if (lds_i[L.o_entu + t] == t) {
-                int rank = 0;
-                for (int x = 0; x < t; ++x) rank += (lds_i[L.o_entu + x] == x);
-                lds_i[L.o_uniq + rank] = lds_i[L.o_ent + t] / N;
-                lds_i[L.o_rank + t] = rank;
-            }
-        }
-        for (int x = 0; x < m; ++x) U += (lds_i[L.o_entu + x] == x);
-        __syncthreads();
-        for (int t = tid; t < m; t += nt) lds_i[L.o_slot + t] = lds_i[L.o_rank + lds_i[L.o_entu + t]];
-        __syncthreads();
-        for (int c0 = 0; c0 < U; c0 += a.ub) {
-            const int Uc = min(a.ub, U - c0);
-            stage_elements<EK, S>(a, L, lds, lds_i, Uc, O::NEEDS_U, c0);
-            // phase B
-            for (int i = tid; i < Uc * a.nq; i += nt)
-                prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + c0 + i / a.nq]);
-            __syncthreads();
-            // phase C: one lane per (entry, other local node)
-            for (int it = tid; it < m * N; it += nt) {
-                const int t = it / N, Jn = it % N;
-                const int an = lds_i[L.o_ent + t] % N;
-                const int u = lds_i[L.o_slot + t] - c0;
-                if (u < 0 || u >= Uc) continue;
-                const int il = lds_i[L.o_entnode + t];
-                const int nj = lds_i[L.o_cn + u * N + Jn];
-                double blk[S][S];
-                const bool swap = an > Jn;
-                pair_block<EK, OP>(L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
-                const int rb = lds_i[L.o_noff + il] - r0, cnt = lds_i[L.o_noff + il + 1] - lds_i[L.o_noff + il];
-                const int pos = find_col_lds(lds_i + L.o_ncols + rb, cnt, nj);
-                double* base = acc + S * S * rb + S * pos;
+        // phase C: one lane per (entry, other local node); entry = (unique slot, local index a, local node)
+        for (int it = tid; it < m * N; it += nt) {
+            const int t = it / N, Jn = it % N;
+            const unsigned packed = ent_in_lds ? (unsigned)lds_i[L.o_ent + t] : a.gt_ent[k0 + t];
+            const int u = (int)(packed >> 16) - c0;
+            if (u < 0 || u >= Uc) continue;
+            const int an = (int)((packed >> 8) & 0xffu);
+            const int il = (int)(packed & 0xffu);
+            const int nj = lds_i[L.o_cn + u * N + Jn];
+            double blk[S][S];
+            const bool swap = an > Jn;
+            pair_block<EK, OP>(L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
+            const int rb = lds_i[L.o_noff + il] - r0, cnt = lds_i[L.o_noff + il + 1] - lds_i[L.o_noff + il];
+            const int pos = find_col_lds(lds_i + L.o_ncols + rb, cnt, nj);
+            double* base = acc + S * S * rb + S * pos;
 #pragma unroll
-                for (int i = 0; i < S; ++i)
+            for (int i = 0; i < S; ++i)
 #pragma unroll
-                    for (int j = 0; j < S; ++j) atomic_add_f64(base + i * S * cnt + j, swap ? blk[j][i] : blk[i][j]);
-            }
-            __syncthreads();
+                for (int j = 0; j < S; ++j) atomic_add_f64(base + i * S * cnt + j, swap ? blk[j][i] : blk[i][j]);
         }
+        __syncthreads();
     }
-    // phase D: rows [S i0, S i1) are contiguous in the CSR values
+    // phase D: rows [S i0, S (i0 + nb)) are contiguous in the CSR values
     double* out = a.vals + (size_t)S * S * r0;
     if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
     else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
+}
+
+// ------------------------------------------------------------------------------------------ gather tables
+// One workgroup per node block.  PASS 0: count the unique adjacent elements of the block (hdr.U);
+// PASS 1: write the unique element list and, per (node, element) entry, the packed word
+// (unique slot << 16 | local index a << 8 | block-local node).  Entries of a block are the contiguous
+// range n2e[n2e_off[i0] .. n2e_off[i1]) -- ascending element per node, so the tables are deterministic.
+template <int PASS>
+__global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk_off, const unsigned* noff, const unsigned* n2e_off,
+                                                             const unsigned* n2e, int N, GatherHdr* hdr, const unsigned* u_off,
+                                                             unsigned* gt_elems, unsigned* gt_ent) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* ent = reinterpret_cast<int*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int i0 = (int)blk_off[b], i1 = (int)blk_off[b + 1];
+    const int k0 = (int)n2e_off[i0], k1 = (int)n2e_off[i1];
+    const int m = k1 - k0;
+    int* first = ent + m;
+    int* rank = first + m;
+    for (int t = tid; t < m; t += nt) ent[t] = (int)(n2e[k0 + t] / (unsigned)N);
+    __syncthreads();
+    for (int t = tid; t < m; t += nt) {
+        const int e = ent[t];
+        int f = t;
+        for (int x = 0; x < t; ++x)
+            if (ent[x] == e) { f = x; break; }
+        first[t] = f;
+    }
+    __syncthreads();
+    for (int t = tid; t < m; t += nt) {
+        if (first[t] == t) {
+            int r = 0;
+            for (int x = 0; x < t; ++x) r += (first[x] == x);
+            rank[t] = r;
+        }
+    }
+    __syncthreads();
+    if (PASS == 0) {
+        if (tid == 0) {
+            int U = 0;
+            for (int x = 0; x < m; ++x) U += (first[x] == x);
+            GatherHdr h;
+            h.i0 = i0; h.nb = i1 - i0; h.r0 = (int)noff[i0]; h.nrow = (int)(noff[i1] - noff[i0]);
+            h.k0 = k0; h.m = m; h.U = U; h.u_off = 0;
+            hdr[b] = h;
+        }
+        return;
+    }
+    const unsigned uo = u_off[b];
+    if (tid == 0) hdr[b].u_off = uo;
+    for (int t = tid; t < m; t += nt) {
+        if (first[t] == t) gt_elems[uo + rank[t]] = (unsigned)ent[t];
+        // owning node: last i with n2e_off[i] <= k0 + t
+        int lo = i0, hi = i1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)n2e_off[mid] <= k0 + t) lo = mid; else hi = mid;
+        }
+        const unsigned a_loc = n2e[k0 + t] % (unsigned)N;
+        gt_ent[k0 + t] = ((unsigned)rank[first[t]] << 16) | (a_loc << 8) | (unsigned)(lo - i0);
+    }
+}
+
+__global__ void k_hdr_counts(const GatherHdr* hdr, int nblk, unsigned* counts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) counts[b] = (unsigned)hdr[b].U;
+    if (b == nblk) counts[b] = 0;
 }
 
 // ============================================================================================ vector
@@ -715,7 +741,7 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
     const int U = (int)min((long long)a.epb, a.work_end - w0);
     for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
     __syncthreads();
-    stage_elements<EK, S>(a, L, lds, lds_i, U, true);
+    stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)
         prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
     __syncthreads();
@@ -755,7 +781,7 @@ __global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {
     const int U = (int)min((long long)a.epb, a.work_end - w0);
     for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
     __syncthreads();
-    stage_elements<EK, S>(a, L, lds, lds_i, U, true);
+    stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)
         prologue<EK, OP, WHAT_SCALAR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
     __syncthreads();

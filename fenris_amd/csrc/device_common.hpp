@@ -47,6 +47,14 @@ struct DevStatus {
     unsigned long long failed_elem;  // lowest failing element (atomicMin)
 };
 
+// per-block header of the owner-computes (gather) tables
+struct GatherHdr {
+    int i0, nb;      // first node, number of nodes
+    int r0, nrow;    // first node-level CSR entry, number of node-level entries of the block's rows
+    int k0, m;       // first (node, element) entry in n2e, number of entries
+    int u_off, U;    // offset into gt_elems, number of unique adjacent elements
+};
+
 // kernel arguments (plain struct, passed by value)
 struct KArgs {
     // mesh
@@ -79,6 +87,9 @@ struct KArgs {
     int epb;                 // elements per block
     // gather work description
     const unsigned* blk_off; // node block boundaries, nblk+1
+    const GatherHdr* gt_hdr; // per block
+    const unsigned* gt_elems;// unique adjacent elements of each block
+    const unsigned* gt_ent;  // per n2e entry: unique slot << 16 | local index << 8 | block-local node
     int nblk;
     int ub;                  // max unique elements staged at a time
     int mb;                  // max (node, element) entries per batch (gather)

@@ -147,7 +147,8 @@ struct fh_ctx {
     uint64_t nnz_nodes = 0;
     std::vector<unsigned> h_noff, h_n2e_off;  // host copies (gather block partition)
     // gather partition
-    DevBuf<unsigned> blk_off;
+    DevBuf<unsigned> blk_off, gt_elems, gt_ent;
+    DevBuf<GatherHdr> gt_hdr;
     int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0;
     bool has_partition = false;
     // colours
@@ -393,7 +394,7 @@ int build_partition(fh_ctx* c) {
     unsigned max_row = 0;
     for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     // nodes per block (tunable), entry capacity per batch, accumulator budget
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 8)));
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 8)));  // < 256: packed in 8 bits
     const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
     const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 78) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
@@ -428,6 +429,42 @@ int build_partition(fh_ctx* c) {
     c->nblk = (int)blk.size() - 1;
     HIP_TRY(c, c->blk_off.alloc(blk.size()));
     HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, blk.data(), sizeof(unsigned) * blk.size(), hipMemcpyHostToDevice, c->stream));
+    // block tables: unique element lists and packed entries (built once per pattern/partition)
+    {
+        unsigned max_m = 0;
+        for (size_t b = 0; b + 1 < blk.size(); ++b)
+            max_m = std::max(max_m, c->h_n2e_off[blk[b + 1]] - c->h_n2e_off[blk[b]]);
+        if (max_m >= 65536) return c->fail(FH_UNSUPPORTED, "gather mode: a node block has more than 65535 adjacent entries");
+        const size_t tb = sizeof(int) * 3 * (size_t)std::max(1u, max_m);
+        if (tb > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "gather mode: node valence too large for the table builder");
+        const int nblk = c->nblk;
+        DevBuf<unsigned> counts, uoff;
+        HIP_TRY(c, c->gt_hdr.alloc((size_t)nblk + 1));
+        HIP_TRY(c, counts.alloc((size_t)nblk + 1));
+        HIP_TRY(c, uoff.alloc((size_t)nblk + 1));
+        HIP_TRY(c, c->gt_ent.alloc((size_t)c->flat_len + 1));
+        auto k0 = k_build_gather_tables<0>;
+        auto k1 = k_build_gather_tables<1>;
+        if (tb > 48 * 1024) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+        }
+        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
+                           c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_hdr_counts, dim3((nblk + 256) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, nblk, counts.p);
+        size_t tmpb = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, counts.p, uoff.p, nblk + 1, c->stream));
+        DevBuf<char> tmp;
+        HIP_TRY(c, tmp.alloc(tmpb + 16));
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmpb, counts.p, uoff.p, nblk + 1, c->stream));
+        unsigned total_u = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total_u, uoff.p + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->gt_elems.alloc((size_t)total_u + 1));
+        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
+                           c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->g_ub = ub;
     c->g_mb = mb;
@@ -455,6 +492,9 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         rc = build_partition(c);
         if (rc) return rc;
         a.blk_off = c->blk_off.p;
+        a.gt_hdr = c->gt_hdr.p;
+        a.gt_elems = c->gt_elems.p;
+        a.gt_ent = c->gt_ent.p;
         a.nblk = c->nblk;
         a.ub = c->g_ub;
         a.mb = c->g_mb;

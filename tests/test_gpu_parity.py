@@ -178,8 +178,13 @@ def test_element_matrices_match_oracle(engine, oracle, kind, op):
     for e in range(E):
         st, oke = ref.element_matrix(e)
         assert st == 0
-        assert np.abs(ke[e] - oke).max() <= TOL * np.abs(oke).max(), (e, np.abs(ke[e] - oke).max() / np.abs(oke).max())
-        assert np.array_equal(ke[e], ke[e].T)
+        nan = np.isnan(oke)  # NeoHookean with J <= 0: NaN positions must coincide (materials.rs:298-300)
+        assert np.array_equal(np.isnan(ke[e]), nan)
+        if nan.all():
+            continue
+        scale = np.abs(oke[~nan]).max()
+        assert np.abs(ke[e][~nan] - oke[~nan]).max() <= TOL * scale, (e, np.abs(ke[e][~nan] - oke[~nan]).max() / scale)
+        assert np.array_equal(ke[e][~nan], ke[e].T[~nan])
 
 
 def test_quad4_reference_element_kat(engine):

@@ -23,28 +23,36 @@ namespace fenris_hip {
 struct Layout {
     int o_gref, o_ggeom, o_qw, o_qpar, o_X, o_U, o_QP, o_ACC, n_doubles;
     int o_uniq, o_cn, o_ent, o_ncols, o_noff, n_ints;
-    int qpd;  // doubles per (element, quadrature point)
+    int qpd;   // doubles per (element, quadrature point), padded to an odd count (LDS bank spread)
+    int fast;  // 1: gradients stored pre-scaled by sqrt(w |det J|), no per-point coefficients
+    int o_pos; // gather: per (entry, local node) column slot, bytes
+    int nqs;   // quadrature points staged per element at a time (== nq unless chunked)
     __host__ __device__ size_t bytes() const { return sizeof(double) * (size_t)n_doubles + sizeof(int) * (size_t)n_ints; }
 };
 
 enum { WHAT_MATRIX = 0, WHAT_VECTOR = 1, WHAT_SCALAR = 2 };
 
 template <int EK, int OP, int WHAT>
-__host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int nb_max, bool gather, int mb = 0) {
+__host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int nb_max, bool gather, int mb = 0, int fast = 0,
+                                               int nq_stage = 0) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     Layout L;
     int o = 0;
     L.o_gref = o;  o += nq * E::N * E::D;
-    L.o_ggeom = o; o += nq * E::NG * E::D;
+    if (E::NG == E::N) L.o_ggeom = L.o_gref;  // iso-parametric: one table
+    else { L.o_ggeom = o; o += nq * E::NG * E::D; }
     L.o_qw = o;    o += nq;
     L.o_qpar = o;  o += 2 * nq;
     L.o_X = o;     o += ub * E::NG * E::D;
-    L.o_U = o;     o += ub * E::N * O::S;
-    if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + O::NCOEF;
+    L.o_U = o;     o += (O::NEEDS_U || WHAT != WHAT_MATRIX) ? ub * E::N * O::S : 0;
+    L.fast = (WHAT == WHAT_MATRIX && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC)) ? fast : 0;
+    if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + (L.fast ? 0 : O::NCOEF);
     else if (WHAT == WHAT_VECTOR) L.qpd = E::N * E::D + O::S * E::D;
     else L.qpd = 1;
-    L.o_QP = o;    o += ub * nq * L.qpd;
+    if (WHAT != WHAT_SCALAR && (L.qpd & 1) == 0) L.qpd += 1;
+    L.nqs = nq_stage > 0 ? nq_stage : nq;  // quadrature points staged at a time
+    L.o_QP = o;    o += ub * L.nqs * L.qpd;
     L.o_ACC = o;   o += gather ? acc_max : 0;
     L.n_doubles = o;
     int i = 0;
@@ -53,6 +61,7 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.o_ent = i;     i += gather ? mb : 0;
     L.o_ncols = i;   i += gather ? acc_max / (O::S * O::S) : 0;
     L.o_noff = i;    i += gather ? nb_max + 1 : 0;
+    L.o_pos = i;     i += gather ? (mb * E::N + 3) / 4 : 0;
     L.n_ints = i + 4;
     return L;
 }
@@ -89,14 +98,14 @@ __device__ __forceinline__ void inv_small(const double (&m)[3][3], double det, d
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
 template <int EK, int OP, int WHAT>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
-                                         long long elem) {
+                                         const int* elem_id, int qslot = -1) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
     const double* X = lds + L.o_X + u * NG * D;
     const double* gg = lds + L.o_ggeom + q * NG * D;
     const double* gr = lds + L.o_gref + q * N * D;
-    double* qp = lds + L.o_QP + (size_t)(u * a.nq + q) * L.qpd;
+    double* qp = lds + L.o_QP + (size_t)(u * L.nqs + (qslot < 0 ? q : qslot)) * L.qpd;
     (void)lds_i;
 
     // J = X G^T  (hexahedron.rs:101-107): J[i][j] = sum_g x_g[i] dN_g/dxi_j
@@ -105,6 +114,8 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j < D; ++j) J[i][j] = 0.0;
+    constexpr int UNR = (N <= 8) ? N : 3;
+#pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -113,7 +124,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     const double detJ = det_small<D>(J);
     double Ji[D][D];
     if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
-        report_singular(a.status, elem);
+        report_singular(a.status, (long long)*elem_id);  // dereferenced only on this (rare) path
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -134,6 +145,10 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     }
     const double* Ue = lds + L.o_U + u * N * S;
     double* gout = qp;  // first node-vector block: physical gradients
+    // FAST path (Laplace / uniform linear elasticity, non-negative weights): store sqrt(s) g_n so that
+    // sum_q s g_I g_J^T = sum_q h_I h_J^T needs no per-point coefficient in phase C
+    const double fast_scale = (WHAT == WHAT_MATRIX && L.fast) ? sqrt(s) : 1.0;
+#pragma unroll UNR
     for (int n = 0; n < N; ++n) {
         double g[D];
 #pragma unroll
@@ -145,7 +160,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         }
         if (WHAT != WHAT_SCALAR) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) gout[n * D + i] = g[i];
+            for (int i = 0; i < D; ++i) gout[n * D + i] = fast_scale * g[i];
         }
         if (want_u) {
 #pragma unroll
@@ -171,7 +186,9 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 
     if (WHAT == WHAT_MATRIX) {
         double* coef = qp + O::NVEC * N * D;
-        if (OP == FH_LAPLACE) {
+        if (L.fast) {
+            // nothing: scale folded into the gradients
+        } else if (OP == FH_LAPLACE) {
             coef[0] = s;
         } else if (OP == FH_LINEAR_ELASTIC) {
             coef[0] = s * mu;
@@ -359,13 +376,44 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 // ------------------------------------------------------------------------------------------ phase C
 // s x s block K_e[(I,.),(J,.)] for I <= J: sum over quadrature points of scale * C(grad u; g_I, g_J).
 template <int EK, int OP>
-__device__ __forceinline__ void pair_block(const Layout& L, const double* lds, int nq, int u, int I, int J,
+__device__ __forceinline__ void pair_block(const KArgs& ka, const Layout& L, const double* lds, int nq, int u, int I, int J,
                                            double (&blk)[OpT<OP, ElemT<EK>::D>::S][OpT<OP, ElemT<EK>::D>::S]) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, S = O::S;
     const double* qp = lds + L.o_QP + (size_t)u * nq * L.qpd;
-    if (OP == FH_LAPLACE) {
+    if ((OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC) && L.fast) {
+        // G = sum_q h_I h_J^T with h = sqrt(w |det J|) grad phi
+        double G[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) G[i][j] = 0.0;
+        const double* a = qp + I * D;
+        const double* b = qp + J * D;
+        for (int q = 0; q < nq; ++q, a += L.qpd, b += L.qpd) {
+            double av[D], bv[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { av[i] = a[i]; bv[i] = b[i]; }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) G[i][j] = fma(av[i], bv[j], G[i][j]);
+        }
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) tr += G[i][i];
+        if (OP == FH_LAPLACE) {
+            blk[0][0] = tr;
+        } else {
+            // mu [(a.b) I + b a^T] + lambda a b^T  summed:  mu (tr G I + G^T) + lambda G
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    blk[i % S][j % S] = ka.mu * ((i == j ? tr : 0.0) + G[j][i]) + ka.lambda * G[i][j];
+        }
+    } else if (OP == FH_LAPLACE) {
         double k = 0.0;
         for (int q = 0; q < nq; ++q, qp += L.qpd) {
             const double* a = qp + I * D;
@@ -500,7 +548,8 @@ __device__ __forceinline__ void stage_tables(const KArgs& a, const Layout& L, do
     using E = ElemT<EK>;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < a.nq * E::N * E::D; i += nt) lds[L.o_gref + i] = a.gref[i];
-    for (int i = tid; i < a.nq * E::NG * E::D; i += nt) lds[L.o_ggeom + i] = a.ggeom[i];
+    if (E::NG != E::N)
+        for (int i = tid; i < a.nq * E::NG * E::D; i += nt) lds[L.o_ggeom + i] = a.ggeom[i];
     for (int i = tid; i < a.nq; i += nt) lds[L.o_qw + i] = a.qw[i];
     for (int i = tid; i < 2 * a.nq; i += nt) lds[L.o_qpar + i] = a.qparams ? a.qparams[i] : 0.0;
 }
@@ -547,7 +596,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
     (void)D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool GATHER = (MODE == MODE_GATHER);
-    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, GATHER, a.mb);
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, GATHER, a.mb, a.fast);
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -562,7 +611,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
         __syncthreads();
         stage_elements<EK, S>(a, L, lds, lds_i, U, O::NEEDS_U, lds_i + L.o_uniq);
         for (int i = tid; i < U * a.nq; i += nt)
-            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
         __syncthreads();
         constexpr int NP = N * (N + 1) / 2;
         for (int it = tid; it < U * NP; it += nt) {
@@ -570,7 +619,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             int I, J;
             unpack_pair(it % NP, I, J);
             double blk[S][S];
-            pair_block<EK, OP>(L, lds, a.nq, u, I, J, blk);
+            pair_block<EK, OP>(a, L, lds, a.nq, u, I, J, blk);
             if (MODE == MODE_DUMP) {
                 // K_e column-major (s n) x (s n), both triangles
                 double* ke = a.ke_out + (size_t)(w0 - a.work_begin + u) * (S * N) * (S * N);
@@ -612,13 +661,17 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
     const int nacc = S * S * nrow;
     double* acc = lds + L.o_ACC;
     for (int i = tid; i <= nb; i += nt) lds_i[L.o_noff + i] = (int)a.noff[i0 + i];
-    for (int i = tid; i < nrow; i += nt) lds_i[L.o_ncols + i] = (int)a.ncols[r0 + i];
+    if (!a.gt_pos)
+        for (int i = tid; i < nrow; i += nt) lds_i[L.o_ncols + i] = (int)a.ncols[r0 + i];
     const bool ent_in_lds = m <= a.mb;  // U <= m, so the unique list fits whenever the entries do
     if (ent_in_lds)
         for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)a.gt_elems[hdr.u_off + i];
     const int* uniq = ent_in_lds ? lds_i + L.o_uniq : reinterpret_cast<const int*>(a.gt_elems + hdr.u_off);
-    if (ent_in_lds)
+    unsigned char* pos_lds = reinterpret_cast<unsigned char*>(lds_i + L.o_pos);
+    if (ent_in_lds) {
         for (int i = tid; i < m; i += nt) lds_i[L.o_ent + i] = (int)a.gt_ent[k0 + i];
+        for (int i = tid; i < m * N; i += nt) pos_lds[i] = a.gt_pos[(size_t)k0 * N + i];
+    }
     for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
     __syncthreads();
 
@@ -627,7 +680,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
         stage_elements<EK, S>(a, L, lds, lds_i, Uc, O::NEEDS_U, uniq + c0);
         // phase B
         for (int i = tid; i < Uc * a.nq; i += nt)
-            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, uniq[c0 + i / a.nq]);
+            prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, uniq + c0 + i / a.nq);
         __syncthreads();
         // phase C: one lane per (entry, other local node); entry = (unique slot, local index a, local node)
         for (int it = tid; it < m * N; it += nt) {
@@ -637,12 +690,16 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             if (u < 0 || u >= Uc) continue;
             const int an = (int)((packed >> 8) & 0xffu);
             const int il = (int)(packed & 0xffu);
-            const int nj = lds_i[L.o_cn + u * N + Jn];
             double blk[S][S];
             const bool swap = an > Jn;
-            pair_block<EK, OP>(L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
+            pair_block<EK, OP>(a, L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
             const int rb = lds_i[L.o_noff + il] - r0, cnt = lds_i[L.o_noff + il + 1] - lds_i[L.o_noff + il];
-            const int pos = find_col_lds(lds_i + L.o_ncols + rb, cnt, nj);
+            int pos;
+            if (a.gt_pos) {
+                pos = ent_in_lds ? (int)pos_lds[it] : (int)a.gt_pos[(size_t)k0 * N + it];
+            } else {
+                pos = find_col_lds(lds_i + L.o_ncols + rb, cnt, lds_i[L.o_cn + u * N + Jn]);
+            }
             double* base = acc + S * S * rb + S * pos;
 #pragma unroll
             for (int i = 0; i < S; ++i)
@@ -657,6 +714,214 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
     else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
 }
 
+// ============================================================================================ pipelined gather
+// Persistent owner-computes kernel: each workgroup walks blocks b = blockIdx.x, += gridDim.x and keeps the
+// global-memory latency off the critical path with a two-stage register prefetch:
+//   top of iteration b:   issue vertex loads of block b+G (its geometry-node indices arrived last iteration)
+//                         issue record loads of block b+2G (fixed-stride tables: address depends on b only)
+//   body:                 phases B, C, D of block b from LDS
+//   bottom:               park the prefetched block b+G in LDS (X, entries, column slots, row offsets)
+// Only for operators that do not read u (Laplace, LinearElastic) and elements with few geometry nodes.
+struct PipeTables {
+    const GatherHdr* hdr;       // [nblk]
+    const int* conn;            // [nblk][cs]   geometry-node indices of the unique elements (padded with 0)
+    const unsigned* ent;        // [nblk][ms]   packed entries
+    const unsigned* pos;        // [nblk][ms*N/4] column slots, 4 per word
+    const int* noffr;           // [nblk][nbs+1] node-level row offsets relative to the block start
+    int cs, ms, nbs;
+};
+
+template <int EK, int OP, int QC>
+__global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const PipeTables T) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
+    constexpr int SLOTS = 2;  // geometry-node slots per thread: U * NG <= 512
+    constexpr int RMAX = 2;   // (entry, local node) items per thread: m * N <= 512
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    unsigned* pos_lds = reinterpret_cast<unsigned*>(lds_i + L.o_pos);
+    double* acc = lds + L.o_ACC;
+    const int tid = threadIdx.x, nt = 256;
+    const int G = gridDim.x, nblk = a.nblk;
+    stage_tables<EK>(a, L, lds);
+
+    struct Rec { GatherHdr h; int conn[SLOTS]; unsigned ent, posw; int noffr; };
+    auto load_rec = [&](int b, Rec& r) {
+        b = min(b, nblk - 1);
+        r.h = T.hdr[b];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int sidx = tid + k * nt;
+            r.conn[k] = (sidx < T.cs) ? T.conn[(size_t)b * T.cs + sidx] : 0;
+        }
+        r.ent = (tid < T.ms) ? T.ent[(size_t)b * T.ms + tid] : 0u;
+        r.posw = (tid < T.ms * N / 4) ? T.pos[(size_t)b * (T.ms * N / 4) + tid] : 0u;
+        r.noffr = (tid <= T.nbs) ? T.noffr[(size_t)b * (T.nbs + 1) + tid] : 0;
+    };
+    double V[SLOTS][D];
+    auto load_verts = [&](const Rec& r) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+#pragma unroll
+            for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
+    };
+    auto park = [&](const Rec& r) {  // registers -> LDS for the block that is computed next
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int sidx = tid + k * nt;
+            if (sidx < r.h.U * NG)
+#pragma unroll
+                for (int c = 0; c < D; ++c) lds[L.o_X + sidx * D + c] = V[k][c];
+        }
+        if (tid < T.ms) lds_i[L.o_ent + tid] = (int)r.ent;
+        if (tid < T.ms * N / 4) pos_lds[tid] = r.posw;
+        if (tid <= T.nbs) lds_i[L.o_noff + tid] = r.noffr;
+    };
+
+    int b = blockIdx.x;
+    if (b >= nblk) return;
+    Rec cur, nxt;
+    load_rec(b, cur);
+    load_verts(cur);
+    load_rec(b + G, nxt);
+    park(cur);
+    __syncthreads();
+    GatherHdr hc = cur.h;
+
+    for (; b < nblk; b += G) {
+        const bool have_next = (b + G) < nblk;
+        if (have_next) load_verts(nxt);      // lands while this block is computed
+        Rec nn;
+        load_rec(b + 2 * G, nn);
+        const int U = hc.U, m = hc.m, nrow = hc.nrow;
+        const int nacc = S * S * nrow;
+        for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
+        // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
+        // elements of the block are staged at once (U <= ub guaranteed by the host)
+        double Gr[RMAX][D][D];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) Gr[r][i][j] = 0.0;
+        for (int qc = 0; qc < a.nq; qc += QC) {
+            // phase B for quadrature points [qc, qc + QC)
+            for (int i = tid; i < U * QC; i += nt) {
+                const int u = i / QC, qs = i % QC;
+                if (qc + qs < a.nq)
+                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs,
+                                                  reinterpret_cast<const int*>(a.gt_elems) + hc.u_off + u, qs);
+            }
+            __syncthreads();
+            // phase C (accumulate)
+            const int nqc = min(QC, a.nq - qc);
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int it = tid + r * nt;
+                if (it < m * N) {
+                    const int t = it / N, Jn = it % N;
+                    const unsigned packed = (unsigned)lds_i[L.o_ent + t];
+                    const int u = (int)(packed >> 16);
+                    const int an = (int)((packed >> 8) & 0xffu);
+                    const int I = min(an, Jn), J = max(an, Jn);
+                    const double* pa = lds + L.o_QP + (size_t)u * QC * L.qpd + I * D;
+                    const double* pb = lds + L.o_QP + (size_t)u * QC * L.qpd + J * D;
+                    for (int q = 0; q < nqc; ++q, pa += L.qpd, pb += L.qpd) {
+                        double av[D], bv[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { av[i] = pa[i]; bv[i] = pb[i]; }
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) Gr[r][i][j] = fma(av[i], bv[j], Gr[r][i][j]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int it = tid + r * nt;
+            if (it < m * N) {
+                const int t = it / N, Jn = it % N;
+                const unsigned packed = (unsigned)lds_i[L.o_ent + t];
+                const int an = (int)((packed >> 8) & 0xffu);
+                const int il = (int)(packed & 0xffu);
+                const bool swap = an > Jn;
+                double blk[S][S];
+                double tr = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) tr += Gr[r][i][i];
+                if (OP == FH_LAPLACE) {
+                    blk[0][0] = tr;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            blk[i % S][j % S] = a.mu * ((i == j ? tr : 0.0) + Gr[r][j][i]) + a.lambda * Gr[r][i][j];
+                }
+                if (an == Jn) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i)
+#pragma unroll
+                        for (int j = 0; j < S; ++j)
+                            if (i > j) blk[i][j] = blk[j][i];
+                }
+                const int rb = lds_i[L.o_noff + il], cnt = lds_i[L.o_noff + il + 1] - rb;
+                const int pos = (int)((pos_lds[it >> 2] >> (8 * (it & 3))) & 0xffu);
+                double* base = acc + S * S * rb + S * pos;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int j = 0; j < S; ++j) atomic_add_f64(base + i * S * cnt + j, swap ? blk[j][i] : blk[i][j]);
+            }
+        }
+        __syncthreads();
+        // phase D
+        double* out = a.vals + (size_t)S * S * hc.r0;
+        if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
+        else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
+        __syncthreads();
+        // park the prefetched block
+        if (have_next) park(nxt);
+        hc = nxt.h;
+        nxt = nn;
+        __syncthreads();
+    }
+}
+
+// fixed-stride tables for the pipelined kernel, one workgroup per block
+template <int NG_T>
+__global__ void __launch_bounds__(256) k_build_pipe_tables(const GatherHdr* hdr, const unsigned* gt_elems, const unsigned* gt_ent,
+                                                           const unsigned char* gt_pos, const unsigned* noff, const int* conn,
+                                                           int N, int cs, int ms, int nbs, int* p_conn, unsigned* p_ent,
+                                                           unsigned* p_pos, int* p_noffr) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const GatherHdr h = hdr[b];
+    for (int sidx = tid; sidx < cs; sidx += 256) {
+        const int u = sidx / NG_T, g = sidx % NG_T;
+        p_conn[(size_t)b * cs + sidx] = (u < h.U) ? conn[(size_t)gt_elems[h.u_off + u] * N + g] : 0;
+    }
+    for (int t = tid; t < ms; t += 256) p_ent[(size_t)b * ms + t] = (t < h.m) ? gt_ent[h.k0 + t] : 0u;
+    const int pw = ms * N / 4;
+    for (int w = tid; w < pw; w += 256) {
+        unsigned word = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int it = 4 * w + k;
+            if (it < h.m * N) word |= (unsigned)gt_pos[(size_t)h.k0 * N + it] << (8 * k);
+        }
+        p_pos[(size_t)b * pw + w] = word;
+    }
+    for (int i = tid; i <= nbs; i += 256)
+        p_noffr[(size_t)b * (nbs + 1) + i] = (i <= h.nb) ? (int)(noff[h.i0 + i] - (unsigned)h.r0) : 0;
+}
+
 // ------------------------------------------------------------------------------------------ gather tables
 // One workgroup per node block.  PASS 0: count the unique adjacent elements of the block (hdr.U);
 // PASS 1: write the unique element list and, per (node, element) entry, the packed word
@@ -665,7 +930,8 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
 template <int PASS>
 __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk_off, const unsigned* noff, const unsigned* n2e_off,
                                                              const unsigned* n2e, int N, GatherHdr* hdr, const unsigned* u_off,
-                                                             unsigned* gt_elems, unsigned* gt_ent) {
+                                                             unsigned* gt_elems, unsigned* gt_ent, const int* conn,
+                                                             const unsigned* ncols, unsigned char* gt_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* ent = reinterpret_cast<int*>(smem);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -715,6 +981,12 @@ __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk
         }
         const unsigned a_loc = n2e[k0 + t] % (unsigned)N;
         gt_ent[k0 + t] = ((unsigned)rank[first[t]] << 16) | (a_loc << 8) | (unsigned)(lo - i0);
+        if (gt_pos) {  // column slot of every local node of the element inside the row of the owning node
+            const unsigned rb = noff[lo], cnt = noff[lo + 1] - rb;
+            for (int Jn = 0; Jn < N; ++Jn)
+                gt_pos[(size_t)(k0 + t) * N + Jn] =
+                    (unsigned char)find_col(ncols + rb, (int)cnt, (unsigned)conn[(size_t)ent[t] * N + Jn]);
+        }
     }
 }
 
@@ -743,7 +1015,7 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
     __syncthreads();
     stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)
-        prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+        prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
     __syncthreads();
     for (int it = tid; it < U * N; it += nt) {
         const int u = it / N, I = it % N;
@@ -783,7 +1055,7 @@ __global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {
     __syncthreads();
     stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)
-        prologue<EK, OP, WHAT_SCALAR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i[L.o_uniq + i / a.nq]);
+        prologue<EK, OP, WHAT_SCALAR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
     __syncthreads();
     // per-element energies in element order, then one partial per block (summed on the host in block
     // order => deterministic)

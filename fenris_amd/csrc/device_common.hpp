@@ -64,6 +64,8 @@ struct KArgs {
     int num_nodes;
     // quadrature tables (device)
     int nq;
+    int fast;              // uniform parameters and non-negative weights: sqrt-scaled gradients
+    double mu, lambda;     // uniform Lame parameters (fast path)
     const double* qw;      // nq
     const double* gref;    // nq x N x D   reference gradients of the element basis
     const double* ggeom;   // nq x NG x D  reference gradients of the geometry map
@@ -90,6 +92,7 @@ struct KArgs {
     const GatherHdr* gt_hdr; // per block
     const unsigned* gt_elems;// unique adjacent elements of each block
     const unsigned* gt_ent;  // per n2e entry: unique slot << 16 | local index << 8 | block-local node
+    const unsigned char* gt_pos; // per (n2e entry, local node): column slot in the owner's row (or null)
     int nblk;
     int ub;                  // max unique elements staged at a time
     int mb;                  // max (node, element) entries per batch (gather)

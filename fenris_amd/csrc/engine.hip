@@ -140,6 +140,8 @@ struct fh_ctx {
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, qparams, u;
     bool has_params = false, has_u = false;
+    bool fast_ok = false;       // uniform parameters and non-negative weights
+    double uni_mu = 0.0, uni_lambda = 0.0;
     std::vector<double> h_points;
     // pattern
     bool has_pattern = false;
@@ -148,8 +150,15 @@ struct fh_ctx {
     std::vector<unsigned> h_noff, h_n2e_off;  // host copies (gather block partition)
     // gather partition
     DevBuf<unsigned> blk_off, gt_elems, gt_ent;
+    DevBuf<unsigned char> gt_pos;
+    bool has_pos = false;
+    // fixed-stride tables of the pipelined gather kernel
+    DevBuf<int> p_conn, p_noffr;
+    DevBuf<unsigned> p_ent, p_pos;
+    int p_cs = 0, p_ms = 0, p_nbs = 0;
+    bool has_pipe = false;
     DevBuf<GatherHdr> gt_hdr;
-    int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0;
+    int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0, g_umax = 0;
     bool has_partition = false;
     // colours
     bool has_colors = false;
@@ -285,9 +294,9 @@ int launch_matrix(fh_ctx* c, KArgs& a, int mode, size_t lds_bytes, int grid) {
 }
 
 template <int EK, int OP>
-size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb) {
+size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb, int fast) {
     switch (what) {
-        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb).bytes();
+        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb, fast).bytes();
         case WHAT_VECTOR: return make_layout<EK, OP, WHAT_VECTOR>(nq, ub, acc, nb, gather, mb).bytes();
         default: return make_layout<EK, OP, WHAT_SCALAR>(nq, ub, acc, nb, gather, mb).bytes();
     }
@@ -312,9 +321,9 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         default: break;                                             \
     }
 
-size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0) {
+size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0) {
     size_t r = 0;
-#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb)
+#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb, fast)
     FH_FOR_ELEM_OP(ek, op, CALL)
 #undef CALL
     return r;
@@ -345,6 +354,9 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.ggeom = c->ggeom.p;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
     a.u = c->has_u ? c->u.p : nullptr;
+    a.fast = (c->fast_ok && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) ? 1 : 0;
+    a.mu = c->uni_mu;
+    a.lambda = c->uni_lambda;
     a.noff = c->noff.p;
     a.ncols = c->ncols.p;
     a.n2e_off = c->n2e_off.p;
@@ -375,7 +387,7 @@ int read_status(fh_ctx* c, uint64_t* failed) {
 int choose_epb(fh_ctx* c, int what) {
     int best = 1;
     for (int epb = 1; epb <= 64; ++epb) {
-        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false);
+        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false, 0, c->fast_ok);
         if (b <= LDS_TARGET) best = epb; else break;
     }
     return best;
@@ -402,16 +414,6 @@ int build_partition(fh_ctx* c) {
     for (int i = 0; i < N; ++i) sum_rows += c->h_noff[i + 1] - c->h_noff[i];
     const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
     int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
-    int ub = 0;
-    for (int t = 1; t <= mb; ++t) {
-        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, t, acc, 64, true, mb);
-        if (b <= lds_target) ub = t; else break;
-    }
-    if (ub == 0) {
-        ub = 1;
-        if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, 1, acc, 64, true, mb) > LDS_LIMIT)
-            return c->fail(FH_UNSUPPORTED, "gather mode: a row block does not fit in LDS; use FH_SCATTER_ATOMIC");
-    }
     std::vector<unsigned> blk;
     blk.push_back(0);
     int i0 = 0;
@@ -427,6 +429,11 @@ int build_partition(fh_ctx* c) {
         i0 = i1;
     }
     c->nblk = (int)blk.size() - 1;
+    {   // tighten the accumulator budget to the largest block actually formed
+        long long mx = 1;
+        for (size_t b = 0; b + 1 < blk.size(); ++b) mx = std::max<long long>(mx, (long long)c->h_noff[blk[b + 1]] - c->h_noff[blk[b]]);
+        acc = (int)(S * S * mx);
+    }
     HIP_TRY(c, c->blk_off.alloc(blk.size()));
     HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, blk.data(), sizeof(unsigned) * blk.size(), hipMemcpyHostToDevice, c->stream));
     // block tables: unique element lists and packed entries (built once per pattern/partition)
@@ -449,8 +456,11 @@ int build_partition(fh_ctx* c) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
         }
+        c->has_pos = max_row < 256 && !std::getenv("FENRIS_HIP_NO_POS");
+        if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
         hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
-                           c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr);
+                           c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                           (const unsigned*)nullptr, (unsigned char*)nullptr);
         hipLaunchKernelGGL(k_hdr_counts, dim3((nblk + 256) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, nblk, counts.p);
         size_t tmpb = 0;
         HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, counts.p, uoff.p, nblk + 1, c->stream));
@@ -462,16 +472,113 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->gt_elems.alloc((size_t)total_u + 1));
         hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
-                           c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p);
+                           c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p, c->conn.p, c->ncols.p,
+                           c->has_pos ? c->gt_pos.p : (unsigned char*)nullptr);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // staging capacity: all unique elements of the largest block if that fits the LDS budget
+    std::vector<GatherHdr> hh((size_t)std::max(c->nblk, 1));
+    if (c->nblk) HIP_TRY(c, hipMemcpy(hh.data(), c->gt_hdr.p, sizeof(GatherHdr) * (size_t)c->nblk, hipMemcpyDeviceToHost));
+    int umax = 1, mmax = 1;
+    for (int b = 0; b < c->nblk; ++b) { umax = std::max(umax, hh[b].U); mmax = std::max(mmax, hh[b].m); }
+    int ub = 0;
+    if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, umax, acc, 64, true, mb, c->fast_ok) <= lds_target) {
+        ub = umax;
+    } else {
+        for (int t = 1; t <= umax; ++t) {
+            const size_t b = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, t, acc, 64, true, mb, c->fast_ok);
+            if (b <= lds_target) ub = t; else break;
+        }
+    }
+    if (ub == 0) {
+        ub = 1;
+        if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, 1, acc, 64, true, mb, c->fast_ok) > LDS_LIMIT)
+            return c->fail(FH_UNSUPPORTED, "gather mode: a row block does not fit in LDS; use FH_SCATTER_ATOMIC");
+    }
+    if (std::getenv("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] gather partition: nblk=%d nb=%d umax=%d mmax=%d acc=%d ub=%d lds=%zu B\n", c->nblk,
+                     nb_target, umax, mmax, acc, ub,
+                     layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, ub, acc, 64, true, mb, c->fast_ok));
+    // fixed-stride tables for the pipelined kernel (elements with few geometry nodes, pos table present)
+    c->has_pipe = false;
+    if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
+        const int n = c->ei.n;
+        const int ms = (mmax + 3) / 4 * 4;
+        if (umax * c->ei.ng <= 512 && ms <= 256 && ms * n <= 512 && ms <= mb && nb_target <= 254 && c->fast_ok) {
+            c->p_cs = umax * c->ei.ng;
+            c->p_ms = ms;
+            c->p_nbs = nb_target;
+            HIP_TRY(c, c->p_conn.alloc((size_t)c->nblk * c->p_cs));
+            HIP_TRY(c, c->p_ent.alloc((size_t)c->nblk * ms));
+            HIP_TRY(c, c->p_pos.alloc((size_t)c->nblk * (ms * n / 4)));
+            HIP_TRY(c, c->p_noffr.alloc((size_t)c->nblk * (nb_target + 1)));
+#define PT_LAUNCH(NGV)                                                                                                         \
+    hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(c->nblk), dim3(256), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->gt_ent.p, \
+                       c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, c->p_conn.p, c->p_ent.p, c->p_pos.p,       \
+                       c->p_noffr.p)
+            switch (c->ei.ng) {
+                case 3: PT_LAUNCH(3); break;
+                case 4: PT_LAUNCH(4); break;
+                case 8: PT_LAUNCH(8); break;
+                default: break;
+            }
+#undef PT_LAUNCH
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->has_pipe = true;
+        }
+    }
     c->g_ub = ub;
+    c->g_umax = umax;
     c->g_mb = mb;
     c->g_acc = acc;
     c->g_nb = 64;
     c->has_partition = true;
     return FH_OK;
+}
+
+template <int EK, int OP, int QC>
+int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
+    const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC).bytes();
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "pipelined gather: LDS footprint too large");
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int wgs = std::max(1, env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int grid = std::min(c->nblk, dev_cus * wgs);
+    auto kern = k_gather_pipelined<EK, OP, QC>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (std::getenv("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] pipelined gather: QC=%d lds=%zu B wgs/cu=%d grid=%d\n", QC, lds, wgs, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int EK, int OP>
+int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
+    const int qc = env_int("FENRIS_HIP_PIPE_QC", 2);
+    if (qc >= a.nq || qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);
+    if (qc >= 4) return launch_pipelined_q<EK, OP, 4>(c, a, T);
+    if (qc >= 2) return launch_pipelined_q<EK, OP, 2>(c, a, T);
+    return launch_pipelined_q<EK, OP, 1>(c, a, T);
+}
+
+int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int grid) {
+    const bool lap = c->op == FH_LAPLACE;
+    switch (c->elem_kind) {
+        case FH_HEX8: return lap ? launch_pipelined_t<FH_HEX8, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_HEX8, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_TET4: return lap ? launch_pipelined_t<FH_TET4, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_TET4, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_QUAD4: return lap ? launch_pipelined_t<FH_QUAD4, FH_LAPLACE>(c, a, T, lds, grid)
+                                  : launch_pipelined_t<FH_QUAD4, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_TRI3: return lap ? launch_pipelined_t<FH_TRI3, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_TRI3, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        default: return c->fail(FH_UNSUPPORTED, "pipelined gather: unsupported element");
+    }
 }
 
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
@@ -495,12 +602,19 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         a.gt_hdr = c->gt_hdr.p;
         a.gt_elems = c->gt_elems.p;
         a.gt_ent = c->gt_ent.p;
+        a.gt_pos = c->has_pos ? c->gt_pos.p : nullptr;
         a.nblk = c->nblk;
         a.ub = c->g_ub;
         a.mb = c->g_mb;
         a.acc_max = c->g_acc;
         a.nb_max = c->g_nb;
-        const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb);
+        const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
+        if (c->has_pipe && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+            PipeTables T{c->gt_hdr.p, c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_cs, c->p_ms, c->p_nbs};
+            a.ub = c->g_umax;  // the pipelined kernel stages every unique element of a block at once
+            c->last_kernel = "k_gather_pipelined";
+            return launch_pipelined(c, a, T, 0, 0);
+        }
         c->last_kernel = "k_assemble_matrix<gather>";
 #define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_GATHER, lds, c->nblk)
         FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
@@ -510,7 +624,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     if (overwrite) HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * nnz, c->stream));
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
-    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false);
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
     if (mode == FH_SCATTER_ATOMIC) {
         a.work_begin = 0;
@@ -756,6 +870,15 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     if (params) HIP_TRY(c, hipMemcpy(c->qparams.p, params, sizeof(double) * 2 * nq, hipMemcpyHostToDevice));
     c->h_points.assign(pts, pts + (size_t)nq * ei.d);
     c->nq = (int)nq;
+    c->fast_ok = true;
+    for (uint32_t q = 0; q < nq; ++q) c->fast_ok = c->fast_ok && (w[q] >= 0.0);
+    c->uni_mu = c->uni_lambda = 0.0;
+    if (params) {
+        c->uni_mu = params[0];
+        c->uni_lambda = params[1];
+        for (uint32_t q = 1; q < nq; ++q) c->fast_ok = c->fast_ok && params[2 * q] == params[0] && params[2 * q + 1] == params[1];
+    }
+    if (std::getenv("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
     c->has_partition = false;
     return FH_OK;
 }
@@ -923,7 +1046,7 @@ int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, doub
     a.work_end = (long long)(first + count);
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
-    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false);
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
     const int grid = (int)((count + a.epb - 1) / a.epb);
 #define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_DUMP, lds, grid)

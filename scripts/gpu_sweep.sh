@@ -13,6 +13,9 @@ run "gather NB=4 LDS=52"  FENRIS_HIP_GATHER_NB=4 FENRIS_HIP_GATHER_LDS_KB=52 $B
 run "gather NB=2 LDS=30"  FENRIS_HIP_GATHER_NB=2 FENRIS_HIP_GATHER_LDS_KB=30 $B
 run "gather NB=1 LDS=20"  FENRIS_HIP_GATHER_NB=1 FENRIS_HIP_GATHER_LDS_KB=20 $B
 run "gather NB=16 LDS=150" FENRIS_HIP_GATHER_NB=16 FENRIS_HIP_GATHER_LDS_KB=150 $B
+run "gather NB=8 LDS=78 nopipe"  FENRIS_HIP_NO_PIPE=1 FENRIS_HIP_GATHER_NB=8 FENRIS_HIP_GATHER_LDS_KB=78 $B
+run "gather NB=8 LDS=78 wgs=1"  FENRIS_HIP_PIPE_WGS_PER_CU=1 FENRIS_HIP_GATHER_NB=8 FENRIS_HIP_GATHER_LDS_KB=78 $B
+run "gather NB=12 LDS=100"  FENRIS_HIP_GATHER_NB=12 FENRIS_HIP_GATHER_LDS_KB=100 $B
 run "atomic" A=1 $B --scatter atomic
 run "colored" A=1 $B --scatter colored
 run "poisson gather" A=1 $B --operator poisson

@@ -406,9 +406,9 @@ int build_partition(fh_ctx* c) {
     unsigned max_row = 0;
     for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     // nodes per block (tunable), entry capacity per batch, accumulator budget
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 8)));  // < 256: packed in 8 bits
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 6)));  // < 256: packed in 8 bits
     const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
-    const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 78) * 1024;
+    const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     long long sum_rows = 0;
     for (int i = 0; i < N; ++i) sum_rows += c->h_noff[i + 1] - c->h_noff[i];
@@ -559,7 +559,15 @@ int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
 
 template <int EK, int OP>
 int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
-    const int qc = env_int("FENRIS_HIP_PIPE_QC", 2);
+    // staged quadrature points per chunk: the largest chunk that still lets >= 3 workgroups share a CU
+    int qc = env_int("FENRIS_HIP_PIPE_QC", 0);
+    if (qc <= 0) {
+        qc = 1;
+        for (int cand : {8, 4, 2}) {
+            const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, std::min(cand, a.nq)).bytes();
+            if (3 * lds + 1024 <= LDS_LIMIT) { qc = cand; break; }
+        }
+    }
     if (qc >= a.nq || qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);
     if (qc >= 4) return launch_pipelined_q<EK, OP, 4>(c, a, T);
     if (qc >= 2) return launch_pipelined_q<EK, OP, 2>(c, a, T);

@@ -112,10 +112,14 @@ def main():
         op, s = fa.LaplaceOperator(), 1
     asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(op)
            .with_quadrature_table(qtable).with_u(None).build())
+    if exchange is not None:
+        eng.set_active_elements(exchange.slab.active)  # numerics over own elements, pattern over own + halo
     t0 = time.perf_counter()
     nnz = eng.build_pattern()
     t_pattern = time.perf_counter() - t0
     E, N = mesh.num_elements(), mesh.num_nodes()
+    if exchange is not None:
+        E = exchange.slab.num_own_elements()
     values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
     if args.scatter == "colored":

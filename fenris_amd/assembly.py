@@ -68,6 +68,15 @@ class Engine:
         en_p = en if len(en) else np.zeros(1, dtype=np.uint64)
         self._check(self._lib.fh_set_connectivity_ragged(self._h, sdim, num_nodes, _ffi.up(eo), _ffi.up(en_p), len(eo) - 1))
 
+    def set_active_elements(self, mask):
+        """Numerics only over elements with mask != 0; the pattern still comes from all elements."""
+        if mask is None:
+            self._check(self._lib.fh_set_active_elements(self._h, None))
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert len(m) == self.num_elements()
+            self._check(self._lib.fh_set_active_elements(self._h, m.ctypes.data_as(C.c_char_p)))
+
     def set_operator(self, op_kind):
         self._check(self._lib.fh_set_operator(self._h, op_kind))
 

@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
     stage_tables<EK>(a, L, lds);
     const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
     const int U = (int)min((long long)a.epb, a.work_end - w0);
-    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
+    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = a.labels ? (int)a.labels[w0 + i] : (int)(w0 + i);
     __syncthreads();
     stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {
     stage_tables<EK>(a, L, lds);
     const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
     const int U = (int)min((long long)a.epb, a.work_end - w0);
-    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = (int)(w0 + i);
+    for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = a.labels ? (int)a.labels[w0 + i] : (int)(w0 + i);
     __syncthreads();
     stage_elements<EK, S>(a, L, lds, lds_i, U, true, lds_i + L.o_uniq);
     for (int i = tid; i < U * a.nq; i += nt)

@@ -143,6 +143,14 @@ struct fh_ctx {
     bool fast_ok = false;       // uniform parameters and non-negative weights
     double uni_mu = 0.0, uni_lambda = 0.0;
     std::vector<double> h_points;
+    // optional element mask: pattern from all elements, numerics from the active ones only
+    bool has_mask = false;
+    DevBuf<unsigned char> active;
+    DevBuf<unsigned> active_list;   // indices of active elements (element-centric kernels)
+    uint64_t num_active = 0;
+    std::vector<unsigned char> h_active;
+    DevBuf<unsigned> n2e_off_c, n2e_c;   // compute adjacency (active elements only)
+    std::vector<unsigned> h_n2e_off_c;
     // pattern
     bool has_pattern = false;
     DevBuf<unsigned> noff, ncols, n2e_off, n2e;
@@ -163,6 +171,7 @@ struct fh_ctx {
     // colours
     bool has_colors = false;
     std::vector<uint64_t> color_offsets;
+    std::vector<uint64_t> host_colors_offs, host_colors_labels;  // unfiltered colouring
     DevBuf<unsigned> labels;
     // status
     DevBuf<DevStatus> status;
@@ -202,6 +211,43 @@ void invalidate_pattern(fh_ctx* c) {
     c->nnz_nodes = 0;
 }
 
+// node -> (active element, local index) adjacency used by the owner-computes kernels when an element
+// mask is set (multi-GPU partitions: the pattern comes from own + halo elements, numerics from own ones)
+int build_compute_adjacency(fh_ctx* c) {
+    c->has_partition = false;
+    if (!c->has_mask || !c->has_pattern) return FH_OK;
+    const int N = (int)c->N;
+    hipStream_t st = c->stream;
+    ConnView cv{c->conn.p, nullptr, nullptr, c->ei.n, (long long)c->flat_len, c->active.p};
+    DevBuf<unsigned> deg, cursor;
+    DevBuf<int> flags;
+    HIP_TRY(c, deg.alloc((size_t)N + 1));
+    HIP_TRY(c, cursor.alloc((size_t)N + 1));
+    HIP_TRY(c, flags.alloc(2));
+    HIP_TRY(c, c->n2e_off_c.alloc((size_t)N + 1));
+    HIP_TRY(c, hipMemsetAsync(deg.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(int) * 2, st));
+    if (c->flat_len > 0)
+        hipLaunchKernelGGL(k_count_degree, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, deg.p, N, flags.p);
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg.p, c->n2e_off_c.p, N + 1, st));
+    DevBuf<char> tmp;
+    HIP_TRY(c, tmp.alloc(tmp_bytes + 16));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, deg.p, c->n2e_off_c.p, N + 1, st));
+    HIP_TRY(c, c->n2e_c.alloc((size_t)c->flat_len + 1));
+    if (c->flat_len > 0) {
+        hipLaunchKernelGGL(k_fill_n2e, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, c->n2e_off_c.p, cursor.p,
+                           c->n2e_c.p, N);
+        hipLaunchKernelGGL(k_sort_n2e, dim3(grid_for(N, 256, 1 << 30)), dim3(256), 0, st, c->n2e_off_c.p, c->n2e_c.p, N);
+    }
+    c->h_n2e_off_c.assign((size_t)N + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_n2e_off_c.data(), c->n2e_off_c.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
 // ---------------------------------------------------------------------------------- pattern build
 int build_pattern(fh_ctx* c) {
     if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_pattern: no mesh/connectivity set");
@@ -209,7 +255,7 @@ int build_pattern(fh_ctx* c) {
     if (c->has_pattern) return FH_OK;
     const int N = (int)c->N;
     hipStream_t st = c->stream;
-    ConnView cv{c->conn.p, c->ragged ? c->eoff.p : nullptr, c->ragged ? c->k2e.p : nullptr, c->ei.n, (long long)c->flat_len};
+    ConnView cv{c->conn.p, c->ragged ? c->eoff.p : nullptr, c->ragged ? c->k2e.p : nullptr, c->ei.n, (long long)c->flat_len, nullptr};
     DevBuf<unsigned> deg, cursor, cnt;
     DevBuf<int> flags;
     HIP_TRY(c, deg.alloc((size_t)N + 1));
@@ -266,7 +312,7 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     c->has_pattern = true;
     c->has_partition = false;
-    return FH_OK;
+    return build_compute_adjacency(c);
 }
 
 // ---------------------------------------------------------------------------------- kernel dispatch
@@ -401,6 +447,10 @@ int env_int(const char* name, int dflt) {
 
 int build_partition(fh_ctx* c) {
     if (c->has_partition) return FH_OK;
+    // adjacency that drives the numerics: all elements, or only the active ones when a mask is set
+    const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
+    const unsigned* adj_off_d = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
+    const unsigned* adj_d = c->has_mask ? c->n2e_c.p : c->n2e.p;
     const int S = c->S();
     const int N = (int)c->N;
     unsigned max_row = 0;
@@ -421,7 +471,7 @@ int build_partition(fh_ctx* c) {
         int i1 = i0 + 1;
         while (i1 < N && i1 - i0 < nb_target) {
             const long long rows = (long long)c->h_noff[i1 + 1] - c->h_noff[i0];
-            const long long ents = (long long)c->h_n2e_off[i1 + 1] - c->h_n2e_off[i0];
+            const long long ents = (long long)adj_off_h[i1 + 1] - adj_off_h[i0];
             if (S * S * rows > acc || ents > mb) break;
             ++i1;
         }
@@ -440,7 +490,7 @@ int build_partition(fh_ctx* c) {
     {
         unsigned max_m = 0;
         for (size_t b = 0; b + 1 < blk.size(); ++b)
-            max_m = std::max(max_m, c->h_n2e_off[blk[b + 1]] - c->h_n2e_off[blk[b]]);
+            max_m = std::max(max_m, adj_off_h[blk[b + 1]] - adj_off_h[blk[b]]);
         if (max_m >= 65536) return c->fail(FH_UNSUPPORTED, "gather mode: a node block has more than 65535 adjacent entries");
         const size_t tb = sizeof(int) * 3 * (size_t)std::max(1u, max_m);
         if (tb > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "gather mode: node valence too large for the table builder");
@@ -458,7 +508,7 @@ int build_partition(fh_ctx* c) {
         }
         c->has_pos = max_row < 256 && !std::getenv("FENRIS_HIP_NO_POS");
         if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
-        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
+        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                            (const unsigned*)nullptr, (unsigned char*)nullptr);
         hipLaunchKernelGGL(k_hdr_counts, dim3((nblk + 256) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, nblk, counts.p);
@@ -471,7 +521,7 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(&total_u, uoff.p + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->gt_elems.alloc((size_t)total_u + 1));
-        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, c->n2e_off.p, c->n2e.p, c->ei.n,
+        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p, c->conn.p, c->ncols.p,
                            c->has_pos ? c->gt_pos.p : (unsigned char*)nullptr);
         HIP_TRY(c, hipGetLastError());
@@ -636,8 +686,10 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
     if (mode == FH_SCATTER_ATOMIC) {
         a.work_begin = 0;
-        a.work_end = (long long)c->E;
-        const int grid = (int)((c->E + a.epb - 1) / a.epb);
+        a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+        a.labels = c->has_mask ? c->active_list.p : nullptr;
+        if (a.work_end == 0) return FH_OK;
+        const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
         c->last_kernel = "k_assemble_matrix<atomic>";
 #define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_ATOMIC, lds, grid)
         FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
@@ -682,6 +734,27 @@ static int launch_scalar(fh_ctx* c, KArgs& a, size_t lds, int grid) {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+
+static int upload_colors(fh_ctx* c, const std::vector<uint64_t>& offs, const std::vector<uint64_t>& labels) {
+    // with an element mask only the active elements of each colour are launched
+    std::vector<unsigned> l32;
+    std::vector<uint64_t> o2(1, 0);
+    l32.reserve(labels.size() + 1);
+    for (size_t col = 0; col + 1 < offs.size(); ++col) {
+        for (uint64_t k = offs[col]; k < offs[col + 1]; ++k)
+            if (!c->has_mask || c->h_active[labels[k]]) l32.push_back((unsigned)labels[k]);
+        o2.push_back(l32.size());
+    }
+    if (l32.empty()) l32.push_back(0);
+    HIP_TRY(c, c->labels.alloc(l32.size()));
+    HIP_TRY(c, hipMemcpy(c->labels.p, l32.data(), sizeof(unsigned) * l32.size(), hipMemcpyHostToDevice));
+    c->color_offsets = o2;
+    c->host_colors_offs = offs;
+    c->host_colors_labels = labels;
+    c->has_colors = true;
     return FH_OK;
 }
 
@@ -744,6 +817,7 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->E = E;
     c->flat_len = E * (uint64_t)ei.n;
     c->has_u = false;
+    c->has_mask = false;
     c->nq = 0;  // reference gradient tables depend on the element kind
     HIP_TRY(c, c->verts.alloc((size_t)N * ei.d));
     HIP_TRY(c, c->conn.alloc((size_t)c->flat_len));
@@ -845,6 +919,36 @@ int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint6
     c->has_host_conn = true;
     c->has_mesh = true;
     return FH_OK;
+}
+
+int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_active_elements: set the mesh first");
+    c->has_partition = false;
+    if (!mask) {
+        c->has_mask = false;
+        if (c->has_colors) return upload_colors(c, c->host_colors_offs, c->host_colors_labels);
+        return FH_OK;
+    }
+    c->h_active.assign(mask, mask + c->E);
+    std::vector<unsigned> list;
+    list.reserve(c->E);
+    for (uint64_t e = 0; e < c->E; ++e) {
+        c->h_active[e] = mask[e] ? 1 : 0;
+        if (mask[e]) list.push_back((unsigned)e);
+    }
+    c->num_active = list.size();
+    if (list.empty()) list.push_back(0);
+    HIP_TRY(c, c->active.alloc((size_t)c->E + 1));
+    HIP_TRY(c, c->active_list.alloc(list.size()));
+    HIP_TRY(c, hipMemcpy(c->active.p, c->h_active.data(), c->E, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->active_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice));
+    c->has_mask = true;
+    if (c->has_colors) {
+        int rc = upload_colors(c, c->host_colors_offs, c->host_colors_labels);
+        if (rc) return rc;
+    }
+    return build_compute_adjacency(c);
 }
 
 int fh_set_operator(fh_ctx* c, int op_kind) {
@@ -953,16 +1057,6 @@ int fh_pattern_cols(fh_ctx* c, uint64_t* col_indices) {
 }
 
 // ---- colouring
-static int upload_colors(fh_ctx* c, const std::vector<uint64_t>& offs, const std::vector<uint64_t>& labels) {
-    std::vector<unsigned> l32(labels.size() ? labels.size() : 1, 0);
-    for (size_t i = 0; i < labels.size(); ++i) l32[i] = (unsigned)labels[i];
-    HIP_TRY(c, c->labels.alloc(l32.size()));
-    HIP_TRY(c, hipMemcpy(c->labels.p, l32.data(), sizeof(unsigned) * l32.size(), hipMemcpyHostToDevice));
-    c->color_offsets = offs;
-    c->has_colors = true;
-    return FH_OK;
-}
-
 int fh_color(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels) {
     if (!c) return FH_BAD_ARGUMENT;
     if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_color: no connectivity set");
@@ -1077,12 +1171,14 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     fill_common(c, a);
     a.vec_out = out_dev;
     a.work_begin = 0;
-    a.work_end = (long long)c->E;
+    a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+    a.labels = c->has_mask ? c->active_list.p : nullptr;
+    if (a.work_end == 0) return read_status(c, failed);
     a.epb = choose_epb(c, WHAT_VECTOR);
     a.ub = a.epb;
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_VECTOR, c->nq, a.ub, 0, 0, false);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
-    const int grid = (int)((c->E + a.epb - 1) / a.epb);
+    const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
 #define CALL(EKC, OPC) rc = launch_vector<EKC, OPC>(c, a, lds, grid)
     FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
 #undef CALL
@@ -1118,11 +1214,13 @@ int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
     KArgs a;
     fill_common(c, a);
     a.work_begin = 0;
-    a.work_end = (long long)c->E;
+    a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+    a.labels = c->has_mask ? c->active_list.p : nullptr;
+    if (a.work_end == 0) return FH_OK;
     a.epb = 1;  // one partial per element, summed in element order on the host (global.rs:703-709)
     a.ub = 1;
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_SCALAR, c->nq, a.ub, 0, 0, false);
-    const int grid = (int)c->E;
+    const int grid = (int)a.work_end;
     DevBuf<double> partial;
     HIP_TRY(c, partial.alloc((size_t)grid));
     a.scalar_out = partial.p;

@@ -15,6 +15,7 @@ struct ConnView {
     const unsigned* k2e;    // flat index -> element (ragged only)
     int n;                  // nodes per element when eoff == null
     long long total;        // flat length
+    const unsigned char* active;  // optional per-element mask (compute adjacency); null = all elements
     __device__ __forceinline__ void elem_range(unsigned e, unsigned& b, unsigned& en) const {
         if (eoff) { b = eoff[e]; en = eoff[e + 1]; } else { b = e * (unsigned)n; en = b + (unsigned)n; }
     }
@@ -25,6 +26,7 @@ __global__ void k_count_degree(ConnView c, unsigned* deg, int num_nodes, int* ba
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
         const int node = c.nodes[k];
         if (node < 0 || node >= num_nodes) { *bad = 1; continue; }
+        if (c.active && !c.active[c.elem_of((unsigned)k)]) continue;
         atomicAdd(&deg[node], 1u);
     }
 }
@@ -33,6 +35,7 @@ __global__ void k_fill_n2e(ConnView c, const unsigned* n2e_off, unsigned* cursor
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
         const int node = c.nodes[k];
         if (node < 0 || node >= num_nodes) continue;
+        if (c.active && !c.active[c.elem_of((unsigned)k)]) continue;
         const unsigned p = atomicAdd(&cursor[node], 1u);
         n2e[n2e_off[node] + p] = (unsigned)k;
     }

@@ -1,0 +1,146 @@
+"""Multi-GPU assembly: slab partition of a structured hex mesh + exchange of interface rows.
+
+fenris itself is single-process; this is the one exchange the assembly path needs when a mesh
+is partitioned: rows of nodes on a partition interface receive contributions from the elements of two
+partitions.  One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).
+
+Partition (z-slabs, interface plane owned by the LOWER slab):
+  * rank r owns element layers [L0, L1) and the node planes (L0, L1]  (rank 0 also owns plane 0);
+  * its *extended* local mesh additionally holds one halo element layer below (if r > 0) and above
+    (if r < P-1).  The sparsity pattern is built on the extended mesh, so the rows of both interface planes
+    carry the complete GLOBAL pattern and have identical layouts on the two ranks that share them;
+  * numerics run over the own elements only (``Engine.set_active_elements``);
+  * exchange: the partial rows of the bottom ghost plane L0 go to rank r-1, which adds them to its (owned)
+    top plane -- a point-to-point transfer per interface (each rides one xGMI link; all interfaces proceed
+    concurrently), never an all-reduce over the matrix.
+Local node numbering is the global one shifted by a constant, so concatenating the owned row blocks of all
+ranks gives the single-GPU CSR (indices after the shift bit-exact, values to rounding).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .mesh import Mesh, procedural
+
+
+@dataclass
+class SlabProblem:
+    mesh: Mesh                    # extended local mesh (own + halo layers), global coordinates
+    active: np.ndarray            # uint8 per local element: 1 = own element
+    node_offset: int              # global index of local node 0
+    owned_nodes: Tuple[int, int]  # local node range [lo, hi) owned by this rank
+    send_nodes: Optional[Tuple[int, int]]  # local node range of the bottom ghost plane (to rank-1) or None
+    recv_nodes: Optional[Tuple[int, int]]  # local node range of the owned top interface plane (from rank+1)
+    rank: int
+    world: int
+
+    def num_own_elements(self):
+        return int(self.active.sum())
+
+
+def slab_layers(cells_z_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Own element layers [L0, L1) of ``rank`` -- as even as possible, lower ranks take the remainder."""
+    base, rem = divmod(cells_z_total, world)
+    l0 = rank * base + min(rank, rem)
+    return l0, l0 + base + (1 if rank < rem else 0)
+
+
+def make_slab(unit_length: float, units_x: int, units_y: int, units_z: int, cells_per_unit: int, rank: int,
+              world: int) -> SlabProblem:
+    """Slab ``rank`` of create_rectangular_uniform_hex_mesh(unit_length, units_x, units_y, units_z, cells_per_unit)."""
+    cx, cy, cz = units_x * cells_per_unit, units_y * cells_per_unit, units_z * cells_per_unit
+    if world > cz:
+        raise ValueError("more ranks than element layers")
+    l0, l1 = slab_layers(cz, rank, world)
+    e0 = l0 - (1 if rank > 0 else 0)            # first element layer of the extended mesh
+    e1 = l1 + (1 if rank < world - 1 else 0)    # one past the last
+    # extended box: same generator, then the z coordinate is re-evaluated from the GLOBAL plane index exactly
+    # like the reference generator does (T::from_usize(k) * cell_size, procedural.rs:247-251)
+    h = unit_length / cells_per_unit
+    local = _box(cx, cy, e1 - e0, h)
+    npl = (cx + 1) * (cy + 1)
+    planes = np.arange(e0, e1 + 1, dtype=np.float64)
+    local.vertices[:, 2] = np.repeat(planes * h, npl)
+    active = np.zeros(local.num_elements(), dtype=np.uint8)
+    per_layer = cx * cy
+    active[(l0 - e0) * per_layer:(l1 - e0) * per_layer] = 1
+    own_lo_plane = (l0 + 1 if rank > 0 else 0) - e0
+    own_hi_plane = l1 - e0
+    send = ((l0 - e0) * npl, (l0 - e0 + 1) * npl) if rank > 0 else None
+    recv = ((l1 - e0) * npl, (l1 - e0 + 1) * npl) if rank < world - 1 else None
+    return SlabProblem(local, active, e0 * npl, (own_lo_plane * npl, (own_hi_plane + 1) * npl), send, recv, rank, world)
+
+
+def _box(cx, cy, cz, h):
+    """cx x cy x cz cells of size h via the engine's host generator (vertex/cell order of procedural.rs:241-271)."""
+    import ctypes as C
+
+    nv, nc = (cx + 1) * (cy + 1) * (cz + 1), cx * cy * cz
+    v = np.zeros((nv, 3))
+    c = np.zeros((nc, 8), dtype=np.uint64)
+    a, b = C.c_uint64(), C.c_uint64()
+    # unit_length = h, one cell per unit: cell_size = h / 1 exactly
+    rc = _ffi.lib().fh_hex_mesh(float(h), cx, cy, cz, 1, _ffi.fp(v), _ffi.up(c), C.byref(a), C.byref(b))
+    if rc or a.value != nv or b.value != nc:
+        raise _ffi.FenrisError(rc, "slab mesh generation failed")
+    # x, y from the global generator formula as well
+    return Mesh(v, c, _ffi.HEX8)
+
+
+class InterfaceExchange:
+    """Sends the partial rows of the bottom ghost plane to rank-1 and adds the rows received from rank+1 to the
+    owned top plane.  Works on any torch tensor (CUDA with nccl, CPU with gloo)."""
+
+    def __init__(self, slab: SlabProblem, group=None):
+        self.slab, self.group = slab, group
+        self.values = None
+        self.send_seg = self.recv_seg = None
+        self.recv_buf = None
+
+    def bind_offsets(self, row_offsets: np.ndarray, solution_dim: int, values):
+        import torch
+
+        s = solution_dim
+        self.values = values
+
+        def seg(nodes):
+            return (int(row_offsets[s * nodes[0]]), int(row_offsets[s * nodes[1]])) if nodes else None
+
+        self.send_seg, self.recv_seg = seg(self.slab.send_nodes), seg(self.slab.recv_nodes)
+        if self.recv_seg:
+            self.recv_buf = torch.empty(self.recv_seg[1] - self.recv_seg[0], dtype=values.dtype, device=values.device)
+        return self
+
+    def bind(self, engine, values):
+        ro, _ = engine.pattern(want_cols=False)
+        return self.bind_offsets(ro, engine.solution_dim(), values)
+
+    def bytes_sent(self):
+        return 8 * (self.send_seg[1] - self.send_seg[0]) if self.send_seg else 0
+
+    def run(self):
+        import torch.distributed as dist
+
+        ops = []
+        if self.send_seg:
+            ops.append(dist.P2POp(dist.isend, self.values[self.send_seg[0]:self.send_seg[1]], self.slab.rank - 1, self.group))
+        if self.recv_seg:
+            ops.append(dist.P2POp(dist.irecv, self.recv_buf, self.slab.rank + 1, self.group))
+        if not ops:
+            return
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if self.recv_seg:
+            self.values[self.recv_seg[0]:self.recv_seg[1]] += self.recv_buf
+
+
+def make_slab_problem(cells: int, rank: int, world: int):
+    """bench.py weak scaling: cells x cells x (cells * world) box, one z-slab of cells^3 own elements per rank.
+    Returns (extended local mesh, exchange); the caller sets the element mask through ``exchange.slab.active``."""
+    slab = make_slab(1.0, 1, 1, world, cells, rank, world)
+    return slab.mesh, InterfaceExchange(slab)

@@ -92,6 +92,11 @@ int fh_update_vertices(fh_ctx*, const double* vertices);
  * fh_color work on such a context.  elem_offsets has num_elements+1 entries. */
 int fh_set_connectivity_ragged(fh_ctx*, uint64_t solution_dim, uint64_t num_nodes, const uint64_t* elem_offsets,
                                const uint64_t* elem_nodes, uint64_t num_elements);
+/* Restrict the NUMERIC assembly (matrix, vector, scalar) to the elements with mask[e] != 0 while the sparsity
+ * pattern keeps coming from all elements.  No reference counterpart (fenris is single-process): this is how a
+ * mesh partition assembles its own elements into rows that carry the global pattern (own + halo elements),
+ * see fenris_amd/distributed.py.  mask has num_elements bytes; NULL removes the mask. */
+int fh_set_active_elements(fh_ctx*, const uint8_t* mask);
 /* Operator: replaces .with_operator(&op) (elliptic.rs:99-108).  Solution dim s = 1 for Laplace, D else. */
 int fh_set_operator(fh_ctx*, int op_kind);
 /* UniformQuadratureTable::from_points_and_weights(points, weights).with_data / with_uniform_data

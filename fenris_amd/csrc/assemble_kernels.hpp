@@ -810,6 +810,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
                 for (int j = 0; j < D; ++j) Gr[r][i][j] = 0.0;
         for (int qc = 0; qc < a.nq; qc += QC) {
             // phase B for quadrature points [qc, qc + QC)
+            if (!(a.ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
                 const int u = i / QC, qs = i % QC;
                 if (qc + qs < a.nq)
@@ -822,7 +823,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
                 const int it = tid + r * nt;
-                if (it < m * N) {
+                if (it < m * N && !(a.ablate & 2)) {
                     const int t = it / N, Jn = it % N;
                     const unsigned packed = (unsigned)lds_i[L.o_ent + t];
                     const int u = (int)(packed >> 16);
@@ -847,7 +848,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int it = tid + r * nt;
-            if (it < m * N) {
+            if (it < m * N && !(a.ablate & 4)) {
                 const int t = it / N, Jn = it % N;
                 const unsigned packed = (unsigned)lds_i[L.o_ent + t];
                 const int an = (int)((packed >> 8) & 0xffu);
@@ -885,7 +886,8 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
         __syncthreads();
         // phase D
         double* out = a.vals + (size_t)S * S * hc.r0;
-        if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
+        if (a.ablate & 8) {
+        } else if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
         else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
         __syncthreads();
         // park the prefetched block

@@ -197,6 +197,11 @@ struct fh_ctx {
 
 namespace {
 
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
 int grid_for(long long n, int block, int cap = 256 * 32) {
     long long g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -408,6 +413,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.n2e_off = c->n2e_off.p;
     a.n2e = c->n2e.p;
     a.status = c->status.p;
+    a.ablate = env_int("FENRIS_HIP_ABLATE", 0);
 }
 
 int reset_status(fh_ctx* c) {
@@ -440,10 +446,6 @@ int choose_epb(fh_ctx* c, int what) {
 }
 
 // greedy partition of the node range into owner blocks (gather mode)
-int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : dflt;
-}
 
 int build_partition(fh_ctx* c) {
     if (c->has_partition) return FH_OK;

@@ -788,6 +788,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
     load_verts(cur);
     load_rec(b + G, nxt);
     park(cur);
+    for (int i = tid; i < a.acc_max; i += nt) acc[i] = 0.0;
     __syncthreads();
     GatherHdr hc = cur.h;
 
@@ -797,8 +798,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
         Rec nn;
         load_rec(b + 2 * G, nn);
         const int U = hc.U, m = hc.m, nrow = hc.nrow;
-        const int nacc = S * S * nrow;
-        for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
+        const int nacc = S * S * nrow;   // accumulators are zero here: cleared by the previous phase D
         // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
         // elements of the block are staged at once (U <= ub guaranteed by the host)
         double Gr[RMAX][D][D];
@@ -809,6 +809,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
 #pragma unroll
                 for (int j = 0; j < D; ++j) Gr[r][i][j] = 0.0;
         for (int qc = 0; qc < a.nq; qc += QC) {
+            if (qc > 0) __syncthreads();  // the previous chunk's phase C is done with the staged points
             // phase B for quadrature points [qc, qc + QC)
             if (!(a.ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
@@ -842,7 +843,6 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
                     }
                 }
             }
-            __syncthreads();
         }
         // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
 #pragma unroll
@@ -884,12 +884,16 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
             }
         }
         __syncthreads();
-        // phase D
+        // phase D (also clears the accumulators for the next block; no barrier needed before parking: the
+        // parked regions -- X, entries, slots, row offsets -- are not read here)
         double* out = a.vals + (size_t)S * S * hc.r0;
         if (a.ablate & 8) {
-        } else if (a.overwrite) for (int i = tid; i < nacc; i += nt) out[i] = acc[i];
-        else for (int i = tid; i < nacc; i += nt) out[i] += acc[i];
-        __syncthreads();
+            for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
+        } else if (a.overwrite) {
+            for (int i = tid; i < nacc; i += nt) { out[i] = acc[i]; acc[i] = 0.0; }
+        } else {
+            for (int i = tid; i < nacc; i += nt) { out[i] += acc[i]; acc[i] = 0.0; }
+        }
         // park the prefetched block
         if (have_next) park(nxt);
         hc = nxt.h;

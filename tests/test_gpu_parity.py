@@ -416,3 +416,65 @@ def test_full_size_properties(engine, oracle, cells, op):
     assert block.shape == oblock.shape
     assert np.abs(block - oblock).max() <= 1e-11 * np.abs(oblock).max()
     eng.close()
+
+
+# ------------------------------------------------------------------------------------ end-to-end golden (MMS)
+@pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad4_summary", "QUAD4", 5),
+                                            ("poisson3d_mms_hex8_summary", "HEX8", 4),
+                                            ("poisson3d_mms_tet4_summary", "TET4", 3)])
+def test_mms_errors_with_gpu_assembled_matrix(engine, oracle, name, kind, nres):
+    """tests/convergence_tests/poisson_{2d,3d}_mms.rs + reference_values/*.json (tolerance 1 %,
+    poisson_mms_common.rs:40-65): the stiffness matrix comes from the HIP engine (owner-computes kernel),
+    Dirichlet rows/columns are applied on the device, the source vector / solve / error norms are the
+    numpy/scipy restatement used to pin the oracle."""
+    import json
+    import os
+
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+
+    from conftest import GOLDEN
+
+    ref = json.load(open(os.path.join(GOLDEN, "mms_reference_values.json")))["summaries"][name]
+    okind = getattr(oracle, kind)
+    if kind == "QUAD4":
+        gen, rule, err_rule = fa.procedural.create_unit_square_uniform_quad_mesh_2d, quadrature.tensor.quadrilateral_gauss(2), oracle.quadrilateral_gauss(6)
+    elif kind == "HEX8":
+        gen, rule, err_rule = fa.procedural.create_unit_box_uniform_hex_mesh_3d, quadrature.tensor.hexahedron_gauss(2), oracle.hexahedron_gauss(6)
+    else:
+        t = json.load(open(os.path.join(GOLDEN, "tet_rule_6_24.json")))
+        gen, rule, err_rule = (fa.procedural.create_unit_box_uniform_tet_mesh_3d, quadrature.total_order.tetrahedron(0),
+                               (np.array(t["weights"]), np.array(t["points"])))
+    for i, res in enumerate([1, 2, 4, 8, 16][:nres]):
+        mesh = gen(res)
+        w, p = rule
+        v, c = mesh.vertices, mesh.connectivity
+        d = v.shape[1]
+        N = len(v)
+        asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(fa.LaplaceOperator())
+               .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w)).with_u(np.zeros(N)).build())
+        k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm, device_values=True)
+        bc = np.where(np.abs(v - 0.5).max(axis=1) > 0.4999)[0]
+        fa.apply_homogeneous_dirichlet_bc_csr(k, bc, 1, asm)
+        A = k.to_scipy()
+        u_exact = lambda x: np.prod(np.sin(np.pi * x), axis=-1)
+        b = np.zeros(N)
+        ci = c.astype(int)
+        for e in range(len(c)):
+            X = v[ci[e]]
+            for wq, xi in zip(w, p):
+                J = X.T @ oracle.element_gradients(okind, xi).T
+                x = oracle.element_basis(okind, xi) @ X
+                b[ci[e]] += wq * abs(np.linalg.det(J)) * (d * np.pi ** 2 * u_exact(x)) * oracle.element_basis(okind, xi)
+        b[bc] = 0.0
+        u_h = spla.spsolve(A.tocsc(), b)
+        l2 = 0.0
+        for e in range(len(c)):
+            X = v[ci[e]]
+            for wq, xi in zip(*err_rule):
+                J = X.T @ oracle.element_gradients(okind, xi).T
+                x = oracle.element_basis(okind, xi) @ X
+                l2 += wq * abs(np.linalg.det(J)) * (oracle.element_basis(okind, xi) @ u_h[ci[e]] - u_exact(x)) ** 2
+        l2 = np.sqrt(l2)
+        assert abs(l2 - ref["L2_errors"][i]) / ref["L2_errors"][i] < 0.01, (res, l2, ref["L2_errors"][i])

@@ -731,13 +731,13 @@ struct PipeTables {
     int cs, ms, nbs;
 };
 
-template <int EK, int OP, int QC>
-__global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const PipeTables T) {
+template <int EK, int OP, int QC, int JT>
+__global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
+    // JT = local nodes J handled per lane in phase C
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
     constexpr int SLOTS = 2;  // geometry-node slots per thread: U * NG <= 512
-    constexpr int RMAX = 2;   // (entry, local node) items per thread: m * N <= 512
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC);
     double* lds = reinterpret_cast<double*>(smem);
@@ -748,10 +748,13 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
     const int G = gridDim.x, nblk = a.nblk;
     stage_tables<EK>(a, L, lds);
 
-    struct Rec { GatherHdr h; int conn[SLOTS]; unsigned ent, posw; int noffr; };
+    // Prefetch state per thread: one header word (threads 0..7), SLOTS geometry-node indices, one packed entry,
+    // one word of column slots, one relative row offset.  Headers are parked in LDS (double-buffered by block
+    // parity) and read back as wave-uniform values, so they cost one VGPR instead of eight.
+    struct Rec { int hword; int conn[SLOTS]; unsigned ent, posw; int noffr; };
     auto load_rec = [&](int b, Rec& r) {
         b = min(b, nblk - 1);
-        r.h = T.hdr[b];
+        r.hword = (tid < 8) ? reinterpret_cast<const int*>(T.hdr + b)[tid] : 0;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int sidx = tid + k * nt;
@@ -768,14 +771,16 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
 #pragma unroll
             for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
     };
-    auto park = [&](const Rec& r) {  // registers -> LDS for the block that is computed next
+    int* hdr_lds = lds_i + L.o_uniq;  // the unique-element list is not staged by this kernel: reuse its slot (>= 16 ints)
+    auto park = [&](const Rec& r, int parity) {  // registers -> LDS for the block that is computed next
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int sidx = tid + k * nt;
-            if (sidx < r.h.U * NG)
+            if (sidx < T.cs)  // padded slots carry vertex 0: harmless
 #pragma unroll
                 for (int c = 0; c < D; ++c) lds[L.o_X + sidx * D + c] = V[k][c];
         }
+        if (tid < 8) hdr_lds[8 * parity + tid] = r.hword;
         if (tid < T.ms) lds_i[L.o_ent + tid] = (int)r.ent;
         if (tid < T.ms * N / 4) pos_lds[tid] = r.posw;
         if (tid <= T.nbs) lds_i[L.o_noff + tid] = r.noffr;
@@ -783,31 +788,45 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
 
     int b = blockIdx.x;
     if (b >= nblk) return;
-    Rec cur, nxt;
-    load_rec(b, cur);
-    load_verts(cur);
-    load_rec(b + G, nxt);
-    park(cur);
+    Rec nxt;
+    {
+        Rec cur;
+        load_rec(b, cur);
+        load_verts(cur);
+        load_rec(b + G, nxt);
+        park(cur, 0);
+    }
     for (int i = tid; i < a.acc_max; i += nt) acc[i] = 0.0;
     __syncthreads();
-    GatherHdr hc = cur.h;
 
-    for (; b < nblk; b += G) {
+    int parity = 0;
+    for (; b < nblk; b += G, parity ^= 1) {
         const bool have_next = (b + G) < nblk;
         if (have_next) load_verts(nxt);      // lands while this block is computed
         Rec nn;
         load_rec(b + 2 * G, nn);
+        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
         const int U = hc.U, m = hc.m, nrow = hc.nrow;
         const int nacc = S * S * nrow;   // accumulators are zero here: cleared by the previous phase D
         // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
-        // elements of the block are staged at once (U <= ub guaranteed by the host)
-        double Gr[RMAX][D][D];
+        // elements of the block are staged at once (U <= ub guaranteed by the host).  One lane owns an entry
+        // (node, element, local index a) and JT consecutive local nodes J: h_a is read once per point for JT
+        // blocks (LDS traffic, not VALU, bounds this kernel).
+        constexpr int NGRP = (JT <= N) ? N / JT : 1;
+        double Gr[JT][D][D];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
+        for (int r = 0; r < JT; ++r)
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
                 for (int j = 0; j < D; ++j) Gr[r][i][j] = 0.0;
+        const bool has_item = tid < m * NGRP;
+        const int t_item = tid / NGRP, j0 = (tid % NGRP) * JT;
+        unsigned packed = 0;
+        if (has_item) packed = (unsigned)lds_i[L.o_ent + t_item];
+        const int u_item = (int)(packed >> 16);
+        const int an = (int)((packed >> 8) & 0xffu);
+        const int il = (int)(packed & 0xffu);
         for (int qc = 0; qc < a.nq; qc += QC) {
             if (qc > 0) __syncthreads();  // the previous chunk's phase C is done with the staged points
             // phase B for quadrature points [qc, qc + QC)
@@ -821,21 +840,18 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
             __syncthreads();
             // phase C (accumulate)
             const int nqc = min(QC, a.nq - qc);
+            if (has_item && !(a.ablate & 2)) {
+                const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
+                for (int q = 0; q < nqc; ++q, pq += L.qpd) {
+                    double av[D];
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                const int it = tid + r * nt;
-                if (it < m * N && !(a.ablate & 2)) {
-                    const int t = it / N, Jn = it % N;
-                    const unsigned packed = (unsigned)lds_i[L.o_ent + t];
-                    const int u = (int)(packed >> 16);
-                    const int an = (int)((packed >> 8) & 0xffu);
-                    const int I = min(an, Jn), J = max(an, Jn);
-                    const double* pa = lds + L.o_QP + (size_t)u * QC * L.qpd + I * D;
-                    const double* pb = lds + L.o_QP + (size_t)u * QC * L.qpd + J * D;
-                    for (int q = 0; q < nqc; ++q, pa += L.qpd, pb += L.qpd) {
-                        double av[D], bv[D];
+                    for (int i = 0; i < D; ++i) av[i] = pq[an * D + i];
 #pragma unroll
-                        for (int i = 0; i < D; ++i) { av[i] = pa[i]; bv[i] = pb[i]; }
+                    for (int r = 0; r < JT; ++r) {
+                        double bv[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) bv[i] = pq[(j0 + r) * D + i];
+                        // G[r] = h_a h_J^T; the (min, max)-role block is G or its transpose (same products)
 #pragma unroll
                         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -845,42 +861,38 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
             }
         }
         // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
+        if (has_item && !(a.ablate & 4)) {
+            const int rb = lds_i[L.o_noff + il], cnt = lds_i[L.o_noff + il + 1] - rb;
+            const unsigned char* pos_b = reinterpret_cast<const unsigned char*>(pos_lds);
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int it = tid + r * nt;
-            if (it < m * N && !(a.ablate & 4)) {
-                const int t = it / N, Jn = it % N;
-                const unsigned packed = (unsigned)lds_i[L.o_ent + t];
-                const int an = (int)((packed >> 8) & 0xffu);
-                const int il = (int)(packed & 0xffu);
-                const bool swap = an > Jn;
-                double blk[S][S];
+            for (int r = 0; r < JT; ++r) {
+                const int Jn = j0 + r;
+                // value for (row comp i of node a, col comp j of node J): the block of the ordered pair
+                // (min, max) is  mu (tr I + Gm^T) + lambda Gm  with Gm = G (a < J) or G^T (a > J); read through
+                // the transpose when a > J, so  out[i][j] = mu (tr d_ij + G[i][j]... ) is written directly:
+                //   a <= J: out[i][j] = mu (tr d_ij + G[j][i]) + lambda G[i][j]
+                //   a >  J: out[i][j] = blk_(J,a)[j][i] = mu (tr d_ij + Gm[i][j]) + lambda Gm[j][i], Gm = G^T
+                //                     = mu (tr d_ij + G[j][i]) + lambda G[i][j]      (same expression)
                 double tr = 0.0;
 #pragma unroll
                 for (int i = 0; i < D; ++i) tr += Gr[r][i][i];
+                const int pos = (int)pos_b[t_item * N + Jn];
+                double* base = acc + S * S * rb + S * pos;
                 if (OP == FH_LAPLACE) {
-                    blk[0][0] = tr;
+                    atomic_add_f64(base, tr);
                 } else {
 #pragma unroll
                     for (int i = 0; i < D; ++i)
 #pragma unroll
-                        for (int j = 0; j < D; ++j)
-                            blk[i % S][j % S] = a.mu * ((i == j ? tr : 0.0) + Gr[r][j][i]) + a.lambda * Gr[r][i][j];
+                        for (int j = 0; j < D; ++j) {
+                            // diagonal block: mirror the upper triangle (util.rs:46-50); both candidates use
+                            // compile-time register indices (a runtime index would push Gr to scratch)
+                            const double v_ij = a.mu * ((i == j ? tr : 0.0) + Gr[r][j][i]) + a.lambda * Gr[r][i][j];
+                            const double v_ji = a.mu * ((i == j ? tr : 0.0) + Gr[r][i][j]) + a.lambda * Gr[r][j][i];
+                            const double v = (an == Jn && i > j) ? v_ji : v_ij;
+                            atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
+                        }
                 }
-                if (an == Jn) {
-#pragma unroll
-                    for (int i = 0; i < S; ++i)
-#pragma unroll
-                        for (int j = 0; j < S; ++j)
-                            if (i > j) blk[i][j] = blk[j][i];
-                }
-                const int rb = lds_i[L.o_noff + il], cnt = lds_i[L.o_noff + il + 1] - rb;
-                const int pos = (int)((pos_lds[it >> 2] >> (8 * (it & 3))) & 0xffu);
-                double* base = acc + S * S * rb + S * pos;
-#pragma unroll
-                for (int i = 0; i < S; ++i)
-#pragma unroll
-                    for (int j = 0; j < S; ++j) atomic_add_f64(base + i * S * cnt + j, swap ? blk[j][i] : blk[i][j]);
             }
         }
         __syncthreads();
@@ -895,8 +907,7 @@ __global__ void __launch_bounds__(256) k_gather_pipelined(const KArgs a, const P
             for (int i = tid; i < nacc; i += nt) { out[i] += acc[i]; acc[i] = 0.0; }
         }
         // park the prefetched block
-        if (have_next) park(nxt);
-        hc = nxt.h;
+        if (have_next) park(nxt, parity ^ 1);
         nxt = nn;
         __syncthreads();
     }

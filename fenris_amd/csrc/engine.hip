@@ -163,7 +163,7 @@ struct fh_ctx {
     // fixed-stride tables of the pipelined gather kernel
     DevBuf<int> p_conn, p_noffr;
     DevBuf<unsigned> p_ent, p_pos;
-    int p_cs = 0, p_ms = 0, p_nbs = 0;
+    int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1;
     bool has_pipe = false;
     DevBuf<GatherHdr> gt_hdr;
     int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0, g_umax = 0;
@@ -458,7 +458,7 @@ int build_partition(fh_ctx* c) {
     unsigned max_row = 0;
     for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     // nodes per block (tunable), entry capacity per batch, accumulator budget
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 6)));  // < 256: packed in 8 bits
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 7)));  // < 256: packed in 8 bits
     const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
     const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
@@ -557,7 +557,12 @@ int build_partition(fh_ctx* c) {
     if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
         const int n = c->ei.n;
         const int ms = (mmax + 3) / 4 * 4;
-        if (umax * c->ei.ng <= 512 && ms <= 256 && ms * n <= 512 && ms <= mb && nb_target <= 254 && c->fast_ok) {
+        // local nodes per lane in the pipelined kernel's phase C
+        int jt = env_int("FENRIS_HIP_PIPE_JT", (n % 2 == 0) ? 2 : n);
+        if (jt != 1 && jt != 2 && jt != 4 && jt != n) jt = 1;
+        if (n % jt != 0) jt = 1;
+        c->p_jt = jt;
+        if (umax * c->ei.ng <= 512 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb && nb_target <= 254 && c->fast_ok) {
             c->p_cs = umax * c->ei.ng;
             c->p_ms = ms;
             c->p_nbs = nb_target;
@@ -590,8 +595,8 @@ int build_partition(fh_ctx* c) {
     return FH_OK;
 }
 
-template <int EK, int OP, int QC>
-int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
+template <int EK, int OP, int QC, int JT>
+int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC).bytes();
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "pipelined gather: LDS footprint too large");
     int dev_cus = 256;
@@ -599,25 +604,36 @@ int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int wgs = std::max(1, env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     const int grid = std::min(c->nblk, dev_cus * wgs);
-    auto kern = k_gather_pipelined<EK, OP, QC>;
+    auto kern = k_gather_pipelined<EK, OP, QC, JT>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("FENRIS_HIP_VERBOSE"))
-        std::fprintf(stderr, "[fenris_hip] pipelined gather: QC=%d lds=%zu B wgs/cu=%d grid=%d\n", QC, lds, wgs, grid);
+        std::fprintf(stderr, "[fenris_hip] pipelined gather: QC=%d JT=%d lds=%zu B wgs/cu=%d grid=%d\n", QC, JT, lds, wgs, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
     HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }
 
+template <int EK, int OP, int QC>
+int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
+    constexpr int N = ElemT<EK>::N;
+    const int jt = c->p_jt;
+    if (N % 4 == 0 && jt == 4) return launch_pipelined_j<EK, OP, QC, 4>(c, a, T);
+    if (N % 2 == 0 && jt == 2) return launch_pipelined_j<EK, OP, QC, 2>(c, a, T);
+    if (jt == N) return launch_pipelined_j<EK, OP, QC, N>(c, a, T);
+    return launch_pipelined_j<EK, OP, QC, 1>(c, a, T);
+}
+
 template <int EK, int OP>
 int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
-    // staged quadrature points per chunk: the largest chunk that still lets >= 3 workgroups share a CU
+    // staged quadrature points per chunk: the largest chunk that still lets >= 2 workgroups share a CU
+    // (measured on Hex8: profiles/r01_sweep_128_pipelined_nb_qc_jt.txt)
     int qc = env_int("FENRIS_HIP_PIPE_QC", 0);
     if (qc <= 0) {
         qc = 1;
         for (int cand : {8, 4, 2}) {
             const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, std::min(cand, a.nq)).bytes();
-            if (3 * lds + 1024 <= LDS_LIMIT) { qc = cand; break; }
+            if (2 * lds + 1024 <= LDS_LIMIT) { qc = cand; break; }
         }
     }
     if (qc >= a.nq || qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);

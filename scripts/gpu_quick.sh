@@ -5,9 +5,6 @@ run() { echo "== $1" >> gpurun_out/quick.log; shift
 }
 B="timeout 300 python bench.py --steps 5 --warmup 2 --cells 128 --no-cpu-baseline"
 run "default" A=1 $B
-for nb in 4 6 8; do for qc in 2 4 8; do run "NB=$nb QC=$qc" FENRIS_HIP_GATHER_NB=$nb FENRIS_HIP_PIPE_QC=$qc $B; done; done
+for jt in 1 2 4; do for nb in 6 8 12; do for qc in 4 8; do run "JT=$jt NB=$nb QC=$qc" FENRIS_HIP_PIPE_JT=$jt FENRIS_HIP_GATHER_NB=$nb FENRIS_HIP_PIPE_QC=$qc $B; done; done; done
 run "poisson default" A=1 $B --operator poisson
-run "poisson NB=8 QC=8" FENRIS_HIP_GATHER_NB=8 FENRIS_HIP_PIPE_QC=8 $B --operator poisson
-run "v1 gather" FENRIS_HIP_NO_PIPE=1 $B
-run "atomic" A=1 $B --scatter atomic
 cat gpurun_out/tests.log gpurun_out/quick.log

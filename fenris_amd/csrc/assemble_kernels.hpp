@@ -537,6 +537,26 @@ __device__ __forceinline__ int find_col_lds(const int* cols, int cnt, int j) {
     return lo;
 }
 
+// explicit LDS fetch of one double (ds_read_b64).  The generic address of an LDS object carries the LDS byte
+// offset in its low 32 bits.  Callers must call lds_wait_all() before using the values.
+template <int OFF_BYTES>
+__device__ __forceinline__ double lds_read_f64(const double* p) {
+    double v;
+    const unsigned addr = (unsigned)(unsigned long long)p;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+template <int D>
+__device__ __forceinline__ void lds_read_vec(const double* p, double (&v)[D]) {
+    v[0] = lds_read_f64<0>(p);
+    v[1] = lds_read_f64<8>(p);
+    if (D == 3) v[D - 1] = lds_read_f64<16>(p);
+}
+__device__ __forceinline__ void lds_wait_all() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // keep consumers below the wait (cdna_hip_programming.md rule 18)
+}
+
 template <int MODE> __device__ __forceinline__ void add_value(double* p, double v) {
     if (MODE == MODE_ATOMIC) atomic_add_f64(p, v);
     else *p += v;  // colours are disjoint: plain read-modify-write (paradis lib.rs:258-278)
@@ -843,14 +863,20 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
             if (has_item && !(a.ablate & 2)) {
                 const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
                 for (int q = 0; q < nqc; ++q, pq += L.qpd) {
-                    double av[D];
+                    // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours
+                    // into ds_read2_b64, which costs 8 cycles for the same 16 bytes (MI355X_MICROARCH.md, LDS
+                    // table), and the LDS pipe -- shared by the CU's four SIMDs -- is what bounds this loop.
+                    // asm loads are invisible to the compiler's waitcnt insertion: wait + sched_barrier below.
+                    double av[D], bvv[JT][D];
+                    lds_read_vec<D>(pq + an * D, av);
 #pragma unroll
-                    for (int i = 0; i < D; ++i) av[i] = pq[an * D + i];
+                    for (int r = 0; r < JT; ++r) lds_read_vec<D>(pq + (j0 + r) * D, bvv[r]);
+                    lds_wait_all();
 #pragma unroll
                     for (int r = 0; r < JT; ++r) {
                         double bv[D];
 #pragma unroll
-                        for (int i = 0; i < D; ++i) bv[i] = pq[(j0 + r) * D + i];
+                        for (int i = 0; i < D; ++i) bv[i] = bvv[r][i];
                         // G[r] = h_a h_J^T; the (min, max)-role block is G or its transpose (same products)
 #pragma unroll
                         for (int i = 0; i < D; ++i)

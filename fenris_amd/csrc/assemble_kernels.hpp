@@ -94,6 +94,30 @@ __device__ __forceinline__ void inv_small(const double (&m)[3][3], double det, d
     o[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * r;
 }
 
+// explicit LDS fetch of one double (ds_read_b64).  The generic address of an LDS object carries the LDS byte
+// offset in its low 32 bits.  Callers must call lds_wait_all() before using the values.
+template <int OFF_BYTES>
+__device__ __forceinline__ double lds_read_f64(const double* p) {
+    double v;
+    const unsigned addr = (unsigned)(unsigned long long)p;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+template <int D>
+__device__ __forceinline__ void lds_read_vec(const double* p, double (&v)[D]) {
+    v[0] = lds_read_f64<0>(p);
+    v[1] = lds_read_f64<8>(p);
+    if (D == 3) v[D - 1] = lds_read_f64<16>(p);
+}
+// wait until at most PENDING LDS operations of this wave are outstanding (they complete in order)
+template <int PENDING>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+    __builtin_amdgcn_sched_barrier(0);  // keep consumers below the wait (cdna_hip_programming.md rule 18)
+}
+__device__ __forceinline__ void lds_wait_all() { lds_wait<0>(); }
+
+
 // ------------------------------------------------------------------------------------------ phase B
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
 template <int EK, int OP, int WHAT>
@@ -115,12 +139,33 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
         for (int j = 0; j < D; ++j) J[i][j] = 0.0;
     constexpr int UNR = (N <= 8) ? N : 3;
+    constexpr bool EXPLICIT_LDS = (N <= 8);  // hand-issued ds_read_b64 (see lds_read_f64): small elements only
+    if (EXPLICIT_LDS) {
+        // software-pipelined: the fetches of node g+1 are in flight while node g is accumulated
+        double xb[2][D], gb[2][D];
+        lds_read_vec<D>(X, xb[0]);
+        lds_read_vec<D>(gg, gb[0]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+                lds_read_vec<D>(X + (g + 1) * D, xb[(g + 1) & 1]);
+                lds_read_vec<D>(gg + (g + 1) * D, gb[(g + 1) & 1]);
+                lds_wait<2 * D>();
+            } else {
+                lds_wait<0>();
+            }
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+            for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) J[i][j] = fma(X[g * D + i], gg[g * D + j], J[i][j]);
+                for (int j = 0; j < D; ++j) J[i][j] = fma(xb[g & 1][i], gb[g & 1][j], J[i][j]);
+        }
+    } else {
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) J[i][j] = fma(X[g * D + i], gg[g * D + j], J[i][j]);
+    }
     const double detJ = det_small<D>(J);
     double Ji[D][D];
     if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
@@ -148,14 +193,29 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     // FAST path (Laplace / uniform linear elasticity, non-negative weights): store sqrt(s) g_n so that
     // sum_q s g_I g_J^T = sum_q h_I h_J^T needs no per-point coefficient in phase C
     const double fast_scale = (WHAT == WHAT_MATRIX && L.fast) ? sqrt(s) : 1.0;
+    double rb[2][D];
+    if (EXPLICIT_LDS) lds_read_vec<D>(gr, rb[0]);
 #pragma unroll UNR
     for (int n = 0; n < N; ++n) {
-        double g[D];
+        double g[D], rv[D];
+        if (EXPLICIT_LDS) {
+            if (n + 1 < N) {
+                lds_read_vec<D>(gr + (n + 1) * D, rb[(n + 1) & 1]);
+                lds_wait<D>();
+            } else {
+                lds_wait<0>();
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) rv[k] = rb[n & 1][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) rv[k] = gr[n * D + k];
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) t = fma(Ji[k][i], gr[n * D + k], t);
+            for (int k = 0; k < D; ++k) t = fma(Ji[k][i], rv[k], t);
             g[i] = t;
         }
         if (WHAT != WHAT_SCALAR) {
@@ -535,26 +595,6 @@ __device__ __forceinline__ int find_col_lds(const int* cols, int cnt, int j) {
         if (cols[mid] < j) lo = mid + 1; else hi = mid;
     }
     return lo;
-}
-
-// explicit LDS fetch of one double (ds_read_b64).  The generic address of an LDS object carries the LDS byte
-// offset in its low 32 bits.  Callers must call lds_wait_all() before using the values.
-template <int OFF_BYTES>
-__device__ __forceinline__ double lds_read_f64(const double* p) {
-    double v;
-    const unsigned addr = (unsigned)(unsigned long long)p;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
-    return v;
-}
-template <int D>
-__device__ __forceinline__ void lds_read_vec(const double* p, double (&v)[D]) {
-    v[0] = lds_read_f64<0>(p);
-    v[1] = lds_read_f64<8>(p);
-    if (D == 3) v[D - 1] = lds_read_f64<16>(p);
-}
-__device__ __forceinline__ void lds_wait_all() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // keep consumers below the wait (cdna_hip_programming.md rule 18)
 }
 
 template <int MODE> __device__ __forceinline__ void add_value(double* p, double v) {

@@ -626,17 +626,19 @@ int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
 
 template <int EK, int OP>
 int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
-    // staged quadrature points per chunk: the largest chunk that still lets >= 2 workgroups share a CU
-    // (measured on Hex8: profiles/r01_sweep_128_pipelined_nb_qc_jt.txt)
+    // staged quadrature points per chunk: the largest chunk (not larger than the rule) that still lets >= 2
+    // workgroups share a CU (measured on Hex8: profiles/r01_sweep_128_pipelined_nb_qc_jt.txt)
     int qc = env_int("FENRIS_HIP_PIPE_QC", 0);
     if (qc <= 0) {
         qc = 1;
         for (int cand : {8, 4, 2}) {
-            const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, std::min(cand, a.nq)).bytes();
+            if (cand > a.nq && cand > 1 && cand / 2 >= a.nq) continue;  // would stage empty slots
+            const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, cand).bytes();
             if (2 * lds + 1024 <= LDS_LIMIT) { qc = cand; break; }
         }
     }
-    if (qc >= a.nq || qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);
+    if (a.nq == 1) qc = 1;
+    if (qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);
     if (qc >= 4) return launch_pipelined_q<EK, OP, 4>(c, a, T);
     if (qc >= 2) return launch_pipelined_q<EK, OP, 2>(c, a, T);
     return launch_pipelined_q<EK, OP, 1>(c, a, T);

@@ -478,3 +478,49 @@ def test_mms_errors_with_gpu_assembled_matrix(engine, oracle, name, kind, nres):
                 l2 += wq * abs(np.linalg.det(J)) * (oracle.element_basis(okind, xi) @ u_h[ci[e]] - u_exact(x)) ** 2
         l2 = np.sqrt(l2)
         assert abs(l2 - ref["L2_errors"][i]) / ref["L2_errors"][i] < 0.01, (res, l2, ref["L2_errors"][i])
+
+
+# ------------------------------------------------------------------------------------ edge cases
+def test_isolated_vertices_and_empty_mesh(engine, oracle):
+    """Vertices that belong to no element give empty CSR rows (like the reference: node_sets stay empty,
+    global.rs:69-93); a mesh without elements assembles to nothing."""
+    base = _mesh("HEX8", distort=True)
+    extra = np.array([[5.0, 5.0, 5.0], [6.0, 5.0, 5.0]])
+    v = np.vstack([base.vertices[:10], extra, base.vertices[10:]])
+    remap = np.concatenate([np.arange(10), np.arange(10, len(base.vertices)) + 2]).astype(np.uint64)
+    mesh = fa.Mesh(v, remap[base.connectivity.astype(int)], fa.HEX8)
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_COLORED, fa.SCATTER_GATHER):
+        asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", mesh=mesh)
+        st, _, oro, oci, ovals = oracle.assemble(ref)
+        assert st == 0
+        k = fa.CsrAssembler(scatter).assemble(asm)
+        assert np.array_equal(k.row_offsets, oro) and np.array_equal(k.col_indices, oci)
+        assert oro[3 * 10] == oro[3 * 12]  # the two isolated vertices own empty rows
+        assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+    empty = fa.Mesh(base.vertices, np.zeros((0, 8), dtype=np.uint64), fa.HEX8)
+    w, p = _rule("HEX8")
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(empty).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w)).with_u(None).build())
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert len(k.values) == 0 and k.row_offsets.tolist() == [0] * (len(base.vertices) + 1)
+    assert fa.VectorAssembler().assemble_vector(asm).tolist() == [0.0] * len(base.vertices)
+    assert fa.assemble_scalar(asm) == 0.0
+
+
+def test_pipelined_kernel_is_the_one_measured(engine, oracle):
+    """The headline kernel (k_gather_pipelined) must be the code path that the parity tests cover."""
+    mesh = fa.procedural.create_unit_box_uniform_hex_mesh_3d(12)
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", mesh=mesh)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert asm.engine.last_kernel_name() == "k_gather_pipelined"
+    assert np.array_equal(k.col_indices, oci)
+    assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+    # distorted (non-affine) elements and the Tet4 / Quad4 instantiations of the same kernel
+    for kind in ("HEX8", "TET4", "QUAD4", "TRI3"):
+        for op in ("LAPLACE", "LINEAR_ELASTIC"):
+            asm, ref = _pair(engine, oracle, kind, op)
+            st, _, oro, oci, ovals = oracle.assemble(ref)
+            k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert asm.engine.last_kernel_name() == "k_gather_pipelined", (kind, op)
+            assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), (kind, op)

@@ -86,10 +86,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # FENRIS_BENCH_SHARE_DEVICE=1 (validation only): all ranks on cuda:0 over gloo -- lets the N > 1 code path be
+    # exercised on a single-GPU box; never used for reported numbers
+    share = os.environ.get("FENRIS_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic input: this rank's slab of the 216 x 216 x (216 world) box
     cells = args.cells

@@ -524,3 +524,88 @@ def test_pipelined_kernel_is_the_one_measured(engine, oracle):
             k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
             assert asm.engine.last_kernel_name() == "k_gather_pipelined", (kind, op)
             assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), (kind, op)
+
+
+def test_full_size_tet4_elasticity_properties(engine, oracle):
+    """BASELINE config C3 (Tet4 linear elasticity, BCC res 75, vertices and elements permuted) at full size:
+    closed-form nnz, owner-computes == atomic == coloured, rigid translations in the null space, and the row
+    block of one interior lattice node equals the oracle's on a small BCC mesh with the same cell size."""
+    import torch
+
+    res = 75
+    m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(res)
+    rng = np.random.Generator(np.random.MT19937(12345))
+    vp = rng.permutation(m.num_nodes())
+    inv = np.empty_like(vp)
+    inv[vp] = np.arange(len(vp))
+    mesh = fa.Mesh(m.vertices[vp], inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64), fa.TET4)
+    w, p = quadrature.total_order.tetrahedron(1)
+    eng = fa.Engine(0)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(LAME)
+    (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(OPS["LINEAR_ELASTIC"]())
+     .with_quadrature_table(qt).with_u(None).build())
+    nnz = eng.build_pattern()
+    assert nnz == 9 * (30 * res ** 3 + 21 * res ** 2 + 9 * res + 1)  # SURVEY.md 8, config table
+    ro, _ = eng.pattern(want_cols=False)
+    vals = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    eng.assemble_matrix(vals, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    scale = float(vals.abs().max())
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_COLORED):
+        v2 = torch.zeros_like(vals)
+        if scatter == fa.SCATTER_COLORED:
+            eng.color()
+        eng.assemble_matrix(v2, scatter)
+        assert float((vals - v2).abs().max()) <= 1e-12 * scale
+    ro_t = torch.from_numpy(ro.astype(np.int64)).cuda()
+    R = len(ro) - 1
+    row_id = torch.repeat_interleave(torch.arange(R, device="cuda"), ro_t[1:] - ro_t[:-1])
+    local = torch.arange(nnz, device="cuda") - ro_t[row_id]
+    for comp in range(3):
+        sums = torch.zeros(R, dtype=torch.float64, device="cuda").index_add_(0, row_id, vals * (local % 3 == comp))
+        assert float(sums.abs().max()) <= 1e-10 * scale
+    # interior lattice node (37,40,33) of the generator numbering -> permuted index; compare its diagonal block and
+    # row sum of squares with the centre lattice node of a 4^3-cell oracle mesh of equal cell size
+    h = 1.0 / res
+    small = fa.procedural.create_rectangular_uniform_tet_mesh(4 * h, 1, 1, 1, 4)
+    ref = oracle.ElementAssembler(oracle.TET4, oracle.LINEAR_ELASTIC, small.vertices, small.connectivity, w, p, params=LAME.as_pair())
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    c = 2 + 5 * 2 + 25 * 2
+    oblock = np.sort(ovals[int(oro[3 * c]): int(oro[3 * c + 3])])
+    node = int(inv[37 + 76 * 40 + 76 * 76 * 33])
+    block = np.sort(vals[int(ro[3 * node]): int(ro[3 * node + 3])].cpu().numpy())
+    assert block.shape == oblock.shape  # same valence
+    assert np.abs(block - oblock).max() <= 1e-10 * np.abs(oblock).max()  # same multiset of values (column order differs)
+    eng.close()
+
+
+def test_full_size_hex27_neo_hookean_properties(engine, oracle):
+    """BASELINE config C4 (Hex27 NeoHookean 50x50x80, 27-point rule) at full size: closed-form nnz, atomic and
+    coloured scatter agree, values finite for the homogeneous deformation u = 0.05 A X."""
+    import torch
+
+    h8 = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 5, 5, 8, 10)
+    mesh = fa.hex27_mesh_from_hex8(h8)
+    assert mesh.num_nodes() == 101 * 101 * 161
+    A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
+    u = (0.05 * mesh.vertices @ A.T).reshape(-1)
+    w, p = quadrature.tensor.hexahedron_gauss(3)
+    eng = fa.Engine(0)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(LAME)
+    (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(OPS["NEO_HOOKEAN"]())
+     .with_quadrature_table(qt).with_u(u).build())
+    nnz = eng.build_pattern()
+    assert nnz == 9 * 401 * 401 * 641  # SURVEY.md 8: 9 * (8m+1) per direction
+    vals = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    eng.color()
+    eng.assemble_matrix(vals, fa.SCATTER_COLORED | fa.ASSEMBLE_OVERWRITE)
+    assert bool(torch.isfinite(vals).all())
+    v2 = torch.zeros_like(vals)
+    eng.assemble_matrix(v2, fa.SCATTER_ATOMIC)
+    assert float((vals - v2).abs().max()) <= 1e-12 * float(vals.abs().max())
+    # one element matrix against the oracle (same inputs)
+    ref = oracle.ElementAssembler(oracle.HEX27, oracle.NEO_HOOKEAN, mesh.vertices, mesh.connectivity[:3], w, p,
+                                  params=LAME.as_pair(), u=u)
+    ke = eng.element_matrices(1, 1)[0]
+    st, oke = ref.element_matrix(1)
+    assert st == 0 and np.abs(ke - oke).max() <= TOL * np.abs(oke).max()
+    eng.close()

@@ -22,7 +22,7 @@ namespace fenris_hip {
 // ------------------------------------------------------------------------------------------ LDS carve
 struct Layout {
     int o_gref, o_ggeom, o_qw, o_qpar, o_X, o_U, o_QP, o_ACC, n_doubles;
-    int o_uniq, o_cn, o_ent, o_ncols, o_noff, n_ints;
+    int o_uniq, o_cn, o_ent, o_ncols, o_noff, o_nc, o_ncr, n_ints;
     int qpd;   // doubles per (element, quadrature point), padded to an odd count (LDS bank spread)
     int fast;  // 1: gradients stored pre-scaled by sqrt(w |det J|), no per-point coefficients
     int o_pos; // gather: per (entry, local node) column slot, bytes
@@ -34,7 +34,7 @@ enum { WHAT_MATRIX = 0, WHAT_VECTOR = 1, WHAT_SCALAR = 2 };
 
 template <int EK, int OP, int WHAT>
 __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int nb_max, bool gather, int mb = 0, int fast = 0,
-                                               int nq_stage = 0) {
+                                               int nq_stage = 0, int nc_row = 0) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     Layout L;
@@ -62,6 +62,10 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.o_ncols = i;   i += gather ? acc_max / (O::S * O::S) : 0;
     L.o_noff = i;    i += gather ? nb_max + 1 : 0;
     L.o_pos = i;     i += gather ? (mb * E::N + 3) / 4 : 0;
+    // element-centric kernels: neighbour lists of the staged elements' nodes (nc_row = longest list) so that the
+    // column search of the scatter runs in LDS instead of dependent global loads
+    L.o_ncr = i;     i += (!gather && nc_row > 0) ? 2 * ub * E::N : 0;
+    L.o_nc = i;      i += (!gather && nc_row > 0) ? ub * E::N * nc_row : 0;
     L.n_ints = i + 4;
     return L;
 }
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
     (void)D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool GATHER = (MODE == MODE_GATHER);
-    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, GATHER, a.mb, a.fast);
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, GATHER, a.mb, a.fast, 0, GATHER ? 0 : a.nc_row);
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -670,6 +674,20 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
         for (int i = tid; i < U; i += nt) lds_i[L.o_uniq + i] = a.labels ? (int)a.labels[w0 + i] : (int)(w0 + i);
         __syncthreads();
         stage_elements<EK, S>(a, L, lds, lds_i, U, O::NEEDS_U, lds_i + L.o_uniq);
+        const bool nc_lds = (a.nc_row > 0) && (MODE != MODE_DUMP);
+        if (nc_lds) {
+            for (int i = tid; i < U * N; i += nt) {
+                const unsigned node = (unsigned)lds_i[L.o_cn + i];
+                const unsigned r0 = a.noff[node];
+                lds_i[L.o_ncr + 2 * i] = (int)r0;
+                lds_i[L.o_ncr + 2 * i + 1] = (int)(a.noff[node + 1] - r0);
+            }
+            __syncthreads();
+            for (int i = tid; i < U * N * a.nc_row; i += nt) {
+                const int un = i / a.nc_row, k = i % a.nc_row;
+                if (k < lds_i[L.o_ncr + 2 * un + 1]) lds_i[L.o_nc + i] = (int)a.ncols[(unsigned)lds_i[L.o_ncr + 2 * un] + k];
+            }
+        }
         for (int i = tid; i < U * a.nq; i += nt)
             prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
         __syncthreads();
@@ -693,8 +711,17 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             } else {
                 const unsigned ni = (unsigned)lds_i[L.o_cn + u * N + I], nj = (unsigned)lds_i[L.o_cn + u * N + J];
                 {
-                    const unsigned r0 = a.noff[ni], cnt = a.noff[ni + 1] - r0;
-                    const int pos = find_col(a.ncols + r0, (int)cnt, nj);
+                    unsigned r0, cnt;
+                    int pos;
+                    if (nc_lds) {
+                        r0 = (unsigned)lds_i[L.o_ncr + 2 * (u * N + I)];
+                        cnt = (unsigned)lds_i[L.o_ncr + 2 * (u * N + I) + 1];
+                        pos = find_col_lds(lds_i + L.o_nc + (u * N + I) * a.nc_row, (int)cnt, (int)nj);
+                    } else {
+                        r0 = a.noff[ni];
+                        cnt = a.noff[ni + 1] - r0;
+                        pos = find_col(a.ncols + r0, (int)cnt, nj);
+                    }
                     double* base = a.vals + (size_t)S * S * r0 + (size_t)S * pos;
 #pragma unroll
                     for (int i = 0; i < S; ++i)
@@ -702,8 +729,17 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
                         for (int j = 0; j < S; ++j) add_value<MODE>(base + (size_t)i * S * cnt + j, blk[i][j]);
                 }
                 if (I != J) {
-                    const unsigned r0 = a.noff[nj], cnt = a.noff[nj + 1] - r0;
-                    const int pos = find_col(a.ncols + r0, (int)cnt, ni);
+                    unsigned r0, cnt;
+                    int pos;
+                    if (nc_lds) {
+                        r0 = (unsigned)lds_i[L.o_ncr + 2 * (u * N + J)];
+                        cnt = (unsigned)lds_i[L.o_ncr + 2 * (u * N + J) + 1];
+                        pos = find_col_lds(lds_i + L.o_nc + (u * N + J) * a.nc_row, (int)cnt, (int)ni);
+                    } else {
+                        r0 = a.noff[nj];
+                        cnt = a.noff[nj + 1] - r0;
+                        pos = find_col(a.ncols + r0, (int)cnt, ni);
+                    }
                     double* base = a.vals + (size_t)S * S * r0 + (size_t)S * pos;
 #pragma unroll
                     for (int j = 0; j < S; ++j)

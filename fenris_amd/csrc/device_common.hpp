@@ -88,6 +88,7 @@ struct KArgs {
     const unsigned* labels;  // element list (colour) or null for identity
     long long work_begin, work_end;
     int epb;                 // elements per block
+    int nc_row;              // > 0: stage the neighbour lists (longest has nc_row entries) of the unit's nodes in LDS
     // gather work description
     const unsigned* blk_off; // node block boundaries, nblk+1
     const GatherHdr* gt_hdr; // per block

@@ -345,9 +345,9 @@ int launch_matrix(fh_ctx* c, KArgs& a, int mode, size_t lds_bytes, int grid) {
 }
 
 template <int EK, int OP>
-size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb, int fast) {
+size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb, int fast, int nc_row) {
     switch (what) {
-        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb, fast).bytes();
+        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb, fast, 0, nc_row).bytes();
         case WHAT_VECTOR: return make_layout<EK, OP, WHAT_VECTOR>(nq, ub, acc, nb, gather, mb).bytes();
         default: return make_layout<EK, OP, WHAT_SCALAR>(nq, ub, acc, nb, gather, mb).bytes();
     }
@@ -372,9 +372,9 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         default: break;                                             \
     }
 
-size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0) {
+size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0, int nc_row = 0) {
     size_t r = 0;
-#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb, fast)
+#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb, fast, nc_row)
     FH_FOR_ELEM_OP(ek, op, CALL)
 #undef CALL
     return r;
@@ -702,7 +702,14 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     if (overwrite) HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * nnz, c->stream));
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
-    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
+    // high-order elements: column search of the scatter in LDS (neighbour lists staged per element)
+    if (c->ei.n > 8 && !std::getenv("FENRIS_HIP_NO_NC_LDS")) {
+        unsigned max_row = 0;
+        for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+        const size_t with_nc = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, (int)max_row);
+        if (with_nc <= LDS_TARGET + 16 * 1024) a.nc_row = (int)max_row;
+    }
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, a.nc_row);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
     if (mode == FH_SCATTER_ATOMIC) {
         a.work_begin = 0;

@@ -113,6 +113,13 @@ __device__ __forceinline__ void lds_read_vec(const double* p, double (&v)[D]) {
     v[1] = lds_read_f64<8>(p);
     if (D == 3) v[D - 1] = lds_read_f64<16>(p);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), which would force the register prefetch of the next blocks to land at every barrier;
+// the data exchanged between the waves of the pipelined kernel lives in LDS, so lgkmcnt(0) + s_barrier suffices.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // wait until at most PENDING LDS operations of this wave are outstanding (they complete in order)
 template <int PENDING>
 __device__ __forceinline__ void lds_wait() {
@@ -819,12 +826,17 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
 //   bottom:               park the prefetched block b+G in LDS (X, entries, column slots, row offsets)
 // Only for operators that do not read u (Laplace, LinearElastic) and elements with few geometry nodes.
 struct PipeTables {
-    const GatherHdr* hdr;       // [nblk]
-    const int* conn;            // [nblk][cs]   geometry-node indices of the unique elements (padded with 0)
-    const unsigned* ent;        // [nblk][ms]   packed entries
-    const unsigned* pos;        // [nblk][ms*N/4] column slots, 4 per word
-    const int* noffr;           // [nblk][nbs+1] node-level row offsets relative to the block start
-    int cs, ms, nbs;
+    // all tables are indexed by POSITION p in the sweep order (blocks reordered into chains whose consecutive
+    // members share elements; the shared elements stay staged in LDS from one block to the next)
+    const GatherHdr* hdr;       // [npos]  header of the block at position p; k0 holds the number of NEW slots
+    const int* conn;            // [npos][cs]   geometry-node indices per LDS slot (padded with 0)
+    const unsigned* ent;        // [npos][ms]   packed entries (persistent slot << 16 | a << 8 | local node)
+    const unsigned* pos;        // [npos][ms*N/4] column slots, 4 per word
+    const int* noffr;           // [npos][nbs+1] node-level row offsets relative to the block start
+    const unsigned* slots;      // [npos][us/4] occupied slots, 1 byte each: the new ones first, then the retained
+    const int* elem;            // [npos][us]   element id per slot (error reporting)
+    int cs, ms, nbs, us;        // strides: cs = us * NG
+    int npos;
 };
 
 template <int EK, int OP, int QC, int JT>
@@ -841,24 +853,28 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
     unsigned* pos_lds = reinterpret_cast<unsigned*>(lds_i + L.o_pos);
     double* acc = lds + L.o_ACC;
     const int tid = threadIdx.x, nt = 256;
-    const int G = gridDim.x, nblk = a.nblk;
+    const int G = gridDim.x;
     stage_tables<EK>(a, L, lds);
 
     // Prefetch state per thread: one header word (threads 0..7), SLOTS geometry-node indices, one packed entry,
     // one word of column slots, one relative row offset.  Headers are parked in LDS (double-buffered by block
     // parity) and read back as wave-uniform values, so they cost one VGPR instead of eight.
-    struct Rec { int hword; int conn[SLOTS]; unsigned ent, posw; int noffr; };
-    auto load_rec = [&](int b, Rec& r) {
-        b = min(b, nblk - 1);
-        r.hword = (tid < 8) ? reinterpret_cast<const int*>(T.hdr + b)[tid] : 0;
+    struct Rec { int hword; int conn[SLOTS]; unsigned ent, posw, slotw; int noffr; };
+    const int npos = T.npos;
+    // contiguous range of positions per workgroup: consecutive positions are chain neighbours
+    const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
+    auto load_rec = [&](int p, Rec& r) {
+        p = min(p, npos - 1);
+        r.hword = (tid < 8) ? reinterpret_cast<const int*>(T.hdr + p)[tid] : 0;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int sidx = tid + k * nt;
-            r.conn[k] = (sidx < T.cs) ? T.conn[(size_t)b * T.cs + sidx] : 0;
+            r.conn[k] = (sidx < T.cs) ? T.conn[(size_t)p * T.cs + sidx] : 0;
         }
-        r.ent = (tid < T.ms) ? T.ent[(size_t)b * T.ms + tid] : 0u;
-        r.posw = (tid < T.ms * N / 4) ? T.pos[(size_t)b * (T.ms * N / 4) + tid] : 0u;
-        r.noffr = (tid <= T.nbs) ? T.noffr[(size_t)b * (T.nbs + 1) + tid] : 0;
+        r.ent = (tid < T.ms) ? T.ent[(size_t)p * T.ms + tid] : 0u;
+        r.posw = (tid < T.ms * N / 4) ? T.pos[(size_t)p * (T.ms * N / 4) + tid] : 0u;
+        r.slotw = (tid < T.us / 4) ? T.slots[(size_t)p * (T.us / 4) + tid] : 0u;
+        r.noffr = (tid <= T.nbs) ? T.noffr[(size_t)p * (T.nbs + 1) + tid] : 0;
     };
     double V[SLOTS][D];
     auto load_verts = [&](const Rec& r) {
@@ -867,43 +883,49 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
 #pragma unroll
             for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
     };
-    int* hdr_lds = lds_i + L.o_uniq;  // the unique-element list is not staged by this kernel: reuse its slot (>= 16 ints)
+    int* hdr_lds = lds_i + L.o_uniq;            // 2 x 8 ints: block headers, double-buffered by parity
+    unsigned* slot_lds = reinterpret_cast<unsigned*>(lds_i + L.o_uniq + 16);  // us bytes: slot list of the current block
     auto park = [&](const Rec& r, int parity) {  // registers -> LDS for the block that is computed next
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int sidx = tid + k * nt;
-            if (sidx < T.cs)  // padded slots carry vertex 0: harmless
+            if (sidx < T.cs)  // padded / retained slots carry valid vertex indices: harmless
 #pragma unroll
                 for (int c = 0; c < D; ++c) lds[L.o_X + sidx * D + c] = V[k][c];
         }
         if (tid < 8) hdr_lds[8 * parity + tid] = r.hword;
         if (tid < T.ms) lds_i[L.o_ent + tid] = (int)r.ent;
         if (tid < T.ms * N / 4) pos_lds[tid] = r.posw;
+        if (tid < T.us / 4) slot_lds[tid] = r.slotw;
         if (tid <= T.nbs) lds_i[L.o_noff + tid] = r.noffr;
     };
 
-    int b = blockIdx.x;
-    if (b >= nblk) return;
+    int p = p_begin;
+    if (p >= p_end) return;
     Rec nxt;
     {
         Rec cur;
-        load_rec(b, cur);
+        load_rec(p, cur);
         load_verts(cur);
-        load_rec(b + G, nxt);
+        load_rec(p + 1, nxt);
         park(cur, 0);
     }
     for (int i = tid; i < a.acc_max; i += nt) acc[i] = 0.0;
     __syncthreads();
 
     int parity = 0;
-    for (; b < nblk; b += G, parity ^= 1) {
-        const bool have_next = (b + G) < nblk;
+    for (; p < p_end; ++p, parity ^= 1) {
+        const bool have_next = (p + 1) < p_end;
         if (have_next) load_verts(nxt);      // lands while this block is computed
         Rec nn;
-        load_rec(b + 2 * G, nn);
+        load_rec(p + 2, nn);
         const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
-        const int U = hc.U, m = hc.m, nrow = hc.nrow;
+        // slots to (re)compute: only the new ones, except at the start of this workgroup's range where nothing
+        // is staged yet (the slot list holds the new slots first, then the retained ones)
+        const int U = (p == p_begin || QC < a.nq) ? hc.U : hc.k0;  // chunked staging keeps nothing across blocks
+        const int m = hc.m, nrow = hc.nrow;
         const int nacc = S * S * nrow;   // accumulators are zero here: cleared by the previous phase D
+        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(slot_lds);
         // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
         // elements of the block are staged at once (U <= ub guaranteed by the host).  One lane owns an entry
         // (node, element, local index a) and JT consecutive local nodes J: h_a is read once per point for JT
@@ -924,16 +946,15 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
         const int an = (int)((packed >> 8) & 0xffu);
         const int il = (int)(packed & 0xffu);
         for (int qc = 0; qc < a.nq; qc += QC) {
-            if (qc > 0) __syncthreads();  // the previous chunk's phase C is done with the staged points
+            if (qc > 0) lds_barrier();  // the previous chunk's phase C is done with the staged points
             // phase B for quadrature points [qc, qc + QC)
             if (!(a.ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
-                const int u = i / QC, qs = i % QC;
+                const int u = (int)slot_b[i / QC], qs = i % QC;
                 if (qc + qs < a.nq)
-                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs,
-                                                  reinterpret_cast<const int*>(a.gt_elems) + hc.u_off + u, qs);
+                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
             }
-            __syncthreads();
+            lds_barrier();
             // phase C (accumulate)
             const int nqc = min(QC, a.nq - qc);
             if (has_item && !(a.ablate & 2)) {
@@ -997,7 +1018,7 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // phase D (also clears the accumulators for the next block; no barrier needed before parking: the
         // parked regions -- X, entries, slots, row offsets -- are not read here)
         double* out = a.vals + (size_t)S * S * hc.r0;
@@ -1011,34 +1032,143 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
         // park the prefetched block
         if (have_next) park(nxt, parity ^ 1);
         nxt = nn;
-        __syncthreads();
+        lds_barrier();
     }
 }
 
-// fixed-stride tables for the pipelined kernel, one workgroup per block
-template <int NG_T>
-__global__ void __launch_bounds__(256) k_build_pipe_tables(const GatherHdr* hdr, const unsigned* gt_elems, const unsigned* gt_ent,
-                                                           const unsigned char* gt_pos, const unsigned* noff, const int* conn,
-                                                           int N, int cs, int ms, int nbs, int* p_conn, unsigned* p_ent,
-                                                           unsigned* p_pos, int* p_noffr) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+// successor of a block in the sweep order: the block that owns most of the nodes (with an index beyond this
+// block) touched by this block's elements -- i.e. the neighbouring block sharing the most elements.  One
+// wavefront per block.
+__global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
+                                                        const int* node2blk, int nblk, int* succ) {
+    __shared__ int cand[1024];
+    __shared__ int best_blk, best_cnt;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const GatherHdr h = hdr[b];
-    for (int sidx = tid; sidx < cs; sidx += 256) {
-        const int u = sidx / NG_T, g = sidx % NG_T;
-        p_conn[(size_t)b * cs + sidx] = (u < h.U) ? conn[(size_t)gt_elems[h.u_off + u] * N + g] : 0;
+    const int last = h.i0 + h.nb - 1;
+    const int total = min(h.U * N, 1024);
+    for (int i = lane; i < total; i += 64) {
+        const int node = conn[(size_t)gt_elems[h.u_off + i / N] * N + i % N];
+        cand[i] = (node > last) ? node2blk[node] : -1;
     }
-    for (int t = tid; t < ms; t += 256) p_ent[(size_t)b * ms + t] = (t < h.m) ? gt_ent[h.k0 + t] : 0u;
-    const int pw = ms * N / 4;
-    for (int w = tid; w < pw; w += 256) {
-        unsigned word = 0;
-        for (int k = 0; k < 4; ++k) {
-            const int it = 4 * w + k;
-            if (it < h.m * N) word |= (unsigned)gt_pos[(size_t)h.k0 * N + it] << (8 * k);
+    if (lane == 0) { best_blk = -1; best_cnt = 0; }
+    __syncthreads();
+    for (int i = lane; i < total; i += 64) {
+        const int c = cand[i];
+        if (c < 0) continue;
+        int cnt = 0;
+        bool first = true;
+        for (int k = 0; k < total; ++k) {
+            if (cand[k] == c) { ++cnt; if (k < i) first = false; }
         }
-        p_pos[(size_t)b * pw + w] = word;
+        if (first) atomicMax(&best_cnt, cnt);  // one representative per candidate
     }
-    for (int i = tid; i <= nbs; i += 256)
-        p_noffr[(size_t)b * (nbs + 1) + i] = (i <= h.nb) ? (int)(noff[h.i0 + i] - (unsigned)h.r0) : 0;
+    __syncthreads();
+    for (int i = lane; i < total; i += 64) {
+        const int c = cand[i];
+        if (c < 0) continue;
+        int cnt = 0;
+        for (int k = 0; k < total; ++k) cnt += (cand[k] == c);
+        if (cnt == best_cnt) atomicMin(reinterpret_cast<unsigned*>(&best_blk), (unsigned)c);  // -1 == 0xffffffff
+    }
+    __syncthreads();
+    if (lane == 0) succ[b] = (best_cnt > 0) ? best_blk : -1;
+    (void)nblk;
+}
+
+__global__ void k_node_to_block(const unsigned* blk_off, int nblk, int* node2blk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    for (unsigned i = blk_off[b]; i < blk_off[b + 1]; ++i) node2blk[i] = b;
+}
+
+// fixed-stride, position-indexed tables of the pipelined kernel.  One wavefront per CHAIN walks its positions in
+// order and assigns every unique element of a block to an LDS slot: elements shared with the previous block of
+// the chain keep their slot (their staged quadrature-point data is reused), new ones take the freed slots.
+template <int NG_T>
+__global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, const int* chain_off, const GatherHdr* hdr,
+                                                          const unsigned* gt_elems, const unsigned* gt_ent,
+                                                          const unsigned char* gt_pos, const unsigned* noff, const int* conn, int N,
+                                                          int cs, int ms, int nbs, int us, GatherHdr* p_hdr, int* p_conn,
+                                                          unsigned* p_ent, unsigned* p_pos, int* p_noffr, unsigned* p_slots,
+                                                          int* p_elem) {
+    __shared__ int slot_elem[256];   // element staged in each slot after the previous block (-1 = free)
+    __shared__ int new_elem[256];    // element per slot after this block
+    __shared__ int map[256];         // block-local unique index -> slot
+    __shared__ unsigned char list[256];
+    __shared__ int s_nnew;
+    const int lane = threadIdx.x;
+    const int p0 = chain_off[blockIdx.x], p1 = chain_off[blockIdx.x + 1];
+    for (int s_ = lane; s_ < us; s_ += 64) slot_elem[s_] = -1;
+    __syncthreads();
+    for (int p = p0; p < p1; ++p) {
+        const GatherHdr h = hdr[order[p]];
+        const unsigned* E = gt_elems + h.u_off;
+        for (int s_ = lane; s_ < us; s_ += 64) new_elem[s_] = -1;
+        for (int k = lane; k < h.U; k += 64) map[k] = -1;
+        __syncthreads();
+        // retained: an element of this block already staged in some slot keeps it
+        for (int s_ = lane; s_ < us; s_ += 64) {
+            const int e = slot_elem[s_];
+            if (e < 0) continue;
+            for (int k = 0; k < h.U; ++k)
+                if ((int)E[k] == e) { map[k] = s_; new_elem[s_] = e; break; }
+        }
+        __syncthreads();
+        if (lane == 0) {  // new elements take the free slots in ascending order; list = new slots, then retained
+            int nnew = 0, free_s = 0;
+            for (int k = 0; k < h.U; ++k) {
+                if (map[k] >= 0) continue;
+                while (new_elem[free_s] >= 0) ++free_s;
+                map[k] = free_s;
+                new_elem[free_s] = (int)E[k];
+                list[nnew++] = (unsigned char)free_s;
+            }
+            int n = nnew;
+            for (int s_ = 0; s_ < us; ++s_)
+                if (new_elem[s_] >= 0 && slot_elem[s_] == new_elem[s_]) list[n++] = (unsigned char)s_;
+            for (; n < us; ++n) list[n] = 0;
+            s_nnew = nnew;
+        }
+        __syncthreads();
+        // write the records of position p
+        if (lane == 0) {
+            GatherHdr o = h;
+            o.k0 = s_nnew;
+            p_hdr[p] = o;
+        }
+        for (int sidx = lane; sidx < cs; sidx += 64) {
+            const int s_ = sidx / NG_T, g = sidx % NG_T;
+            const int e = new_elem[s_];
+            p_conn[(size_t)p * cs + sidx] = (e >= 0) ? conn[(size_t)e * N + g] : 0;
+        }
+        for (int s_ = lane; s_ < us; s_ += 64) p_elem[(size_t)p * us + s_] = new_elem[s_];
+        for (int w = lane; w < us / 4; w += 64)
+            p_slots[(size_t)p * (us / 4) + w] = (unsigned)list[4 * w] | ((unsigned)list[4 * w + 1] << 8) |
+                                                ((unsigned)list[4 * w + 2] << 16) | ((unsigned)list[4 * w + 3] << 24);
+        for (int t = lane; t < ms; t += 64) {
+            unsigned word = 0;
+            if (t < h.m) {
+                const unsigned old = gt_ent[h.k0 + t];
+                word = ((unsigned)map[old >> 16] << 16) | (old & 0xffffu);
+            }
+            p_ent[(size_t)p * ms + t] = word;
+        }
+        const int pw = ms * N / 4;
+        for (int w = lane; w < pw; w += 64) {
+            unsigned word = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int it = 4 * w + k;
+                if (it < h.m * N) word |= (unsigned)gt_pos[(size_t)h.k0 * N + it] << (8 * k);
+            }
+            p_pos[(size_t)p * pw + w] = word;
+        }
+        for (int i = lane; i <= nbs; i += 64)
+            p_noffr[(size_t)p * (nbs + 1) + i] = (i <= h.nb) ? (int)(noff[h.i0 + i] - (unsigned)h.r0) : 0;
+        __syncthreads();
+        for (int s_ = lane; s_ < us; s_ += 64) slot_elem[s_] = new_elem[s_];
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------ gather tables

@@ -161,9 +161,10 @@ struct fh_ctx {
     DevBuf<unsigned char> gt_pos;
     bool has_pos = false;
     // fixed-stride tables of the pipelined gather kernel
-    DevBuf<int> p_conn, p_noffr;
-    DevBuf<unsigned> p_ent, p_pos;
-    int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1;
+    DevBuf<int> p_conn, p_noffr, p_elem;
+    DevBuf<unsigned> p_ent, p_pos, p_slots;
+    DevBuf<GatherHdr> p_hdr;
+    int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1, p_us = 0;
     bool has_pipe = false;
     DevBuf<GatherHdr> gt_hdr;
     int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0, g_umax = 0;
@@ -552,28 +553,66 @@ int build_partition(fh_ctx* c) {
         std::fprintf(stderr, "[fenris_hip] gather partition: nblk=%d nb=%d umax=%d mmax=%d acc=%d ub=%d lds=%zu B\n", c->nblk,
                      nb_target, umax, mmax, acc, ub,
                      layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, ub, acc, 64, true, mb, c->fast_ok));
-    // fixed-stride tables for the pipelined kernel (elements with few geometry nodes, pos table present)
+    // position-indexed tables for the pipelined kernel (elements with few geometry nodes, pos table present)
     c->has_pipe = false;
     if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
         const int n = c->ei.n;
         const int ms = (mmax + 3) / 4 * 4;
+        const int us = (umax + 3) / 4 * 4;
         // local nodes per lane in the pipelined kernel's phase C
         int jt = env_int("FENRIS_HIP_PIPE_JT", (n % 2 == 0) ? 2 : n);
         if (jt != 1 && jt != 2 && jt != 4 && jt != n) jt = 1;
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
-        if (umax * c->ei.ng <= 512 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb && nb_target <= 254 && c->fast_ok) {
-            c->p_cs = umax * c->ei.ng;
+        if (us * c->ei.ng <= 512 && us <= 252 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb &&
+            nb_target <= 254 && c->fast_ok) {
+            const int nblk = c->nblk;
+            // sweep order: chains of blocks whose consecutive members share elements (their staged data is reused)
+            std::vector<int> order, chain_off(1, 0);
+            order.reserve(nblk);
+            if (!std::getenv("FENRIS_HIP_NO_SWEEP")) {
+                DevBuf<int> node2blk, succ_d;
+                HIP_TRY(c, node2blk.alloc((size_t)N + 1));
+                HIP_TRY(c, succ_d.alloc((size_t)nblk));
+                hipLaunchKernelGGL(k_node_to_block, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->blk_off.p, nblk, node2blk.p);
+                hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
+                                   node2blk.p, nblk, succ_d.p);
+                std::vector<int> succ((size_t)nblk);
+                HIP_TRY(c, hipMemcpyAsync(succ.data(), succ_d.p, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                std::vector<unsigned char> visited((size_t)nblk, 0);
+                for (int b = 0; b < nblk; ++b) {
+                    if (visited[b]) continue;
+                    for (int cur = b; cur >= 0 && cur < nblk && !visited[cur]; cur = succ[cur]) {
+                        visited[cur] = 1;
+                        order.push_back(cur);
+                    }
+                    chain_off.push_back((int)order.size());
+                }
+            } else {
+                for (int b = 0; b < nblk; ++b) { order.push_back(b); chain_off.push_back(b + 1); }
+            }
+            const int nchains = (int)chain_off.size() - 1;
+            DevBuf<int> order_d, chain_d;
+            HIP_TRY(c, order_d.alloc(order.size()));
+            HIP_TRY(c, chain_d.alloc(chain_off.size()));
+            HIP_TRY(c, hipMemcpyAsync(order_d.p, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(chain_d.p, chain_off.data(), sizeof(int) * chain_off.size(), hipMemcpyHostToDevice, c->stream));
+            c->p_cs = us * c->ei.ng;
             c->p_ms = ms;
             c->p_nbs = nb_target;
-            HIP_TRY(c, c->p_conn.alloc((size_t)c->nblk * c->p_cs));
-            HIP_TRY(c, c->p_ent.alloc((size_t)c->nblk * ms));
-            HIP_TRY(c, c->p_pos.alloc((size_t)c->nblk * (ms * n / 4)));
-            HIP_TRY(c, c->p_noffr.alloc((size_t)c->nblk * (nb_target + 1)));
-#define PT_LAUNCH(NGV)                                                                                                         \
-    hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(c->nblk), dim3(256), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->gt_ent.p, \
-                       c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, c->p_conn.p, c->p_ent.p, c->p_pos.p,       \
-                       c->p_noffr.p)
+            c->p_us = us;
+            HIP_TRY(c, c->p_hdr.alloc((size_t)nblk));
+            HIP_TRY(c, c->p_conn.alloc((size_t)nblk * c->p_cs));
+            HIP_TRY(c, c->p_ent.alloc((size_t)nblk * ms));
+            HIP_TRY(c, c->p_pos.alloc((size_t)nblk * (ms * n / 4)));
+            HIP_TRY(c, c->p_noffr.alloc((size_t)nblk * (nb_target + 1)));
+            HIP_TRY(c, c->p_slots.alloc((size_t)nblk * (us / 4)));
+            HIP_TRY(c, c->p_elem.alloc((size_t)nblk * us));
+#define PT_LAUNCH(NGV)                                                                                                           \
+    hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(nchains), dim3(64), 0, c->stream, order_d.p, chain_d.p, c->gt_hdr.p,        \
+                       c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_hdr.p,   \
+                       c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_slots.p, c->p_elem.p)
             switch (c->ei.ng) {
                 case 3: PT_LAUNCH(3); break;
                 case 4: PT_LAUNCH(4); break;
@@ -584,6 +623,8 @@ int build_partition(fh_ctx* c) {
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             c->has_pipe = true;
+            if (std::getenv("FENRIS_HIP_VERBOSE"))
+                std::fprintf(stderr, "[fenris_hip] sweep order: %d blocks in %d chains (us=%d ms=%d)\n", nblk, nchains, us, ms);
         }
     }
     c->g_ub = ub;
@@ -688,8 +729,9 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         a.nb_max = c->g_nb;
         const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
         if (c->has_pipe && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
-            PipeTables T{c->gt_hdr.p, c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_cs, c->p_ms, c->p_nbs};
-            a.ub = c->g_umax;  // the pipelined kernel stages every unique element of a block at once
+            PipeTables T{c->p_hdr.p, c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_slots.p, c->p_elem.p,
+                         c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->nblk};
+            a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
             c->last_kernel = "k_gather_pipelined";
             return launch_pipelined(c, a, T, 0, 0);
         }

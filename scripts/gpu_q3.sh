@@ -7,7 +7,11 @@ B="timeout 300 python bench.py --steps 5 --warmup 2 --cells 128 --no-cpu-baselin
 run "default" A=1 $B
 run "NB=6" FENRIS_HIP_GATHER_NB=6 $B
 run "NB=8 QC=4" FENRIS_HIP_GATHER_NB=8 FENRIS_HIP_PIPE_QC=4 $B
-run "JT=4 NB=8 QC=4" FENRIS_HIP_PIPE_JT=4 FENRIS_HIP_GATHER_NB=8 FENRIS_HIP_PIPE_QC=4 $B
+run "nosweep" FENRIS_HIP_NO_SWEEP=1 $B
+run "NB=8" FENRIS_HIP_GATHER_NB=8 $B
+run "NB=10 MB=256" FENRIS_HIP_GATHER_NB=10 FENRIS_HIP_GATHER_MB=256 $B
 run "poisson" A=1 $B --operator poisson
-for ab in 1 2 4 8 15; do run "ablate=$ab" FENRIS_HIP_ABLATE=$ab $B; done
+for ab in 1 2 4; do run "ablate=$ab" FENRIS_HIP_ABLATE=$ab $B; done
+run "poisson nosweep" FENRIS_HIP_NO_SWEEP=1 $B --operator poisson
+export FENRIS_HIP_VERBOSE=1; $B 2>&1 | grep "sweep order" | head -2 >> gpurun_out/q3.log
 cat gpurun_out/tests.log gpurun_out/q3.log

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfenris_hip.so")
 
 FH_OK, FH_SINGULAR_JACOBIAN, FH_BAD_ARGUMENT, FH_HIP_ERROR, FH_INVALID_STATE, FH_UNSUPPORTED = 0, 1, 2, 3, 5, 6
 QUAD4, HEX8, TET4, HEX27, TRI3 = 0, 1, 2, 3, 4
-LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK = 0, 1, 2, 3
+LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER = 0, 1, 2
 ASSEMBLE_OVERWRITE = 0x100
 

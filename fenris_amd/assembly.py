@@ -342,6 +342,42 @@ class ElementEllipticAssembler:
         return self
 
 
+class ElementMassAssembler(ElementEllipticAssembler):
+    """ElementMassAssembler (src/assembly/local/mass.rs:48-160): ``with_solution_dim(s).with_space(mesh)
+    .with_quadrature_table(table)`` where the table's data is ``Density`` per point.  s must be 1 or the geometry
+    dimension.  Only the matrix form exists (ElementMatrixAssembler)."""
+
+    def __init__(self, solution_dim, engine=None):
+        self._sdim, self._engine0, self._space0, self._qt0 = solution_dim, engine, None, None
+
+    @classmethod
+    def with_solution_dim(cls, solution_dim, engine: Optional[Engine] = None):
+        return cls(solution_dim, engine)
+
+    def with_space(self, space: Mesh):
+        self._space0 = space
+        return self._maybe_build()
+
+    def with_quadrature_table(self, qtable: "UniformQuadratureTable"):
+        self._qt0 = qtable
+        return self._maybe_build()
+
+    def _maybe_build(self):
+        if self._space0 is None or self._qt0 is None:
+            return self
+        d = _ffi.ELEM_DIM[self._space0.elem_kind]
+        if self._sdim not in (1, d):
+            raise ValueError("solution_dim must be 1 or the geometry dimension")
+        if self._qt0.data is None:
+            raise ValueError("the mass assembler needs a Density per quadrature point")
+
+        class _Op:
+            op_kind = _ffi.MASS_SCALAR if self._sdim == 1 else _ffi.MASS_VECTOR
+
+        ElementEllipticAssembler.__init__(self, self._engine0 or Engine(), self._space0, _Op(), self._qt0, None)
+        return self
+
+
 class MockElementAssembler:
     """Generic ElementConnectivityAssembler with ragged node lists
     (tests/unit_tests/assembly/global.rs MockElementAssembler)."""

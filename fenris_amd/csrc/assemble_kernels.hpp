@@ -137,6 +137,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
+    constexpr bool IS_MASS = (OP == FH_MASS_SCALAR || OP == FH_MASS_VECTOR);
     const double* X = lds + L.o_X + u * NG * D;
     const double* gg = lds + L.o_ggeom + q * NG * D;
     const double* gr = lds + L.o_gref + q * N * D;
@@ -180,7 +181,8 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     const double detJ = det_small<D>(J);
     double Ji[D][D];
     if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
-        report_singular(a.status, (long long)*elem_id);  // dereferenced only on this (rare) path
+        // the mass assembler only uses |det J| (mass.rs:245): a degenerate element contributes zero, no error
+        if (!IS_MASS) report_singular(a.status, (long long)*elem_id);  // dereferenced only on this (rare) path
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -204,6 +206,18 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     // FAST path (Laplace / uniform linear elasticity, non-negative weights): store sqrt(s) g_n so that
     // sum_q s g_I g_J^T = sum_q h_I h_J^T needs no per-point coefficient in phase C
     const double fast_scale = (WHAT == WHAT_MATRIX && L.fast) ? sqrt(s) : 1.0;
+    if (IS_MASS) {
+        // mass.rs:243-270: only |det J|, the density and the basis values enter; phi_n goes to the first component
+        if (WHAT == WHAT_MATRIX) {
+            for (int n = 0; n < N; ++n) {
+                gout[n * D] = a.phiref[q * N + n];
+#pragma unroll
+                for (int i = 1; i < D; ++i) gout[n * D + i] = 0.0;
+            }
+            qp[O::NVEC * N * D] = s * lds[L.o_qpar + 2 * q];
+        }
+        return;
+    }
     double rb[2][D];
     if (EXPLICIT_LDS) lds_read_vec<D>(gr, rb[0]);
 #pragma unroll UNR
@@ -484,6 +498,13 @@ __device__ __forceinline__ void pair_block(const KArgs& ka, const Layout& L, con
                 for (int j = 0; j < D; ++j)
                     blk[i % S][j % S] = ka.mu * ((i == j ? tr : 0.0) + G[j][i]) + ka.lambda * G[i][j];
         }
+    } else if (OP == FH_MASS_SCALAR || OP == FH_MASS_VECTOR) {
+        double m = 0.0;  // sum_q (s rho) phi_I phi_J ; block = m I_s (mass.rs:262-270)
+        for (int q = 0; q < nq; ++q, qp += L.qpd) m = fma(qp[N * D] * qp[I * D], qp[J * D], m);
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j) blk[i][j] = (i == j) ? m : 0.0;
     } else if (OP == FH_LAPLACE) {
         double k = 0.0;
         for (int q = 0; q < nq; ++q, qp += L.qpd) {

@@ -38,6 +38,16 @@ template <int D> struct OpT<FH_STVK, D> {
     static constexpr bool NEEDS_U = true;
 };
 
+// mass matrix (src/assembly/local/mass.rs): the node "vector" slot carries phi_n in its first component
+template <int D> struct OpT<FH_MASS_SCALAR, D> {
+    static constexpr int S = 1, NVEC = 1, NCOEF = 1;  // [s * rho]
+    static constexpr bool NEEDS_U = false;
+};
+template <int D> struct OpT<FH_MASS_VECTOR, D> {
+    static constexpr int S = D, NVEC = 1, NCOEF = 1;
+    static constexpr bool NEEDS_U = false;
+};
+
 enum { MODE_ATOMIC = 0, MODE_COLORED = 1, MODE_GATHER = 2, MODE_DUMP = 3 };
 
 // status words in device memory
@@ -70,6 +80,7 @@ struct KArgs {
     const double* qw;      // nq
     const double* gref;    // nq x N x D   reference gradients of the element basis
     const double* ggeom;   // nq x NG x D  reference gradients of the geometry map
+    const double* phiref;  // nq x N       basis values (mass matrix only)
     const double* qparams; // nq x 2 (mu, lambda) or null
     const double* u;       // S x N or null
     // node-level pattern

@@ -100,6 +100,33 @@ void ref_gradients(int kind, const double* xi, double* out) {
     }
 }
 
+// out: n basis values (src/element: quadrilateral.rs:79-90, hexahedron.rs:43-59, 222-265, tetrahedron.rs:551-558,
+// triangle.rs:72-78)
+void ref_basis(int kind, const double* xi, double* out) {
+    switch (kind) {
+        case FH_QUAD4:
+            for (int n = 0; n < 4; ++n) out[n] = (1.0 + QUAD_SIGN[n][0] * xi[0]) * (1.0 + QUAD_SIGN[n][1] * xi[1]) / 4.0;
+            break;
+        case FH_HEX8:
+            for (int n = 0; n < 8; ++n) out[n] = lin(HEX_SIGN[n][0], xi[0]) * lin(HEX_SIGN[n][1], xi[1]) * lin(HEX_SIGN[n][2], xi[2]);
+            break;
+        case FH_HEX27:
+            for (int n = 0; n < 27; ++n) out[n] = quad(HEX_SIGN[n][0], xi[0]) * quad(HEX_SIGN[n][1], xi[1]) * quad(HEX_SIGN[n][2], xi[2]);
+            break;
+        case FH_TET4:
+            out[0] = -0.5 * xi[0] - 0.5 * xi[1] - 0.5 * xi[2] - 0.5;
+            out[1] = 0.5 * xi[0] + 0.5;
+            out[2] = 0.5 * xi[1] + 0.5;
+            out[3] = 0.5 * xi[2] + 0.5;
+            break;
+        case FH_TRI3:
+            out[0] = -0.5 * xi[0] - 0.5 * xi[1];
+            out[1] = 0.5 * xi[0] + 0.5;
+            out[2] = 0.5 * xi[1] + 0.5;
+            break;
+    }
+}
+
 struct ElemInfo { int d, n, ng, geom_kind; };
 bool elem_info(int kind, ElemInfo& e) {
     switch (kind) {
@@ -138,7 +165,7 @@ struct fh_ctx {
     int op = -1;
     uint64_t sdim_ragged = 1;
     int nq = 0;
-    DevBuf<double> qw, gref, ggeom, qparams, u;
+    DevBuf<double> qw, gref, ggeom, phiref, qparams, u;
     bool has_params = false, has_u = false;
     bool fast_ok = false;       // uniform parameters and non-negative weights
     double uni_mu = 0.0, uni_lambda = 0.0;
@@ -181,7 +208,7 @@ struct fh_ctx {
     int S() const {
         if (ragged) return (int)sdim_ragged;
         if (op < 0) return 0;
-        return op == FH_LAPLACE ? 1 : ei.d;
+        return (op == FH_LAPLACE || op == FH_MASS_SCALAR) ? 1 : ei.d;
     }
     int fail(int code, const std::string& msg) { err = msg; return code; }
     int hip_fail(hipError_t e, const char* what) {
@@ -370,6 +397,8 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         case FH_LINEAR_ELASTIC: CALL(EKC, FH_LINEAR_ELASTIC); break;\
         case FH_NEO_HOOKEAN: CALL(EKC, FH_NEO_HOOKEAN); break;      \
         case FH_STVK: CALL(EKC, FH_STVK); break;                    \
+        case FH_MASS_SCALAR: CALL(EKC, FH_MASS_SCALAR); break;      \
+        case FH_MASS_VECTOR: CALL(EKC, FH_MASS_VECTOR); break;      \
         default: break;                                             \
     }
 
@@ -404,6 +433,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.qw = c->qw.p;
     a.gref = c->gref.p;
     a.ggeom = c->ggeom.p;
+    a.phiref = c->phiref.p;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
     a.u = c->has_u ? c->u.p : nullptr;
     a.fast = (c->fast_ok && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) ? 1 : 0;
@@ -1022,7 +1052,7 @@ int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
 
 int fh_set_operator(fh_ctx* c, int op_kind) {
     if (!c) return FH_BAD_ARGUMENT;
-    if (op_kind < FH_LAPLACE || op_kind > FH_STVK) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
+    if (op_kind < FH_LAPLACE || op_kind > FH_MASS_VECTOR) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
     if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
     const int old_s = c->S();
     c->op = op_kind;
@@ -1035,11 +1065,14 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_uniform: set the mesh first");
     if (!w || !pts || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform: bad argument");
     const ElemInfo& ei = c->ei;
-    std::vector<double> gref((size_t)nq * ei.n * ei.d), ggeom((size_t)nq * ei.ng * ei.d);
+    std::vector<double> gref((size_t)nq * ei.n * ei.d), ggeom((size_t)nq * ei.ng * ei.d), phiref((size_t)nq * ei.n);
     for (uint32_t q = 0; q < nq; ++q) {
         ref_gradients(c->elem_kind, pts + (size_t)q * ei.d, gref.data() + (size_t)q * ei.n * ei.d);
         ref_gradients(ei.geom_kind, pts + (size_t)q * ei.d, ggeom.data() + (size_t)q * ei.ng * ei.d);
+        ref_basis(c->elem_kind, pts + (size_t)q * ei.d, phiref.data() + (size_t)q * ei.n);
     }
+    HIP_TRY(c, c->phiref.alloc(phiref.size()));
+    HIP_TRY(c, hipMemcpy(c->phiref.p, phiref.data(), sizeof(double) * phiref.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, c->qw.alloc(nq));
     HIP_TRY(c, c->gref.alloc(gref.size()));
     HIP_TRY(c, c->ggeom.alloc(ggeom.size()));
@@ -1232,6 +1265,7 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
     int rc = check_ready(c, "fh_assemble_vector", false);
     if (rc) return rc;
+    if (c->op > FH_STVK) return c->fail(FH_UNSUPPORTED, "fh_assemble_vector: the mass assembler has no vector form");
     if (!out_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_vector: out is null");
     rc = reset_status(c);
     if (rc) return rc;
@@ -1275,6 +1309,7 @@ int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
     int rc = check_ready(c, "fh_assemble_scalar", false);
     if (rc) return rc;
+    if (c->op > FH_STVK) return c->fail(FH_UNSUPPORTED, "fh_assemble_scalar: the mass assembler has no scalar form");
     if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_scalar: out is null");
     rc = reset_status(c);
     if (rc) return rc;

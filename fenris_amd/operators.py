@@ -62,3 +62,12 @@ class MaterialEllipticOperator:
     @classmethod
     def new(cls, material):
         return cls(material)
+
+
+@dataclass(frozen=True)
+class Density:
+    """src/assembly/local/mass.rs:15-17"""
+    value: float = 0.0
+
+    def as_pair(self):
+        return (self.value, 0.0)

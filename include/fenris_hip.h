@@ -53,7 +53,10 @@ enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4 };
 /* operator kinds: LaplaceOperator (src/assembly/operators/laplace.rs), MaterialEllipticOperator over
  * LinearElasticMaterial / NeoHookeanMaterial / StVKMaterial (fenris-solid/src/lib.rs:412-508,
  * fenris-solid/src/materials.rs:83-123, 236-353, 392-469) */
-enum { FH_LAPLACE = 0, FH_LINEAR_ELASTIC = 1, FH_NEO_HOOKEAN = 2, FH_STVK = 3 };
+enum { FH_LAPLACE = 0, FH_LINEAR_ELASTIC = 1, FH_NEO_HOOKEAN = 2, FH_STVK = 3,
+       /* ElementMassAssembler::with_solution_dim(1 | D) (src/assembly/local/mass.rs:48-286): M_IJ = I_s sum_q w |det J|
+        * rho phi_I phi_J; the per-point parameter pair carries Density(rho) in its first slot.  Matrix only. */
+       FH_MASS_SCALAR = 4, FH_MASS_VECTOR = 5 };
 
 /* how K_e contributions reach the CSR values (flags argument of fh_assemble_matrix*):
  *   FH_SCATTER_ATOMIC  : element-parallel, fp64 atomic adds (replaces the rayon colour loop)

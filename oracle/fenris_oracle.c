@@ -136,7 +136,7 @@ int fo_element_dim(int k) {
         default: return -1;
     }
 }
-int fo_operator_solution_dim(int op, int d) { return op == FO_LAPLACE ? 1 : d; }
+int fo_operator_solution_dim(int op, int d) { return (op == FO_LAPLACE || op == FO_MASS_SCALAR) ? 1 : d; }
 
 /* src/element.rs:244-298 */
 static double phi_linear_1d(double alpha, double xi) { return (1.0 + alpha * xi) / 2.0; }
@@ -902,8 +902,36 @@ static void contraction(const fo_assembler* a, int d, const double* u_grad, cons
     fo_material_stress_contraction(a->op_kind, d, F, ga, gb, params[0], params[1], C);
 }
 
+/* assemble_element_mass_matrix, src/assembly/local/mass.rs:204-286:
+ * M_IJ = I_s * sum_q w |det J| rho phi_I phi_J, upper triangle then clone_upper_to_lower */
+static int assemble_element_mass_matrix(const fo_assembler* a, uint64_t e, double* me) {
+    elem_ws ws;
+    if (ws_init(a, &ws)) return FO_BAD_ARGUMENT;
+    int d = ws.d, n = ws.n, s = ws.s, ld = s * n;
+    if (!a->q_params) return FO_BAD_ARGUMENT;
+    for (int i = 0; i < ld * ld; ++i) me[i] = 0.0;
+    double phi[MAXN], J[9];
+    for (uint32_t q = 0; q < a->nq; ++q) {
+        const double* xi = a->q_points + (size_t)d * q;
+        gather_element(a, e, n, d, ws.ev);
+        fo_element_reference_jacobian(a->elem_kind, ws.ev, xi, J);
+        double j_det = det(d, J);
+        fo_element_basis(a->elem_kind, xi, phi);
+        double scale = a->q_weights[q] * fabs(j_det) * a->q_params[2 * (size_t)q];
+        for (int I = 0; I < n; ++I)
+            for (int Jn = I; Jn < n; ++Jn) {
+                double m = scale * phi[I] * phi[Jn];
+                for (int i = 0; i < s; ++i) me[CM(s * I + i, s * Jn + i, ld)] += m;
+            }
+    }
+    for (int j = 0; j < ld; ++j)
+        for (int i = j + 1; i < ld; ++i) me[CM(i, j, ld)] = me[CM(j, i, ld)];
+    return FO_OK;
+}
+
 /* assemble_element_elliptic_matrix, src/assembly/local/elliptic.rs:361-439 */
 int fo_assemble_element_matrix(const fo_assembler* a, uint64_t e, double* ke) {
+    if (a->op_kind == FO_MASS_SCALAR || a->op_kind == FO_MASS_VECTOR) return assemble_element_mass_matrix(a, e, ke);
     elem_ws ws;
     if (ws_init(a, &ws)) return FO_BAD_ARGUMENT;
     int d = ws.d, n = ws.n, s = ws.s, ld = s * n;
@@ -963,6 +991,7 @@ static void elliptic_operator_transpose(const fo_assembler* a, int d, int s, con
 
 /* assemble_element_elliptic_vector, elliptic.rs:457-531 */
 int fo_assemble_element_vector(const fo_assembler* a, uint64_t e, double* fe) {
+    if (a->op_kind > FO_STVK) return FO_BAD_ARGUMENT;
     elem_ws ws;
     if (ws_init(a, &ws)) return FO_BAD_ARGUMENT;
     int d = ws.d, n = ws.n, s = ws.s;
@@ -992,6 +1021,7 @@ int fo_assemble_element_vector(const fo_assembler* a, uint64_t e, double* fe) {
 
 /* compute_element_elliptic_energy, elliptic.rs:551-605 */
 int fo_assemble_element_scalar(const fo_assembler* a, uint64_t e, double* energy) {
+    if (a->op_kind > FO_STVK) return FO_BAD_ARGUMENT;
     elem_ws ws;
     if (ws_init(a, &ws)) return FO_BAD_ARGUMENT;
     int d = ws.d, n = ws.n, s = ws.s;

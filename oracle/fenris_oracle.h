@@ -41,7 +41,9 @@ extern "C" {
 /* element kinds (node orders: SURVEY Appendix A.2) */
 enum { FO_QUAD4 = 0, FO_HEX8 = 1, FO_TET4 = 2, FO_HEX27 = 3, FO_TRI3 = 4 };
 /* operator kinds */
-enum { FO_LAPLACE = 0, FO_LINEAR_ELASTIC = 1, FO_NEO_HOOKEAN = 2, FO_STVK = 3 };
+enum { FO_LAPLACE = 0, FO_LINEAR_ELASTIC = 1, FO_NEO_HOOKEAN = 2, FO_STVK = 3,
+       /* ElementMassAssembler (src/assembly/local/mass.rs) with solution_dim 1 / geometry dim; q_params[2q] = density */
+       FO_MASS_SCALAR = 4, FO_MASS_VECTOR = 5 };
 /* status codes */
 enum { FO_OK = 0, FO_SINGULAR_JACOBIAN = 1, FO_BAD_ARGUMENT = 2, FO_COLUMN_NOT_FOUND = 4 };
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfenris_oracle.so")
 
 QUAD4, HEX8, TET4, HEX27, TRI3 = 0, 1, 2, 3, 4
-LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK = 0, 1, 2, 3
+LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 OK, SINGULAR_JACOBIAN, BAD_ARGUMENT, COLUMN_NOT_FOUND = 0, 1, 2, 4
 
 _u64p = C.POINTER(C.c_uint64)

@@ -609,3 +609,48 @@ def test_full_size_hex27_neo_hookean_properties(engine, oracle):
     st, oke = ref.element_matrix(1)
     assert st == 0 and np.abs(ke - oke).max() <= TOL * np.abs(oke).max()
     eng.close()
+
+
+def test_colored_scatter_is_bitwise_reproducible(engine, oracle):
+    """Like the reference's coloured path (disjoint subsets, colours in sequence) the COLORED strategy has a fixed
+    summation order: repeated runs are bit-identical.  (ATOMIC and GATHER sum in hardware order and are only
+    reproducible to rounding -- test_repeated_runs_agree.)"""
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC")
+    runs = [fa.CsrAssembler(fa.SCATTER_COLORED).assemble(asm).values for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
+# ------------------------------------------------------------------------------------ mass matrix (row N1)
+def _mass_pair(engine, oracle, kind, sdim, density=2.5):
+    mesh = _mesh(kind)
+    w, p = _rule(kind) if kind != "QUAD4" else quadrature.tensor.quadrilateral_gauss(3)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.Density(density))
+    asm = fa.ElementMassAssembler.with_solution_dim(sdim, engine).with_space(mesh).with_quadrature_table(qt)
+    d = mesh.vertices.shape[1]
+    ref = oracle.ElementAssembler(KIND[kind], oracle.MASS_SCALAR if sdim == 1 else oracle.MASS_VECTOR, mesh.vertices,
+                                  mesh.connectivity, w, p, params=(density, 0.0))
+    assert sdim in (1, d)
+    return asm, ref
+
+
+def test_mass_matrix_reference_element_kat(engine):
+    # tests/unit_tests/assembly/local.rs:38-69
+    mesh = fa.Mesh(np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float), np.array([[0, 1, 2, 3]]), fa.QUAD4)
+    w, p = quadrature.tensor.quadrilateral_gauss(3)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.Density(3.0))
+    asm = fa.ElementMassAssembler.with_solution_dim(2, engine).with_space(mesh).with_quadrature_table(qt)
+    expected = np.kron(3.0 / 9.0 * np.array([[4, 2, 1, 2], [2, 4, 2, 1], [1, 2, 4, 2], [2, 1, 2, 4]], dtype=float), np.eye(2))
+    assert np.allclose(asm.assemble_element_matrix(0), expected, rtol=0, atol=2e-15)
+
+
+@pytest.mark.parametrize("kind,sdim", [("HEX8", 1), ("HEX8", 3), ("TET4", 3), ("QUAD4", 2), ("HEX27", 1), ("TRI3", 1)])
+@pytest.mark.parametrize("scatter", [fa.SCATTER_ATOMIC, fa.SCATTER_COLORED, fa.SCATTER_GATHER])
+def test_mass_matrix_matches_oracle(engine, oracle, kind, sdim, scatter):
+    asm, ref = _mass_pair(engine, oracle, kind, sdim)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(scatter).assemble(asm)
+    assert np.array_equal(k.row_offsets, oro) and np.array_equal(k.col_indices, oci)
+    assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+    with pytest.raises(fa.FenrisError):
+        fa.VectorAssembler().assemble_vector(asm)

@@ -509,3 +509,25 @@ def test_mms_tet4_matches_reference_values(oracle):
         l2, h1 = _mms_errors(oracle, oracle.TET4, v, c, oracle.tetrahedron_rule(1), err_rule)
         assert abs(l2 - ref["L2_errors"][i]) / ref["L2_errors"][i] < 0.01, (res, l2)
         assert abs(h1 - ref["H1_seminorm_errors"][i]) / ref["H1_seminorm_errors"][i] < 0.01, (res, h1)
+
+
+# ------------------------------------------------------------------ mass matrix (next row N1)
+def test_quad4_reference_mass_matrix_kat(oracle):
+    # tests/unit_tests/assembly/local.rs:38-69: M = rho/9 [[4,2,1,2],[2,4,2,1],[1,2,4,2],[2,1,2,4]] (x) I_2
+    verts = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float)
+    conn = np.array([[0, 1, 2, 3]], dtype=np.uint64)
+    w, p = oracle.quadrilateral_gauss(3)  # exact for the bi-quadratic integrand, like the strength-5 rule of the test
+    asm = oracle.ElementAssembler(oracle.QUAD4, oracle.MASS_VECTOR, verts, conn, w, p, params=(3.0, 0.0))
+    st, me = asm.element_matrix(0)
+    assert st == 0
+    expected = np.kron(3.0 / 9.0 * np.array([[4, 2, 1, 2], [2, 4, 2, 1], [1, 2, 4, 2], [2, 1, 2, 4]], dtype=float), np.eye(2))
+    assert np.allclose(me, expected, rtol=0, atol=4e-16 * 4)
+
+
+def test_mass_matrix_total_mass(oracle):
+    # sum of all entries of the scalar mass matrix = rho * volume
+    v, c = oracle.unit_box_hex_mesh(3)
+    w, p = oracle.hexahedron_gauss(2)
+    asm = oracle.ElementAssembler(oracle.HEX8, oracle.MASS_SCALAR, v, c, w, p, params=(2.5, 0.0))
+    st, _, ro, ci, vals = oracle.assemble(asm)
+    assert st == 0 and vals.sum() == pytest.approx(2.5, rel=1e-13)

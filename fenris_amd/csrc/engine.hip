@@ -489,7 +489,7 @@ int build_partition(fh_ctx* c) {
     unsigned max_row = 0;
     for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     // nodes per block (tunable), entry capacity per batch, accumulator budget
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", 7)));  // < 256: packed in 8 bits
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", S == 1 ? 8 : 7)));  // < 256: packed in 8 bits
     const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
     const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block

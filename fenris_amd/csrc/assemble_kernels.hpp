@@ -861,7 +861,7 @@ struct PipeTables {
 };
 
 template <int EK, int OP, int QC, int JT>
-__global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
+__global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, const PipeTables T) {
     // JT = local nodes J handled per lane in phase C
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
@@ -884,18 +884,22 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
     const int npos = T.npos;
     // contiguous range of positions per workgroup: consecutive positions are chain neighbours
     const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
+    // every lane loads (clamped index, same cache lines) so that the prefetch is branch-free: with predicated
+    // loads the compiler's waitcnt bookkeeping merges divergent paths and falls back to vmcnt(0) right after
+    // the issue, which serialises the prefetch with the block's compute
     auto load_rec = [&](int p, Rec& r) {
         p = min(p, npos - 1);
-        r.hword = (tid < 8) ? reinterpret_cast<const int*>(T.hdr + p)[tid] : 0;
+        r.hword = reinterpret_cast<const int*>(T.hdr + p)[tid & 7];
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const int sidx = tid + k * nt;
-            r.conn[k] = (sidx < T.cs) ? T.conn[(size_t)p * T.cs + sidx] : 0;
-        }
-        r.ent = (tid < T.ms) ? T.ent[(size_t)p * T.ms + tid] : 0u;
-        r.posw = (tid < T.ms * N / 4) ? T.pos[(size_t)p * (T.ms * N / 4) + tid] : 0u;
-        r.slotw = (tid < T.us / 4) ? T.slots[(size_t)p * (T.us / 4) + tid] : 0u;
-        r.noffr = (tid <= T.nbs) ? T.noffr[(size_t)p * (T.nbs + 1) + tid] : 0;
+        for (int k = 0; k < SLOTS; ++k) r.conn[k] = T.conn[(size_t)p * T.cs + min(tid + k * nt, T.cs - 1)];
+        r.ent = T.ent[(size_t)p * T.ms + min(tid, T.ms - 1)];
+        r.posw = T.pos[(size_t)p * (T.ms * N / 4) + min(tid, T.ms * N / 4 - 1)];
+        r.slotw = T.slots[(size_t)p * (T.us / 4) + min(tid, T.us / 4 - 1)];
+        r.noffr = T.noffr[(size_t)p * (T.nbs + 1) + min(tid, T.nbs)];
+    };
+    // pins the record in registers: the compiler places the vmcnt wait for its loads here
+    auto land_rec = [&](Rec& r) {
+        asm volatile("" : "+v"(r.hword), "+v"(r.conn[0]), "+v"(r.conn[1]), "+v"(r.ent), "+v"(r.posw), "+v"(r.slotw), "+v"(r.noffr));
     };
     double V[SLOTS][D];
     auto load_verts = [&](const Rec& r) {
@@ -930,14 +934,24 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
         load_verts(cur);
         load_rec(p + 1, nxt);
         park(cur, 0);
+        land_rec(nxt);
     }
     for (int i = tid; i < a.acc_max; i += nt) acc[i] = 0.0;
     __syncthreads();
 
+    // optional phase timing (FENRIS_HIP_TRACE): lane 0 of every wave accumulates s_memtime deltas per phase
+    unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tr_t = a.trace ? __builtin_amdgcn_s_memtime() : 0;
+#define FH_STAMP(K)                                              \
+    if (a.trace) {                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tr_acc[K] += now_ - tr_t;                                \
+        tr_t = now_;                                             \
+    }
     int parity = 0;
     for (; p < p_end; ++p, parity ^= 1) {
         const bool have_next = (p + 1) < p_end;
-        if (have_next) load_verts(nxt);      // lands while this block is computed
+        load_verts(nxt);      // lands while this block is computed (clamped past the end: harmless)
         Rec nn;
         load_rec(p + 2, nn);
         const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
@@ -968,6 +982,7 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
         const int il = (int)(packed & 0xffu);
         for (int qc = 0; qc < a.nq; qc += QC) {
             if (qc > 0) lds_barrier();  // the previous chunk's phase C is done with the staged points
+            FH_STAMP(0)  // top of block: prefetch issue, header, item decode
             // phase B for quadrature points [qc, qc + QC)
             if (!(a.ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
@@ -975,35 +990,61 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
                 if (qc + qs < a.nq)
                     prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
             }
+            FH_STAMP(1)  // phase B
             lds_barrier();
+            FH_STAMP(2)  // barrier after B
             // phase C (accumulate)
             const int nqc = min(QC, a.nq - qc);
             if (has_item && !(a.ablate & 2)) {
                 const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
-                for (int q = 0; q < nqc; ++q, pq += L.qpd) {
-                    // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours
-                    // into ds_read2_b64, which costs 8 cycles for the same 16 bytes (MI355X_MICROARCH.md, LDS
-                    // table), and the LDS pipe -- shared by the CU's four SIMDs -- is what bounds this loop.
-                    // asm loads are invisible to the compiler's waitcnt insertion: wait + sched_barrier below.
-                    double av[D], bvv[JT][D];
-                    lds_read_vec<D>(pq + an * D, av);
+                // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours
+                // into ds_read2_b64, which costs 8 cycles for the same 16 bytes (MI355X_MICROARCH.md, LDS
+                // table), and the LDS pipe -- shared by the CU's four SIMDs -- is what bounds this loop.
+                // asm loads are invisible to the compiler's waitcnt insertion: explicit waits + sched_barrier.
+                // Software pipeline in straight-line groups of GQ points: the fetches of point k+1 are in
+                // flight while the products of point k issue (no in-flight value crosses a loop back-edge).
+                constexpr int NL = D * (1 + JT);  // fetches per point
+                auto fetch = [&](const double* pp, double (&av)[D], double (&bvv)[JT][D]) {
+                    lds_read_vec<D>(pp + an * D, av);
 #pragma unroll
-                    for (int r = 0; r < JT; ++r) lds_read_vec<D>(pq + (j0 + r) * D, bvv[r]);
-                    lds_wait_all();
+                    for (int r = 0; r < JT; ++r) lds_read_vec<D>(pp + (j0 + r) * D, bvv[r]);
+                };
+                auto products = [&](const double (&av)[D], const double (&bvv)[JT][D]) {
+                    // G[r] = h_a h_J^T; the (min, max)-role block is G or its transpose (same products)
 #pragma unroll
-                    for (int r = 0; r < JT; ++r) {
-                        double bv[D];
-#pragma unroll
-                        for (int i = 0; i < D; ++i) bv[i] = bvv[r][i];
-                        // G[r] = h_a h_J^T; the (min, max)-role block is G or its transpose (same products)
+                    for (int r = 0; r < JT; ++r)
 #pragma unroll
                         for (int i = 0; i < D; ++i)
 #pragma unroll
-                            for (int j = 0; j < D; ++j) Gr[r][i][j] = fma(av[i], bv[j], Gr[r][i][j]);
+                            for (int j = 0; j < D; ++j) Gr[r][i][j] = fma(av[i], bvv[r][j], Gr[r][i][j]);
+                };
+                constexpr int GQ = (QC >= 4 && JT <= 2) ? 4 : 1;
+                int q = 0;
+                if (GQ > 1) {
+                    for (; q + GQ <= nqc; q += GQ, pq += GQ * L.qpd) {
+                        double av[2][D], bvv[2][JT][D];
+                        fetch(pq, av[0], bvv[0]);
+#pragma unroll
+                        for (int k = 0; k < GQ; ++k) {
+                            if (k + 1 < GQ) {
+                                fetch(pq + (k + 1) * L.qpd, av[(k + 1) & 1], bvv[(k + 1) & 1]);
+                                lds_wait<NL>();
+                            } else {
+                                lds_wait<0>();
+                            }
+                            products(av[k & 1], bvv[k & 1]);
+                        }
                     }
+                }
+                for (; q < nqc; ++q, pq += L.qpd) {
+                    double av[D], bvv[JT][D];
+                    fetch(pq, av, bvv);
+                    lds_wait_all();
+                    products(av, bvv);
                 }
             }
         }
+        FH_STAMP(3)  // phase C
         // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
         if (has_item && !(a.ablate & 4)) {
             const int rb = lds_i[L.o_noff + il], cnt = lds_i[L.o_noff + il + 1] - rb;
@@ -1040,8 +1081,15 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
             }
         }
         lds_barrier();
-        // phase D (also clears the accumulators for the next block; no barrier needed before parking: the
-        // parked regions -- X, entries, slots, row offsets -- are not read here)
+        FH_STAMP(4)  // finalize + barrier
+        // park the prefetched block before the write-out: vmcnt counts loads and stores in one queue, so a wait
+        // for the prefetch placed after the stores would wait for the stores as well.  The parked regions -- X,
+        // entries, slots, row offsets -- are not read below.
+        if (have_next) park(nxt, parity ^ 1);
+        land_rec(nn);
+        nxt = nn;
+        // phase D (also clears the accumulators for the next block); the stores stay in flight across the
+        // loop back-edge
         double* out = a.vals + (size_t)S * S * hc.r0;
         if (a.ablate & 8) {
             for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
@@ -1050,10 +1098,13 @@ __global__ void __launch_bounds__(256, (JT >= 4 ? 2 : 3)) k_gather_pipelined(con
         } else {
             for (int i = tid; i < nacc; i += nt) { out[i] += acc[i]; acc[i] = 0.0; }
         }
-        // park the prefetched block
-        if (have_next) park(nxt, parity ^ 1);
-        nxt = nn;
         lds_barrier();
+        FH_STAMP(5)  // write-out, parking, end barrier
+    }
+#undef FH_STAMP
+    if (a.trace && (tid & 63) == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(a.trace + k, tr_acc[k]);
+        atomicAdd(a.trace + 6, 1ull);
     }
 }
 

@@ -95,6 +95,7 @@ struct KArgs {
     double* ke_out;
     int overwrite;
     DevStatus* status;
+    unsigned long long* trace;  // profiling only: 7 counters (6 phase cycle sums over waves, wave count) or null
     // element-centric work description
     const unsigned* labels;  // element list (colour) or null for identity
     long long work_begin, work_end;

@@ -204,6 +204,7 @@ struct fh_ctx {
     // status
     DevBuf<DevStatus> status;
     DevBuf<double> scratch;
+    DevBuf<unsigned long long> trace;
 
     int S() const {
         if (ragged) return (int)sdim_ragged;
@@ -445,6 +446,11 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.n2e = c->n2e.p;
     a.status = c->status.p;
     a.ablate = env_int("FENRIS_HIP_ABLATE", 0);
+    a.trace = nullptr;
+    if (std::getenv("FENRIS_HIP_TRACE")) {
+        if (!c->trace.p && c->trace.alloc(8) == hipSuccess) (void)hipMemset(c->trace.p, 0, 64);
+        a.trace = c->trace.p;
+    }
 }
 
 int reset_status(fh_ctx* c) {
@@ -878,6 +884,18 @@ fh_ctx* fh_create(int device_id) {
 void fh_destroy(fh_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->trace.p) {  // FENRIS_HIP_TRACE: average cycles per wave and phase of the pipelined kernel
+        unsigned long long h[8] = {0};
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
+            static const char* names[6] = {"top", "phaseB", "barrierB", "phaseC", "finalize+barrier", "writeout+park+barrier"};
+            unsigned long long tot = 0;
+            for (int k = 0; k < 6; ++k) tot += h[k];
+            for (int k = 0; k < 6; ++k)
+                std::fprintf(stderr, "[fenris_hip trace] %-24s %12.0f cycles/wave  %5.1f %%\n", names[k], (double)h[k] / (double)h[6],
+                             100.0 * (double)h[k] / (double)tot);
+        }
+    }
     delete c;
 }
 

@@ -27,6 +27,10 @@ struct Layout {
     int fast;  // 1: gradients stored pre-scaled by sqrt(w |det J|), no per-point coefficients
     int o_pos; // gather: per (entry, local node) column slot, bytes
     int nqs;   // quadrature points staged per element at a time (== nq unless chunked)
+    // strides in doubles, rounded up to odd counts: phase B runs one lane per (element, point), so lanes differ
+    // in the element (X, U) or in the point (gradient tables); an even stride such as 24 maps eight of them onto
+    // two LDS bank pairs (4-way conflicts on three quarters of phase B's LDS traffic)
+    int xs, us, gs, ggs;  // per element: vertices, u;  per point: reference gradients, geometry gradients
     __host__ __device__ size_t bytes() const { return sizeof(double) * (size_t)n_doubles + sizeof(int) * (size_t)n_ints; }
 };
 
@@ -39,13 +43,17 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     using O = OpT<OP, E::D>;
     Layout L;
     int o = 0;
-    L.o_gref = o;  o += nq * E::N * E::D;
+    L.xs = (E::NG * E::D) | 1;
+    L.us = (E::N * O::S) | 1;
+    L.gs = (E::N * E::D) | 1;
+    L.ggs = (E::NG * E::D) | 1;
+    L.o_gref = o;  o += nq * L.gs;
     if (E::NG == E::N) L.o_ggeom = L.o_gref;  // iso-parametric: one table
-    else { L.o_ggeom = o; o += nq * E::NG * E::D; }
+    else { L.o_ggeom = o; o += nq * L.ggs; }
     L.o_qw = o;    o += nq;
     L.o_qpar = o;  o += 2 * nq;
-    L.o_X = o;     o += ub * E::NG * E::D;
-    L.o_U = o;     o += (O::NEEDS_U || WHAT != WHAT_MATRIX) ? ub * E::N * O::S : 0;
+    L.o_X = o;     o += ub * L.xs;
+    L.o_U = o;     o += (O::NEEDS_U || WHAT != WHAT_MATRIX) ? ub * L.us : 0;
     L.fast = (WHAT == WHAT_MATRIX && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC)) ? fast : 0;
     if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + (L.fast ? 0 : O::NCOEF);
     else if (WHAT == WHAT_VECTOR) L.qpd = E::N * E::D + O::S * E::D;
@@ -67,6 +75,9 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.o_ncr = i;     i += (!gather && nc_row > 0) ? 2 * ub * E::N : 0;
     L.o_nc = i;      i += (!gather && nc_row > 0) ? ub * E::N * nc_row : 0;
     L.n_ints = i + 4;
+    // pipelined gather (the only kernel that stages quadrature points in chunks) lays out its integers itself:
+    // 16 header words + two parity copies of (slot list | entries | column slots | row offsets)
+    if (gather && nq_stage > 0) L.n_ints = 16 + 2 * (ub / 4 + 1 + mb + (mb * E::N + 3) / 4 + nb_max + 1) + 4;
     return L;
 }
 
@@ -138,9 +149,9 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
     constexpr bool IS_MASS = (OP == FH_MASS_SCALAR || OP == FH_MASS_VECTOR);
-    const double* X = lds + L.o_X + u * NG * D;
-    const double* gg = lds + L.o_ggeom + q * NG * D;
-    const double* gr = lds + L.o_gref + q * N * D;
+    const double* X = lds + L.o_X + u * L.xs;
+    const double* gg = lds + L.o_ggeom + q * L.ggs;
+    const double* gr = lds + L.o_gref + q * L.gs;
     double* qp = lds + L.o_QP + (size_t)(u * L.nqs + (qslot < 0 ? q : qslot)) * L.qpd;
     (void)lds_i;
 
@@ -152,16 +163,21 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         for (int j = 0; j < D; ++j) J[i][j] = 0.0;
     constexpr int UNR = (N <= 8) ? N : 3;
     constexpr bool EXPLICIT_LDS = (N <= 8);  // hand-issued ds_read_b64 (see lds_read_f64): small elements only
+    // iso-parametric small elements: the rows of the gradient table fetched for J stay in registers for the
+    // physical gradients below (a quarter of phase B's LDS traffic)
+    constexpr bool KEEP_G = EXPLICIT_LDS && NG == N && !IS_MASS;
+    double gkeep[KEEP_G ? N : 1][D];
     if (EXPLICIT_LDS) {
         // software-pipelined: the fetches of node g+1 are in flight while node g is accumulated
         double xb[2][D], gb[2][D];
         lds_read_vec<D>(X, xb[0]);
-        lds_read_vec<D>(gg, gb[0]);
+        if (KEEP_G) lds_read_vec<D>(gg, gkeep[0]); else lds_read_vec<D>(gg, gb[0]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) {
                 lds_read_vec<D>(X + (g + 1) * D, xb[(g + 1) & 1]);
-                lds_read_vec<D>(gg + (g + 1) * D, gb[(g + 1) & 1]);
+                if (KEEP_G) lds_read_vec<D>(gg + (g + 1) * D, gkeep[KEEP_G ? g + 1 : 0]);
+                else lds_read_vec<D>(gg + (g + 1) * D, gb[(g + 1) & 1]);
                 lds_wait<2 * D>();
             } else {
                 lds_wait<0>();
@@ -169,7 +185,8 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int j = 0; j < D; ++j) J[i][j] = fma(xb[g & 1][i], gb[g & 1][j], J[i][j]);
+                for (int j = 0; j < D; ++j)
+                    J[i][j] = fma(xb[g & 1][i], KEEP_G ? gkeep[KEEP_G ? g : 0][j] : gb[g & 1][j], J[i][j]);
         }
     } else {
         for (int g = 0; g < NG; ++g)
@@ -201,7 +218,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
             for (int k = 0; k < S; ++k) gu[i][k] = 0.0;
     }
-    const double* Ue = lds + L.o_U + u * N * S;
+    const double* Ue = lds + L.o_U + u * L.us;
     double* gout = qp;  // first node-vector block: physical gradients
     // FAST path (Laplace / uniform linear elasticity, non-negative weights): store sqrt(s) g_n so that
     // sum_q s g_I g_J^T = sum_q h_I h_J^T needs no per-point coefficient in phase C
@@ -219,11 +236,14 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         return;
     }
     double rb[2][D];
-    if (EXPLICIT_LDS) lds_read_vec<D>(gr, rb[0]);
+    if (EXPLICIT_LDS && !KEEP_G) lds_read_vec<D>(gr, rb[0]);
 #pragma unroll UNR
     for (int n = 0; n < N; ++n) {
         double g[D], rv[D];
-        if (EXPLICIT_LDS) {
+        if (KEEP_G) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) rv[k] = gkeep[KEEP_G ? n : 0][k];
+        } else if (EXPLICIT_LDS) {
             if (n + 1 < N) {
                 lds_read_vec<D>(gr + (n + 1) * D, rb[(n + 1) & 1]);
                 lds_wait<D>();
@@ -458,6 +478,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     }
 }
 
+
 // ------------------------------------------------------------------------------------------ phase C
 // s x s block K_e[(I,.),(J,.)] for I <= J: sum over quadrature points of scale * C(grad u; g_I, g_J).
 template <int EK, int OP>
@@ -639,9 +660,10 @@ template <int EK>
 __device__ __forceinline__ void stage_tables(const KArgs& a, const Layout& L, double* lds) {
     using E = ElemT<EK>;
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < a.nq * E::N * E::D; i += nt) lds[L.o_gref + i] = a.gref[i];
+    for (int i = tid; i < a.nq * E::N * E::D; i += nt) lds[L.o_gref + (i / (E::N * E::D)) * L.gs + i % (E::N * E::D)] = a.gref[i];
     if (E::NG != E::N)
-        for (int i = tid; i < a.nq * E::NG * E::D; i += nt) lds[L.o_ggeom + i] = a.ggeom[i];
+        for (int i = tid; i < a.nq * E::NG * E::D; i += nt)
+            lds[L.o_ggeom + (i / (E::NG * E::D)) * L.ggs + i % (E::NG * E::D)] = a.ggeom[i];
     for (int i = tid; i < a.nq; i += nt) lds[L.o_qw + i] = a.qw[i];
     for (int i = tid; i < 2 * a.nq; i += nt) lds[L.o_qpar + i] = a.qparams ? a.qparams[i] : 0.0;
 }
@@ -659,12 +681,12 @@ __device__ __forceinline__ void stage_elements(const KArgs& a, const Layout& L, 
     __syncthreads();
     for (int i = tid; i < U * E::NG * E::D; i += nt) {
         const int u = i / (E::NG * E::D), r = i % (E::NG * E::D), g = r / E::D, c = r % E::D;
-        lds[L.o_X + i] = a.verts[(size_t)lds_i[L.o_cn + u * E::N + g] * E::D + c];
+        lds[L.o_X + u * L.xs + r] = a.verts[(size_t)lds_i[L.o_cn + u * E::N + g] * E::D + c];
     }
     if (need_u) {
         for (int i = tid; i < U * E::N * S; i += nt) {
             const int u = i / (E::N * S), r = i % (E::N * S), n = r / S, c = r % S;
-            lds[L.o_U + i] = a.u ? a.u[(size_t)lds_i[L.o_cn + u * E::N + n] * S + c] : 0.0;
+            lds[L.o_U + u * L.us + r] = a.u ? a.u[(size_t)lds_i[L.o_cn + u * E::N + n] * S + c] : 0.0;
         }
     }
     __syncthreads();
@@ -871,7 +893,6 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
     const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC);
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
-    unsigned* pos_lds = reinterpret_cast<unsigned*>(lds_i + L.o_pos);
     double* acc = lds + L.o_ACC;
     const int tid = threadIdx.x, nt = 256;
     const int G = gridDim.x;
@@ -908,21 +929,45 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
 #pragma unroll
             for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
     };
-    int* hdr_lds = lds_i + L.o_uniq;            // 2 x 8 ints: block headers, double-buffered by parity
-    unsigned* slot_lds = reinterpret_cast<unsigned*>(lds_i + L.o_uniq + 16);  // us bytes: slot list of the current block
+    // integer LDS: 2 x 8 header words, then one record per block parity (slot list | entries | column slots |
+    // row offsets).  Everything parked for block p+1 is double-buffered, so parking needs no barrier of its own;
+    // X is single-buffered: it is only read by phase B, which lies behind the barrier that precedes phase C.
+    int* hdr_lds = lds_i;
+    const int rec_ints = T.us / 4 + T.ms + T.ms * N / 4 + T.nbs + 1;
+    auto rec_base = [&](int parity) { return lds_i + 16 + parity * rec_ints; };
     auto park = [&](const Rec& r, int parity) {  // registers -> LDS for the block that is computed next
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             const int sidx = tid + k * nt;
             if (sidx < T.cs)  // padded / retained slots carry valid vertex indices: harmless
 #pragma unroll
-                for (int c = 0; c < D; ++c) lds[L.o_X + sidx * D + c] = V[k][c];
+                for (int c = 0; c < D; ++c) lds[L.o_X + (sidx / NG) * L.xs + (sidx % NG) * D + c] = V[k][c];
         }
+        int* rb = rec_base(parity);
         if (tid < 8) hdr_lds[8 * parity + tid] = r.hword;
-        if (tid < T.ms) lds_i[L.o_ent + tid] = (int)r.ent;
-        if (tid < T.ms * N / 4) pos_lds[tid] = r.posw;
-        if (tid < T.us / 4) slot_lds[tid] = r.slotw;
-        if (tid <= T.nbs) lds_i[L.o_noff + tid] = r.noffr;
+        if (tid < T.us / 4) rb[tid] = (int)r.slotw;
+        if (tid < T.ms) rb[T.us / 4 + tid] = (int)r.ent;
+        if (tid < T.ms * N / 4) rb[T.us / 4 + T.ms + tid] = (int)r.posw;
+        if (tid <= T.nbs) rb[T.us / 4 + T.ms + T.ms * N / 4 + tid] = r.noffr;
+    };
+    // phase D: rows of a finished block -> global memory, accumulators cleared.  NTH threads take part, in
+    // reverse thread order, so that the waves with no phase-B work do it while the others run phase B.
+    auto write_out = [&](double* out, int nacc, int nth) {
+        const int rt = nt - 1 - tid;
+        if (rt >= nth) return;
+        if (a.ablate & 8) {
+            for (int i = rt; i < nacc; i += nth) acc[i] = 0.0;
+        } else if (a.overwrite) {
+            int i = rt;
+            for (; i + 3 * nth < nacc; i += 4 * nth) {  // batches of four: the LDS reads overlap
+                const double v0 = acc[i], v1 = acc[i + nth], v2 = acc[i + 2 * nth], v3 = acc[i + 3 * nth];
+                out[i] = v0; out[i + nth] = v1; out[i + 2 * nth] = v2; out[i + 3 * nth] = v3;
+                acc[i] = 0.0; acc[i + nth] = 0.0; acc[i + 2 * nth] = 0.0; acc[i + 3 * nth] = 0.0;
+            }
+            for (; i < nacc; i += nth) { out[i] = acc[i]; acc[i] = 0.0; }
+        } else {
+            for (int i = rt; i < nacc; i += nth) { out[i] += acc[i]; acc[i] = 0.0; }
+        }
     };
 
     int p = p_begin;
@@ -949,23 +994,32 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
         tr_t = now_;                                             \
     }
     int parity = 0;
+    double* prev_out = nullptr;  // rows of the previous block, still in the accumulators
+    int prev_nacc = 0;
     for (; p < p_end; ++p, parity ^= 1) {
         const bool have_next = (p + 1) < p_end;
+        // LDS reads of this block's header and item first, the global prefetch is issued while they are in flight
+        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
+        const int* rec = rec_base(parity);
+        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(rec);
+        const int* ent_l = rec + T.us / 4;
+        const unsigned char* pos_b = reinterpret_cast<const unsigned char*>(rec + T.us / 4 + T.ms);
+        const int* noff_l = rec + T.us / 4 + T.ms + T.ms * N / 4;
+        constexpr int NGRP = (JT <= N) ? N / JT : 1;
+        const int t_item = tid / NGRP, j0 = (tid % NGRP) * JT;
+        const unsigned packed_raw = (unsigned)ent_l[min(t_item, T.ms - 1)];
         load_verts(nxt);      // lands while this block is computed (clamped past the end: harmless)
         Rec nn;
         load_rec(p + 2, nn);
-        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
         // slots to (re)compute: only the new ones, except at the start of this workgroup's range where nothing
         // is staged yet (the slot list holds the new slots first, then the retained ones)
         const int U = (p == p_begin || QC < a.nq) ? hc.U : hc.k0;  // chunked staging keeps nothing across blocks
         const int m = hc.m, nrow = hc.nrow;
-        const int nacc = S * S * nrow;   // accumulators are zero here: cleared by the previous phase D
-        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(slot_lds);
+        const int nacc = S * S * nrow;
         // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
         // elements of the block are staged at once (U <= ub guaranteed by the host).  One lane owns an entry
         // (node, element, local index a) and JT consecutive local nodes J: h_a is read once per point for JT
         // blocks (LDS traffic, not VALU, bounds this kernel).
-        constexpr int NGRP = (JT <= N) ? N / JT : 1;
         double Gr[JT][D][D];
 #pragma unroll
         for (int r = 0; r < JT; ++r)
@@ -974,9 +1028,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
 #pragma unroll
                 for (int j = 0; j < D; ++j) Gr[r][i][j] = 0.0;
         const bool has_item = tid < m * NGRP;
-        const int t_item = tid / NGRP, j0 = (tid % NGRP) * JT;
-        unsigned packed = 0;
-        if (has_item) packed = (unsigned)lds_i[L.o_ent + t_item];
+        const unsigned packed = has_item ? packed_raw : 0u;
         const int u_item = (int)(packed >> 16);
         const int an = (int)((packed >> 8) & 0xffu);
         const int il = (int)(packed & 0xffu);
@@ -990,7 +1042,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
                 if (qc + qs < a.nq)
                     prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
             }
-            FH_STAMP(1)  // phase B
+            // phase D of the previous block, overlapped with phase B: its accumulators are complete (barrier at the
+            // end of the last iteration) and are not touched again before the barrier below
+            if (qc == 0 && prev_nacc > 0 && !(a.ablate & 16)) write_out(prev_out, prev_nacc, (U * QC <= nt / 2) ? nt / 2 : nt);
+            FH_STAMP(1)  // phase B (+ write-out of the previous block)
             lds_barrier();
             FH_STAMP(2)  // barrier after B
             // phase C (accumulate)
@@ -1047,8 +1102,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
         FH_STAMP(3)  // phase C
         // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
         if (has_item && !(a.ablate & 4)) {
-            const int rb = lds_i[L.o_noff + il], cnt = lds_i[L.o_noff + il + 1] - rb;
-            const unsigned char* pos_b = reinterpret_cast<const unsigned char*>(pos_lds);
+            const int rb = noff_l[il], cnt = noff_l[il + 1] - rb;
 #pragma unroll
             for (int r = 0; r < JT; ++r) {
                 const int Jn = j0 + r;
@@ -1066,41 +1120,44 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
                 if (OP == FH_LAPLACE) {
                     atomic_add_f64(base, tr);
                 } else {
+                    double val[D][D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                            val[i][j] = (i == j) ? fma(a.mu, tr + Gr[r][i][i], a.lambda * Gr[r][i][i])
+                                                 : fma(a.mu, Gr[r][j][i], a.lambda * Gr[r][i][j]);
+                    const bool diag = (an == Jn);
 #pragma unroll
                     for (int i = 0; i < D; ++i)
 #pragma unroll
                         for (int j = 0; j < D; ++j) {
-                            // diagonal block: mirror the upper triangle (util.rs:46-50); both candidates use
-                            // compile-time register indices (a runtime index would push Gr to scratch)
-                            const double v_ij = a.mu * ((i == j ? tr : 0.0) + Gr[r][j][i]) + a.lambda * Gr[r][i][j];
-                            const double v_ji = a.mu * ((i == j ? tr : 0.0) + Gr[r][i][j]) + a.lambda * Gr[r][j][i];
-                            const double v = (an == Jn && i > j) ? v_ji : v_ij;
+                            // diagonal block: the lower triangle mirrors the upper one (util.rs:46-50); compile-time
+                            // register indices only (a runtime index would push Gr to scratch)
+                            const double v = (i > j && diag) ? val[j][i] : val[i][j];
                             atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
                         }
                 }
             }
         }
-        lds_barrier();
-        FH_STAMP(4)  // finalize + barrier
-        // park the prefetched block before the write-out: vmcnt counts loads and stores in one queue, so a wait
-        // for the prefetch placed after the stores would wait for the stores as well.  The parked regions -- X,
-        // entries, slots, row offsets -- are not read below.
+        // park the prefetched block (double-buffered regions, see above).  vmcnt counts loads and stores in one
+        // queue: waiting for the prefetch here, a whole accumulate phase after the write-out stores were issued,
+        // costs nothing.
         if (have_next) park(nxt, parity ^ 1);
         land_rec(nn);
         nxt = nn;
-        // phase D (also clears the accumulators for the next block); the stores stay in flight across the
-        // loop back-edge
-        double* out = a.vals + (size_t)S * S * hc.r0;
-        if (a.ablate & 8) {
-            for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
-        } else if (a.overwrite) {
-            for (int i = tid; i < nacc; i += nt) { out[i] = acc[i]; acc[i] = 0.0; }
-        } else {
-            for (int i = tid; i < nacc; i += nt) { out[i] += acc[i]; acc[i] = 0.0; }
-        }
+        prev_out = a.vals + (size_t)S * S * hc.r0;
+        prev_nacc = nacc;
+        FH_STAMP(4)  // finalize + park
         lds_barrier();
-        FH_STAMP(5)  // write-out, parking, end barrier
+        if (a.ablate & 16) {  // experiment: write-out by all threads behind the barrier instead of overlapped
+            write_out(prev_out, prev_nacc, nt);
+            prev_nacc = 0;
+            lds_barrier();
+        }
+        FH_STAMP(5)  // end barrier
     }
+    write_out(prev_out, prev_nacc, nt);
 #undef FH_STAMP
     if (a.trace && (tid & 63) == 0) {
         for (int k = 0; k < 6; ++k) atomicAdd(a.trace + k, tr_acc[k]);

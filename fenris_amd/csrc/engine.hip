@@ -768,6 +768,8 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             PipeTables T{c->p_hdr.p, c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_slots.p, c->p_elem.p,
                          c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->nblk};
             a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
+            a.mb = c->p_ms;  // the LDS layout is sized by the table strides
+            a.nb_max = c->p_nbs;
             c->last_kernel = "k_gather_pipelined";
             return launch_pipelined(c, a, T, 0, 0);
         }
@@ -888,7 +890,7 @@ void fh_destroy(fh_ctx* c) {
         unsigned long long h[8] = {0};
         (void)hipDeviceSynchronize();
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
-            static const char* names[6] = {"top", "phaseB", "barrierB", "phaseC", "finalize+barrier", "writeout+park+barrier"};
+            static const char* names[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};
             unsigned long long tot = 0;
             for (int k = 0; k < 6; ++k) tot += h[k];
             for (int k = 0; k < 6; ++k)

@@ -7,11 +7,12 @@ from . import _ffi, assembly, mesh, operators, quadrature
 from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
                    SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,
-                       ElementEllipticAssemblerBuilder, Engine, MockElementAssembler, UniformQuadratureTable,
+                       ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,
+                       MockElementAssembler, UniformQuadratureTable,
                        VectorAssembler, VectorParAssembler, apply_homogeneous_dirichlet_bc_csr,
                        apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes)
 from .mesh import Mesh, hex27_mesh_from_hex8, procedural
-from .operators import (Density, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
+from .operators import (Density, GravitySource, SourceFunction, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
                         NeoHookeanMaterial, StVKMaterial, YoungPoisson)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -174,6 +174,23 @@ class Engine:
             rc = self._lib.fh_assemble_vector(self._h, _ffi.fp(out), C.byref(failed))
         self._check(rc, failed)
 
+    def assemble_source_vector(self, out, solution_dim, g=None, values=None):
+        """fh_assemble_source_vector(_dev): out += sum_q w |det J| f phi (source.rs:219-278)"""
+        gp = _ffi.fp(np.ascontiguousarray(g, dtype=np.float64)) if g is not None else None
+        if _is_torch(out):
+            vp = C.c_void_p(values.data_ptr()) if values is not None else None
+            rc = self._lib.fh_assemble_source_vector_dev(self._h, solution_dim, gp, vp, C.c_void_p(out.data_ptr()))
+        else:
+            vp = _ffi.fp(np.ascontiguousarray(values, dtype=np.float64)) if values is not None else None
+            rc = self._lib.fh_assemble_source_vector(self._h, solution_dim, gp, vp, _ffi.fp(out))
+        self._check(rc)
+
+    def physical_quadrature_points(self, nq):
+        d = _ffi.ELEM_DIM[self._mesh.elem_kind]
+        x = np.zeros((self.num_elements(), nq, d))
+        self._check(self._lib.fh_physical_quadrature_points(self._h, _ffi.fp(x)))
+        return x
+
     def assemble_scalar(self):
         out, failed = C.c_double(), C.c_uint64(0)
         self._check(self._lib.fh_assemble_scalar(self._h, C.byref(out), C.byref(failed)), failed)
@@ -378,6 +395,82 @@ class ElementMassAssembler(ElementEllipticAssembler):
         return self
 
 
+class ElementSourceAssemblerBuilder:
+    """src/assembly/local/source.rs:24-94"""
+
+    def __init__(self, engine: Optional[Engine] = None):
+        self._engine, self._space, self._source, self._qtable = engine, None, None, None
+
+    @classmethod
+    def new(cls, engine: Optional[Engine] = None):
+        return cls(engine)
+
+    def with_finite_element_space(self, space: Mesh):
+        self._space = space
+        return self
+
+    def with_source(self, source):
+        self._source = source
+        return self
+
+    def with_quadrature_table(self, qtable: "UniformQuadratureTable"):
+        self._qtable = qtable
+        return self
+
+    def build(self) -> "ElementSourceAssembler":
+        if self._space is None or self._source is None or self._qtable is None:
+            raise ValueError("space, source and quadrature table are required")
+        return ElementSourceAssembler(self._engine or Engine(), self._space, self._source, self._qtable)
+
+
+class ElementSourceAssembler:
+    """src/assembly/local/source.rs:96-216: an ElementVectorAssembler for the (f, v) term.  ``source`` is a
+    GravitySource (uniform Density table) or a SourceFunction (sampled on the host at the physical quadrature
+    points, integrated on the device)."""
+
+    def __init__(self, engine, space, source, qtable):
+        self.engine, self.space, self.source, self.qtable = engine, space, source, qtable
+        d = _ffi.ELEM_DIM[space.elem_kind]
+        if source.solution_dim not in (1, d):
+            raise ValueError("solution_dim must be 1 or the geometry dimension")
+        engine.set_mesh(space)
+        engine.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
+
+    def solution_dim(self):
+        return self.source.solution_dim
+
+    def num_elements(self):
+        return self.space.num_elements()
+
+    def num_nodes(self):
+        return self.space.num_nodes()
+
+    def element_node_count(self, _element_index):
+        return _ffi.ELEM_NODES[self.space.elem_kind]
+
+    def populate_element_nodes(self, output, element_index):
+        output[:] = self.space.connectivity[element_index]
+
+    def assemble_vector_into_engine(self, output):
+        s = self.source.solution_dim
+        if hasattr(self.source, "gravitational_acceleration"):
+            if self.qtable.data is None:
+                raise ValueError("GravitySource needs a Density per quadrature point")
+            self.engine.assemble_source_vector(output, s, g=self.source.gravitational_acceleration)
+            return
+        x = self.engine.physical_quadrature_points(len(self.qtable.weights))
+        vals = np.ascontiguousarray(self.source.evaluate(x, self.qtable.data), dtype=np.float64)
+        if vals.shape != (self.num_elements(), len(self.qtable.weights), s):
+            raise ValueError("source values must have shape (E, nq, solution_dim)")
+        if _is_torch(output):
+            import torch
+
+            vals_t = torch.from_numpy(vals).to(output.device)
+            self.engine.assemble_source_vector(output, s, values=vals_t)
+        else:
+            self.engine.assemble_source_vector(output, s, values=vals)
+
+
 class MockElementAssembler:
     """Generic ElementConnectivityAssembler with ragged node lists
     (tests/unit_tests/assembly/global.rs MockElementAssembler)."""
@@ -460,7 +553,10 @@ class VectorAssembler:
         n = element_assembler.solution_dim() * element_assembler.num_nodes()
         if (output.numel() if _is_torch(output) else len(output)) != n:
             raise ValueError("Output dimensions mismatch")  # global.rs:592
-        element_assembler.engine.assemble_vector(output)
+        if hasattr(element_assembler, "assemble_vector_into_engine"):  # ElementSourceAssembler
+            element_assembler.assemble_vector_into_engine(output)
+        else:
+            element_assembler.engine.assemble_vector(output)
 
 
 class VectorParAssembler(VectorAssembler):

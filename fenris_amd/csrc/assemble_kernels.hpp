@@ -1415,6 +1415,89 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
     }
 }
 
+// ============================================================================================ source
+// ElementSourceAssembler (src/assembly/local/source.rs:219-278): f_e = sum_q w |det J| f(x_q) phi(xi_q), scattered
+// with fp64 atomics into out[s node + c].  One lane per (element, point) computes w |det J| (only the determinant
+// of J enters: no singular-Jacobian error on this path), then one lane per (element, node) sums over the points.
+// The source is either density_q * g (GravitySource, fenris-solid/src/gravity_source.rs:57-65; density_q is the
+// first parameter of the quadrature table) or values sampled by the caller at the physical points.
+struct SourceArgs {
+    int N, NG;                 // nodes per element (solution / geometry; the geometry nodes come first)
+    const double* phigeom;     // nq x NG  basis values of the geometry map
+    const double* g;           // S (device) or null
+    const double* values;      // E x nq x S (device) or null
+    double* xq;                // E x nq x D physical points (k_physical_points)
+};
+
+template <int D>
+__device__ __forceinline__ double source_wdet(const KArgs& a, const SourceArgs& sa, long long e, int q, double* x_out) {
+    double J[D][D], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        x[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) J[i][j] = 0.0;
+    }
+    for (int g = 0; g < sa.NG; ++g) {
+        const double* v = a.verts + (size_t)a.conn[(size_t)e * sa.N + g] * D;
+        const double* gg = a.ggeom + ((size_t)q * sa.NG + g) * D;
+        const double ph = sa.phigeom[(size_t)q * sa.NG + g];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            x[i] = fma(v[i], ph, x[i]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) J[i][j] = fma(v[i], gg[j], J[i][j]);
+        }
+    }
+    if (x_out)
+#pragma unroll
+        for (int i = 0; i < D; ++i) x_out[i] = x[i];
+    return a.qw[q] * fabs(det_small<D>(J));
+}
+
+template <int D, int S>
+__global__ void __launch_bounds__(256) k_assemble_source(const KArgs a, const SourceArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* wd = reinterpret_cast<double*>(smem);  // epb x nq
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long long w0 = a.work_begin + (long long)blockIdx.x * a.epb;
+    const int U = (int)min((long long)a.epb, a.work_end - w0);
+    for (int i = tid; i < U * a.nq; i += nt) {
+        const long long e = a.labels ? (long long)a.labels[w0 + i / a.nq] : w0 + i / a.nq;
+        wd[i] = source_wdet<D>(a, sa, e, i % a.nq, nullptr);
+    }
+    __syncthreads();
+    for (int it = tid; it < U * sa.N; it += nt) {
+        const int u = it / sa.N, I = it % sa.N;
+        const long long e = a.labels ? (long long)a.labels[w0 + u] : w0 + u;
+        double f[S];
+#pragma unroll
+        for (int c = 0; c < S; ++c) f[c] = 0.0;
+        for (int q = 0; q < a.nq; ++q) {
+            const double t = wd[u * a.nq + q] * a.phiref[(size_t)q * sa.N + I];
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                const double fc = sa.values ? sa.values[((size_t)e * a.nq + q) * S + c] : sa.g[c] * a.qparams[2 * q];
+                f[c] = fma(t, fc, f[c]);
+            }
+        }
+        const int node = a.conn[(size_t)e * sa.N + I];
+#pragma unroll
+        for (int c = 0; c < S; ++c) atomic_add_f64(a.vec_out + (size_t)node * S + c, f[c]);
+    }
+}
+
+// x_q = map_reference_coords(xi_q) of every element (source.rs:263), E x nq x D
+template <int D>
+__global__ void __launch_bounds__(256) k_physical_points(const KArgs a, const SourceArgs sa) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.num_elements * a.nq) return;
+    double x[D];
+    (void)source_wdet<D>(a, sa, i / a.nq, (int)(i % a.nq), x);
+#pragma unroll
+    for (int k = 0; k < D; ++k) sa.xq[(size_t)i * D + k] = x[k];
+}
+
 // ============================================================================================ scalar
 template <int EK, int OP>
 __global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {

@@ -165,7 +165,7 @@ struct fh_ctx {
     int op = -1;
     uint64_t sdim_ragged = 1;
     int nq = 0;
-    DevBuf<double> qw, gref, ggeom, phiref, qparams, u;
+    DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u;
     bool has_params = false, has_u = false;
     bool fast_ok = false;       // uniform parameters and non-negative weights
     double uni_mu = 0.0, uni_lambda = 0.0;
@@ -1086,6 +1086,10 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     if (!w || !pts || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform: bad argument");
     const ElemInfo& ei = c->ei;
     std::vector<double> gref((size_t)nq * ei.n * ei.d), ggeom((size_t)nq * ei.ng * ei.d), phiref((size_t)nq * ei.n);
+    std::vector<double> phigeom((size_t)nq * ei.ng);
+    for (uint32_t q = 0; q < nq; ++q) ref_basis(ei.geom_kind, pts + (size_t)q * ei.d, phigeom.data() + (size_t)q * ei.ng);
+    HIP_TRY(c, c->phigeom.alloc(phigeom.size()));
+    HIP_TRY(c, hipMemcpy(c->phigeom.p, phigeom.data(), sizeof(double) * phigeom.size(), hipMemcpyHostToDevice));
     for (uint32_t q = 0; q < nq; ++q) {
         ref_gradients(c->elem_kind, pts + (size_t)q * ei.d, gref.data() + (size_t)q * ei.n * ei.d);
         ref_gradients(ei.geom_kind, pts + (size_t)q * ei.d, ggeom.data() + (size_t)q * ei.ng * ei.d);
@@ -1321,6 +1325,111 @@ int fh_assemble_vector(fh_ctx* c, double* out, uint64_t* failed) {
     rc = fh_assemble_vector_dev(c, d.p, failed);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, d.p, sizeof(double) * len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+// ---- ElementSourceAssembler (src/assembly/local/source.rs) ------------------------------------------------------
+static int source_ready(fh_ctx* c, const char* who) {
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, std::string(who) + ": no finite element mesh set");
+    if (c->nq <= 0) return c->fail(FH_INVALID_STATE, std::string(who) + ": no quadrature table set");
+    return FH_OK;
+}
+
+int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, const double* values_dev, double* out_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = source_ready(c, "fh_assemble_source_vector");
+    if (rc) return rc;
+    const int D = c->ei.d;
+    if (!out_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_source_vector: out is null");
+    if (sdim != 1 && (int)sdim != D) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_source_vector: solution dim must be 1 or the geometry dim");
+    if (!values_dev && !g) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_source_vector: neither g nor values given");
+    if (!values_dev && !c->has_params)
+        return c->fail(FH_INVALID_STATE, "fh_assemble_source_vector: the uniform source needs the density in the quadrature table");
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    SourceArgs sa{};
+    sa.N = c->ei.n;
+    sa.NG = c->ei.ng;
+    sa.phigeom = c->phigeom.p;
+    sa.values = values_dev;
+    DevBuf<double> gd;
+    if (!values_dev) {
+        HIP_TRY(c, gd.alloc(sdim));
+        HIP_TRY(c, hipMemcpyAsync(gd.p, g, sizeof(double) * sdim, hipMemcpyHostToDevice, c->stream));
+        sa.g = gd.p;
+    }
+    a.vec_out = out_dev;
+    a.work_begin = 0;
+    a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+    a.labels = c->has_mask ? c->active_list.p : nullptr;
+    if (a.work_end == 0) return FH_OK;
+    a.epb = std::max(1, 256 / std::max(c->nq, c->ei.n));
+    const size_t lds = sizeof(double) * (size_t)a.epb * c->nq;
+    const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
+    c->last_kernel = "k_assemble_source";
+    if (D == 2 && sdim == 1) hipLaunchKernelGGL((k_assemble_source<2, 1>), dim3(grid), dim3(256), lds, c->stream, a, sa);
+    else if (D == 2) hipLaunchKernelGGL((k_assemble_source<2, 2>), dim3(grid), dim3(256), lds, c->stream, a, sa);
+    else if (sdim == 1) hipLaunchKernelGGL((k_assemble_source<3, 1>), dim3(grid), dim3(256), lds, c->stream, a, sa);
+    else hipLaunchKernelGGL((k_assemble_source<3, 3>), dim3(grid), dim3(256), lds, c->stream, a, sa);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // gd is released on return
+    return FH_OK;
+}
+
+int fh_assemble_source_vector(fh_ctx* c, uint32_t sdim, const double* g, const double* values, double* out) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = source_ready(c, "fh_assemble_source_vector");
+    if (rc) return rc;
+    if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_source_vector: out is null");
+    const size_t len = (size_t)sdim * c->N, nv = (size_t)c->E * c->nq * sdim;
+    DevBuf<double> d, v;
+    HIP_TRY(c, d.alloc(len + 1));
+    HIP_TRY(c, hipMemcpyAsync(d.p, out, sizeof(double) * len, hipMemcpyHostToDevice, c->stream));
+    if (values) {
+        HIP_TRY(c, v.alloc(nv + 1));
+        HIP_TRY(c, hipMemcpyAsync(v.p, values, sizeof(double) * nv, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = fh_assemble_source_vector_dev(c, sdim, g, values ? v.p : nullptr, d.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, d.p, sizeof(double) * len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_physical_quadrature_points_dev(fh_ctx* c, double* x_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = source_ready(c, "fh_physical_quadrature_points");
+    if (rc) return rc;
+    if (!x_dev) return c->fail(FH_BAD_ARGUMENT, "fh_physical_quadrature_points: output is null");
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    SourceArgs sa{};
+    sa.N = c->ei.n;
+    sa.NG = c->ei.ng;
+    sa.phigeom = c->phigeom.p;
+    sa.xq = x_dev;
+    const long long total = (long long)c->E * c->nq;
+    const int grid = (int)((total + 255) / 256);
+    if (c->ei.d == 2) hipLaunchKernelGGL((k_physical_points<2>), dim3(grid), dim3(256), 0, c->stream, a, sa);
+    else hipLaunchKernelGGL((k_physical_points<3>), dim3(grid), dim3(256), 0, c->stream, a, sa);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+int fh_physical_quadrature_points(fh_ctx* c, double* x) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = source_ready(c, "fh_physical_quadrature_points");
+    if (rc) return rc;
+    if (!x) return c->fail(FH_BAD_ARGUMENT, "fh_physical_quadrature_points: output is null");
+    const size_t n = (size_t)c->E * c->nq * c->ei.d;
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc(n + 1));
+    rc = fh_physical_quadrature_points_dev(c, d.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(x, d.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FH_OK;
 }

@@ -71,3 +71,30 @@ class Density:
 
     def as_pair(self):
         return (self.value, 0.0)
+
+
+class GravitySource:
+    """fenris-solid/src/gravity_source.rs:21-65: force density rho * g (SolutionDim = GeometryDim,
+    Parameters = Density per quadrature point)."""
+
+    def __init__(self, gravitational_acceleration):
+        self.gravitational_acceleration = [float(x) for x in gravitational_acceleration]
+
+    @classmethod
+    def from_acceleration(cls, gravitational_acceleration):
+        return cls(gravitational_acceleration)
+
+    @property
+    def solution_dim(self):
+        return len(self.gravitational_acceleration)
+
+
+class SourceFunction:
+    """src/assembly/local/source.rs:14-22.  The reference evaluates arbitrary Rust code per quadrature point; here
+    ``evaluate(x, data)`` is a vectorised Python callable: ``x`` is the (E, nq, d) array of physical points, ``data``
+    the table's per-point data (nq, 2) or None, and it returns (E, nq, solution_dim) values that the device kernel
+    integrates against the basis."""
+
+    def __init__(self, solution_dim, evaluate):
+        self.solution_dim = int(solution_dim)
+        self.evaluate = evaluate

@@ -150,6 +150,20 @@ int fh_assemble_vector(fh_ctx*, double* out, uint64_t* failed_element);
 int fh_assemble_vector_dev(fh_ctx*, double* out_dev, uint64_t* failed_element);
 /* assemble_scalar (global.rs:697-711) with compute_element_elliptic_energy (elliptic.rs:551-605) */
 int fh_assemble_scalar(fh_ctx*, double* out, uint64_t* failed_element);
+/* ElementSourceAssembler through VectorAssembler (src/assembly/local/source.rs:159-278, global.rs:582-608):
+ *   out[s node + c] += sum_e sum_q w |det J| f_c(e, q) phi_node(xi_q)
+ * independent of fh_set_operator; solution_dim is 1 or the geometry dimension.  The reference's SourceFunction is
+ * arbitrary code; the closed family behind this ABI:
+ *   values == NULL: f(e, q) = density_q * g   -- GravitySource (fenris-solid/src/gravity_source.rs:57-65); density_q
+ *                   is the first parameter of the quadrature table (Density<T>), g has solution_dim entries (host)
+ *   values != NULL: f(e, q) = values[(e nq + q) solution_dim ..] -- any source, sampled by the caller at the physical
+ *                   points returned by fh_physical_quadrature_points (x = map_reference_coords(xi_q), source.rs:263)
+ * Only |det J| enters (source.rs:276): no singular-Jacobian error on this path. */
+int fh_assemble_source_vector(fh_ctx*, uint32_t solution_dim, const double* g, const double* values, double* out);
+int fh_assemble_source_vector_dev(fh_ctx*, uint32_t solution_dim, const double* g /* host */, const double* values_dev,
+                                  double* out_dev);
+int fh_physical_quadrature_points(fh_ctx*, double* x /* E x nq x d */);
+int fh_physical_quadrature_points_dev(fh_ctx*, double* x_dev);
 /* single element matrix, (s n)^2 column-major: ElementMatrixAssembler::assemble_element_matrix_into
  * (src/assembly/local.rs:78, elliptic.rs:299-340) -- for unit tests of the element kernels */
 int fh_assemble_element_matrices(fh_ctx*, uint64_t first_element, uint64_t count, double* ke_out);

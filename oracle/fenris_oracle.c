@@ -1264,6 +1264,60 @@ int fo_par_assemble_into_csr(const fo_assembler* a, uint64_t num_colors, const u
     return status;
 }
 
+/* assemble_element_source_vector, src/assembly/local/source.rs:219-278:
+ *   f_e (s x n) = sum_q w |det J| f(x_q, data_q) phi(xi_q)   (output.gemm(w |det J|, f, phi, 1)).
+ * The source function is arbitrary code in the reference; the closed family restated here:
+ *   values == NULL:  f = density_q * g          (GravitySource, fenris-solid/src/gravity_source.rs:57-65)
+ *   values != NULL:  f = values[(e nq + q) s ..] (source sampled at the physical points x_q) */
+int fo_assemble_element_source_vector(const fo_assembler* a, uint64_t e, int s, const double* g, const double* values,
+                                      double* fe) {
+    int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);
+    if (n < 0 || s < 1 || s > MAXD) return FO_BAD_ARGUMENT;
+    if (!values && (!g || !a->q_params)) return FO_BAD_ARGUMENT;
+    double ev[MAXN * MAXD], phi[MAXN], J[9], f[MAXD];
+    gather_element(a, e, n, d, ev);
+    for (int i = 0; i < s * n; ++i) fe[i] = 0.0; /* output.fill(0) :257 */
+    for (uint32_t q = 0; q < a->nq; ++q) {
+        const double* xi = a->q_points + (size_t)d * q;
+        fo_element_basis(a->elem_kind, xi, phi);                       /* populate_basis :261 */
+        fo_element_reference_jacobian(a->elem_kind, ev, xi, J);        /* :264 */
+        for (int c = 0; c < s; ++c)
+            f[c] = values ? values[((size_t)e * a->nq + q) * (size_t)s + (size_t)c] : g[c] * a->q_params[2 * (size_t)q];
+        double alpha = a->q_weights[q] * fabs(det(d, J));
+        for (int I = 0; I < n; ++I)
+            for (int c = 0; c < s; ++c) fe[s * I + c] += alpha * (f[c] * phi[I]);
+    }
+    return FO_OK;
+}
+
+/* VectorAssembler::assemble_vector_into (global.rs:582-608) driven by an ElementSourceAssembler */
+int fo_assemble_source_vector_into(const fo_assembler* a, int s, const double* g, const double* values, double* out) {
+    int n = fo_element_num_nodes(a->elem_kind);
+    if (n < 0) return FO_BAD_ARGUMENT;
+    double fe[MAXN * MAXD];
+    for (uint64_t e = 0; e < a->num_elements; ++e) {
+        int st = fo_assemble_element_source_vector(a, e, s, g, values, fe);
+        if (st) return st;
+        const uint64_t* nodes = a->connectivity + (size_t)n * e;
+        for (int ln = 0; ln < n; ++ln)
+            for (int i = 0; i < s; ++i) out[(size_t)s * nodes[ln] + (size_t)i] += fe[s * ln + i];
+    }
+    return FO_OK;
+}
+
+/* physical quadrature points x = map_reference_coords(xi_q) of every element (source.rs:263), E x nq x d */
+int fo_physical_quadrature_points(const fo_assembler* a, double* x_out) {
+    int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);
+    if (n < 0) return FO_BAD_ARGUMENT;
+    double ev[MAXN * MAXD];
+    for (uint64_t e = 0; e < a->num_elements; ++e) {
+        gather_element(a, e, n, d, ev);
+        for (uint32_t q = 0; q < a->nq; ++q)
+            map_reference_coords(a->elem_kind, ev, a->q_points + (size_t)d * q, x_out + ((size_t)e * a->nq + q) * (size_t)d);
+    }
+    return FO_OK;
+}
+
 /* VectorAssembler::assemble_vector_into, global.rs:582-608 + add_local_to_global :770-796 */
 int fo_assemble_vector_into(const fo_assembler* a, double* out, uint64_t* failed) {
     int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);

@@ -134,6 +134,12 @@ int fo_par_assemble_into_csr(const fo_assembler* a, uint64_t num_colors, const u
 int fo_assemble_vector_into(const fo_assembler* a, double* out, uint64_t* failed_element);
 int fo_par_assemble_vector_into(const fo_assembler* a, uint64_t num_colors, const uint64_t* color_offsets,
                                 const uint64_t* labels, double* out, int num_threads, uint64_t* failed_element);
+/* ElementSourceAssembler (src/assembly/local/source.rs:159-278) through VectorAssembler; see the .c file for the
+ * two source kinds (uniform density * g, or values sampled at the physical quadrature points) */
+int fo_assemble_element_source_vector(const fo_assembler* a, uint64_t element, int s, const double* g,
+                                      const double* values, double* fe /* s n */);
+int fo_assemble_source_vector_into(const fo_assembler* a, int s, const double* g, const double* values, double* out);
+int fo_physical_quadrature_points(const fo_assembler* a, double* x_out /* E nq d */);
 /* assemble_scalar global.rs:697-711 */
 int fo_assemble_scalar(const fo_assembler* a, double* out, uint64_t* failed_element);
 /* apply_homogeneous_dirichlet_bc_csr global.rs:379-451 / rhs :479-495 */

@@ -85,6 +85,9 @@ def lib():
         _lib.fo_assemble_vector_into.argtypes = [ap, _f64p, _u64p]
         _lib.fo_par_assemble_vector_into.argtypes = [ap, C.c_uint64, _u64p, _u64p, _f64p, C.c_int, _u64p]
         _lib.fo_assemble_scalar.argtypes = [ap, _f64p, _u64p]
+        _lib.fo_assemble_source_vector_into.argtypes = [ap, C.c_int, _f64p, _f64p, _f64p]
+        _lib.fo_assemble_element_source_vector.argtypes = [ap, C.c_uint64, C.c_int, _f64p, _f64p, _f64p]
+        _lib.fo_physical_quadrature_points.argtypes = [ap, _f64p]
         _lib.fo_apply_homogeneous_dirichlet_bc_csr.argtypes = [C.c_uint64, _u64p, _u64p, _f64p, _u64p, C.c_uint64,
                                                                C.c_uint64]
         _lib.fo_element_gradients.argtypes = [C.c_int, _f64p, _f64p]
@@ -392,6 +395,24 @@ def par_assemble_vector(asm, colors, out=None, num_threads=0):
     st = lib().fo_par_assemble_vector_into(C.byref(asm._st), len(co) - 1, _u(co), _u(labels), _f(out), num_threads,
                                            C.byref(failed))
     return st, int(failed.value), out
+
+
+def assemble_source_vector(asm, s, g=None, values=None, out=None):
+    """VectorAssembler + ElementSourceAssembler (source.rs:219-278); asm.op_kind is ignored"""
+    if out is None:
+        out = np.zeros(s * asm.N)
+    g = None if g is None else np.ascontiguousarray(g, dtype=np.float64)
+    values = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+    st = lib().fo_assemble_source_vector_into(C.byref(asm._st), s, _f(g) if g is not None else None,
+                                              _f(values) if values is not None else None, _f(out))
+    return st, out
+
+
+def physical_quadrature_points(asm):
+    x = np.zeros((asm.E, len(asm.weights), asm.d))
+    st = lib().fo_physical_quadrature_points(C.byref(asm._st), _f(x))
+    assert st == 0
+    return x
 
 
 def assemble_scalar(asm):

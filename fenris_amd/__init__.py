@@ -10,7 +10,9 @@ from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsets
                        ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,
                        MockElementAssembler, UniformQuadratureTable,
                        VectorAssembler, VectorParAssembler, apply_homogeneous_dirichlet_bc_csr,
-                       apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes)
+                       apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes, CgSolveError, ConjugateGradient,
+                       IdentityOperator, JacobiPreconditioner, RelativeResidualCriterion, estimate_H1_seminorm_error,
+                       estimate_H1_seminorm_error_squared, estimate_L2_error, estimate_L2_error_squared)
 from .mesh import Mesh, hex27_mesh_from_hex8, procedural
 from .operators import (Density, GravitySource, SourceFunction, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
                         NeoHookeanMaterial, StVKMaterial, YoungPoisson)

@@ -79,6 +79,13 @@ _SIGS = {
     "fh_assemble_source_vector_dev": (C.c_int, [C.c_void_p, C.c_uint32, f64p, C.c_void_p, C.c_void_p]),
     "fh_physical_quadrature_points": (C.c_int, [C.c_void_p, f64p]),
     "fh_physical_quadrature_points_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fh_spmv_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fh_cg_solve": (C.c_int, [C.c_void_p, f64p, f64p, f64p, C.c_int, C.c_double, C.c_uint64, u64p]),
+    "fh_cg_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_uint64, u64p]),
+    "fh_estimate_L2_error_squared": (C.c_int, [C.c_void_p, C.c_uint32, f64p, f64p, f64p]),
+    "fh_estimate_L2_error_squared_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, f64p]),
+    "fh_estimate_H1_seminorm_error_squared": (C.c_int, [C.c_void_p, C.c_uint32, f64p, f64p, f64p]),
+    "fh_estimate_H1_seminorm_error_squared_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, f64p]),
     "fh_assemble_element_matrices": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p]),
     "fh_apply_dirichlet_csr_dev": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_uint64]),
     "fh_apply_dirichlet_rhs_dev": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_uint64]),

@@ -191,6 +191,39 @@ class Engine:
         self._check(self._lib.fh_physical_quadrature_points(self._h, _ffi.fp(x)))
         return x
 
+    def spmv(self, values_t, x_t, y_t):
+        self._check(self._lib.fh_spmv_dev(self._h, C.c_void_p(values_t.data_ptr()), C.c_void_p(x_t.data_ptr()),
+                                          C.c_void_p(y_t.data_ptr())))
+
+    def cg_solve(self, values, b, x, preconditioner=1, rel_tol=1e-9, max_iter=0):
+        """fh_cg_solve(_dev): x is the initial guess on entry and the solution on return; returns the iteration count.
+        Raises CgSolveError (carrying the iteration count) like ConjugateGradient::solve_with_guess."""
+        it = C.c_uint64(0)
+        if _is_torch(values):
+            rc = self._lib.fh_cg_solve_dev(self._h, C.c_void_p(values.data_ptr()), C.c_void_p(b.data_ptr()),
+                                           C.c_void_p(x.data_ptr()), preconditioner, rel_tol, max_iter, C.byref(it))
+        else:
+            rc = self._lib.fh_cg_solve(self._h, _ffi.fp(values), _ffi.fp(b), _ffi.fp(x), preconditioner, rel_tol, max_iter,
+                                       C.byref(it))
+        if rc in (7, 8, 9):
+            raise CgSolveError(rc, (self._lib.fh_last_error(self._h) or b"").decode(), int(it.value))
+        self._check(rc)
+        return int(it.value)
+
+    def estimate_error_squared(self, which, solution_dim, u_h, exact):
+        out = C.c_double()
+        names = ("fh_estimate_L2_error_squared", "fh_estimate_H1_seminorm_error_squared")
+        if _is_torch(u_h):
+            fn = getattr(self._lib, names[which] + "_dev")
+            rc = fn(self._h, solution_dim, C.c_void_p(u_h.data_ptr()), C.c_void_p(exact.data_ptr()), C.byref(out))
+        else:
+            fn = getattr(self._lib, names[which])
+            rc = fn(self._h, solution_dim, _ffi.fp(np.ascontiguousarray(u_h, dtype=np.float64)),
+                    _ffi.fp(np.ascontiguousarray(exact, dtype=np.float64)), C.byref(out))
+        failed = C.c_uint64(0)
+        self._check(rc, failed)
+        return out.value
+
     def assemble_scalar(self):
         out, failed = C.c_double(), C.c_uint64(0)
         self._check(self._lib.fh_assemble_scalar(self._h, C.byref(out), C.byref(failed)), failed)
@@ -210,6 +243,17 @@ class Engine:
     def apply_dirichlet_rhs_dev(self, rhs_t, nodes):
         nodes = _ffi.as_u64(nodes)
         self._check(self._lib.fh_apply_dirichlet_rhs_dev(self._h, C.c_void_p(rhs_t.data_ptr()), _ffi.up(nodes), len(nodes)))
+
+
+class CgSolveError(FenrisError):
+    """SolveError of fenris-sparse/src/cg.rs:277-318 (kind + iterations so far)"""
+
+    KINDS = {7: "MaxIterationsReached", 8: "IndefiniteOperator", 9: "IndefinitePreconditioner"}
+
+    def __init__(self, code, message, num_iterations):
+        super().__init__(code, message)
+        self.kind = self.KINDS.get(code, "?")
+        self.num_iterations = num_iterations
 
 
 def _is_torch(x):
@@ -599,3 +643,84 @@ def apply_homogeneous_dirichlet_bc_rhs(rhs, nodes, solution_dim):
     nodes = np.asarray(nodes, dtype=np.int64)
     for i in range(solution_dim):
         rhs[solution_dim * nodes + i] = 0.0
+
+
+# ------------------------------------------------------------------------------------------ solve + error estimation
+class RelativeResidualCriterion:
+    """fenris-sparse/src/cg.rs:86-124: ||r|| <= tol ||b|| on CG's own residual (default 1e-8 for f64)"""
+
+    def __init__(self, tol=1e-8):
+        self.tol = float(tol)
+
+
+class JacobiPreconditioner:
+    """the inverse diagonal, built on the device (matrix.diagonal_as_csr() + recip, poisson_mms_common.rs:148-151)"""
+
+
+class IdentityOperator:
+    """fenris-sparse/src/cg.rs:54-61"""
+
+
+class ConjugateGradient:
+    """fenris-sparse/src/cg.rs:196-478, builder style.  The operator is the CSR matrix assembled by an element
+    assembler of this package (its engine holds the pattern); values, right-hand side and solution may be numpy
+    arrays or device tensors (all of one kind)."""
+
+    def __init__(self):
+        self._csr, self._asm, self._pre, self._crit, self._max_iter = None, None, IdentityOperator(), None, 0
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def with_operator(self, csr: "CsrMatrix", element_assembler):
+        self._csr, self._asm = csr, element_assembler
+        return self
+
+    def with_preconditioner(self, preconditioner):
+        self._pre = preconditioner
+        return self
+
+    def with_max_iter(self, max_iter):
+        self._max_iter = int(max_iter)
+        return self
+
+    def with_stopping_criterion(self, criterion: RelativeResidualCriterion):
+        self._crit = criterion
+        return self
+
+    def solve_with_guess(self, b, x):
+        """x: initial guess, overwritten by the solution; returns CgOutput.num_iterations"""
+        if self._csr is None or self._crit is None:
+            raise ValueError("operator and stopping criterion are required")
+        pre = 1 if isinstance(self._pre, JacobiPreconditioner) else 0
+        return self._asm.engine.cg_solve(self._csr.values, b, x, pre, self._crit.tol, self._max_iter)
+
+
+def _sample(space_assembler, fn, nq):
+    x = space_assembler.engine.physical_quadrature_points(nq)
+    return np.ascontiguousarray(fn(x), dtype=np.float64)
+
+
+def estimate_L2_error_squared(element_assembler, u, u_h, solution_dim=None):
+    """src/error.rs:287-311.  ``u(x)`` is vectorised: (E, nq, d) physical points -> (E, nq, s) values."""
+    s = solution_dim or element_assembler.solution_dim()
+    nq = len(element_assembler.qtable.weights)
+    return element_assembler.engine.estimate_error_squared(0, s, u_h, _sample(element_assembler, u, nq))
+
+
+def estimate_L2_error(element_assembler, u, u_h, solution_dim=None):
+    """src/error.rs:313-328"""
+    return float(np.sqrt(estimate_L2_error_squared(element_assembler, u, u_h, solution_dim)))
+
+
+def estimate_H1_seminorm_error_squared(element_assembler, u_grad, u_h, solution_dim=None):
+    """src/error.rs:330-354.  ``u_grad(x)``: (E, nq, d) points -> (E, nq, d, s) with [i][k] = d u_k / d x_i."""
+    s = solution_dim or element_assembler.solution_dim()
+    nq = len(element_assembler.qtable.weights)
+    return element_assembler.engine.estimate_error_squared(1, s, u_h, _sample(element_assembler, u_grad, nq))
+
+
+def estimate_H1_seminorm_error(element_assembler, u_grad, u_h, solution_dim=None):
+    """src/error.rs:356-372"""
+    return float(np.sqrt(estimate_H1_seminorm_error_squared(element_assembler, u_grad, u_h, solution_dim)))

@@ -1,0 +1,202 @@
+// Callers of the assembly path that keep K on the device: Jacobi-preconditioned conjugate
+// gradients on the node-blocked CSR (fenris-sparse/src/cg.rs:196-474 as driven by solve_linear_system,
+// tests/convergence_tests/poisson_mms_common.rs:142-163) and the L2 / H1 error integrals (src/error.rs:287-372).
+// All reductions are two-stage: per-workgroup partial sums in a fixed order, summed in workgroup order by the
+// host => bitwise reproducible runs (no floating-point atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "assemble_kernels.hpp"
+#include "device_common.hpp"
+
+namespace fenris_hip {
+
+// sum over the 64 lanes of a wavefront (butterfly, every lane gets the total)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum of K per-thread values over a 256-thread workgroup, in a fixed order; thread 0 stores to out[0..K).
+template <int K>
+__device__ __forceinline__ void block_sum_store(double (&v)[K], double* out) {
+    __shared__ double part[4][K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) part[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+}
+
+// y = A x on the node-blocked CSR: the S rows of node i are contiguous, each S * cnt long, and share the
+// node-level column list (global.rs:100-118).  One wavefront per node (grid-stride); lanes stride over the
+// row entries, S row sums per lane, butterfly reduction.  Optionally the partial of  x . y  per workgroup.
+template <int S>
+__global__ void __launch_bounds__(256) k_spmv_blocked(int num_nodes, const unsigned* noff, const unsigned* ncols, const double* vals,
+                                                      const double* x, double* y, double* dot_partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dot[1] = {0.0};
+    for (int i = blockIdx.x * 4 + wave; i < num_nodes; i += gridDim.x * 4) {
+        const unsigned r0 = noff[i], cnt = noff[i + 1] - r0;
+        const int len = S * (int)cnt;
+        const double* row = vals + (size_t)S * S * r0;
+        double acc[S];
+#pragma unroll
+        for (int a = 0; a < S; ++a) acc[a] = 0.0;
+        for (int t = lane; t < len; t += 64) {
+            const double xv = x[(size_t)S * ncols[r0 + t / S] + t % S];
+#pragma unroll
+            for (int a = 0; a < S; ++a) acc[a] = fma(row[(size_t)a * len + t], xv, acc[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+            const double s = wave_sum(acc[a]);
+            if (lane == 0) {
+                y[(size_t)S * i + a] = s;
+                dot[0] = fma(x[(size_t)S * i + a], s, dot[0]);
+            }
+        }
+    }
+    if (dot_partial) block_sum_store<1>(dot, dot_partial + blockIdx.x);
+}
+
+// 1 / diagonal of the blocked CSR (matrix.diagonal_as_csr() + recip, poisson_mms_common.rs:148-151)
+template <int S>
+__global__ void __launch_bounds__(256) k_inverse_diagonal(int num_nodes, const unsigned* noff, const unsigned* ncols, const double* vals,
+                                                          double* dinv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S * num_nodes) return;
+    const int i = r / S, a = r % S;
+    const unsigned r0 = noff[i], cnt = noff[i + 1] - r0;
+    const int pos = find_col(ncols + r0, (int)cnt, (unsigned)i);
+    dinv[r] = 1.0 / vals[(size_t)S * S * r0 + (size_t)a * S * cnt + (size_t)S * pos + a];
+}
+
+// r = b - r (r holds A x),  z = M^-1 r,  p = z;  partials of (z.r, b.b, r.r)      cg.rs:388-404
+__global__ void __launch_bounds__(256) k_cg_init(int n, const double* b, const double* dinv, double* r, double* z, double* p,
+                                                 double* partial /* gridDim.x x 3 */) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double ri = b[i] - r[i];
+        const double zi = dinv ? dinv[i] * ri : ri;
+        r[i] = ri;
+        z[i] = zi;
+        p[i] = zi;
+        s[0] = fma(zi, ri, s[0]);
+        s[1] = fma(b[i], b[i], s[1]);
+        s[2] = fma(ri, ri, s[2]);
+    }
+    block_sum_store<3>(s, partial + 3 * blockIdx.x);
+}
+
+// x += alpha p,  r -= alpha Ap,  z = M^-1 r;  partials of (z.r, r.r)               cg.rs:453-468
+__global__ void __launch_bounds__(256) k_cg_update(int n, double alpha, const double* p, const double* Ap, const double* dinv,
+                                                   double* x, double* r, double* z, double* partial /* gridDim.x x 2 */) {
+    double s[2] = {0.0, 0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        const double zi = dinv ? dinv[i] * ri : ri;
+        r[i] = ri;
+        z[i] = zi;
+        s[0] = fma(zi, ri, s[0]);
+        s[1] = fma(ri, ri, s[1]);
+    }
+    block_sum_store<2>(s, partial + 2 * blockIdx.x);
+}
+
+// p = beta p + z                                                                   cg.rs:470-474
+__global__ void __launch_bounds__(256) k_cg_direction(int n, double beta, const double* z, double* p) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = beta * p[i] + z[i];
+}
+
+// ---- error integrals (src/error.rs:287-372): one lane per (element, quadrature point)
+//   WHICH 0:  w |det J| |u_h(x_q) - u(x_q)|^2                      make_L2_error_squared_integrand   :222-236
+//   WHICH 1:  w |det J| |grad u_h(x_q) - grad u(x_q)|_F^2          make_H1_seminorm_error_squared_integrand :238-254
+// exact[] holds the reference solution sampled by the caller at the physical points:  (E, nq, S) values, or
+// (E, nq, D, S) gradients with grad[i][k] = d u_k / d x_i (OMatrix<GeometryDim, SolutionDim>).
+template <int D, int S, int WHICH>
+__global__ void __launch_bounds__(256) k_error_squared(const KArgs a, const SourceArgs sa, const double* uh, const double* exact,
+                                                       double* partial) {
+    double s[1] = {0.0};
+    const long long total = a.num_elements * a.nq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i / a.nq;
+        const int q = (int)(i % a.nq);
+        const int* nodes = a.conn + (size_t)e * sa.N;
+        double J[D][D];
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int c = 0; c < D; ++c) J[r][c] = 0.0;
+        for (int g = 0; g < sa.NG; ++g) {
+            const double* v = a.verts + (size_t)nodes[g] * D;
+            const double* gg = a.ggeom + ((size_t)q * sa.NG + g) * D;
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) J[r][c] = fma(v[r], gg[c], J[r][c]);
+        }
+        const double detJ = det_small<D>(J);
+        double err2 = 0.0;
+        if (WHICH == 0) {
+            double u[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) u[k] = 0.0;
+            for (int n = 0; n < sa.N; ++n) {
+                const double ph = a.phiref[(size_t)q * sa.N + n];
+#pragma unroll
+                for (int k = 0; k < S; ++k) u[k] = fma(ph, uh[(size_t)nodes[n] * S + k], u[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const double d = u[k] - exact[(size_t)i * S + k];
+                err2 = fma(d, d, err2);
+            }
+        } else {
+            double Ji[D][D];
+            if (detJ == 0.0) {
+                report_singular(a.status, e);
+                continue;
+            }
+            inv_small(J, detJ, Ji);
+            double gu[D][S];
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int k = 0; k < S; ++k) gu[r][k] = 0.0;
+            for (int n = 0; n < sa.N; ++n) {
+                const double* gr = a.gref + ((size_t)q * sa.N + n) * D;
+                double g[D];
+#pragma unroll
+                for (int r = 0; r < D; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) t = fma(Ji[c][r], gr[c], t);  // J^-T grad_ref
+                    g[r] = t;
+                }
+#pragma unroll
+                for (int r = 0; r < D; ++r)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) gu[r][k] = fma(g[r], uh[(size_t)nodes[n] * S + k], gu[r][k]);
+            }
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const double d = gu[r][k] - exact[((size_t)i * D + r) * S + k];
+                    err2 = fma(d, d, err2);
+                }
+        }
+        s[0] = fma(a.qw[q] * fabs(detJ), err2, s[0]);
+    }
+    block_sum_store<1>(s, partial + blockIdx.x);
+}
+
+}  // namespace fenris_hip

@@ -42,7 +42,11 @@ enum {
     FH_BAD_ARGUMENT = 2,
     FH_HIP_ERROR = 3,
     FH_INVALID_STATE = 5,     /* e.g. assemble before pattern, operator/element dimension mismatch */
-    FH_UNSUPPORTED = 6
+    FH_UNSUPPORTED = 6,
+    /* SolveErrorKind of the conjugate-gradient solver (fenris-sparse/src/cg.rs:277-286) */
+    FH_CG_MAX_ITERATIONS = 7,
+    FH_CG_INDEFINITE_OPERATOR = 8,
+    FH_CG_INDEFINITE_PRECONDITIONER = 9
 };
 
 /* element kinds: Quad4d2Element (src/element/quadrilateral.rs:70-142), Hex8Element
@@ -200,6 +204,32 @@ int fh_lame_from_young_poisson(double young, double poisson, double* mu, double*
 /* ---- introspection for benchmarks --------------------------------------------------------------- */
 /* name of the device kernel the last fh_assemble_matrix* call launched (for rocprof matching) */
 const char* fh_last_kernel_name(const fh_ctx*);
+
+/* ---- solve + error estimation on the device-resident system (what every caller does next) ------------ */
+/* y = K x on the CSR of the context's pattern: LinearOperator for CsrMatrix (fenris-sparse/src/cg.rs:44-52) */
+int fh_spmv_dev(fh_ctx*, const double* values_dev, const double* x_dev, double* y_dev);
+/* ConjugateGradient::solve_with_guess (fenris-sparse/src/cg.rs:366-478) with RelativeResidualCriterion(rel_tol)
+ * (:86-124, the solver's own residual, ||r|| <= tol ||b||) and, for FH_PRECOND_JACOBI, the inverse diagonal as
+ * the preconditioner -- exactly how solve_linear_system drives it (tests/convergence_tests/
+ * poisson_mms_common.rs:142-163: max_iter 10000, tol 1e-9).  x holds the initial guess on entry and the solution on
+ * return (the iterate reached so far on failure); max_iter == 0 means no limit; *num_iterations counts the updates
+ * of x.  Errors: FH_CG_MAX_ITERATIONS, FH_CG_INDEFINITE_OPERATOR (p.Ap <= 0), FH_CG_INDEFINITE_PRECONDITIONER
+ * (z.r <= 0).  Reductions are ordered (no floating-point atomics): runs are bitwise reproducible. */
+enum { FH_PRECOND_IDENTITY = 0, FH_PRECOND_JACOBI = 1 };
+int fh_cg_solve(fh_ctx*, const double* values, const double* b, double* x, int preconditioner, double rel_tol,
+                uint64_t max_iter, uint64_t* num_iterations);
+int fh_cg_solve_dev(fh_ctx*, const double* values_dev, const double* b_dev, double* x_dev, int preconditioner, double rel_tol,
+                    uint64_t max_iter, uint64_t* num_iterations);
+/* estimate_L2_error_squared / estimate_H1_seminorm_error_squared (src/error.rs:287-372):
+ *   sum_e sum_q w |det J| |u_h(x_q) - u(x_q)|^2      resp.   |grad u_h(x_q) - grad u(x_q)|_F^2
+ * with the quadrature table of the context.  The reference solution is arbitrary code in the reference; here the
+ * caller samples it at the physical points of fh_physical_quadrature_points: u_exact is (E, nq, s); grad_exact is
+ * (E, nq, d, s) with grad[i][k] = d u_k / d x_i.  The H1 form inverts J: FH_SINGULAR_JACOBIAN if det J == 0. */
+int fh_estimate_L2_error_squared(fh_ctx*, uint32_t solution_dim, const double* u_h, const double* u_exact, double* out);
+int fh_estimate_L2_error_squared_dev(fh_ctx*, uint32_t solution_dim, const double* u_h_dev, const double* u_exact_dev, double* out);
+int fh_estimate_H1_seminorm_error_squared(fh_ctx*, uint32_t solution_dim, const double* u_h, const double* grad_exact, double* out);
+int fh_estimate_H1_seminorm_error_squared_dev(fh_ctx*, uint32_t solution_dim, const double* u_h_dev, const double* grad_exact_dev,
+                                              double* out);
 
 #ifdef __cplusplus
 }

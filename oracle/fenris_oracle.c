@@ -1318,6 +1318,120 @@ int fo_physical_quadrature_points(const fo_assembler* a, double* x_out) {
     return FO_OK;
 }
 
+/* ---- callers of the path: CG solve and error integrals -------------------------------------------------
+ * ConjugateGradient::solve_with_guess, fenris-sparse/src/cg.rs:366-478, with operator = CSR matrix (spmm_csr_dense,
+ * row by row, entries in column order), preconditioner = inverse diagonal (jacobi != 0; tests/convergence_tests/
+ * poisson_mms_common.rs:148-151) or identity, RelativeResidualCriterion(tol) (cg.rs:86-124).
+ * Returns 0 ok, 7 max iterations, 8 indefinite operator, 9 indefinite preconditioner (codes of fenris_hip.h). */
+static void csr_spmv(uint64_t n, const uint64_t* ro, const uint64_t* ci, const double* v, const double* x, double* y) {
+    for (uint64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (uint64_t k = ro[i]; k < ro[i + 1]; ++k) s += v[k] * x[ci[k]];
+        y[i] = s;
+    }
+}
+static double dotn(uint64_t n, const double* a, const double* b) {
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+int fo_cg_solve(uint64_t n, const uint64_t* ro, const uint64_t* ci, const double* values, const double* b, double* x,
+                int jacobi, double tol, uint64_t max_iter, uint64_t* num_iterations) {
+    double* r = malloc(sizeof(double) * (n + 1)), *z = malloc(sizeof(double) * (n + 1));
+    double* p = malloc(sizeof(double) * (n + 1)), *Ap = malloc(sizeof(double) * (n + 1)), *dinv = NULL;
+    int status = 0;
+    uint64_t it = 0;
+    if (jacobi) {
+        dinv = malloc(sizeof(double) * (n + 1));
+        for (uint64_t i = 0; i < n; ++i) {
+            dinv[i] = 0.0;
+            for (uint64_t k = ro[i]; k < ro[i + 1]; ++k)
+                if (ci[k] == i) dinv[i] = 1.0 / values[k];
+        }
+    }
+    csr_spmv(n, ro, ci, values, x, r);                               /* r <- A x        :388 */
+    for (uint64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];             /* r <- b - r      :392 */
+    for (uint64_t i = 0; i < n; ++i) z[i] = dinv ? dinv[i] * r[i] : r[i]; /* z = P r    :395 */
+    memcpy(p, z, sizeof(double) * n);                                /* p = z           :400 */
+    double zTr = dotn(n, z, r);
+    double b_norm = sqrt(dotn(n, b, b));
+    if (b_norm == 0.0) {                                             /* :409-412 */
+        for (uint64_t i = 0; i < n; ++i) x[i] = 0.0;
+        goto done;
+    }
+    for (;;) {
+        if (sqrt(dotn(n, r, r)) <= tol * b_norm) break;              /* :108-124 */
+        if (max_iter && it >= max_iter) { status = 7; break; }       /* :427-431 */
+        csr_spmv(n, ro, ci, values, p, Ap);
+        double pAp = dotn(n, p, Ap);
+        if (pAp <= 0.0) { status = 8; break; }
+        if (zTr <= 0.0) { status = 9; break; }
+        double alpha = zTr / pAp;
+        for (uint64_t i = 0; i < n; ++i) x[i] += alpha * p[i];
+        for (uint64_t i = 0; i < n; ++i) r[i] -= alpha * Ap[i];
+        ++it;
+        for (uint64_t i = 0; i < n; ++i) z[i] = dinv ? dinv[i] * r[i] : r[i];
+        double zTr_next = dotn(n, z, r);
+        double beta = zTr_next / zTr;
+        for (uint64_t i = 0; i < n; ++i) { p[i] *= beta; p[i] += z[i]; }
+        zTr = zTr_next;
+    }
+done:
+    if (num_iterations) *num_iterations = it;
+    free(r); free(z); free(p); free(Ap); free(dinv);
+    return status;
+}
+
+/* estimate_L2_error_squared / estimate_H1_seminorm_error_squared, src/error.rs:287-372 via assemble_scalar
+ * (element order).  which = 0: sum_q w |det J| |u_h - u|^2 (u_h = sum_n phi_n u_n);  which = 1: sum_q w |det J|
+ * |grad u_h - grad u|_F^2 with grad u_h = sum_n (J^-T grad phi_n) u_n^T (d x s).  The reference solution is given
+ * sampled at the physical points: (E, nq, s) values or (E, nq, d, s) gradients. */
+int fo_estimate_error_squared(const fo_assembler* a, int which, int s, const double* uh, const double* exact, double* out) {
+    int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);
+    if (n < 0 || s < 1 || s > MAXD) return FO_BAD_ARGUMENT;
+    double total = 0.0;
+    double ev[MAXN * MAXD], phi[MAXN], G[MAXD * MAXN], J[9], Jinv[9];
+    for (uint64_t e = 0; e < a->num_elements; ++e) {
+        gather_element(a, e, n, d, ev);
+        const uint64_t* nodes = a->connectivity + (size_t)n * e;
+        double elem = 0.0;
+        for (uint32_t q = 0; q < a->nq; ++q) {
+            const double* xi = a->q_points + (size_t)d * q;
+            fo_element_reference_jacobian(a->elem_kind, ev, xi, J);
+            double j_det = det(d, J);
+            double err2 = 0.0;
+            size_t base = (size_t)e * a->nq + q;
+            if (which == 0) {
+                fo_element_basis(a->elem_kind, xi, phi);
+                for (int k = 0; k < s; ++k) {
+                    double u = 0.0;
+                    for (int I = 0; I < n; ++I) u += phi[I] * uh[(size_t)s * nodes[I] + (size_t)k];
+                    double dd = u - exact[base * (size_t)s + (size_t)k];
+                    err2 += dd * dd;
+                }
+            } else {
+                if (!try_inverse(d, J, Jinv)) return FO_SINGULAR_JACOBIAN;
+                fo_element_gradients(a->elem_kind, xi, G);
+                for (int i = 0; i < d; ++i)
+                    for (int k = 0; k < s; ++k) {
+                        double gu = 0.0;
+                        for (int I = 0; I < n; ++I) {
+                            double g = 0.0; /* (J^-T grad_ref)_i = sum_c Jinv[c][i] G[c][I] */
+                            for (int c = 0; c < d; ++c) g += Jinv[CM(c, i, d)] * G[CM(c, I, d)];
+                            gu += g * uh[(size_t)s * nodes[I] + (size_t)k];
+                        }
+                        double dd = gu - exact[(base * (size_t)d + (size_t)i) * (size_t)s + (size_t)k];
+                        err2 += dd * dd;
+                    }
+            }
+            elem += a->q_weights[q] * fabs(j_det) * err2;
+        }
+        total += elem;
+    }
+    *out = total;
+    return FO_OK;
+}
+
 /* VectorAssembler::assemble_vector_into, global.rs:582-608 + add_local_to_global :770-796 */
 int fo_assemble_vector_into(const fo_assembler* a, double* out, uint64_t* failed) {
     int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);

@@ -146,6 +146,11 @@ int fo_assemble_scalar(const fo_assembler* a, double* out, uint64_t* failed_elem
 int fo_apply_homogeneous_dirichlet_bc_csr(uint64_t num_rows, const uint64_t* row_offsets, const uint64_t* col_indices,
                                           double* values, const uint64_t* nodes, uint64_t num_bc_nodes,
                                           uint64_t solution_dim);
+/* ConjugateGradient::solve_with_guess (fenris-sparse/src/cg.rs:366-478) on a CSR matrix; see the .c file */
+int fo_cg_solve(uint64_t n, const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, const double* b,
+                double* x, int jacobi, double tol, uint64_t max_iter, uint64_t* num_iterations);
+/* estimate_L2_error_squared (which = 0) / estimate_H1_seminorm_error_squared (which = 1), src/error.rs:287-372 */
+int fo_estimate_error_squared(const fo_assembler* a, int which, int s, const double* u_h, const double* exact, double* out);
 int fo_max_threads(void);
 
 #ifdef __cplusplus

@@ -88,6 +88,8 @@ def lib():
         _lib.fo_assemble_source_vector_into.argtypes = [ap, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_assemble_element_source_vector.argtypes = [ap, C.c_uint64, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_physical_quadrature_points.argtypes = [ap, _f64p]
+        _lib.fo_cg_solve.argtypes = [C.c_uint64, _u64p, _u64p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_uint64, _u64p]
+        _lib.fo_estimate_error_squared.argtypes = [ap, C.c_int, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_apply_homogeneous_dirichlet_bc_csr.argtypes = [C.c_uint64, _u64p, _u64p, _f64p, _u64p, C.c_uint64,
                                                                C.c_uint64]
         _lib.fo_element_gradients.argtypes = [C.c_int, _f64p, _f64p]
@@ -406,6 +408,27 @@ def assemble_source_vector(asm, s, g=None, values=None, out=None):
     st = lib().fo_assemble_source_vector_into(C.byref(asm._st), s, _f(g) if g is not None else None,
                                               _f(values) if values is not None else None, _f(out))
     return st, out
+
+
+def cg_solve(ro, ci, values, b, x0=None, jacobi=True, tol=1e-9, max_iter=10000):
+    """ConjugateGradient as driven by solve_linear_system (poisson_mms_common.rs:142-163); returns (status, x, iterations)"""
+    ro = np.ascontiguousarray(ro, dtype=np.uint64)
+    ci = np.ascontiguousarray(ci, dtype=np.uint64)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(len(b)) if x0 is None else np.array(x0, dtype=np.float64)
+    it = C.c_uint64(0)
+    st = lib().fo_cg_solve(len(b), _u(ro), _u(ci), _f(values), _f(b), _f(x), 1 if jacobi else 0, tol, max_iter, C.byref(it))
+    return st, x, int(it.value)
+
+
+def estimate_error_squared(asm, which, s, u_h, exact):
+    """src/error.rs:287-372: which = 0 L2, 1 H1 seminorm; exact sampled at the physical quadrature points"""
+    out = C.c_double()
+    u_h = np.ascontiguousarray(u_h, dtype=np.float64)
+    exact = np.ascontiguousarray(exact, dtype=np.float64)
+    st = lib().fo_estimate_error_squared(C.byref(asm._st), which, s, _f(u_h), _f(exact), C.byref(out))
+    return st, out.value
 
 
 def physical_quadrature_points(asm):

@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--cells", type=int, default=216, help="cells per unit box edge (216 = north-star point)")
     ap.add_argument("--scatter", default="gather", choices=["gather", "atomic", "colored"])
     ap.add_argument("--operator", default="elasticity", choices=["elasticity", "poisson"])
+    ap.add_argument("--partition", default="exchange", choices=["exchange", "halo"],
+                    help="N > 1: interface rows sent to their owner over RCCL (headline), or the halo element layer "
+                         "recomputed locally with no communication")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange after the kernel instead of beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=88)
     args = ap.parse_args()
@@ -102,14 +106,6 @@ def main():
     # ---- synthetic input: this rank's slab of the 216 x 216 x (216 world) box
     cells = args.cells
     stream = torch.cuda.current_stream().cuda_stream
-    eng = fa.Engine(local_rank, stream=stream)
-    if world == 1:
-        mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
-        exchange = None
-    else:
-        from fenris_amd import distributed as fd
-
-        mesh, exchange = fd.make_slab_problem(cells, rank, world)
     weights, points = quadrature.tensor.hexahedron_gauss(2)
     qtable = fa.UniformQuadratureTable.from_points_and_weights(points, weights)
     if args.operator == "elasticity":
@@ -118,32 +114,46 @@ def main():
         op, s = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), 3
     else:
         op, s = fa.LaplaceOperator(), 1
-    asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(op)
-           .with_quadrature_table(qtable).with_u(None).build())
-    if exchange is not None:
-        eng.set_active_elements(exchange.slab.active)  # numerics over own elements, pattern over own + halo
-    t0 = time.perf_counter()
-    nnz = eng.build_pattern()
-    t_pattern = time.perf_counter() - t0
-    E, N = mesh.num_elements(), mesh.num_nodes()
-    if exchange is not None:
-        E = exchange.slab.num_own_elements()
-    values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+
+    def configure(engine, mesh_):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh_).with_operator(op)
+                .with_quadrature_table(qtable).with_u(None).build())
+
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
+    slab_asm = None
+    t0 = time.perf_counter()
+    if world == 1:
+        mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
+        eng = fa.Engine(local_rank, stream=stream)
+        configure(eng, mesh)
+        nnz = eng.build_pattern()
+        E = mesh.num_elements()
+        values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    else:
+        from fenris_amd import distributed as fd
+
+        slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world, args.partition)
+        mesh = slab.mesh
+        # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
+        slab_asm = fd.SlabAssembly(slab, configure, device=local_rank, overlap=(args.scatter == "gather" and not args.no_overlap),
+                                   stream=stream)
+        eng, values, nnz = slab_asm.main, slab_asm.values, slab_asm.values.numel()
+        E = slab.num_own_elements()  # numerics over own (+ halo in "halo" mode) elements, pattern over own + halo
+    t_pattern = time.perf_counter() - t0
+    N = mesh.num_nodes()
     if args.scatter == "colored":
         eng.color()
     flags |= fa.ASSEMBLE_OVERWRITE
-    if exchange is not None:
-        exchange.bind(eng, values)
 
     def step():
-        eng.assemble_matrix_async(values, flags)
-        if exchange is not None:
-            exchange.run()
+        if slab_asm is not None:
+            slab_asm.enqueue(flags)
+        else:
+            eng.assemble_matrix_async(values, flags)
 
     for _ in range(args.warmup):
         step()
-    eng.poll_status()
+    (slab_asm or eng).poll_status()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,16 +162,19 @@ def main():
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        eng.assemble_matrix_async(values, flags)
-        b.record()
-        if exchange is not None:
-            exchange.run()
+        if slab_asm is None or slab_asm.comm is not None:
+            step()      # N > 1 overlapped: the events bracket both launches and the wait for the transfer
+            b.record()
+        else:
+            eng.assemble_matrix_async(values, flags)
+            b.record()
+            slab_asm.exchange.run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    eng.poll_status()
+    (slab_asm or eng).poll_status()
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
     if world > 1:
@@ -190,7 +203,8 @@ def main():
                                    f"({int(total_elements)} elements), hexahedron_gauss(2), "
                                    f"YoungPoisson(1e6, 0.2), u = 0, CSR pattern pre-built, values overwritten",
                        "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
-                       "partition": "single" if world == 1 else f"{world} z-slabs, interface rows exchanged",
+                       "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
+                                                                   else f"{world} z-slabs, halo element layer recomputed, no communication"),
                        "pattern_build_s": t_pattern},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": None,

@@ -77,6 +77,10 @@ class Engine:
             assert len(m) == self.num_elements()
             self._check(self._lib.fh_set_active_elements(self._h, m.ctypes.data_as(C.c_char_p)))
 
+    def set_row_range(self, node_begin, node_end):
+        """owner-computes assembly of the rows of nodes [node_begin, node_end) only (fh_set_row_range)"""
+        self._check(self._lib.fh_set_row_range(self._h, int(node_begin), int(node_end)))
+
     def set_operator(self, op_kind):
         self._check(self._lib.fh_set_operator(self._h, op_kind))
 

@@ -197,6 +197,7 @@ struct fh_ctx {
     DevBuf<GatherHdr> gt_hdr;
     int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0, g_umax = 0;
     bool has_partition = false;
+    long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
     // colours
     bool has_colors = false;
     std::vector<uint64_t> color_offsets;
@@ -505,11 +506,14 @@ int build_partition(fh_ctx* c) {
     const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
     int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
     std::vector<unsigned> blk;
-    blk.push_back(0);
-    int i0 = 0;
-    while (i0 < N) {
+    // owner-computes covers the nodes [n_lo, n_hi): everything, or the range of fh_set_row_range
+    const int n_lo = (c->row_hi < 0) ? 0 : (int)std::min<long long>(c->row_lo, N);
+    const int n_hi = (c->row_hi < 0) ? N : (int)std::min<long long>(c->row_hi, N);
+    blk.push_back((unsigned)n_lo);
+    int i0 = n_lo;
+    while (i0 < n_hi) {
         int i1 = i0 + 1;
-        while (i1 < N && i1 - i0 < nb_target) {
+        while (i1 < n_hi && i1 - i0 < nb_target) {
             const long long rows = (long long)c->h_noff[i1 + 1] - c->h_noff[i0];
             const long long ents = (long long)adj_off_h[i1 + 1] - adj_off_h[i0];
             if (S * S * rows > acc || ents > mb) break;
@@ -610,6 +614,7 @@ int build_partition(fh_ctx* c) {
             if (!std::getenv("FENRIS_HIP_NO_SWEEP")) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
+                HIP_TRY(c, hipMemsetAsync(node2blk.p, 0xff, sizeof(int) * ((size_t)N + 1), c->stream));  // -1: not in a block
                 HIP_TRY(c, succ_d.alloc((size_t)nblk));
                 hipLaunchKernelGGL(k_node_to_block, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->blk_off.p, nblk, node2blk.p);
                 hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
@@ -754,6 +759,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
         if (rc) return rc;
+        if (c->nblk == 0) return FH_OK;  // empty row range
         a.blk_off = c->blk_off.p;
         a.gt_hdr = c->gt_hdr.p;
         a.gt_elems = c->gt_elems.p;
@@ -780,6 +786,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
 #undef CALL
         return rc;
     }
+    if (c->row_hi >= 0) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix: a row range needs FH_SCATTER_GATHER");
     if (overwrite) HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * nnz, c->stream));
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
@@ -1069,6 +1076,16 @@ int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
         if (rc) return rc;
     }
     return build_compute_adjacency(c);
+}
+
+int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_row_range: set the mesh first");
+    if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_set_row_range: bad node range");
+    if (node_begin == 0 && node_end == c->N) { c->row_lo = 0; c->row_hi = -1; }
+    else { c->row_lo = (long long)node_begin; c->row_hi = (long long)node_end; }
+    c->has_partition = false;
+    return FH_OK;
 }
 
 int fh_set_operator(fh_ctx* c, int op_kind) {

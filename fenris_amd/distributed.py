@@ -16,6 +16,11 @@ Partition (z-slabs, interface plane owned by the LOWER slab):
     concurrently), never an all-reduce over the matrix.
 Local node numbering is the global one shifted by a constant, so concatenating the owned row blocks of all
 ranks gives the single-GPU CSR (indices after the shift bit-exact, values to rounding).
+
+Alternative without communication (``mode="halo"``, SURVEY.md 8e "halo-element recomputation"): the rank also
+runs the numerics of the halo element layer ABOVE its top interface plane, which completes the rows of that
+(owned) plane locally; nothing is sent.  Costs one extra element layer per interior interface; the rows of the two
+non-owned planes of the extended mesh stay partial and are ignored.
 """
 from __future__ import annotations
 
@@ -38,8 +43,13 @@ class SlabProblem:
     recv_nodes: Optional[Tuple[int, int]]  # local node range of the owned top interface plane (from rank+1)
     rank: int
     world: int
+    mode: str = "exchange"        # "exchange": interface rows are sent to the owner; "halo": recomputed, no traffic
+    own_elements: int = 0         # elements of the partition proper (the unit of the throughput metric)
 
     def num_own_elements(self):
+        return int(self.own_elements)
+
+    def num_active_elements(self):
         return int(self.active.sum())
 
 
@@ -51,8 +61,10 @@ def slab_layers(cells_z_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def make_slab(unit_length: float, units_x: int, units_y: int, units_z: int, cells_per_unit: int, rank: int,
-              world: int) -> SlabProblem:
+              world: int, mode: str = "exchange") -> SlabProblem:
     """Slab ``rank`` of create_rectangular_uniform_hex_mesh(unit_length, units_x, units_y, units_z, cells_per_unit)."""
+    if mode not in ("exchange", "halo"):
+        raise ValueError("mode must be 'exchange' or 'halo'")
     cx, cy, cz = units_x * cells_per_unit, units_y * cells_per_unit, units_z * cells_per_unit
     if world > cz:
         raise ValueError("more ranks than element layers")
@@ -69,11 +81,14 @@ def make_slab(unit_length: float, units_x: int, units_y: int, units_z: int, cell
     active = np.zeros(local.num_elements(), dtype=np.uint8)
     per_layer = cx * cy
     active[(l0 - e0) * per_layer:(l1 - e0) * per_layer] = 1
+    if mode == "halo" and rank < world - 1:
+        active[(l1 - e0) * per_layer:(l1 + 1 - e0) * per_layer] = 1  # the layer above completes the owned top plane
     own_lo_plane = (l0 + 1 if rank > 0 else 0) - e0
     own_hi_plane = l1 - e0
-    send = ((l0 - e0) * npl, (l0 - e0 + 1) * npl) if rank > 0 else None
-    recv = ((l1 - e0) * npl, (l1 - e0 + 1) * npl) if rank < world - 1 else None
-    return SlabProblem(local, active, e0 * npl, (own_lo_plane * npl, (own_hi_plane + 1) * npl), send, recv, rank, world)
+    send = ((l0 - e0) * npl, (l0 - e0 + 1) * npl) if (rank > 0 and mode == "exchange") else None
+    recv = ((l1 - e0) * npl, (l1 - e0 + 1) * npl) if (rank < world - 1 and mode == "exchange") else None
+    return SlabProblem(local, active, e0 * npl, (own_lo_plane * npl, (own_hi_plane + 1) * npl), send, recv, rank, world,
+                       mode, (l1 - l0) * per_layer)
 
 
 def _box(cx, cy, cz, h):
@@ -123,9 +138,14 @@ class InterfaceExchange:
     def bytes_sent(self):
         return 8 * (self.send_seg[1] - self.send_seg[0]) if self.send_seg else 0
 
-    def run(self):
+    def start(self, comm_stream=None):
+        """Post the send of the bottom ghost plane and the receive for the owned top plane.  With a CUDA
+        ``comm_stream`` the transfers are ordered after the work enqueued so far on the current stream and run
+        beside whatever is enqueued next (the rows to send must already be queued: launch them first)."""
+        import torch
         import torch.distributed as dist
 
+        self._reqs = []
         ops = []
         if self.send_seg:
             ops.append(dist.P2POp(dist.isend, self.values[self.send_seg[0]:self.send_seg[1]], self.slab.rank - 1, self.group))
@@ -133,14 +153,86 @@ class InterfaceExchange:
             ops.append(dist.P2POp(dist.irecv, self.recv_buf, self.slab.rank + 1, self.group))
         if not ops:
             return
-        for req in dist.batch_isend_irecv(ops):
+        if comm_stream is not None:
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                self._reqs = dist.batch_isend_irecv(ops)
+        else:
+            self._reqs = dist.batch_isend_irecv(ops)
+
+    def finish(self):
+        """Wait for the transfers (the current stream waits) and add the received rows to the owned top plane."""
+        for req in getattr(self, "_reqs", []):
             req.wait()
+        self._reqs = []
         if self.recv_seg:
             self.values[self.recv_seg[0]:self.recv_seg[1]] += self.recv_buf
 
+    def run(self):
+        self.start()
+        self.finish()
 
-def make_slab_problem(cells: int, rank: int, world: int):
+
+class SlabAssembly:
+    """One rank of the multi-GPU stiffness assembly.
+
+    ``configure(engine, mesh)`` sets operator / quadrature / u on an engine for the given mesh (typically by building
+    an ElementEllipticAssembler).  In "exchange" mode with ``overlap`` the rows of the bottom ghost plane are
+    produced by a first, small launch (a second context restricted to those rows, ``fh_set_row_range``); their
+    transfer to the owner rides a separate stream while the main launch computes all other rows; the received
+    rows are added at the end.  In "halo" mode nothing is exchanged."""
+
+    def __init__(self, slab: SlabProblem, configure, device: int = 0, overlap: bool = True, group=None, stream=None):
+        import torch
+
+        from .assembly import Engine
+
+        self.slab = slab
+        self.main = Engine(device, stream=stream)
+        configure(self.main, slab.mesh)
+        self.main.set_active_elements(slab.active)
+        nnz = self.main.build_pattern()
+        self.values = torch.zeros(nnz, dtype=torch.float64, device=f"cuda:{device}")
+        self.first = None
+        self.comm = None
+        if overlap and slab.send_nodes is not None:
+            split = slab.send_nodes[1]  # the nodes below the ghost plane carry no active element
+            self.first = Engine(device, stream=stream)
+            configure(self.first, slab.mesh)
+            self.first.set_active_elements(slab.active)
+            self.first.build_pattern()
+            self.first.set_row_range(0, split)
+            self.main.set_row_range(split, slab.mesh.num_nodes())
+        if overlap and (slab.send_nodes is not None or slab.recv_nodes is not None):
+            self.comm = torch.cuda.Stream(device=device)
+        self.exchange = InterfaceExchange(slab, group).bind(self.main, self.values)
+
+    def enqueue(self, flags):
+        """one assembly of this rank's rows (values overwritten or accumulated according to ``flags``)"""
+        if self.first is not None:
+            self.first.assemble_matrix_async(self.values, flags)
+        if self.comm is not None:
+            self.exchange.start(self.comm)
+            self.main.assemble_matrix_async(self.values, flags)
+            self.exchange.finish()
+        else:
+            self.main.assemble_matrix_async(self.values, flags)
+            self.exchange.run()
+
+    def poll_status(self):
+        self.main.poll_status()
+        if self.first is not None:
+            self.first.poll_status()
+
+    def close(self):
+        self.main.close()
+        if self.first is not None:
+            self.first.close()
+
+
+def make_slab_problem(cells: int, rank: int, world: int, mode: str = "exchange"):
     """bench.py weak scaling: cells x cells x (cells * world) box, one z-slab of cells^3 own elements per rank.
-    Returns (extended local mesh, exchange); the caller sets the element mask through ``exchange.slab.active``."""
-    slab = make_slab(1.0, 1, 1, world, cells, rank, world)
+    Returns (extended local mesh, exchange); the caller sets the element mask through ``exchange.slab.active``.
+    With ``mode="halo"`` the exchange object has nothing to send (its ``run`` is a no-op)."""
+    slab = make_slab(1.0, 1, 1, world, cells, rank, world, mode)
     return slab.mesh, InterfaceExchange(slab)

@@ -104,6 +104,11 @@ int fh_set_connectivity_ragged(fh_ctx*, uint64_t solution_dim, uint64_t num_node
  * mesh partition assembles its own elements into rows that carry the global pattern (own + halo elements),
  * see fenris_amd/distributed.py.  mask has num_elements bytes; NULL removes the mask. */
 int fh_set_active_elements(fh_ctx*, const uint8_t* mask);
+/* Restrict FH_SCATTER_GATHER assembly to the rows of the nodes [node_begin, node_end): only those CSR rows are
+ * produced (the others are left untouched).  Two contexts on the same mesh with complementary ranges assemble the
+ * matrix in two launches -- the multi-GPU path launches the rows of a partition interface first and sends them
+ * while the rest is computed (fenris_amd/distributed.py).  (0, num_nodes) restores the default. */
+int fh_set_row_range(fh_ctx*, uint64_t node_begin, uint64_t node_end);
 /* Operator: replaces .with_operator(&op) (elliptic.rs:99-108).  Solution dim s = 1 for Laplace, D else. */
 int fh_set_operator(fh_ctx*, int op_kind);
 /* UniformQuadratureTable::from_points_and_weights(points, weights).with_data / with_uniform_data

@@ -69,6 +69,27 @@ def test_slab_partition_covers_mesh():
     assert seen_nodes == (cells + 1) ** 2 * (cells * world + 1)
 
 
+@pytest.mark.parametrize("op_name", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_halo_recompute_needs_no_exchange(oracle, op_name):
+    """mode="halo" (SURVEY 8e alternative): own elements + the halo layer above complete every owned row locally"""
+    op = getattr(oracle, op_name)
+    s = 1 if op_name == "LAPLACE" else 3
+    world, cells = 3, 2
+    gro, gci, gvals = _global_reference(oracle, world, cells, op)
+    own_total = 0
+    for r in range(world):
+        slab = fd.make_slab(1.0, 1, 1, world, cells, r, world, mode="halo")
+        assert slab.send_nodes is None and slab.recv_nodes is None
+        assert slab.num_active_elements() == slab.num_own_elements() + (cells * cells if r < world - 1 else 0)
+        own_total += slab.num_own_elements()
+        ro, ci, vals = _oracle_partial(oracle, slab, op)
+        _check_owned_rows(slab, s, ro, ci, vals, gro, gci, gvals)
+        ex = fd.InterfaceExchange(slab).bind_offsets(ro, s, vals)
+        assert ex.bytes_sent() == 0
+        ex.run()  # no process group needed: nothing to send or receive
+    assert own_total == cells * cells * cells * world
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -120,6 +141,71 @@ def test_two_rank_exchange_over_gloo(op_name):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.gpu
+def test_row_range_split_equals_single_launch():
+    """SlabAssembly's two launches (rows of the ghost plane first, then the rest; fh_set_row_range) write exactly
+    the rows a single launch writes, with the same values up to the summation order inside the row accumulators"""
+    import torch
+
+    world, cells = 3, 4
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters(*LAME))
+
+    def configure(engine, mesh):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh)
+                .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt).with_u(None).build())
+
+    slab = fd.make_slab(1.0, 1, 1, world, cells, 1, world)
+    sa = fd.SlabAssembly(slab, configure, device=0, overlap=True)
+    assert sa.first is not None and sa.comm is not None
+    flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+    sa.values.fill_(7.0)
+    sa.first.assemble_matrix_async(sa.values, flags)
+    torch.cuda.synchronize()
+    a, b = sa.exchange.send_seg
+    v1 = sa.values.cpu().numpy().copy()
+    assert np.all(v1[b:] == 7.0)  # rows beyond the ghost plane untouched by the first launch
+    sa.main.assemble_matrix_async(sa.values, flags)
+    sa.poll_status()
+    torch.cuda.synchronize()
+    v2 = sa.values.cpu().numpy()
+    assert np.array_equal(v1[:b], v2[:b])  # ... and the ghost-plane rows untouched by the main launch
+    ref = fa.Engine(0)
+    configure(ref, slab.mesh)
+    ref.set_active_elements(slab.active)
+    ref.build_pattern()
+    full = torch.zeros_like(sa.values)
+    ref.assemble_matrix(full, flags)
+    fv = full.cpu().numpy()
+    assert np.abs(v2 - fv).max() <= 1e-12 * np.abs(fv).max()
+    with pytest.raises(fa.FenrisError):  # a row range is an owner-computes notion
+        sa.first.assemble_matrix(sa.values, fa.SCATTER_ATOMIC)
+    ref.close()
+    sa.close()
+
+
+@pytest.mark.gpu
+def test_halo_slabs_through_engine_match_global_oracle(oracle):
+    """halo-recompute partition driven through the engine: every rank's owned rows are complete without exchange"""
+    import torch
+
+    world, cells = 3, 3
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    gro, gci, gvals = _global_reference(oracle, world, cells, oracle.LINEAR_ELASTIC)
+    for r in range(world):
+        slab = fd.make_slab(1.0, 1, 1, world, cells, r, world, mode="halo")
+        eng = fa.Engine(0)
+        qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters(*LAME))
+        (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(slab.mesh)
+         .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt).with_u(None).build())
+        eng.set_active_elements(slab.active)
+        ro, ci = eng.pattern()
+        values = torch.zeros(len(ci), dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        _check_owned_rows(slab, 3, ro, ci, values.cpu().numpy(), gro, gci, gvals)
+        eng.close()
 
 
 @pytest.mark.gpu

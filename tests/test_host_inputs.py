@@ -14,7 +14,7 @@ from conftest import ROOT, load_golden_mesh
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "fenris_hip.h")).read()
-    declared = set(re.findall(r"\b(fh_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(fh_[A-Za-z0-9_]+)\s*\(", header))
     declared.discard("fh_ctx")
     lib = _ffi.lib()
     for name in sorted(declared):

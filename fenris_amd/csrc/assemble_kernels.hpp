@@ -1159,9 +1159,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
     }
     write_out(prev_out, prev_nacc, nt);
 #undef FH_STAMP
-    if (a.trace && (tid & 63) == 0) {
-        for (int k = 0; k < 6; ++k) atomicAdd(a.trace + k, tr_acc[k]);
-        atomicAdd(a.trace + 6, 1ull);
+    if (a.trace && (tid & 63) == 0) {  // one row of 7 counters per wave index
+        unsigned long long* row = a.trace + 7 * (tid >> 6);
+        for (int k = 0; k < 6; ++k) atomicAdd(row + k, tr_acc[k]);
+        atomicAdd(row + 6, 1ull);
     }
 }
 
@@ -1366,6 +1367,23 @@ __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk
                     (unsigned char)find_col(ncols + rb, (int)cnt, (unsigned)conn[(size_t)ent[t] * N + Jn]);
         }
     }
+}
+
+// link[i] = 1 if nodes i and i+1 share an element (sorted merge of their adjacency lists; entries are e * n + a).
+// Runs of linked nodes are what a structured numbering calls grid lines; the block partition aligns to them.
+__global__ void k_linked_to_next(const unsigned* n2e_off, const unsigned* n2e, int N, int num_nodes, unsigned char* link) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_nodes) return;
+    unsigned char r = 0;
+    if (i + 1 < num_nodes) {
+        unsigned a = n2e_off[i], ae = n2e_off[i + 1], b = ae, be = n2e_off[i + 2];
+        while (a < ae && b < be) {
+            const unsigned ea = n2e[a] / (unsigned)N, eb = n2e[b] / (unsigned)N;
+            if (ea == eb) { r = 1; break; }
+            if (ea < eb) ++a; else ++b;
+        }
+    }
+    link[i] = r;
 }
 
 __global__ void k_hdr_counts(const GatherHdr* hdr, int nblk, unsigned* counts) {

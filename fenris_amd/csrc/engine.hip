@@ -450,7 +450,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.ablate = env_int("FENRIS_HIP_ABLATE", 0);
     a.trace = nullptr;
     if (std::getenv("FENRIS_HIP_TRACE")) {
-        if (!c->trace.p && c->trace.alloc(8) == hipSuccess) (void)hipMemset(c->trace.p, 0, 64);
+        if (!c->trace.p && c->trace.alloc(32) == hipSuccess) (void)hipMemset(c->trace.p, 0, 256);
         a.trace = c->trace.p;
     }
 }
@@ -510,17 +510,59 @@ int build_partition(fh_ctx* c) {
     const int n_lo = (c->row_hi < 0) ? 0 : (int)std::min<long long>(c->row_lo, N);
     const int n_hi = (c->row_hi < 0) ? N : (int)std::min<long long>(c->row_hi, N);
     blk.push_back((unsigned)n_lo);
+    // Blocks are aligned to RUNS of consecutive nodes that share an element with their successor (the grid lines of
+    // a structured numbering): a run of L >= nb_target nodes is cut into ceil(L / nb_target) blocks of balanced size,
+    // so that every line of a structured mesh is cut at the same places and consecutive blocks of a sweep chain
+    // share exactly the elements between two lines.  Short runs (unstructured numberings) are merged greedily.
+    std::vector<unsigned char> link((size_t)N + 1, 1);
+    if (N > 0 && !std::getenv("FENRIS_HIP_NO_ALIGN")) {
+        DevBuf<unsigned char> link_d;
+        HIP_TRY(c, link_d.alloc((size_t)N + 1));
+        hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(link.data(), link_d.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    auto fits = [&](int a, int b) {  // nodes [a, b) within the accumulator and entry budgets
+        return S * S * ((long long)c->h_noff[b] - c->h_noff[a]) <= acc && (long long)adj_off_h[b] - adj_off_h[a] <= mb;
+    };
+    auto cut_greedy = [&](int a, int b) {  // blocks of up to nb_target nodes, shrunk where the budgets demand it
+        while (a < b) {
+            int e = std::min(b, a + nb_target);
+            while (e > a + 1 && !fits(a, e)) --e;
+            blk.push_back((unsigned)e);
+            a = e;
+        }
+    };
     int i0 = n_lo;
     while (i0 < n_hi) {
-        int i1 = i0 + 1;
-        while (i1 < n_hi && i1 - i0 < nb_target) {
-            const long long rows = (long long)c->h_noff[i1 + 1] - c->h_noff[i0];
-            const long long ents = (long long)adj_off_h[i1 + 1] - adj_off_h[i0];
-            if (S * S * rows > acc || ents > mb) break;
-            ++i1;
+        int r1 = i0 + 1;  // end of the run that starts at i0
+        while (r1 < n_hi && link[r1 - 1]) ++r1;
+        const int L = r1 - i0;
+        if (L >= nb_target) {
+            const int k = (L + nb_target - 1) / nb_target;
+            bool ok = true;
+            std::vector<int> ends;
+            for (int j = 1; j <= k && ok; ++j) {
+                const int e = i0 + (int)((long long)L * j / k);
+                ok = fits(ends.empty() ? i0 : ends.back(), e);
+                ends.push_back(e);
+            }
+            if (ok) for (int e : ends) blk.push_back((unsigned)e);
+            else cut_greedy(i0, r1);
+            i0 = r1;
+        } else {
+            // short run: keep absorbing following short runs until the block is full
+            int e = r1;
+            while (e < n_hi && e - i0 < nb_target) {
+                int r2 = e + 1;
+                while (r2 < n_hi && link[r2 - 1]) ++r2;
+                if (r2 - e >= nb_target || r2 - i0 > nb_target) break;
+                e = r2;
+            }
+            cut_greedy(i0, e);
+            i0 = e;
         }
-        blk.push_back((unsigned)i1);
-        i0 = i1;
     }
     c->nblk = (int)blk.size() - 1;
     {   // tighten the accumulator budget to the largest block actually formed
@@ -895,15 +937,19 @@ void fh_destroy(fh_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->trace.p) {  // FENRIS_HIP_TRACE: average cycles per wave and phase of the pipelined kernel
-        unsigned long long h[8] = {0};
+        unsigned long long h[32] = {0};
         (void)hipDeviceSynchronize();
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
             static const char* names[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};
-            unsigned long long tot = 0;
-            for (int k = 0; k < 6; ++k) tot += h[k];
-            for (int k = 0; k < 6; ++k)
-                std::fprintf(stderr, "[fenris_hip trace] %-24s %12.0f cycles/wave  %5.1f %%\n", names[k], (double)h[k] / (double)h[6],
-                             100.0 * (double)h[k] / (double)tot);
+            for (int w = 0; w < 4; ++w) {
+                const unsigned long long* r = h + 7 * w;
+                if (!r[6]) continue;
+                unsigned long long tot = 0;
+                for (int k = 0; k < 6; ++k) tot += r[k];
+                for (int k = 0; k < 6; ++k)
+                    std::fprintf(stderr, "[fenris_hip trace] wave %d %-24s %12.0f cycles/wave  %5.1f %%\n", w, names[k],
+                                 (double)r[k] / (double)r[6], 100.0 * (double)r[k] / (double)tot);
+            }
         }
     }
     delete c;

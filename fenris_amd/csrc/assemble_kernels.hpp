@@ -77,7 +77,7 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.n_ints = i + 4;
     // pipelined gather (the only kernel that stages quadrature points in chunks) lays out its integers itself:
     // 16 header words + two parity copies of (slot list | entries | column slots | row offsets)
-    if (gather && nq_stage > 0) L.n_ints = 16 + 2 * (ub / 4 + 1 + mb + (mb * E::N + 3) / 4 + nb_max + 1) + 4;
+    if (gather && nq_stage > 0) L.n_ints = 2 * (8 + ub / 4 + mb + (mb * E::N + 3) / 4 + nb_max + 1) + 8;
     return L;
 }
 
@@ -871,16 +871,21 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
 struct PipeTables {
     // all tables are indexed by POSITION p in the sweep order (blocks reordered into chains whose consecutive
     // members share elements; the shared elements stay staged in LDS from one block to the next)
-    const GatherHdr* hdr;       // [npos]  header of the block at position p; k0 holds the number of NEW slots
+    // rec: one packed record of rw 32-bit words per position, laid out exactly like its LDS copy:
+    //   [0, 8)            GatherHdr of the block; k0 holds the number of NEW slots
+    //   [8, +us/4)        occupied slots, 1 byte each: the new ones first, then the retained
+    //   [.., +ms)         packed entries (persistent slot << 16 | a << 8 | local node)
+    //   [.., +ms*N/4)     column slots, 4 per word
+    //   [.., +nbs+1)      node-level row offsets relative to the block start
+    const int* rec;             // [npos][rw]
     const int* conn;            // [npos][cs]   geometry-node indices per LDS slot (padded with 0)
-    const unsigned* ent;        // [npos][ms]   packed entries (persistent slot << 16 | a << 8 | local node)
-    const unsigned* pos;        // [npos][ms*N/4] column slots, 4 per word
-    const int* noffr;           // [npos][nbs+1] node-level row offsets relative to the block start
-    const unsigned* slots;      // [npos][us/4] occupied slots, 1 byte each: the new ones first, then the retained
     const int* elem;            // [npos][us]   element id per slot (error reporting)
+    int rw;                     // words per record
     int cs, ms, nbs, us;        // strides: cs = us * NG
     int npos;
 };
+
+__host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs) { return 8 + us / 4 + ms + ms * N / 4 + nbs + 1; }
 
 template <int EK, int OP, int QC, int JT>
 __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, const PipeTables T) {
@@ -901,7 +906,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
     // Prefetch state per thread: one header word (threads 0..7), SLOTS geometry-node indices, one packed entry,
     // one word of column slots, one relative row offset.  Headers are parked in LDS (double-buffered by block
     // parity) and read back as wave-uniform values, so they cost one VGPR instead of eight.
-    struct Rec { int hword; int conn[SLOTS]; unsigned ent, posw, slotw; int noffr; };
+    constexpr int RL = 2;  // record words per thread: rw <= 512 (checked by the host)
+    struct Rec { int w[RL]; int conn[SLOTS]; };
     const int npos = T.npos;
     // contiguous range of positions per workgroup: consecutive positions are chain neighbours
     const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
@@ -910,17 +916,14 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
     // the issue, which serialises the prefetch with the block's compute
     auto load_rec = [&](int p, Rec& r) {
         p = min(p, npos - 1);
-        r.hword = reinterpret_cast<const int*>(T.hdr + p)[tid & 7];
+#pragma unroll
+        for (int k = 0; k < RL; ++k) r.w[k] = T.rec[(size_t)p * T.rw + min(tid + k * nt, T.rw - 1)];
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) r.conn[k] = T.conn[(size_t)p * T.cs + min(tid + k * nt, T.cs - 1)];
-        r.ent = T.ent[(size_t)p * T.ms + min(tid, T.ms - 1)];
-        r.posw = T.pos[(size_t)p * (T.ms * N / 4) + min(tid, T.ms * N / 4 - 1)];
-        r.slotw = T.slots[(size_t)p * (T.us / 4) + min(tid, T.us / 4 - 1)];
-        r.noffr = T.noffr[(size_t)p * (T.nbs + 1) + min(tid, T.nbs)];
     };
     // pins the record in registers: the compiler places the vmcnt wait for its loads here
     auto land_rec = [&](Rec& r) {
-        asm volatile("" : "+v"(r.hword), "+v"(r.conn[0]), "+v"(r.conn[1]), "+v"(r.ent), "+v"(r.posw), "+v"(r.slotw), "+v"(r.noffr));
+        asm volatile("" : "+v"(r.w[0]), "+v"(r.w[1]), "+v"(r.conn[0]), "+v"(r.conn[1]));
     };
     double V[SLOTS][D];
     auto load_verts = [&](const Rec& r) {
@@ -929,12 +932,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
 #pragma unroll
             for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
     };
-    // integer LDS: 2 x 8 header words, then one record per block parity (slot list | entries | column slots |
-    // row offsets).  Everything parked for block p+1 is double-buffered, so parking needs no barrier of its own;
-    // X is single-buffered: it is only read by phase B, which lies behind the barrier that precedes phase C.
-    int* hdr_lds = lds_i;
-    const int rec_ints = T.us / 4 + T.ms + T.ms * N / 4 + T.nbs + 1;
-    auto rec_base = [&](int parity) { return lds_i + 16 + parity * rec_ints; };
+    // integer LDS: one packed record (see PipeTables) per block parity.  Everything parked for block p+1 is
+    // double-buffered, so parking needs no barrier of its own; X is single-buffered: it is only read by phase B,
+    // which lies behind the barrier that precedes phase C.
+    auto rec_base = [&](int parity) { return lds_i + parity * T.rw; };
     auto park = [&](const Rec& r, int parity) {  // registers -> LDS for the block that is computed next
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
@@ -944,11 +945,9 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
                 for (int c = 0; c < D; ++c) lds[L.o_X + (sidx / NG) * L.xs + (sidx % NG) * D + c] = V[k][c];
         }
         int* rb = rec_base(parity);
-        if (tid < 8) hdr_lds[8 * parity + tid] = r.hword;
-        if (tid < T.us / 4) rb[tid] = (int)r.slotw;
-        if (tid < T.ms) rb[T.us / 4 + tid] = (int)r.ent;
-        if (tid < T.ms * N / 4) rb[T.us / 4 + T.ms + tid] = (int)r.posw;
-        if (tid <= T.nbs) rb[T.us / 4 + T.ms + T.ms * N / 4 + tid] = r.noffr;
+#pragma unroll
+        for (int k = 0; k < RL; ++k)
+            if (tid + k * nt < T.rw) rb[tid + k * nt] = r.w[k];
     };
     // phase D: rows of a finished block -> global memory, accumulators cleared.  NTH threads take part, in
     // reverse thread order, so that the waves with no phase-B work do it while the others run phase B.
@@ -999,12 +998,12 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
     for (; p < p_end; ++p, parity ^= 1) {
         const bool have_next = (p + 1) < p_end;
         // LDS reads of this block's header and item first, the global prefetch is issued while they are in flight
-        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(hdr_lds + 8 * parity);
         const int* rec = rec_base(parity);
-        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(rec);
-        const int* ent_l = rec + T.us / 4;
-        const unsigned char* pos_b = reinterpret_cast<const unsigned char*>(rec + T.us / 4 + T.ms);
-        const int* noff_l = rec + T.us / 4 + T.ms + T.ms * N / 4;
+        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(rec);
+        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(rec + 8);
+        const int* ent_l = rec + 8 + T.us / 4;
+        const unsigned char* pos_b = reinterpret_cast<const unsigned char*>(rec + 8 + T.us / 4 + T.ms);
+        const int* noff_l = rec + 8 + T.us / 4 + T.ms + T.ms * N / 4;
         constexpr int NGRP = (JT <= N) ? N / JT : 1;
         const int t_item = tid / NGRP, j0 = (tid % NGRP) * JT;
         const unsigned packed_raw = (unsigned)ent_l[min(t_item, T.ms - 1)];
@@ -1219,8 +1218,7 @@ template <int NG_T>
 __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, const int* chain_off, const GatherHdr* hdr,
                                                           const unsigned* gt_elems, const unsigned* gt_ent,
                                                           const unsigned char* gt_pos, const unsigned* noff, const int* conn, int N,
-                                                          int cs, int ms, int nbs, int us, GatherHdr* p_hdr, int* p_conn,
-                                                          unsigned* p_ent, unsigned* p_pos, int* p_noffr, unsigned* p_slots,
+                                                          int cs, int ms, int nbs, int us, int rw, int* p_rec, int* p_conn,
                                                           int* p_elem) {
     __shared__ int slot_elem[256];   // element staged in each slot after the previous block (-1 = free)
     __shared__ int new_elem[256];    // element per slot after this block
@@ -1262,10 +1260,15 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
         }
         __syncthreads();
         // write the records of position p
+        int* rec = p_rec + (size_t)p * rw;  // packed record, layout of PipeTables::rec
+        unsigned* p_slots_r = reinterpret_cast<unsigned*>(rec + 8);
+        unsigned* p_ent_r = reinterpret_cast<unsigned*>(rec + 8 + us / 4);
+        unsigned* p_pos_r = reinterpret_cast<unsigned*>(rec + 8 + us / 4 + ms);
+        int* p_noff_r = rec + 8 + us / 4 + ms + ms * N / 4;
         if (lane == 0) {
             GatherHdr o = h;
             o.k0 = s_nnew;
-            p_hdr[p] = o;
+            *reinterpret_cast<GatherHdr*>(rec) = o;
         }
         for (int sidx = lane; sidx < cs; sidx += 64) {
             const int s_ = sidx / NG_T, g = sidx % NG_T;
@@ -1274,7 +1277,7 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
         }
         for (int s_ = lane; s_ < us; s_ += 64) p_elem[(size_t)p * us + s_] = new_elem[s_];
         for (int w = lane; w < us / 4; w += 64)
-            p_slots[(size_t)p * (us / 4) + w] = (unsigned)list[4 * w] | ((unsigned)list[4 * w + 1] << 8) |
+            p_slots_r[w] = (unsigned)list[4 * w] | ((unsigned)list[4 * w + 1] << 8) |
                                                 ((unsigned)list[4 * w + 2] << 16) | ((unsigned)list[4 * w + 3] << 24);
         for (int t = lane; t < ms; t += 64) {
             unsigned word = 0;
@@ -1282,7 +1285,7 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
                 const unsigned old = gt_ent[h.k0 + t];
                 word = ((unsigned)map[old >> 16] << 16) | (old & 0xffffu);
             }
-            p_ent[(size_t)p * ms + t] = word;
+            p_ent_r[t] = word;
         }
         const int pw = ms * N / 4;
         for (int w = lane; w < pw; w += 64) {
@@ -1291,10 +1294,10 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
                 const int it = 4 * w + k;
                 if (it < h.m * N) word |= (unsigned)gt_pos[(size_t)h.k0 * N + it] << (8 * k);
             }
-            p_pos[(size_t)p * pw + w] = word;
+            p_pos_r[w] = word;
         }
         for (int i = lane; i <= nbs; i += 64)
-            p_noffr[(size_t)p * (nbs + 1) + i] = (i <= h.nb) ? (int)(noff[h.i0 + i] - (unsigned)h.r0) : 0;
+            p_noff_r[i] = (i <= h.nb) ? (int)(noff[h.i0 + i] - (unsigned)h.r0) : 0;
         __syncthreads();
         for (int s_ = lane; s_ < us; s_ += 64) slot_elem[s_] = new_elem[s_];
         __syncthreads();

@@ -189,9 +189,8 @@ struct fh_ctx {
     DevBuf<unsigned char> gt_pos;
     bool has_pos = false;
     // fixed-stride tables of the pipelined gather kernel
-    DevBuf<int> p_conn, p_noffr, p_elem;
-    DevBuf<unsigned> p_ent, p_pos, p_slots;
-    DevBuf<GatherHdr> p_hdr;
+    DevBuf<int> p_conn, p_rec, p_elem;
+    int p_rw = 0;
     int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1, p_us = 0;
     bool has_pipe = false;
     DevBuf<GatherHdr> gt_hdr;
@@ -648,7 +647,7 @@ int build_partition(fh_ctx* c) {
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
         if (us * c->ei.ng <= 512 && us <= 252 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb &&
-            nb_target <= 254 && c->fast_ok) {
+            nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
             const int nblk = c->nblk;
             // sweep order: chains of blocks whose consecutive members share elements (their staged data is reused)
             std::vector<int> order, chain_off(1, 0);
@@ -686,17 +685,14 @@ int build_partition(fh_ctx* c) {
             c->p_ms = ms;
             c->p_nbs = nb_target;
             c->p_us = us;
-            HIP_TRY(c, c->p_hdr.alloc((size_t)nblk));
+            c->p_rw = pipe_record_words(us, ms, n, nb_target);
+            HIP_TRY(c, c->p_rec.alloc((size_t)nblk * c->p_rw));
             HIP_TRY(c, c->p_conn.alloc((size_t)nblk * c->p_cs));
-            HIP_TRY(c, c->p_ent.alloc((size_t)nblk * ms));
-            HIP_TRY(c, c->p_pos.alloc((size_t)nblk * (ms * n / 4)));
-            HIP_TRY(c, c->p_noffr.alloc((size_t)nblk * (nb_target + 1)));
-            HIP_TRY(c, c->p_slots.alloc((size_t)nblk * (us / 4)));
             HIP_TRY(c, c->p_elem.alloc((size_t)nblk * us));
 #define PT_LAUNCH(NGV)                                                                                                           \
     hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(nchains), dim3(64), 0, c->stream, order_d.p, chain_d.p, c->gt_hdr.p,        \
-                       c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_hdr.p,   \
-                       c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_slots.p, c->p_elem.p)
+                       c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_rw,     \
+                       c->p_rec.p, c->p_conn.p, c->p_elem.p)
             switch (c->ei.ng) {
                 case 3: PT_LAUNCH(3); break;
                 case 4: PT_LAUNCH(4); break;
@@ -814,7 +810,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         a.nb_max = c->g_nb;
         const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
         if (c->has_pipe && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
-            PipeTables T{c->p_hdr.p, c->p_conn.p, c->p_ent.p, c->p_pos.p, c->p_noffr.p, c->p_slots.p, c->p_elem.p,
+            PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, c->p_rw,
                          c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->nblk};
             a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
             a.mb = c->p_ms;  // the LDS layout is sized by the table strides

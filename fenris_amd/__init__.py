@@ -8,7 +8,7 @@ from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO
                    SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,
                        ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,
-                       MockElementAssembler, UniformQuadratureTable,
+                       MockElementAssembler, UniformQuadratureTable, CompactQuadratureTable,
                        VectorAssembler, VectorParAssembler, apply_homogeneous_dirichlet_bc_csr,
                        apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes, CgSolveError, ConjugateGradient,
                        IdentityOperator, JacobiPreconditioner, RelativeResidualCriterion, estimate_H1_seminorm_error,

@@ -54,6 +54,7 @@ _SIGS = {
     "fh_update_vertices": (C.c_int, [C.c_void_p, f64p]),
     "fh_set_connectivity_ragged": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, u64p, u64p, C.c_uint64]),
     "fh_set_active_elements": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "fh_set_quadrature_compact": (C.c_int, [C.c_void_p, f64p, f64p, C.c_uint32, C.c_uint64, f64p, u64p]),
     "fh_set_row_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "fh_set_operator": (C.c_int, [C.c_void_p, C.c_int]),
     "fh_set_quadrature_uniform": (C.c_int, [C.c_void_p, f64p, f64p, C.c_uint32, f64p]),

@@ -89,6 +89,16 @@ class Engine:
         q = None if params is None else _ffi.as_f64(params)
         self._check(self._lib.fh_set_quadrature_uniform(self._h, _ffi.fp(w), _ffi.fp(p), len(w), _ffi.fp(q)))
 
+    def set_quadrature_table(self, qtable):
+        """UniformQuadratureTable or CompactQuadratureTable"""
+        if hasattr(qtable, "rule_params"):
+            w, p = _ffi.as_f64(qtable.weights), _ffi.as_f64(qtable.points)
+            self._keep_q = (w, p, qtable.rule_params, qtable.element_to_rule_map)
+            self._check(self._lib.fh_set_quadrature_compact(self._h, _ffi.fp(w), _ffi.fp(p), len(w), len(qtable.rule_params),
+                                                            _ffi.fp(qtable.rule_params), _ffi.up(qtable.element_to_rule_map)))
+        else:
+            self.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
+
     def set_u(self, u):
         if u is None:
             self._check(self._lib.fh_set_u(self._h, None))
@@ -299,6 +309,34 @@ class UniformQuadratureTable:
         return UniformQuadratureTable(self.points, self.weights, arr)
 
 
+class CompactQuadratureTable:
+    """src/assembly/local/quadrature_table.rs:300-439 (``from_quadrature_rules_and_map``) for rules that share one
+    set of points and weights and differ in their data: ``rule_data[r]`` holds one Parameters value per point (or a
+    single value, repeated), ``element_to_rule_map[e]`` picks the rule of element e.  Piecewise material data."""
+
+    def __init__(self, points, weights, rule_data, element_to_rule_map):
+        self.points = _ffi.as_f64(points)
+        self.weights = _ffi.as_f64(weights)
+        nq = len(self.weights)
+        rules = []
+        for rd in rule_data:
+            if hasattr(rd, "as_pair"):
+                rd = [rd] * nq
+            arr = np.array([d.as_pair() if hasattr(d, "as_pair") else tuple(d) for d in rd], dtype=np.float64)
+            if arr.shape != (nq, 2):
+                raise ValueError("every rule needs one data value per quadrature point")  # check_rules_consistency
+            rules.append(arr)
+        self.rule_params = np.ascontiguousarray(np.stack(rules))
+        self.element_to_rule_map = _ffi.as_u64(element_to_rule_map)
+        if len(self.element_to_rule_map) and int(self.element_to_rule_map.max()) >= len(rules):
+            raise ValueError("Each rule index must correspond to a provided quadrature rule.")  # quadrature_table.rs:366-372
+        self.data = self.rule_params[0]
+
+    @classmethod
+    def from_quadrature_rules_and_map(cls, points, weights, data, element_to_rule_map):
+        return cls(points, weights, data, element_to_rule_map)
+
+
 @dataclass
 class DisjointSubsetsColors:
     """Vec<DisjointSubsets> (fenris-paradis/src/lib.rs:171-181) flattened: elements of colour c are
@@ -379,7 +417,7 @@ class ElementEllipticAssembler:
             u = _ffi.as_f64(u)
             if len(u) != s * space.num_nodes():
                 raise ValueError("Local element dofs (u) dimension mismatch")  # elliptic.rs:385-389
-        engine.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
+        engine.set_quadrature_table(qtable)
         engine.set_u(u)
 
     # ElementConnectivityAssembler (src/assembly/local.rs:18-47)
@@ -482,7 +520,7 @@ class ElementSourceAssembler:
         if source.solution_dim not in (1, d):
             raise ValueError("solution_dim must be 1 or the geometry dimension")
         engine.set_mesh(space)
-        engine.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
+        engine.set_quadrature_table(qtable)
 
     def solution_dim(self):
         return self.source.solution_dim

@@ -231,7 +231,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
                 for (int i = 1; i < D; ++i) gout[n * D + i] = 0.0;
             }
-            qp[O::NVEC * N * D] = s * lds[L.o_qpar + 2 * q];
+            qp[O::NVEC * N * D] = s * (a.rule_map ? a.rparams[((size_t)a.rule_map[*elem_id] * a.nq + q) * 2] : lds[L.o_qpar + 2 * q]);
         }
         return;
     }
@@ -276,8 +276,14 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     }
     double mu = 0.0, lambda = 0.0;
     if (OP != FH_LAPLACE) {
-        mu = lds[L.o_qpar + 2 * q];
-        lambda = lds[L.o_qpar + 2 * q + 1];
+        if (a.rule_map) {  // per-element data (compact table): the slow path, never with L.fast
+            const double* par = a.rparams + ((size_t)a.rule_map[*elem_id] * a.nq + q) * 2;
+            mu = par[0];
+            lambda = par[1];
+        } else {
+            mu = lds[L.o_qpar + 2 * q];
+            lambda = lds[L.o_qpar + 2 * q + 1];
+        }
     }
 
     // deformation gradient F = I + (grad u)^T  (fenris-solid/src/lib.rs:20-29)
@@ -1498,7 +1504,8 @@ __global__ void __launch_bounds__(256) k_assemble_source(const KArgs a, const So
             const double t = wd[u * a.nq + q] * a.phiref[(size_t)q * sa.N + I];
 #pragma unroll
             for (int c = 0; c < S; ++c) {
-                const double fc = sa.values ? sa.values[((size_t)e * a.nq + q) * S + c] : sa.g[c] * a.qparams[2 * q];
+                const double rho = a.rule_map ? a.rparams[((size_t)a.rule_map[e] * a.nq + q) * 2] : (a.qparams ? a.qparams[2 * q] : 0.0);
+                const double fc = sa.values ? sa.values[((size_t)e * a.nq + q) * S + c] : sa.g[c] * rho;
                 f[c] = fma(t, fc, f[c]);
             }
         }

@@ -82,6 +82,9 @@ struct KArgs {
     const double* ggeom;   // nq x NG x D  reference gradients of the geometry map
     const double* phiref;  // nq x N       basis values (mass matrix only)
     const double* qparams; // nq x 2 (mu, lambda) or null
+    // CompactQuadratureTable with shared points / weights: element e reads rparams[(rule_map[e] nq + q) 2 ..]
+    const unsigned* rule_map;  // E, or null (uniform table)
+    const double* rparams;     // num_rules x nq x 2
     const double* u;       // S x N or null
     // node-level pattern
     const unsigned* noff;     // N+1

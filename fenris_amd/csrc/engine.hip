@@ -166,7 +166,9 @@ struct fh_ctx {
     int op = -1;
     uint64_t sdim_ragged = 1;
     int nq = 0;
-    DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u;
+    DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
+    DevBuf<unsigned> rule_map;
+    bool has_rules = false;
     bool has_params = false, has_u = false;
     bool fast_ok = false;       // uniform parameters and non-negative weights
     double uni_mu = 0.0, uni_lambda = 0.0;
@@ -437,6 +439,8 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
+    a.rule_map = c->has_rules ? c->rule_map.p : nullptr;
+    a.rparams = c->has_rules ? c->rparams.p : nullptr;
     a.u = c->has_u ? c->u.p : nullptr;
     a.fast = (c->fast_ok && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) ? 1 : 0;
     a.mu = c->uni_mu;
@@ -1177,6 +1181,29 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
         for (uint32_t q = 1; q < nq; ++q) c->fast_ok = c->fast_ok && params[2 * q] == params[0] && params[2 * q + 1] == params[1];
     }
     if (std::getenv("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
+    c->has_rules = false;
+    c->has_partition = false;
+    return FH_OK;
+}
+
+int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uint32_t nq, uint64_t num_rules,
+                              const double* rule_params, const uint64_t* elem_to_rule) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!rule_params || !elem_to_rule || num_rules == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_compact: bad argument");
+    int rc = fh_set_quadrature_uniform(c, w, pts, nq, rule_params);  // tables; rule 0 stands in for the uniform data
+    if (rc) return rc;
+    std::vector<unsigned> map((size_t)c->E + 1, 0u);
+    for (uint64_t e = 0; e < c->E; ++e) {
+        // "Each rule index must correspond to a provided quadrature rule" (quadrature_table.rs:366-372 panics)
+        if (elem_to_rule[e] >= num_rules) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_compact: rule index out of bounds");
+        map[e] = (unsigned)elem_to_rule[e];
+    }
+    HIP_TRY(c, c->rule_map.alloc(map.size()));
+    HIP_TRY(c, c->rparams.alloc((size_t)num_rules * nq * 2));
+    HIP_TRY(c, hipMemcpy(c->rule_map.p, map.data(), sizeof(unsigned) * map.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->rparams.p, rule_params, sizeof(double) * (size_t)num_rules * nq * 2, hipMemcpyHostToDevice));
+    c->has_rules = true;
+    c->fast_ok = false;  // per-element data: per-point coefficients, generic kernels
     c->has_partition = false;
     return FH_OK;
 }

@@ -116,6 +116,13 @@ int fh_set_operator(fh_ctx*, int op_kind);
  * per point, fenris-solid/src/materials.rs:8-12) or NULL for operators without parameters. */
 int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* points, uint32_t nq,
                               const double* params);
+/* CompactQuadratureTable::from_quadrature_rules_and_map (src/assembly/local/quadrature_table.rs:300-439) for rules
+ * that share points and weights and differ in their per-point data -- piecewise material parameters: element e
+ * uses rule_params[elem_to_rule[e]] (num_rules x nq x 2, same pair layout as the uniform table).  A rule index out
+ * of bounds is FH_BAD_ARGUMENT (the reference panics).  Rules with different point sets are not expressible here:
+ * assemble them rule by rule with fh_set_active_elements. */
+int fh_set_quadrature_compact(fh_ctx*, const double* weights, const double* points, uint32_t nq, uint64_t num_rules,
+                              const double* rule_params, const uint64_t* elem_to_rule);
 /* .with_u(&u) (elliptic.rs:123-137); u has s*N entries; NULL = zeros */
 int fh_set_u(fh_ctx*, const double* u);
 int fh_set_u_dev(fh_ctx*, const double* u_dev);

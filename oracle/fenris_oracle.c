@@ -839,6 +839,13 @@ typedef struct {
 } elem_ws;
 
 /* space_impl.rs:40-52,81-86 : gather element vertices from the mesh */
+/* populate_element_data (quadrature_table.rs:283-291 uniform, :396-409 compact): the per-point data of element e */
+static const double* element_params(const fo_assembler* a, uint64_t e, uint32_t q) {
+    static const double zero_params[2] = {0, 0};
+    if (a->elem_to_rule && a->rule_params) return a->rule_params + ((size_t)a->elem_to_rule[e] * a->nq + q) * 2;
+    return a->q_params ? a->q_params + 2 * (size_t)q : zero_params;
+}
+
 static void gather_element(const fo_assembler* a, uint64_t e, int n, int d, double* ev) {
     const uint64_t* c = a->connectivity + (size_t)n * e;
     for (int k = 0; k < n; ++k)
@@ -908,7 +915,7 @@ static int assemble_element_mass_matrix(const fo_assembler* a, uint64_t e, doubl
     elem_ws ws;
     if (ws_init(a, &ws)) return FO_BAD_ARGUMENT;
     int d = ws.d, n = ws.n, s = ws.s, ld = s * n;
-    if (!a->q_params) return FO_BAD_ARGUMENT;
+    if (!a->q_params && !a->rule_params) return FO_BAD_ARGUMENT;
     for (int i = 0; i < ld * ld; ++i) me[i] = 0.0;
     double phi[MAXN], J[9];
     for (uint32_t q = 0; q < a->nq; ++q) {
@@ -917,7 +924,7 @@ static int assemble_element_mass_matrix(const fo_assembler* a, uint64_t e, doubl
         fo_element_reference_jacobian(a->elem_kind, ws.ev, xi, J);
         double j_det = det(d, J);
         fo_element_basis(a->elem_kind, xi, phi);
-        double scale = a->q_weights[q] * fabs(j_det) * a->q_params[2 * (size_t)q];
+        double scale = a->q_weights[q] * fabs(j_det) * element_params(a, e, q)[0];
         for (int I = 0; I < n; ++I)
             for (int Jn = I; Jn < n; ++Jn) {
                 double m = scale * phi[I] * phi[Jn];
@@ -939,11 +946,10 @@ int fo_assemble_element_matrix(const fo_assembler* a, uint64_t e, double* ke) {
     gather_element(a, e, n, d, ws.ev);
     gather_u(a, e, n, s, ws.ue);
     for (int i = 0; i < ld * ld; ++i) ke[i] = 0.0; /* output.fill(0) :393 */
-    static const double zero_params[2] = {0, 0};
     for (uint32_t q = 0; q < a->nq; ++q) {
         double weight = a->q_weights[q];
         const double* xi = a->q_points + (size_t)d * q;
-        const double* params = a->q_params ? a->q_params + 2 * (size_t)q : zero_params;
+        const double* params = element_params(a, e, q);
         double j_det, jinv_t[9], u_grad[9];
         int st = qp_prologue(a, e, &ws, xi, &j_det, jinv_t, u_grad);
         if (st) return st;
@@ -998,11 +1004,10 @@ int fo_assemble_element_vector(const fo_assembler* a, uint64_t e, double* fe) {
     gather_element(a, e, n, d, ws.ev);
     gather_u(a, e, n, s, ws.ue);
     for (int i = 0; i < s * n; ++i) fe[i] = 0.0;
-    static const double zero_params[2] = {0, 0};
     for (uint32_t q = 0; q < a->nq; ++q) {
         double weight = a->q_weights[q];
         const double* xi = a->q_points + (size_t)d * q;
-        const double* params = a->q_params ? a->q_params + 2 * (size_t)q : zero_params;
+        const double* params = element_params(a, e, q);
         double j_det, jinv_t[9], u_grad[9], g_t[9], gj[9];
         int st = qp_prologue(a, e, &ws, xi, &j_det, jinv_t, u_grad);
         if (st) return st;
@@ -1027,12 +1032,11 @@ int fo_assemble_element_scalar(const fo_assembler* a, uint64_t e, double* energy
     int d = ws.d, n = ws.n, s = ws.s;
     gather_element(a, e, n, d, ws.ev);
     gather_u(a, e, n, s, ws.ue);
-    static const double zero_params[2] = {0, 0};
     double integral = 0.0;
     for (uint32_t q = 0; q < a->nq; ++q) {
         double weight = a->q_weights[q];
         const double* xi = a->q_points + (size_t)d * q;
-        const double* params = a->q_params ? a->q_params + 2 * (size_t)q : zero_params;
+        const double* params = element_params(a, e, q);
         double j_det, jinv_t[9], u_grad[9], psi;
         int st = qp_prologue(a, e, &ws, xi, &j_det, jinv_t, u_grad);
         if (st) return st;
@@ -1273,7 +1277,7 @@ int fo_assemble_element_source_vector(const fo_assembler* a, uint64_t e, int s, 
                                       double* fe) {
     int n = fo_element_num_nodes(a->elem_kind), d = fo_element_dim(a->elem_kind);
     if (n < 0 || s < 1 || s > MAXD) return FO_BAD_ARGUMENT;
-    if (!values && (!g || !a->q_params)) return FO_BAD_ARGUMENT;
+    if (!values && (!g || (!a->q_params && !a->rule_params))) return FO_BAD_ARGUMENT;
     double ev[MAXN * MAXD], phi[MAXN], J[9], f[MAXD];
     gather_element(a, e, n, d, ev);
     for (int i = 0; i < s * n; ++i) fe[i] = 0.0; /* output.fill(0) :257 */
@@ -1282,7 +1286,7 @@ int fo_assemble_element_source_vector(const fo_assembler* a, uint64_t e, int s, 
         fo_element_basis(a->elem_kind, xi, phi);                       /* populate_basis :261 */
         fo_element_reference_jacobian(a->elem_kind, ev, xi, J);        /* :264 */
         for (int c = 0; c < s; ++c)
-            f[c] = values ? values[((size_t)e * a->nq + q) * (size_t)s + (size_t)c] : g[c] * a->q_params[2 * (size_t)q];
+            f[c] = values ? values[((size_t)e * a->nq + q) * (size_t)s + (size_t)c] : g[c] * element_params(a, e, q)[0];
         double alpha = a->q_weights[q] * fabs(det(d, J));
         for (int I = 0; I < n; ++I)
             for (int c = 0; c < s; ++c) fe[s * I + c] += alpha * (f[c] * phi[I]);

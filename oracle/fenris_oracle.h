@@ -106,6 +106,12 @@ typedef struct {
     const double* q_points;   /* nq x d */
     uint32_t nq;
     const double* q_params;   /* nq x 2 (mu, lambda) per point, or NULL for Laplace */
+    /* CompactQuadratureTable (src/assembly/local/quadrature_table.rs:300-439) restricted to rules that share the
+     * points and weights above and differ in their per-point data: element e uses rule_params[elem_to_rule[e]]
+     * (num_rules x nq x 2).  NULL: the uniform table. */
+    const uint64_t* elem_to_rule;
+    const double* rule_params;
+    uint64_t num_rules;
 } fo_assembler;
 
 /* per-element kernels (src/assembly/local/elliptic.rs:361-439, 457-531, 551-605) */

@@ -36,6 +36,9 @@ class _Assembler(C.Structure):
         ("q_points", _f64p),
         ("nq", C.c_uint32),
         ("q_params", _f64p),
+        ("elem_to_rule", _u64p),
+        ("rule_params", _f64p),
+        ("num_rules", C.c_uint64),
     ]
 
 
@@ -266,7 +269,8 @@ def element_basis(kind, xi):
 class ElementAssembler:
     """Mirror of ElementEllipticAssembler<Mesh, Op, UniformQuadratureTable> for the oracle."""
 
-    def __init__(self, elem_kind, op_kind, vertices, connectivity, weights, points, params=None, u=None):
+    def __init__(self, elem_kind, op_kind, vertices, connectivity, weights, points, params=None, u=None, elem_to_rule=None,
+                 rule_params=None):
         self.elem_kind, self.op_kind = elem_kind, op_kind
         self.n, self.d = element_num_nodes(elem_kind), element_dim(elem_kind)
         self.s = solution_dim(op_kind, self.d)
@@ -284,9 +288,15 @@ class ElementAssembler:
             self.params = np.ascontiguousarray(p)
         self.u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
         self.N, self.E = len(self.vertices), len(self.connectivity)
+        # CompactQuadratureTable with shared points / weights: rule_params (R, nq, 2), elem_to_rule (E,)
+        self.elem_to_rule = None if elem_to_rule is None else np.ascontiguousarray(elem_to_rule, dtype=np.uint64)
+        self.rule_params = None if rule_params is None else np.ascontiguousarray(rule_params, dtype=np.float64).reshape(-1, nq, 2)
         self._st = _Assembler(elem_kind, op_kind, _f(self.vertices), self.N, _u(self.connectivity), self.E,
                               _f(self.u) if self.u is not None else None, _f(self.weights), _f(self.points), nq,
-                              _f(self.params) if self.params is not None else None)
+                              _f(self.params) if self.params is not None else None,
+                              _u(self.elem_to_rule) if self.elem_to_rule is not None else None,
+                              _f(self.rule_params) if self.rule_params is not None else None,
+                              0 if self.rule_params is None else len(self.rule_params))
 
     # ElementConnectivityAssembler (src/assembly/local.rs:18-47)
     def solution_dim(self):

@@ -1,0 +1,140 @@
+"""CompactQuadratureTable (src/assembly/local/quadrature_table.rs:300-439) with shared points / weights: per-element
+material data.  Oracle properties on the CPU, HIP parity on the GPU."""
+import numpy as np
+import pytest
+
+import fenris_amd as fa
+from fenris_amd import quadrature
+
+RULES = np.array([[416666.67, 277777.78], [8.0e4, 1.2e5], [3.0e5, 2.0e5]])  # (mu, lambda) per rule
+
+
+def _setup(kind, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "HEX8":
+        m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, 3)
+        w, p = quadrature.tensor.hexahedron_gauss(2)
+    elif kind == "TET4":
+        m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
+        w, p = quadrature.total_order.tetrahedron(2)
+    else:
+        m = fa.procedural.create_unit_square_uniform_quad_mesh_2d(4)
+        w, p = quadrature.tensor.quadrilateral_gauss(2)
+    m = fa.Mesh(m.vertices + rng.uniform(-0.02, 0.02, m.vertices.shape), m.connectivity, m.elem_kind)
+    emap = rng.integers(0, len(RULES), m.num_elements()).astype(np.uint64)
+    # per-point variation inside a rule as well
+    rp = RULES[:, None, :] * (1.0 + 0.05 * np.arange(len(w))[None, :, None])
+    return m, w, p, emap, np.ascontiguousarray(rp)
+
+
+# ------------------------------------------------------------------------------------------- CPU: oracle properties
+@pytest.mark.parametrize("op_name", ["LINEAR_ELASTIC", "NEO_HOOKEAN"])
+def test_oracle_compact_table_is_sum_over_rules(oracle, op_name):
+    """K(compact) == sum_r K(uniform table with rule r's data, elements of rule r only)"""
+    m, w, p, emap, rp = _setup("HEX8")
+    op = getattr(oracle, op_name)
+    u = 0.01 * np.random.default_rng(3).standard_normal(3 * m.num_nodes())
+    full = oracle.ElementAssembler(oracle.HEX8, op, m.vertices, m.connectivity, w, p, params=rp[0], u=u,
+                                   elem_to_rule=emap, rule_params=rp)
+    st, _, ro, ci, vals = oracle.assemble(full)
+    assert st == 0
+    acc = np.zeros_like(vals)
+    for r in range(len(rp)):
+        sub = oracle.ElementAssembler(oracle.HEX8, op, m.vertices, m.connectivity[emap == r], w, p, params=rp[r], u=u)
+        st, _ = oracle.assemble_into_csr(sub, ro, ci, acc)
+        assert st == 0
+    assert np.abs(acc - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_oracle_compact_with_one_rule_equals_uniform(oracle):
+    m, w, p, emap, rp = _setup("TET4")
+    a = oracle.ElementAssembler(oracle.TET4, oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=rp[1])
+    b = oracle.ElementAssembler(oracle.TET4, oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=rp[0],
+                                elem_to_rule=np.ones(m.num_elements(), dtype=np.uint64), rule_params=rp)
+    va, vb = oracle.assemble(a)[4], oracle.assemble(b)[4]
+    assert np.array_equal(va, vb)
+
+
+def test_compact_table_rejects_bad_rule_index():
+    m, w, p, emap, rp = _setup("HEX8")
+    emap[0] = 7
+    with pytest.raises(ValueError):
+        fa.CompactQuadratureTable(p, w, [[fa.LameParameters(*x) for x in r] for r in rp], emap)
+
+
+# ------------------------------------------------------------------------------------------- GPU parity
+@pytest.fixture(scope="module")
+def engine():
+    eng = fa.Engine(0)
+    yield eng
+    eng.close()
+
+
+def _table(p, w, rp, emap, cls=fa.LameParameters):
+    return fa.CompactQuadratureTable.from_quadrature_rules_and_map(p, w, [[cls(*x) if cls is fa.LameParameters else cls(x[0]) for x in r]
+                                                                          for r in rp], emap)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,op_name", [("HEX8", "LINEAR_ELASTIC"), ("HEX8", "NEO_HOOKEAN"), ("TET4", "STVK"),
+                                          ("QUAD4", "LINEAR_ELASTIC")])
+@pytest.mark.parametrize("scatter", ["gather", "atomic", "colored"])
+def test_compact_table_matrix_vector_scalar_match_oracle(engine, oracle, kind, op_name, scatter):
+    m, w, p, emap, rp = _setup(kind, seed=2)
+    d = m.vertices.shape[1]
+    u = 0.01 * np.random.default_rng(5).standard_normal(d * m.num_nodes())
+    mat = {"LINEAR_ELASTIC": fa.LinearElasticMaterial, "NEO_HOOKEAN": fa.NeoHookeanMaterial, "STVK": fa.StVKMaterial}[op_name]()
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(fa.MaterialEllipticOperator(mat))
+           .with_quadrature_table(_table(p, w, rp, emap)).with_u(u).build())
+    flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[scatter]
+    if scatter == "colored":
+        k = fa.CsrParAssembler().assemble(fa.color_nodes(asm), asm)
+    else:
+        k = fa.CsrAssembler(flags).assemble(asm)
+    oasm = oracle.ElementAssembler(getattr(oracle, kind), getattr(oracle, op_name), m.vertices, m.connectivity, w, p, params=rp[0], u=u,
+                                   elem_to_rule=emap, rule_params=rp)
+    st, _, ro, ci, vals = oracle.assemble(oasm)
+    assert st == 0
+    assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    if scatter == "gather":
+        f = fa.VectorAssembler().assemble_vector(asm)
+        st, _, fo = oracle.assemble_vector(oasm)
+        assert st == 0 and np.abs(f - fo).max() <= 1e-12 * np.abs(fo).max()
+        e = fa.assemble_scalar(asm)
+        st, _, eo = oracle.assemble_scalar(oasm)
+        assert st == 0 and abs(e - eo) <= 1e-12 * abs(eo)
+
+
+@pytest.mark.gpu
+def test_compact_table_mass_and_gravity_match_oracle(engine, oracle):
+    m, w, p, emap, rp = _setup("HEX8", seed=4)
+    rho = np.ascontiguousarray(np.stack([1000.0 + 100.0 * rp[:, :, 0] / rp[0, 0, 0], np.zeros(rp.shape[:2])], axis=-1))
+    qt = _table(p, w, rho, emap, cls=fa.Density)
+    mass = fa.ElementMassAssembler.with_solution_dim(3, engine).with_space(m).with_quadrature_table(qt)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(mass)
+    oasm = oracle.ElementAssembler(oracle.HEX8, oracle.MASS_VECTOR, m.vertices, m.connectivity, w, p, params=rho[0],
+                                   elem_to_rule=emap, rule_params=rho)
+    st, _, ro, ci, vals = oracle.assemble(oasm)
+    assert st == 0 and np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    src = (fa.ElementSourceAssemblerBuilder.new(engine).with_finite_element_space(m)
+           .with_source(fa.GravitySource([0.0, 0.0, -9.81])).with_quadrature_table(qt).build())
+    f = fa.VectorAssembler().assemble_vector(src)
+    st, fo = oracle.assemble_source_vector(oasm, 3, g=[0.0, 0.0, -9.81])
+    assert st == 0 and np.abs(f - fo).max() <= 1e-12 * np.abs(fo).max()
+
+
+@pytest.mark.gpu
+def test_uniform_table_after_compact_restores_fast_path(engine, oracle):
+    m, w, p, emap, rp = _setup("HEX8", seed=6)
+    lame = fa.LameParameters(*RULES[0])
+    op = fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+    (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(op)
+     .with_quadrature_table(_table(p, w, rp, emap)).with_u(None).build())
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(op)
+           .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(lame)).with_u(None).build())
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() == "k_gather_pipelined"
+    oasm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=RULES[0])
+    vals = oracle.assemble(oasm)[4]
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -427,6 +428,86 @@ int fh_hex8_to_hex27(const double* v, uint64_t nv, const uint64_t* hex8, uint64_
     hex8_to_hex27(v, hex8, ncells, out_v, out_nv, out_c);
     return FH_OK;
 }
+// cuthill_mckee (src/mesh/reorder.rs:171-233): breadth-first search from the first unvisited vertex of least degree,
+// neighbours visited by ascending degree.  The reference sorts the neighbours with sort_unstable_by_key, which leaves
+// the order of equal-degree neighbours unspecified; ties are resolved here by ascending vertex index (a stable sort
+// of the ascending column list), which reproduces the reference's known answers (tests/unit_tests/reorder.rs).
+int fh_cuthill_mckee(uint64_t n, const uint64_t* row_offsets, const uint64_t* col_indices, uint64_t* perm_out) {
+    if (!row_offsets || !perm_out || (n && !col_indices && row_offsets[n])) return FH_BAD_ARGUMENT;
+    std::vector<unsigned char> visited((size_t)n, 0);
+    std::vector<uint64_t> queue;
+    queue.reserve((size_t)n);
+    std::vector<uint64_t> ws;
+    auto degree = [&](uint64_t v) { return row_offsets[v + 1] - row_offsets[v]; };
+    // unvisited vertices by ascending (degree, index): the restart rule "first unvisited vertex of least degree"
+    // (reorder.rs:196-198) without the reference's O(N) rescan per component
+    std::vector<uint64_t> by_degree((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) by_degree[(size_t)i] = i;
+    std::stable_sort(by_degree.begin(), by_degree.end(), [&](uint64_t a, uint64_t b) { return degree(a) < degree(b); });
+    size_t next_start = 0, head = 0;
+    uint64_t count = 0;
+    while (count < n) {
+        while (visited[(size_t)by_degree[next_start]]) ++next_start;
+        const uint64_t start = by_degree[next_start];
+        visited[(size_t)start] = 1;
+        queue.push_back(start);
+        while (head < queue.size()) {
+            const uint64_t v = queue[head++];
+            ws.assign(col_indices + row_offsets[v], col_indices + row_offsets[v + 1]);
+            for (uint64_t c : ws)
+                if (c >= n) return FH_BAD_ARGUMENT;
+            std::stable_sort(ws.begin(), ws.end(), [&](uint64_t a, uint64_t b) { return degree(a) < degree(b); });
+            perm_out[count++] = v;
+            for (uint64_t a : ws)
+                if (!visited[(size_t)a]) { visited[(size_t)a] = 1; queue.push_back(a); }
+        }
+    }
+    return FH_OK;
+}
+
+// reorder_mesh_par (src/mesh/reorder.rs:54-95): reverse Cuthill-McKee on the vertex graph (the solution-dim-1
+// pattern of the mesh), then the elements stably sorted by their smallest NEW vertex index.
+int fh_reorder_mesh(uint64_t num_vertices, uint64_t nodes_per_element, const uint64_t* connectivity, uint64_t num_elements,
+                    uint64_t* vertex_perm, uint64_t* connectivity_perm) {
+    if (!connectivity || !vertex_perm || !connectivity_perm || nodes_per_element == 0) return FH_BAD_ARGUMENT;
+    const uint64_t N = num_vertices, n = nodes_per_element, E = num_elements;
+    for (uint64_t i = 0; i < n * E; ++i)
+        if (connectivity[i] >= N) return FH_BAD_ARGUMENT;
+    // vertex graph = assemble_pattern of the mesh (global.rs:65-120 with solution dim 1): node -> sorted unique neighbours
+    std::vector<uint64_t> deg((size_t)N + 1, 0);
+    for (uint64_t i = 0; i < n * E; ++i) deg[(size_t)connectivity[i] + 1] += n;
+    for (uint64_t i = 0; i < N; ++i) deg[(size_t)i + 1] += deg[(size_t)i];
+    std::vector<uint64_t> raw((size_t)deg[(size_t)N]), fill(deg.begin(), deg.end() - 1);
+    for (uint64_t e = 0; e < E; ++e)
+        for (uint64_t a = 0; a < n; ++a) {
+            const uint64_t i = connectivity[e * n + a];
+            for (uint64_t b = 0; b < n; ++b) raw[(size_t)fill[(size_t)i]++] = connectivity[e * n + b];
+        }
+    std::vector<uint64_t> ro((size_t)N + 1, 0), ci;
+    ci.reserve(raw.size() / 2);
+    for (uint64_t i = 0; i < N; ++i) {
+        auto b = raw.begin() + (std::ptrdiff_t)deg[(size_t)i], e2 = raw.begin() + (std::ptrdiff_t)deg[(size_t)i + 1];
+        std::sort(b, e2);
+        auto u = std::unique(b, e2);
+        ci.insert(ci.end(), b, u);
+        ro[(size_t)i + 1] = ci.size();
+    }
+    int rc = fh_cuthill_mckee(N, ro.data(), ci.data(), vertex_perm);
+    if (rc) return rc;
+    std::reverse(vertex_perm, vertex_perm + N);  // reverse_cuthill_mckee (reorder.rs:235-239)
+    std::vector<uint64_t> inv((size_t)N);
+    for (uint64_t t = 0; t < N; ++t) inv[(size_t)vertex_perm[t]] = t;  // old -> new index (Permutation::inverse)
+    std::vector<uint64_t> key((size_t)E);
+    for (uint64_t e = 0; e < E; ++e) {
+        uint64_t m = UINT64_MAX;
+        for (uint64_t a = 0; a < n; ++a) m = std::min(m, inv[(size_t)connectivity[e * n + a]]);
+        key[(size_t)e] = m;
+    }
+    for (uint64_t e = 0; e < E; ++e) connectivity_perm[e] = e;
+    std::stable_sort(connectivity_perm, connectivity_perm + E, [&](uint64_t a, uint64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+    return FH_OK;
+}
+
 int fh_lame_from_young_poisson(double young, double poisson, double* mu, double* lambda) {
     if (!mu || !lambda) return FH_BAD_ARGUMENT;
     // fenris-solid/src/materials.rs:36-42

@@ -210,6 +210,14 @@ int fh_tet_mesh(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t
  * 27*num_cells*3 doubles, out_connectivity 27*num_cells. */
 int fh_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64_t* hex8, uint64_t num_cells,
                      double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
+/* cuthill_mckee on a square sparsity pattern (src/mesh/reorder.rs:171-233): perm_out[target] = source.  The
+ * reference orders equal-degree neighbours with an unstable sort (unspecified); ties are broken by ascending index. */
+int fh_cuthill_mckee(uint64_t num_rows, const uint64_t* row_offsets, const uint64_t* col_indices, uint64_t* perm_out);
+/* reorder_mesh_par (src/mesh/reorder.rs:54-95): reverse Cuthill-McKee vertex permutation + elements sorted by their
+ * smallest new vertex index.  vertex_perm[new] = old, connectivity_perm[new] = old; MeshPermutation::apply
+ * (reorder.rs:29-52) relabels the vertex indices inside the elements with the inverse vertex permutation. */
+int fh_reorder_mesh(uint64_t num_vertices, uint64_t nodes_per_element, const uint64_t* connectivity, uint64_t num_elements,
+                    uint64_t* vertex_perm, uint64_t* connectivity_perm);
 /* LameParameters::from(YoungPoisson) (fenris-solid/src/materials.rs:31-43) */
 int fh_lame_from_young_poisson(double young, double poisson, double* mu, double* lambda);
 

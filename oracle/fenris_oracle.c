@@ -1322,6 +1322,83 @@ int fo_physical_quadrature_points(const fo_assembler* a, double* x_out) {
     return FO_OK;
 }
 
+/* cuthill_mckee, src/mesh/reorder.rs:171-233, statement for statement (including the O(N) rescan for the next start
+ * vertex).  sort_unstable_by_key leaves the order of equal-degree neighbours unspecified in the reference; a stable
+ * insertion sort of the ascending column list is used here (ties by ascending index) -- it reproduces the known
+ * answers of tests/unit_tests/reorder.rs.  perm[target] = source. */
+int fo_cuthill_mckee(uint64_t n, const uint64_t* ro, const uint64_t* ci, uint64_t* perm) {
+    unsigned char* visited = calloc(n + 1, 1);
+    uint64_t* queue = malloc(sizeof(uint64_t) * (n + 1));
+    uint64_t maxdeg = 0;
+    for (uint64_t i = 0; i < n; ++i) if (ro[i + 1] - ro[i] > maxdeg) maxdeg = ro[i + 1] - ro[i];
+    uint64_t* ws = malloc(sizeof(uint64_t) * (maxdeg + 1));
+    uint64_t count = 0;
+    for (;;) {
+        /* least-degree unvisited vertex, the first one among equals (Iterator::min_by_key) :196-198 */
+        uint64_t start = UINT64_MAX, best = UINT64_MAX;
+        for (uint64_t v = 0; v < n; ++v)
+            if (!visited[v] && ro[v + 1] - ro[v] < best) { best = ro[v + 1] - ro[v]; start = v; }
+        if (start == UINT64_MAX) break;
+        uint64_t head = 0, tail = 0;
+        queue[tail++] = start;
+        visited[start] = 1;
+        while (head < tail) {
+            uint64_t v = queue[head++];
+            uint64_t m = ro[v + 1] - ro[v];
+            for (uint64_t k = 0; k < m; ++k) ws[k] = ci[ro[v] + k];
+            for (uint64_t a = 1; a < m; ++a) { /* stable insertion sort by degree */
+                uint64_t x = ws[a], dx = ro[x + 1] - ro[x], b = a;
+                while (b > 0 && ro[ws[b - 1] + 1] - ro[ws[b - 1]] > dx) { ws[b] = ws[b - 1]; --b; }
+                ws[b] = x;
+            }
+            perm[count++] = v;
+            for (uint64_t k = 0; k < m; ++k)
+                if (!visited[ws[k]]) { visited[ws[k]] = 1; queue[tail++] = ws[k]; }
+        }
+    }
+    free(visited); free(queue); free(ws);
+    return count == n ? FO_OK : FO_BAD_ARGUMENT;
+}
+
+/* reorder_mesh_par, src/mesh/reorder.rs:54-95: RCM on the mesh's vertex graph (assemble_pattern with solution dim 1),
+ * elements stably sorted by their smallest new vertex index. */
+int fo_reorder_mesh(uint64_t N, uint64_t n, const uint64_t* conn, uint64_t E, uint64_t* vertex_perm, uint64_t* conn_perm) {
+    uint64_t* offs = malloc(sizeof(uint64_t) * (E + 1));
+    for (uint64_t e = 0; e <= E; ++e) offs[e] = e * n;
+    uint64_t* ro = malloc(sizeof(uint64_t) * (N + 1));
+    uint64_t nnz = 0;
+    int st = fo_assemble_pattern(1, N, E, offs, conn, ro, NULL, &nnz);
+    uint64_t* ci = malloc(sizeof(uint64_t) * (nnz + 1));
+    if (!st) st = fo_assemble_pattern(1, N, E, offs, conn, ro, ci, &nnz);
+    if (!st) st = fo_cuthill_mckee(N, ro, ci, vertex_perm);
+    if (!st) {
+        for (uint64_t a = 0, b = N; a + 1 < b; ++a) { --b; uint64_t t = vertex_perm[a]; vertex_perm[a] = vertex_perm[b]; vertex_perm[b] = t; }
+        uint64_t* inv = malloc(sizeof(uint64_t) * (N + 1));
+        for (uint64_t t = 0; t < N; ++t) inv[vertex_perm[t]] = t;
+        uint64_t* key = malloc(sizeof(uint64_t) * (E + 1));
+        for (uint64_t e = 0; e < E; ++e) {
+            uint64_t m = UINT64_MAX;
+            for (uint64_t a = 0; a < n; ++a) if (inv[conn[e * n + a]] < m) m = inv[conn[e * n + a]];
+            key[e] = m;
+            conn_perm[e] = e;
+        }
+        /* stable sort by key (sort_by_key :78-85): bottom-up merge sort */
+        uint64_t* tmp = malloc(sizeof(uint64_t) * (E + 1));
+        for (uint64_t w = 1; w < E; w *= 2) {
+            for (uint64_t lo = 0; lo < E; lo += 2 * w) {
+                uint64_t mid = lo + w < E ? lo + w : E, hi = lo + 2 * w < E ? lo + 2 * w : E, i = lo, j = mid, k = lo;
+                while (i < mid && j < hi) tmp[k++] = (key[conn_perm[j]] < key[conn_perm[i]]) ? conn_perm[j++] : conn_perm[i++];
+                while (i < mid) tmp[k++] = conn_perm[i++];
+                while (j < hi) tmp[k++] = conn_perm[j++];
+            }
+            memcpy(conn_perm, tmp, sizeof(uint64_t) * E);
+        }
+        free(tmp); free(key); free(inv);
+    }
+    free(offs); free(ro); free(ci);
+    return st;
+}
+
 /* ---- callers of the path: CG solve and error integrals -------------------------------------------------
  * ConjugateGradient::solve_with_guess, fenris-sparse/src/cg.rs:366-478, with operator = CSR matrix (spmm_csr_dense,
  * row by row, entries in column order), preconditioner = inverse diagonal (jacobi != 0; tests/convergence_tests/

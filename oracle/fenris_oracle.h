@@ -157,6 +157,10 @@ int fo_cg_solve(uint64_t n, const uint64_t* row_offsets, const uint64_t* col_ind
                 double* x, int jacobi, double tol, uint64_t max_iter, uint64_t* num_iterations);
 /* estimate_L2_error_squared (which = 0) / estimate_H1_seminorm_error_squared (which = 1), src/error.rs:287-372 */
 int fo_estimate_error_squared(const fo_assembler* a, int which, int s, const double* u_h, const double* exact, double* out);
+/* cuthill_mckee / reorder_mesh_par (src/mesh/reorder.rs:54-95, 171-239); perm[target] = source */
+int fo_cuthill_mckee(uint64_t n, const uint64_t* row_offsets, const uint64_t* col_indices, uint64_t* perm);
+int fo_reorder_mesh(uint64_t num_vertices, uint64_t nodes_per_element, const uint64_t* connectivity, uint64_t num_elements,
+                    uint64_t* vertex_perm, uint64_t* connectivity_perm);
 int fo_max_threads(void);
 
 #ifdef __cplusplus

@@ -91,6 +91,8 @@ def lib():
         _lib.fo_assemble_source_vector_into.argtypes = [ap, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_assemble_element_source_vector.argtypes = [ap, C.c_uint64, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_physical_quadrature_points.argtypes = [ap, _f64p]
+        _lib.fo_cuthill_mckee.argtypes = [C.c_uint64, _u64p, _u64p, _u64p]
+        _lib.fo_reorder_mesh.argtypes = [C.c_uint64, C.c_uint64, _u64p, C.c_uint64, _u64p, _u64p]
         _lib.fo_cg_solve.argtypes = [C.c_uint64, _u64p, _u64p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_uint64, _u64p]
         _lib.fo_estimate_error_squared.argtypes = [ap, C.c_int, C.c_int, _f64p, _f64p, _f64p]
         _lib.fo_apply_homogeneous_dirichlet_bc_csr.argtypes = [C.c_uint64, _u64p, _u64p, _f64p, _u64p, C.c_uint64,
@@ -418,6 +420,25 @@ def assemble_source_vector(asm, s, g=None, values=None, out=None):
     st = lib().fo_assemble_source_vector_into(C.byref(asm._st), s, _f(g) if g is not None else None,
                                               _f(values) if values is not None else None, _f(out))
     return st, out
+
+
+def cuthill_mckee(ro, ci):
+    """src/mesh/reorder.rs:171-233; perm[target] = source"""
+    ro = np.ascontiguousarray(ro, dtype=np.uint64)
+    ci = np.ascontiguousarray(ci, dtype=np.uint64)
+    perm = np.zeros(len(ro) - 1, dtype=np.uint64)
+    st = lib().fo_cuthill_mckee(len(ro) - 1, _u(ro), _u(ci if len(ci) else np.zeros(1, dtype=np.uint64)), _u(perm))
+    assert st == 0
+    return perm
+
+
+def reorder_mesh(num_vertices, connectivity):
+    """reorder_mesh_par (reorder.rs:54-95) -> (vertex_perm, connectivity_perm)"""
+    c = np.ascontiguousarray(connectivity, dtype=np.uint64)
+    vp, cp = np.zeros(num_vertices, dtype=np.uint64), np.zeros(len(c), dtype=np.uint64)
+    st = lib().fo_reorder_mesh(num_vertices, c.shape[1], _u(c), len(c), _u(vp), _u(cp))
+    assert st == 0
+    return vp, cp
 
 
 def cg_solve(ro, ci, values, b, x0=None, jacobi=True, tol=1e-9, max_iter=10000):

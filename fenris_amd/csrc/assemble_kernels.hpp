@@ -894,7 +894,7 @@ struct PipeTables {
 __host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs) { return 8 + us / 4 + ms + ms * N / 4 + nbs + 1; }
 
 template <int EK, int OP, int QC, int JT>
-__global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, const PipeTables T) {
+__global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
     // JT = local nodes J handled per lane in phase C
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
@@ -1049,7 +1049,9 @@ __global__ void __launch_bounds__(256, 2) k_gather_pipelined(const KArgs a, cons
             }
             // phase D of the previous block, overlapped with phase B: its accumulators are complete (barrier at the
             // end of the last iteration) and are not touched again before the barrier below
-            if (qc == 0 && prev_nacc > 0 && !(a.ablate & 16)) write_out(prev_out, prev_nacc, (U * QC <= nt / 2) ? nt / 2 : nt);
+            // (phase B fills half of the waves: the other half writes out; a smaller phase B is not worth idling for)
+            if (qc == 0 && prev_nacc > 0 && !(a.ablate & 16))
+                write_out(prev_out, prev_nacc, (U * QC > nt / 4 && U * QC <= nt / 2) ? nt / 2 : nt);
             FH_STAMP(1)  // phase B (+ write-out of the previous block)
             lds_barrier();
             FH_STAMP(2)  // barrier after B

@@ -555,12 +555,12 @@ int build_partition(fh_ctx* c) {
             else cut_greedy(i0, r1);
             i0 = r1;
         } else {
-            // short run: keep absorbing following short runs until the block is full
+            // short runs (unstructured numbering): the whole stretch up to the next long run is cut greedily
             int e = r1;
-            while (e < n_hi && e - i0 < nb_target) {
+            while (e < n_hi) {
                 int r2 = e + 1;
                 while (r2 < n_hi && link[r2 - 1]) ++r2;
-                if (r2 - e >= nb_target || r2 - i0 > nb_target) break;
+                if (r2 - e >= nb_target) break;
                 e = r2;
             }
             cut_greedy(i0, e);

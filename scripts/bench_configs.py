@@ -3,6 +3,7 @@
 C4 Hex27 NeoHookean 50x50x80) timed on one GPU: kernel ms, elements/s, algorithmic GB/s.  Not the headline
 bench (that is bench.py); results are copied under profiles/."""
 import json
+import os
 import sys
 import time
 
@@ -79,6 +80,13 @@ def main():
         conn = inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64)
         run("C3 Tet4 linear elasticity BCC res 75, vertices+elements permuted (seed 12345)", fa.Mesh(verts, conn, fa.TET4),
             fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), quadrature.total_order.tetrahedron(1), lame, None, 4, 3, 3)
+        from fenris_amd import reorder
+        t0 = time.perf_counter()
+        mp = reorder.reorder_mesh_par(fa.Mesh(verts, conn, fa.TET4))
+        t_rcm = time.perf_counter() - t0
+        run(f"C3'' permuted mesh after reorder_mesh_par (reverse Cuthill-McKee on the host, {t_rcm:.1f} s)",
+            mp.apply(fa.Mesh(verts, conn, fa.TET4)), fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
+            quadrature.total_order.tetrahedron(1), lame, None, 4, 3, 3)
         run("C3' same mesh, generator order", m, fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
             quadrature.total_order.tetrahedron(1), lame, None, 4, 3, 3)
     if "C4" in which:

@@ -88,6 +88,7 @@ _SIGS = {
     "fh_estimate_L2_error_squared_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, f64p]),
     "fh_estimate_H1_seminorm_error_squared": (C.c_int, [C.c_void_p, C.c_uint32, f64p, f64p, f64p]),
     "fh_estimate_H1_seminorm_error_squared_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, f64p]),
+    "fh_assemble_element_matrices_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "fh_assemble_element_matrices": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p]),
     "fh_apply_dirichlet_csr_dev": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_uint64]),
     "fh_apply_dirichlet_rhs_dev": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_uint64]),

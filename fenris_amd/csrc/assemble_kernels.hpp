@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             pair_block<EK, OP>(a, L, lds, a.nq, u, I, J, blk);
             if (MODE == MODE_DUMP) {
                 // K_e column-major (s n) x (s n), both triangles
-                double* ke = a.ke_out + (size_t)(w0 - a.work_begin + u) * (S * N) * (S * N);
+                double* ke = a.ke_out + (size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * (S * N) * (S * N);
 #pragma unroll
                 for (int i = 0; i < S; ++i)
 #pragma unroll
@@ -1441,6 +1441,91 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
         const int node = lds_i[L.o_cn + u * N + I];
 #pragma unroll
         for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node * S + i, f[i]);
+    }
+}
+
+// ============================================================================================ rows from dense K_e
+// Second pass of the two-pass owner-computes assembly used for high-order elements (n > 8): the dense element
+// matrices were written by k_assemble_matrix<MODE_DUMP> (column-major, both triangles); here one wavefront owns a
+// node, walks the node's (element, local index a) entries and adds the columns S a .. S a + S - 1 of K_e -- by
+// symmetry its rows, but contiguous -- into the node's CSR rows held in LDS, then writes the rows once, coalesced.
+// Every K_e entry is read exactly once and every CSR value written exactly once; no atomics (the lanes of a
+// wavefront hit distinct targets within an entry, and a wavefront's LDS operations execute in order).
+// column slot of every local node of every (node, element) entry inside the owning node's row (one byte or one
+// 16-bit word per (entry, local node)); built once per pattern for the two-pass assembly
+template <typename PT>
+__global__ void __launch_bounds__(256) k_entry_positions(long long total, int n, const unsigned* adj_off, const unsigned* adj,
+                                                         const unsigned* noff, const unsigned* ncols, const int* conn,
+                                                         const int* entry_node, PT* pos) {
+    const long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= total) return;
+    const long long t = it / n;
+    const int J = (int)(it % n);
+    const int i = entry_node[t];
+    const unsigned ent = adj[t];
+    const unsigned r0 = noff[i];
+    pos[it] = (PT)find_col(ncols + r0, (int)(noff[i + 1] - r0), (unsigned)conn[(size_t)(ent / (unsigned)n) * n + J]);
+    (void)adj_off;
+}
+__global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsigned* adj_off, int* entry_node) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_nodes) return;
+    for (unsigned t = adj_off[i]; t < adj_off[i + 1]; ++t) entry_node[t] = i;
+}
+
+template <int S, typename PT>
+__global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
+                                                         const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
+                                                         int overwrite, int max_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
+    const int ld = S * n;
+    for (int i = blockIdx.x * 4 + wave; i < num_nodes; i += gridDim.x * 4) {
+        const unsigned r0 = noff[i];
+        const int cnt = (int)(noff[i + 1] - r0);
+        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
+        // Groups of EB entries: (element, local index) are wave-uniform (scalar loads); all K_e loads of the group
+        // (clamped, branch-free) are issued before the first LDS add, so that EB x 2 x S loads per lane are in
+        // flight -- with the loads of one entry at a time the pass ran at a quarter of the HBM rate.
+        // Targets of different entries may coincide (two elements sharing a neighbour node) => LDS atomics.
+        constexpr int EB = 4, HB = 2;  // entries per group, 64-lane column halves (S n <= 128 per half pair)
+        const unsigned t0 = __builtin_amdgcn_readfirstlane(adj_off[i]), t1 = __builtin_amdgcn_readfirstlane(adj_off[i + 1]);
+        for (unsigned t = t0; t < t1; t += EB) {
+            for (int h0 = 0; h0 * 64 < ld; h0 += HB) {
+                double v[EB][HB][S];
+                int pos[EB][HB];
+#pragma unroll
+                for (int k = 0; k < EB; ++k) {
+                    const unsigned tk = min(t + (unsigned)k, t1 - 1);
+                    const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
+                    const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
+                    const double* kb = ke + (size_t)e * ld * ld + (size_t)S * a * ld;
+                    const PT* pp = pos_tab + (size_t)tk * n;
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) {
+                        const int idx = min(lane + 64 * (h0 + h), ld - 1);
+                        pos[k][h] = (int)pp[idx / S];
+#pragma unroll
+                        for (int r = 0; r < S; ++r) v[k][h][r] = kb[(size_t)r * ld + idx];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < EB; ++k)
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) {
+                        const int idx = lane + 64 * (h0 + h);
+                        if (t + (unsigned)k < t1 && idx < ld) {
+                            double* dst = acc + S * pos[k][h] + idx % S;
+#pragma unroll
+                            for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][h][r]);
+                        }
+                    }
+            }
+        }
+        double* out = vals + (size_t)S * S * r0;
+        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
+        else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
     }
 }
 

@@ -96,6 +96,7 @@ struct KArgs {
     double* vec_out;
     double* scalar_out;
     double* ke_out;
+    int ke_by_elem;          // MODE_DUMP: index ke_out by element id instead of by work position
     int overwrite;
     DevStatus* status;
     unsigned long long* trace;  // profiling only: 7 counters (6 phase cycle sums over waves, wave count) or null

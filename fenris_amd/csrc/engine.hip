@@ -207,6 +207,10 @@ struct fh_ctx {
     // status
     DevBuf<DevStatus> status;
     DevBuf<double> scratch;
+    DevBuf<double> ke_dense;  // two-pass assembly of high-order elements: E dense element matrices
+    DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
+    DevBuf<unsigned short> tp_pos16;
+    bool has_tp_pos = false;
     DevBuf<unsigned long long> trace;
 
     int S() const {
@@ -243,7 +247,7 @@ int grid_for(long long n, int block, int cap = 256 * 32) {
 
 void invalidate_pattern(fh_ctx* c) {
     c->has_pattern = false;
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     c->has_colors = false;
     c->nnz_nodes = 0;
 }
@@ -251,7 +255,7 @@ void invalidate_pattern(fh_ctx* c) {
 // node -> (active element, local index) adjacency used by the owner-computes kernels when an element
 // mask is set (multi-GPU partitions: the pattern comes from own + halo elements, numerics from own ones)
 int build_compute_adjacency(fh_ctx* c) {
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     if (!c->has_mask || !c->has_pattern) return FH_OK;
     const int N = (int)c->N;
     hipStream_t st = c->stream;
@@ -348,7 +352,7 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
     c->has_pattern = true;
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     return build_compute_adjacency(c);
 }
 
@@ -784,6 +788,82 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
     }
 }
 
+// dense element matrices of the elements [first, first + count) into device memory (no status read-back)
+static int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem) {
+    KArgs a;
+    fill_common(c, a);
+    a.ke_out = ke_dev;
+    a.ke_by_elem = by_elem ? 1 : 0;
+    a.labels = (by_elem && c->has_mask) ? c->active_list.p : nullptr;  // two-pass assembly: the active elements only
+    a.work_begin = (long long)first;
+    a.work_end = (long long)(first + count);
+    a.epb = choose_epb(c, WHAT_MATRIX);
+    a.ub = a.epb;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    const int grid = (int)((count + a.epb - 1) / a.epb);
+    int rc = FH_OK;
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_DUMP, lds, grid)
+    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+    return rc;
+}
+
+// Owner-computes for high-order elements (n > 8), two passes: dense element matrices (element-parallel, every K_e
+// computed once), then one wavefront per node gathers the columns of its elements' K_e into its CSR rows.
+// Recomputing K_e per owning node block, as the one-pass kernels do, costs 8-27x for a 27-node element.
+int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
+    const int S = c->S();
+    const size_t ld = (size_t)S * c->ei.n;
+    if (c->ke_dense.n < ld * ld * c->E) HIP_TRY(c, c->ke_dense.alloc(ld * ld * c->E));
+    int rc = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
+    if (rc) return rc;
+    unsigned max_row = 0;
+    for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+    const size_t lds = (size_t)4 * sizeof(double) * S * S * max_row;
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "two-pass gather: a node row does not fit in LDS");
+    if (max_row >= 65536) return c->fail(FH_UNSUPPORTED, "two-pass gather: node valence too large");
+    const unsigned* adj_off = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
+    const unsigned* adj = c->has_mask ? c->n2e_c.p : c->n2e.p;
+    const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
+    const long long entries = adj_off_h.empty() ? 0 : (long long)adj_off_h[c->N];
+    const bool wide = max_row >= 256;
+    if (!c->has_tp_pos) {  // once per pattern / element mask
+        DevBuf<int> entry_node;
+        HIP_TRY(c, entry_node.alloc((size_t)entries + 1));
+        hipLaunchKernelGGL(k_entry_nodes, dim3(((int)c->N + 255) / 256), dim3(256), 0, c->stream, (int)c->N, adj_off, entry_node.p);
+        const long long total = entries * c->ei.n;
+        const int g = (int)((total + 255) / 256);
+        if (wide) {
+            HIP_TRY(c, c->tp_pos16.alloc((size_t)total + 1));
+            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned short>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj,
+                                          c->noff.p, c->ncols.p, c->conn.p, entry_node.p, c->tp_pos16.p);
+        } else {
+            HIP_TRY(c, c->tp_pos8.alloc((size_t)total + 1));
+            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned char>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj,
+                                          c->noff.p, c->ncols.p, c->conn.p, entry_node.p, c->tp_pos8.p);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // entry_node is released on scope exit
+        c->has_tp_pos = true;
+    }
+    const int grid = (int)std::min<uint64_t>((c->N + 3) / 4, 1u << 20);
+    c->last_kernel = "k_assemble_matrix<dump> + k_rows_from_dense";
+#define ROWS(SS, PT, PTR)                                                                                                     \
+    do {                                                                                                                       \
+        auto kern = k_rows_from_dense<SS, PT>;                                                                                 \
+        if (lds > 48 * 1024)                                                                                                   \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (int)c->N, c->ei.n, c->noff.p, adj_off, adj, PTR,         \
+                           c->ke_dense.p, values_dev, overwrite, (int)max_row);                                                \
+    } while (0)
+    if (wide) { if (S == 1) ROWS(1, unsigned short, c->tp_pos16.p); else if (S == 2) ROWS(2, unsigned short, c->tp_pos16.p); else ROWS(3, unsigned short, c->tp_pos16.p); }
+    else      { if (S == 1) ROWS(1, unsigned char, c->tp_pos8.p); else if (S == 2) ROWS(2, unsigned char, c->tp_pos8.p); else ROWS(3, unsigned char, c->tp_pos8.p); }
+#undef ROWS
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     int rc = check_ready(c, "fh_assemble_matrix", true);
     if (rc) return rc;
@@ -798,6 +878,8 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     a.vals = values_dev;
     a.overwrite = overwrite;
     const uint64_t nnz = (uint64_t)c->S() * c->S() * c->nnz_nodes;
+    if (mode == FH_SCATTER_GATHER && c->ei.n > 8 && c->row_hi < 0 && !std::getenv("FENRIS_HIP_NO_TWO_PASS"))
+        return assemble_two_pass(c, values_dev, overwrite);
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
         if (rc) return rc;
@@ -1097,7 +1179,7 @@ int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint6
 int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
     if (!c) return FH_BAD_ARGUMENT;
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_active_elements: set the mesh first");
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     if (!mask) {
         c->has_mask = false;
         if (c->has_colors) return upload_colors(c, c->host_colors_offs, c->host_colors_labels);
@@ -1130,7 +1212,7 @@ int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
     if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_set_row_range: bad node range");
     if (node_begin == 0 && node_end == c->N) { c->row_lo = 0; c->row_hi = -1; }
     else { c->row_lo = (long long)node_begin; c->row_hi = (long long)node_end; }
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -1140,7 +1222,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
     if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
     const int old_s = c->S();
     c->op = op_kind;
-    if (c->S() != old_s) { c->has_u = false; c->has_partition = false; }
+    if (c->S() != old_s) { c->has_u = false; c->has_partition = false; c->has_tp_pos = false; }
     return FH_OK;
 }
 
@@ -1182,7 +1264,7 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     if (std::getenv("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
     c->has_rules = false;
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -1204,7 +1286,7 @@ int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uin
     HIP_TRY(c, hipMemcpy(c->rparams.p, rule_params, sizeof(double) * (size_t)num_rules * nq * 2, hipMemcpyHostToDevice));
     c->has_rules = true;
     c->fast_ok = false;  // per-element data: per-point coefficients, generic kernels
-    c->has_partition = false;
+    c->has_partition = false; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -1343,33 +1425,33 @@ int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
     return FH_OK;
 }
 
+int fh_assemble_element_matrices_dev(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    int rc = check_ready(c, "fh_assemble_element_matrices", false);
+    if (rc) return rc;
+    if (first + count > c->E || (count && !ke_dev)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
+    if (count == 0) return FH_OK;
+    rc = reset_status(c);
+    if (rc) return rc;
+    rc = element_matrices_enqueue(c, first, count, ke_dev, false);
+    if (rc) return rc;
+    return read_status(c, nullptr);
+}
+
 int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, double* ke_out) {
     if (!c) return FH_BAD_ARGUMENT;
     int rc = check_ready(c, "fh_assemble_element_matrices", false);
     if (rc) return rc;
     if (first + count > c->E || (count && !ke_out)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
     if (count == 0) return FH_OK;
-    rc = reset_status(c);
-    if (rc) return rc;
     const size_t ld = (size_t)c->S() * c->ei.n;
     DevBuf<double> d;
     HIP_TRY(c, d.alloc(ld * ld * count));
-    KArgs a;
-    fill_common(c, a);
-    a.ke_out = d.p;
-    a.work_begin = (long long)first;
-    a.work_end = (long long)(first + count);
-    a.epb = choose_epb(c, WHAT_MATRIX);
-    a.ub = a.epb;
-    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
-    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
-    const int grid = (int)((count + a.epb - 1) / a.epb);
-#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_DUMP, lds, grid)
-    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
-#undef CALL
+    rc = fh_assemble_element_matrices_dev(c, first, count, d.p);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(ke_out, d.p, sizeof(double) * ld * ld * count, hipMemcpyDeviceToHost, c->stream));
-    return read_status(c, nullptr);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
 }
 
 int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {

@@ -183,6 +183,7 @@ int fh_physical_quadrature_points_dev(fh_ctx*, double* x_dev);
 /* single element matrix, (s n)^2 column-major: ElementMatrixAssembler::assemble_element_matrix_into
  * (src/assembly/local.rs:78, elliptic.rs:299-340) -- for unit tests of the element kernels */
 int fh_assemble_element_matrices(fh_ctx*, uint64_t first_element, uint64_t count, double* ke_out);
+int fh_assemble_element_matrices_dev(fh_ctx*, uint64_t first_element, uint64_t count, double* ke_out_dev);
 
 /* ---- post-assembly helpers (callers of the path) ------------------------------------------------ */
 /* apply_homogeneous_dirichlet_bc_csr / _rhs (global.rs:379-451, 479-495) on device-resident CSR */

@@ -95,7 +95,7 @@ def main():
         A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
         u = (0.05 * m.vertices @ A.T).reshape(-1)
         run("C4 Hex27 NeoHookean 50x50x80, hexahedron_gauss(3)", m, fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()),
-            quadrature.tensor.hexahedron_gauss(3), lame, u, 27, 3, 3, scatters=("colored", "atomic"))
+            quadrature.tensor.hexahedron_gauss(3), lame, u, 27, 3, 3, scatters=("gather", "colored", "atomic"))
 
 
 if __name__ == "__main__":

@@ -1473,7 +1473,9 @@ __global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsign
     for (unsigned t = adj_off[i]; t < adj_off[i + 1]; ++t) entry_node[t] = i;
 }
 
-template <int S, typename PT>
+// PLANAR: the dense matrices are stored as S x S planes ke[e][r][c][I][J] (what the MFMA kernel writes) instead of one
+// column-major (S n) x (S n) matrix; a lane then walks (c, J) with J fastest so that its reads stay contiguous.
+template <int S, typename PT, bool PLANAR>
 __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
                                                          const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
                                                          int overwrite, int max_cnt) {
@@ -1500,14 +1502,15 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                     const unsigned tk = min(t + (unsigned)k, t1 - 1);
                     const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
                     const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                    const double* kb = ke + (size_t)e * ld * ld + (size_t)S * a * ld;
+                    const double* kb = PLANAR ? ke + (size_t)e * ld * ld + (size_t)a * n : ke + (size_t)e * ld * ld + (size_t)S * a * ld;
                     const PT* pp = pos_tab + (size_t)tk * n;
 #pragma unroll
                     for (int h = 0; h < HB; ++h) {
                         const int idx = min(lane + 64 * (h0 + h), ld - 1);
-                        pos[k][h] = (int)pp[idx / S];
+                        pos[k][h] = (int)pp[PLANAR ? idx % n : idx / S];
 #pragma unroll
-                        for (int r = 0; r < S; ++r) v[k][h][r] = kb[(size_t)r * ld + idx];
+                        for (int r = 0; r < S; ++r)
+                            v[k][h][r] = PLANAR ? kb[(size_t)(r * S + idx / n) * n * n + idx % n] : kb[(size_t)r * ld + idx];
                     }
                 }
 #pragma unroll
@@ -1516,7 +1519,7 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                     for (int h = 0; h < HB; ++h) {
                         const int idx = lane + 64 * (h0 + h);
                         if (t + (unsigned)k < t1 && idx < ld) {
-                            double* dst = acc + S * pos[k][h] + idx % S;
+                            double* dst = acc + S * pos[k][h] + (PLANAR ? idx / n : idx % S);
 #pragma unroll
                             for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][h][r]);
                         }

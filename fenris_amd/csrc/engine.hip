@@ -14,6 +14,7 @@
 #include "../../include/fenris_hip.h"
 #include "assemble_kernels.hpp"
 #include "solver_kernels.hpp"
+#include "hex27_mfma.hpp"
 #include "device_common.hpp"
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
@@ -816,8 +817,38 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     const int S = c->S();
     const size_t ld = (size_t)S * c->ei.n;
     if (c->ke_dense.n < ld * ld * c->E) HIP_TRY(c, c->ke_dense.alloc(ld * ld * c->E));
-    int rc = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
-    if (rc) return rc;
+    // first pass: Hex27 LinearElastic / NeoHookean with a uniform table run on the matrix cores (hex27_mfma.hpp) and
+    // write the planar layout; everything else takes the generic element kernel (column-major K_e)
+    const bool mfma = c->elem_kind == FH_HEX27 && (c->op == FH_LINEAR_ELASTIC || c->op == FH_NEO_HOOKEAN) && !c->has_rules &&
+                      c->nq == 27 && c->has_params && !std::getenv("FENRIS_HIP_NO_MFMA");
+    int rc = FH_OK;
+    if (mfma) {
+        KArgs a;
+        fill_common(c, a);
+        a.ke_out = c->ke_dense.p;
+        a.labels = c->has_mask ? c->active_list.p : nullptr;
+        a.work_begin = 0;
+        a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+        const size_t lds1 = sizeof(double) * (size_t)Hex27Lds::total;
+        int dev_cus = 256;
+        (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        const int grid1 = (int)std::min<long long>(a.work_end, (long long)dev_cus * 2);
+        if (grid1 > 0) {
+            if (c->op == FH_NEO_HOOKEAN) {
+                auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN>;
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, c->stream, a, c->uni_mu, c->uni_lambda);
+            } else {
+                auto kern = k_hex27_dense_mfma<FH_LINEAR_ELASTIC>;
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, c->stream, a, c->uni_mu, c->uni_lambda);
+            }
+            HIP_TRY(c, hipGetLastError());
+        }
+    } else {
+        rc = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
+        if (rc) return rc;
+    }
     unsigned max_row = 0;
     for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     const size_t lds = (size_t)4 * sizeof(double) * S * S * max_row;
@@ -848,10 +879,14 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         c->has_tp_pos = true;
     }
     const int grid = (int)std::min<uint64_t>((c->N + 3) / 4, 1u << 20);
-    c->last_kernel = "k_assemble_matrix<dump> + k_rows_from_dense";
+    c->last_kernel = mfma ? "k_hex27_dense_mfma + k_rows_from_dense" : "k_assemble_matrix<dump> + k_rows_from_dense";
 #define ROWS(SS, PT, PTR)                                                                                                     \
     do {                                                                                                                       \
-        auto kern = k_rows_from_dense<SS, PT>;                                                                                 \
+        if (mfma) { ROWS2(SS, PT, PTR, true); } else { ROWS2(SS, PT, PTR, false); }                                            \
+    } while (0)
+#define ROWS2(SS, PT, PTR, PL)                                                                                                \
+    do {                                                                                                                       \
+        auto kern = k_rows_from_dense<SS, PT, PL>;                                                                                 \
         if (lds > 48 * 1024)                                                                                                   \
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (int)c->N, c->ei.n, c->noff.p, adj_off, adj, PTR,         \
@@ -860,6 +895,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     if (wide) { if (S == 1) ROWS(1, unsigned short, c->tp_pos16.p); else if (S == 2) ROWS(2, unsigned short, c->tp_pos16.p); else ROWS(3, unsigned short, c->tp_pos16.p); }
     else      { if (S == 1) ROWS(1, unsigned char, c->tp_pos8.p); else if (S == 2) ROWS(2, unsigned char, c->tp_pos8.p); else ROWS(3, unsigned char, c->tp_pos8.p); }
 #undef ROWS
+#undef ROWS2
     HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }

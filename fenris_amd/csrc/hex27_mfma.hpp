@@ -1,0 +1,220 @@
+// Dense element matrices of tri-quadratic hexahedra (Hex27, s = 3) with the fp64 matrix cores: first pass of the
+// two-pass owner-computes assembly for LinearElastic and NeoHookean operators with a uniform quadrature table.
+//
+// Per quadrature point the stress contraction of both materials has the form (materials.rs:108-118, 302-313)
+//     C(I, J)[i][j] = c_l a_I[i] a_J[j]  -  c_a a_J[i] a_I[j]  +  delta_ij c_m g_I . g_J
+// with g_n the physical gradients, a_n = F^-T g_n (NeoHookean) or a_n = g_n (LinearElastic) and
+//     NeoHookean:     c_l = s lambda,  c_a = s alpha = s (-mu + lambda ln det F),  c_m = s mu      (s = w |det J|)
+//     LinearElastic:  c_l = s lambda,  c_a = -s mu,                                c_m = s mu.
+// For a component pair (i, j) the 27 x 27 matrix over the node pairs is therefore a sum of Gram-type products
+//     K_ij = (c_l A_i) A_j^T - (c_a A_j) A_i^T  [+ delta_ij sum_k (c_m G_k) G_k^T],     A_k, G_k: 27 nodes x 27 points
+// = "B^T D B" with K = 54 (+81): exactly the shape v_mfma_f64_16x16x4_f64 wants.  One workgroup (4 wavefronts) per
+// element: a cooperative prologue leaves G_k, A_k (rows padded to 32, points to 28, zeros) and the coefficients in
+// LDS; wavefront w owns the 16 x 16 tile (w >> 1, w & 1) of all nine K_ij and of the trace term (147 MFMAs); the
+// fragments are stored straight to the PLANAR dense layout ke[e][i][j][I][J] (J fastest: 16 lanes = 128 contiguous
+// bytes) that k_rows_from_dense reads in its second pass.  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
+// the gain is not flops but operand traffic: 2 LDS doubles per lane feed 1024 FMAs (0.002 reads per FMA per lane
+// against 0.5 in the VALU pair loop).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "assemble_kernels.hpp"
+#include "device_common.hpp"
+
+namespace fenris_hip {
+
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+
+struct Hex27Lds {
+    static constexpr int N = 27, NG = 8, NQ = 27, RP = 32, QS = 29;  // padded rows, point stride (odd: bank spread)
+    static constexpr int o_gref = 0;                       // [q][n][3]
+    static constexpr int o_ggeom = o_gref + NQ * N * 3;    // [q][g][3]
+    static constexpr int o_qw = o_ggeom + NQ * NG * 3;     // [q]
+    static constexpr int o_X = o_qw + 28;                  // [g][3]
+    static constexpr int o_U = o_X + NG * 3;               // [n][3]
+    static constexpr int o_Jinv = o_U + N * 3;             // [q][9]  J^-1, row-major
+    static constexpr int o_s = o_Jinv + NQ * 9 + 1;        // [q]     w |det J|
+    static constexpr int o_gu = o_s + 28;                  // [q][k][c] grad u (d x s)
+    static constexpr int o_Fi = o_gu + NQ * 9 + 1;         // [q][9]  F^-1
+    static constexpr int o_coef = o_Fi + NQ * 9 + 1;       // [3][28] c_l, c_a, c_m (entry 27 = 0)
+    static constexpr int o_G = o_coef + 3 * 28;            // [k][RP][QS]
+    static constexpr int o_A = o_G + 3 * RP * QS;          // [k][RP][QS]
+    static constexpr int total = o_A + 3 * RP * QS;
+};
+
+template <int OP>
+__global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
+    using L = Hex27Lds;
+    constexpr int N = L::N, NG = L::NG, NQ = L::NQ, RP = L::RP, QS = L::QS;
+    constexpr bool NH = (OP == FH_NEO_HOOKEAN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
+    // tables, and zeros in the padding of G / A / coef (written once: the prologue only touches n < 27, q < 27)
+    for (int i = tid; i < NQ * N * 3; i += nt) lds[L::o_gref + i] = a.gref[i];
+    for (int i = tid; i < NQ * NG * 3; i += nt) lds[L::o_ggeom + i] = a.ggeom[i];
+    for (int i = tid; i < 28; i += nt) lds[L::o_qw + i] = (i < NQ) ? a.qw[i] : 0.0;
+    for (int i = tid; i < 2 * 3 * RP * QS; i += nt) lds[L::o_G + i] = 0.0;
+    for (int i = tid; i < 3 * 28; i += nt) lds[L::o_coef + i] = 0.0;
+    __syncthreads();
+    double* G = lds + L::o_G;
+    double* A = NH ? lds + L::o_A : G;  // LinearElastic: a_n = g_n
+
+    for (long long w = a.work_begin + blockIdx.x; w < a.work_end; w += gridDim.x) {
+        const long long e = a.labels ? (long long)a.labels[w] : w;
+        const int* nodes = a.conn + (size_t)e * N;
+        // P0: geometry nodes (the first 8) and u of the element
+        if (tid < NG * 3) lds[L::o_X + tid] = a.verts[(size_t)nodes[tid / 3] * 3 + tid % 3];
+        if (NH && tid >= 64 && tid < 64 + N * 3) {
+            const int i = tid - 64;
+            lds[L::o_U + i] = a.u ? a.u[(size_t)nodes[i / 3] * 3 + i % 3] : 0.0;
+        }
+        __syncthreads();
+        // P1: one lane per point: J = X G^T (hexahedron.rs:324-326 -> :101-107), inverse, s = w |det J|
+        if (tid < NQ) {
+            const int q = tid;
+            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) J[i][j] = fma(lds[L::o_X + g * 3 + i], lds[L::o_ggeom + (q * NG + g) * 3 + j], J[i][j]);
+            const double detJ = det_small<3>(J);
+            double Ji[3][3];
+            if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
+                report_singular(a.status, e);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) Ji[i][j] = 0.0;
+            } else {
+                inv_small(J, detJ, Ji);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) lds[L::o_Jinv + q * 9 + i * 3 + j] = Ji[i][j];
+            const double s = lds[L::o_qw + q] * fabs(detJ);  // elliptic.rs:422
+            lds[L::o_s + q] = s;
+            const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
+            if (!NH) {
+                lds[L::o_coef + q] = s * lambda;
+                lds[L::o_coef + 28 + q] = -(s * mu);
+                lds[L::o_coef + 56 + q] = s * mu;
+            }
+        }
+        __syncthreads();
+        // P2: one lane per (point, node): g_n = J^-T grad_ref phi_n
+        for (int it = tid; it < NQ * N; it += nt) {
+            const int q = it / N, n = it % N;
+            const double* Ji = lds + L::o_Jinv + q * 9;
+            const double* rv = lds + L::o_gref + (q * N + n) * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) G[(i * RP + n) * QS + q] = fma(Ji[0 * 3 + i], rv[0], fma(Ji[1 * 3 + i], rv[1], Ji[2 * 3 + i] * rv[2]));
+        }
+        __syncthreads();
+        if (NH) {
+            // P3: grad u (d x s) = sum_n g_n u_n^T, one lane per (point, k, c)
+            for (int it = tid; it < NQ * 9; it += nt) {
+                const int q = it / 9, k = (it % 9) / 3, c = it % 3;
+                double t = 0.0;
+                for (int n = 0; n < N; ++n) t = fma(G[(k * RP + n) * QS + q], lds[L::o_U + n * 3 + c], t);
+                lds[L::o_gu + it] = t;
+            }
+            __syncthreads();
+            // P4: one lane per point: F = I + (grad u)^T (fenris-solid/src/lib.rs:20-29), coefficients of
+            // materials.rs:287-315 (J <= 0 => NaN block)
+            if (tid < NQ) {
+                const int q = tid;
+                double F[3][3], Fi[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) F[i][j] = (i == j ? 1.0 : 0.0) + lds[L::o_gu + q * 9 + j * 3 + i];
+                const double Jd = det_small<3>(F);
+                const double s = lds[L::o_s + q];
+                const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
+                double c_l, c_a, c_m;
+                if (Jd <= 0.0) {
+                    c_l = c_a = c_m = __builtin_nan("");
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Fi[i][j] = 0.0;
+                } else {
+                    inv_small(F, Jd, Fi);
+                    c_l = s * lambda;
+                    c_a = s * (-mu + lambda * log(Jd));
+                    c_m = s * mu;
+                }
+                lds[L::o_coef + q] = c_l;
+                lds[L::o_coef + 28 + q] = c_a;
+                lds[L::o_coef + 56 + q] = c_m;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) lds[L::o_Fi + q * 9 + i * 3 + j] = Fi[i][j];
+            }
+            __syncthreads();
+            // P5: a_n = F^-T g_n
+            for (int it = tid; it < NQ * N; it += nt) {
+                const int q = it / N, n = it % N;
+                const double* Fi = lds + L::o_Fi + q * 9;
+                const double g0 = G[(0 * RP + n) * QS + q], g1 = G[(1 * RP + n) * QS + q], g2 = G[(2 * RP + n) * QS + q];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) A[(i * RP + n) * QS + q] = fma(Fi[0 * 3 + i], g0, fma(Fi[1 * 3 + i], g1, Fi[2 * 3 + i] * g2));
+            }
+            __syncthreads();
+        }
+        // ---- matrix cores: wavefront w owns tile (tI, tJ) of the nine K_ij and of the trace term
+        const int tI = wave >> 1, tJ = wave & 1;
+        const int rI = 16 * tI + (lane & 15), rJ = 16 * tJ + (lane & 15), kq = lane >> 4;
+        mfma_f64x4 acc[3][3], accM = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int q = 4 * ks + kq;  // q = 27 is padding: operands and coefficients are zero there
+            double ar[3], ac[3], gr[3], gc[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ar[k] = A[(k * RP + rI) * QS + q];
+                ac[k] = A[(k * RP + rJ) * QS + q];
+                gr[k] = G[(k * RP + rI) * QS + q];
+                gc[k] = G[(k * RP + rJ) * QS + q];
+            }
+            const double cl = lds[L::o_coef + q], ca = lds[L::o_coef + 28 + q], cm = lds[L::o_coef + 56 + q];
+            double arl[3], ara[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { arl[k] = cl * ar[k]; ara[k] = -(ca * ar[k]); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(arl[i], ac[j], acc[i][j], 0, 0, 0);  // c_l a_I[i] a_J[j]
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ara[j], ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cm * gr[k], gc[k], accM, 0, 0, 0);
+        }
+        // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
+        double* ke = a.ke_out + (size_t)e * (81 * 81);
+        const int J = 16 * tJ + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const mfma_f64x4 v = (i == j) ? acc[i][j] + accM : acc[i][j];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int I = 16 * tI + (lane >> 4) + 4 * reg;
+                    if (I < N && J < N) ke[(size_t)(i * 3 + j) * (N * N) + I * N + J] = v[reg];
+                }
+            }
+        __syncthreads();  // the next element's prologue overwrites G / A
+    }
+}
+
+}  // namespace fenris_hip

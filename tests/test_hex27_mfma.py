@@ -1,0 +1,127 @@
+"""Two-pass owner-computes assembly of Hex27 (dense element matrices on the fp64 matrix cores, then row gather):
+parity with the oracle, NaN / singular semantics, accumulation, element mask.  GPU only."""
+import numpy as np
+import pytest
+
+import fenris_amd as fa
+from fenris_amd import quadrature
+
+pytestmark = pytest.mark.gpu
+LAME = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
+OPS = {"LINEAR_ELASTIC": fa.LinearElasticMaterial, "NEO_HOOKEAN": fa.NeoHookeanMaterial, "STVK": fa.StVKMaterial}
+
+
+@pytest.fixture(scope="module")
+def engine():
+    eng = fa.Engine(0)
+    yield eng
+    eng.close()
+
+
+def _mesh(seed=0, cells=(2, 2, 3)):
+    rng = np.random.default_rng(seed)
+    m8 = fa.procedural.create_rectangular_uniform_hex_mesh(0.5, *cells, 1)
+    m8 = fa.Mesh(m8.vertices + rng.uniform(-0.04, 0.04, m8.vertices.shape), m8.connectivity, m8.elem_kind)
+    return fa.hex27_mesh_from_hex8(m8)
+
+
+def _build(engine, oracle, mesh, op, u, per_point=False):
+    w, p = quadrature.tensor.hexahedron_gauss(3)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if per_point:
+        params = np.array([[LAME.mu * (1 + 0.02 * q), LAME.lambda_ * (1 - 0.01 * q)] for q in range(len(w))])
+        qt = qt.with_data([fa.LameParameters(*x) for x in params])
+    else:
+        params = np.array(LAME.as_pair())
+        qt = qt.with_uniform_data(LAME)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh)
+           .with_operator(fa.MaterialEllipticOperator(OPS[op]())).with_quadrature_table(qt).with_u(u).build())
+    ref = oracle.ElementAssembler(oracle.HEX27, getattr(oracle, op), mesh.vertices, mesh.connectivity, w, p, params=params, u=u)
+    return asm, ref
+
+
+@pytest.mark.parametrize("op,per_point", [("LINEAR_ELASTIC", False), ("NEO_HOOKEAN", False), ("NEO_HOOKEAN", True),
+                                          ("LINEAR_ELASTIC", True)])
+def test_mfma_path_matches_oracle(engine, oracle, op, per_point):
+    mesh = _mesh(1)
+    u = 0.01 * np.random.default_rng(2).standard_normal(3 * mesh.num_nodes())
+    asm, ref = _build(engine, oracle, mesh, op, u, per_point)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+    st, _, ro, ci, vals = oracle.assemble(ref)
+    assert st == 0 and np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    # exactly symmetric like clone_upper_to_lower leaves it?  the reference mirrors; here both triangles come out of
+    # the same products in a different order: symmetric to rounding
+    a = k.to_scipy()
+    assert abs(a - a.T).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_generic_first_pass_for_other_operators(engine, oracle):
+    mesh = _mesh(3, cells=(1, 2, 2))
+    u = 0.01 * np.random.default_rng(4).standard_normal(3 * mesh.num_nodes())
+    asm, ref = _build(engine, oracle, mesh, "STVK", u)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
+    vals = oracle.assemble(ref)[4]
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_mfma_path_accumulates_and_overwrites(engine, oracle):
+    import torch
+
+    mesh = _mesh(5, cells=(1, 1, 2))
+    u = 0.005 * np.random.default_rng(6).standard_normal(3 * mesh.num_nodes())
+    asm, ref = _build(engine, oracle, mesh, "NEO_HOOKEAN", u)
+    vals = oracle.assemble(ref)[4]
+    nnz = engine.build_pattern()
+    v = torch.full((nnz,), 2.0, dtype=torch.float64, device="cuda")
+    engine.assemble_matrix(v, fa.SCATTER_GATHER)  # assemble_into_csr accumulates (global.rs:133-182)
+    assert np.abs(v.cpu().numpy() - (vals + 2.0)).max() <= 1e-12 * np.abs(vals).max()
+    engine.assemble_matrix(v, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    assert np.abs(v.cpu().numpy() - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_mfma_path_nan_positions_for_inverted_element(engine, oracle):
+    # fenris-solid/src/materials.rs:298-300: J <= 0 => all-NaN blocks, not an error
+    mesh = _mesh(7)
+    u = 0.002 * np.random.default_rng(8).standard_normal(3 * mesh.num_nodes())
+    nodes = mesh.connectivity[4].astype(int)
+    centre = mesh.vertices[nodes].mean(axis=0)
+    for n in nodes:  # reflect element 4 through its centre: F = -1.2 I there
+        u[3 * n: 3 * n + 3] = -2.2 * (mesh.vertices[n] - centre)
+    asm, ref = _build(engine, oracle, mesh, "NEO_HOOKEAN", u)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert "mfma" in engine.last_kernel_name()
+    vals = oracle.assemble(ref)[4]
+    assert np.isnan(vals).any() and np.array_equal(np.isnan(k.values), np.isnan(vals))
+    ok = ~np.isnan(vals)
+    assert np.abs(k.values[ok] - vals[ok]).max() <= 1e-12 * np.abs(vals[ok]).max()
+
+
+def test_mfma_path_singular_jacobian(engine, oracle):
+    mesh = _mesh(9, cells=(1, 2, 2))
+    v = mesh.vertices.copy()
+    v[mesh.connectivity[2].astype(int)[:8]] = v[int(mesh.connectivity[2][0])]  # collapse the corners: det J == 0
+    bad = fa.Mesh(v, mesh.connectivity, mesh.elem_kind)
+    asm, _ = _build(engine, oracle, bad, "LINEAR_ELASTIC", np.zeros(3 * bad.num_nodes()))
+    with pytest.raises(fa.SingularJacobianError) as ei:
+        fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert ei.value.element == 2
+
+
+def test_mfma_path_with_element_mask(engine, oracle):
+    mesh = _mesh(11)
+    u = 0.01 * np.random.default_rng(12).standard_normal(3 * mesh.num_nodes())
+    asm, ref = _build(engine, oracle, mesh, "NEO_HOOKEAN", u)
+    mask = (np.arange(mesh.num_elements()) % 3 != 1).astype(np.uint8)
+    engine.set_active_elements(mask)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    engine.set_active_elements(None)
+    ro, ci = oracle.pattern_for(ref)
+    w, p = quadrature.tensor.hexahedron_gauss(3)
+    sub = oracle.ElementAssembler(oracle.HEX27, oracle.NEO_HOOKEAN, mesh.vertices, mesh.connectivity[mask.astype(bool)], w, p,
+                                  params=np.array(LAME.as_pair()), u=u)
+    vals = np.zeros(len(ci))
+    st, _ = oracle.assemble_into_csr(sub, ro, ci, vals)
+    assert st == 0 and np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()

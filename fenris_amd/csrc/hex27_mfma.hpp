@@ -14,7 +14,11 @@
 // fragments are stored straight to the PLANAR dense layout ke[e][i][j][I][J] (J fastest: 16 lanes = 128 contiguous
 // bytes) that k_rows_from_dense reads in its second pass.  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
 // the gain is not flops but operand traffic: 2 LDS doubles per lane feed 1024 FMAs (0.002 reads per FMA per lane
-// against 0.5 in the VALU pair loop).
+// against 0.5 in the VALU pair loop).  Measured (C4, 200 k elements): VALU element kernel 9.85 ms, this kernel 6.0 ms, of
+// which the 588 MFMAs per element take 2.9 ms (the fp64 MFMA floor is 3.06 ms) and do not overlap with the prologue
+// of the second resident workgroup -- starting the two workgroups of a CU half a period apart changed nothing, i.e.
+// fp64 MFMA and fp64 VALU work do not run side by side on gfx950.  FENRIS_HIP_ABLATE bits 1/2/4 skip prologue / MFMA /
+// stores for such measurements.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         }
         __syncthreads();
         // P1: one lane per point: J = X G^T (hexahedron.rs:324-326 -> :101-107), inverse, s = w |det J|
-        if (tid < NQ) {
+        if (tid < NQ && !(a.ablate & 1)) {
             const int q = tid;
             double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int g = 0; g < NG; ++g)
@@ -105,6 +109,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         }
         __syncthreads();
         // P2: one lane per (point, node): g_n = J^-T grad_ref phi_n
+        if (!(a.ablate & 1))
         for (int it = tid; it < NQ * N; it += nt) {
             const int q = it / N, n = it % N;
             const double* Ji = lds + L::o_Jinv + q * 9;
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             for (int i = 0; i < 3; ++i) G[(i * RP + n) * QS + q] = fma(Ji[0 * 3 + i], rv[0], fma(Ji[1 * 3 + i], rv[1], Ji[2 * 3 + i] * rv[2]));
         }
         __syncthreads();
-        if (NH) {
+        if (NH && !(a.ablate & 1)) {
             // P3: grad u (d x s) = sum_n g_n u_n^T, one lane per (point, k, c)
             for (int it = tid; it < NQ * 9; it += nt) {
                 const int q = it / 9, k = (it % 9) / 3, c = it % 3;
@@ -174,6 +179,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
+        if (!(a.ablate & 2))
 #pragma unroll
         for (int ks = 0; ks < 7; ++ks) {
             const int q = 4 * ks + kq;  // q = 27 is padding: operands and coefficients are zero there
@@ -202,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
         double* ke = a.ke_out + (size_t)e * (81 * 81);
         const int J = 16 * tJ + (lane & 15);
+        if (!(a.ablate & 4))
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -914,8 +914,16 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
     a.vals = values_dev;
     a.overwrite = overwrite;
     const uint64_t nnz = (uint64_t)c->S() * c->S() * c->nnz_nodes;
-    if (mode == FH_SCATTER_GATHER && c->ei.n > 8 && c->row_hi < 0 && !std::getenv("FENRIS_HIP_NO_TWO_PASS"))
-        return assemble_two_pass(c, values_dev, overwrite);
+    if (mode == FH_SCATTER_GATHER && c->row_hi < 0 && !std::getenv("FENRIS_HIP_NO_TWO_PASS")) {
+        // two-pass owner-computes (dense element matrices, then a row gather) where recomputing the element prologue per
+        // owning node block is the expensive part: high-order elements, and the nonlinear materials on any element
+        // (measured, Hex8 128^3: NeoHookean 11.1 -> 9.2 ms, StVK 19.2 -> 10.0 ms; LinearElastic with per-point
+        // parameters is faster one-pass: 5.7 vs 8.2 ms).  The dense buffer costs E (s n)^2 doubles: capped.
+        const size_t ld = (size_t)c->S() * c->ei.n;
+        const double dense_gb = (double)c->E * ld * ld * 8.0 / 1e9;
+        const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || std::getenv("FENRIS_HIP_TWO_PASS");
+        if (want && dense_gb <= (double)env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) return assemble_two_pass(c, values_dev, overwrite);
+    }
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
         if (rc) return rc;

@@ -3,7 +3,7 @@
 Python host layer over the C ABI of libfenris_hip.so (include/fenris_hip.h).  Only the hot path of
 fenris -- global stiffness / residual assembly -- lives here; see DESIGN.md.
 """
-from . import _ffi, assembly, mesh, operators, quadrature, reorder
+from . import _ffi, assembly, io, mesh, operators, quadrature, reorder
 from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
                    SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,

@@ -101,6 +101,8 @@ _SIGS = {
     "fh_hex_mesh": (C.c_int, [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, f64p, u64p, u64p, u64p]),
     "fh_tet_mesh": (C.c_int, [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, f64p, u64p, u64p, u64p]),
     "fh_hex8_to_hex27": (C.c_int, [f64p, C.c_uint64, u64p, C.c_uint64, f64p, u64p, u64p]),
+    "fh_load_msh": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, f64p, u64p, u64p, u64p]),
+    "fh_msh_last_error": (C.c_char_p, []),
     "fh_cuthill_mckee": (C.c_int, [C.c_uint64, u64p, u64p, u64p]),
     "fh_reorder_mesh": (C.c_int, [C.c_uint64, C.c_uint64, u64p, C.c_uint64, u64p, u64p]),
     "fh_lame_from_young_poisson": (C.c_int, [C.c_double, C.c_double, f64p, f64p]),

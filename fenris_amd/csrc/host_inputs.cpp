@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <unordered_map>
+#include <string>
 #include <vector>
 
 #include "../../include/fenris_hip.h"
@@ -505,6 +506,151 @@ int fh_reorder_mesh(uint64_t num_vertices, uint64_t nodes_per_element, const uin
     }
     for (uint64_t e = 0; e < E; ++e) connectivity_perm[e] = e;
     std::stable_sort(connectivity_perm, connectivity_perm + E, [&](uint64_t a, uint64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+    return FH_OK;
+}
+
+// ---- Gmsh MSH 4.1 (ASCII) loader: load_msh_from_bytes, src/io/msh.rs:47-111 ---------------------------------------
+// The reference parses with the mshio crate and then (a) concatenates the vertices of all node blocks in file order,
+// refusing blocks whose tags are not consecutive, (b) concatenates the elements of every block whose (element type,
+// entity dimension) matches the requested connectivity, node tags minus one, no reordering (msh.rs:232-274).
+namespace {
+thread_local std::string g_msh_error;
+int msh_fail(const std::string& m) { g_msh_error = m; return FH_BAD_ARGUMENT; }
+int msh_nodes_of_type(long t) {  // Gmsh element type -> node count (the types a 4.1 file commonly carries)
+    switch (t) {
+        case 1: return 2;  case 2: return 3;  case 3: return 4;  case 4: return 4;  case 5: return 8;  case 6: return 6;
+        case 7: return 5;  case 8: return 3;  case 9: return 6;  case 10: return 9; case 11: return 10; case 12: return 27;
+        case 13: return 18; case 14: return 14; case 15: return 1; case 16: return 8; case 17: return 20; case 18: return 15;
+        case 19: return 13; case 20: return 9; case 21: return 10; case 26: return 4; case 29: return 20; case 92: return 64;
+        default: return -1;
+    }
+}
+struct MshCursor {
+    const char* p;
+    const char* end;
+    bool token(std::string& out) {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+        if (p >= end) return false;
+        const char* b = p;
+        while (p < end && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+        out.assign(b, p);
+        return true;
+    }
+    bool integer(long long& v) {
+        std::string t;
+        if (!token(t)) return false;
+        char* e = nullptr;
+        v = std::strtoll(t.c_str(), &e, 10);
+        return e && *e == 0;
+    }
+    bool real(double& v) {
+        std::string t;
+        if (!token(t)) return false;
+        char* e = nullptr;
+        v = std::strtod(t.c_str(), &e);
+        return e && *e == 0;
+    }
+};
+}  // namespace
+
+const char* fh_msh_last_error(void) { return g_msh_error.c_str(); }
+
+int fh_load_msh(const char* bytes, uint64_t len, int elem_kind, double* vertices, uint64_t* num_vertices, uint64_t* connectivity,
+                uint64_t* num_elements) {
+    if (!bytes || !num_vertices || !num_elements) return msh_fail("null argument");
+    long want_type;
+    int want_dim, gdim, nper;
+    switch (elem_kind) {  // impl_msh_connectivity!, msh.rs:276-284
+        case FH_TRI3: want_type = 2; want_dim = 2; gdim = 2; nper = 3; break;
+        case FH_QUAD4: want_type = 3; want_dim = 2; gdim = 2; nper = 4; break;
+        case FH_TET4: want_type = 4; want_dim = 3; gdim = 3; nper = 4; break;
+        case FH_HEX8: want_type = 5; want_dim = 3; gdim = 3; nper = 8; break;
+        case FH_HEX27: want_type = 12; want_dim = 3; gdim = 3; nper = 27; break;
+        default: return msh_fail("unsupported element kind");
+    }
+    MshCursor c{bytes, bytes + len};
+    std::string tok;
+    bool have_format = false, have_nodes = false, have_elements = false, matched = false;
+    uint64_t nv = 0, ne = 0;
+    long long claimed_nodes = 0;
+    while (c.token(tok)) {
+        if (tok == "$MeshFormat") {
+            double ver;
+            long long ftype, dsize;
+            if (!c.real(ver) || !c.integer(ftype) || !c.integer(dsize)) return msh_fail("failed to parse msh file: bad $MeshFormat");
+            if (ver < 4.1 || ver >= 4.2) return msh_fail("failed to parse msh file: only MSH 4.1 is supported");
+            if (ftype != 0) return msh_fail("failed to parse msh file: binary MSH files are not supported by this loader");
+            have_format = true;
+        } else if (tok == "$Nodes") {
+            long long nblocks, nn, mn, mx;
+            if (!c.integer(nblocks) || !c.integer(nn) || !c.integer(mn) || !c.integer(mx)) return msh_fail("failed to parse msh file: bad $Nodes header");
+            claimed_nodes = nn;
+            for (long long b = 0; b < nblocks; ++b) {
+                long long edim, etag, param, cnt;
+                if (!c.integer(edim) || !c.integer(etag) || !c.integer(param) || !c.integer(cnt)) return msh_fail("failed to parse msh file: bad node block");
+                long long first = 0;
+                for (long long k = 0; k < cnt; ++k) {
+                    long long tag;
+                    if (!c.integer(tag)) return msh_fail("failed to parse msh file: bad node tag");
+                    if (k == 0) first = tag;
+                    // mshio keeps explicit tags only for non-consecutive blocks; the reference refuses those (msh.rs:117-122)
+                    if (tag != first + k) return msh_fail("node block tags are not consecutive in msh file (sparse tags are not supported)");
+                    // element nodes are addressed as tag - 1 (msh.rs:264): the k-th vertex read must carry tag k
+                    if ((uint64_t)tag != nv + (uint64_t)k + 1) return msh_fail("node tags do not follow the file order (sparse tags are not supported)");
+                }
+                for (long long k = 0; k < cnt; ++k) {
+                    double xyz[3], skip;
+                    if (!c.real(xyz[0]) || !c.real(xyz[1]) || !c.real(xyz[2])) return msh_fail("failed to parse msh file: bad node coordinates");
+                    for (long long q = 0; q < (param ? edim : 0); ++q)
+                        if (!c.real(skip)) return msh_fail("failed to parse msh file: bad parametric coordinates");
+                    if (vertices)
+                        for (int d = 0; d < gdim; ++d) vertices[(nv + (uint64_t)k) * gdim + d] = xyz[d];  // point_from_msh_node :206-224
+                }
+                nv += (uint64_t)cnt;
+            }
+            have_nodes = true;
+        } else if (tok == "$Elements") {
+            long long nblocks, nel, mn, mx;
+            if (!c.integer(nblocks) || !c.integer(nel) || !c.integer(mn) || !c.integer(mx)) return msh_fail("failed to parse msh file: bad $Elements header");
+            for (long long b = 0; b < nblocks; ++b) {
+                long long edim, etag, etype, cnt;
+                if (!c.integer(edim) || !c.integer(etag) || !c.integer(etype) || !c.integer(cnt)) return msh_fail("failed to parse msh file: bad element block");
+                const int nn = msh_nodes_of_type((long)etype);
+                if (nn < 0) return msh_fail("failed to parse msh file: unknown element type");
+                const bool take = (etype == want_type && edim == want_dim);  // element_block_matches_connectivity :176-187
+                matched = matched || take;
+                long long first = 0;
+                for (long long k = 0; k < cnt; ++k) {
+                    long long tag;
+                    if (!c.integer(tag)) return msh_fail("failed to parse msh file: bad element tag");
+                    if (k == 0) first = tag;
+                    if (tag != first + k) return msh_fail("element block tags are not consecutive in msh file (sparse tags are not supported)");
+                    for (int j = 0; j < nn; ++j) {
+                        long long node;
+                        if (!c.integer(node)) return msh_fail("failed to parse msh file: bad element nodes");
+                        if (take && connectivity) connectivity[(ne + (uint64_t)k) * nper + j] = (uint64_t)(node - 1);
+                    }
+                }
+                if (take) ne += (uint64_t)cnt;
+            }
+            have_elements = true;
+        } else if (tok.size() > 1 && tok[0] == '$' && tok.compare(0, 4, "$End") != 0) {
+            // any other section: skip to its end marker
+            const std::string endm = "$End" + tok.substr(1);
+            while (c.token(tok) && tok != endm) {}
+        }
+    }
+    if (!have_format) return msh_fail("failed to parse msh file: no $MeshFormat section");
+    if (!have_nodes) return msh_fail("MSH file does not contain nodes");
+    if (!have_elements) return msh_fail("MSH file does not contain elements");
+    if (!matched) return msh_fail("MSH file does not contain an element block of the requested type");
+    if ((long long)nv != claimed_nodes) return msh_fail("fewer vertices were read than the msh file claims to contain");
+    if (connectivity)
+        for (uint64_t i = 0; i < ne * (uint64_t)nper; ++i)
+            if (connectivity[i] >= nv) return msh_fail("element references a node that does not exist");
+    *num_vertices = nv;
+    *num_elements = ne;
+    g_msh_error.clear();
     return FH_OK;
 }
 

@@ -211,6 +211,14 @@ int fh_tet_mesh(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t
  * 27*num_cells*3 doubles, out_connectivity 27*num_cells. */
 int fh_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64_t* hex8, uint64_t num_cells,
                      double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
+/* load_msh_from_bytes (src/io/msh.rs:47-111), Gmsh MSH 4.1 ASCII: vertices of all node blocks in file order (x, y for the
+ * 2-D kinds), the elements of every block whose (Gmsh element type, entity dimension) matches elem_kind, node tags
+ * minus one, no reordering.  Two-phase: call with vertices = connectivity = NULL for the sizes.  Blocks with
+ * non-consecutive tags are refused like in the reference; binary files are not supported (FH_BAD_ARGUMENT, message
+ * from fh_msh_last_error, thread-local). */
+int fh_load_msh(const char* bytes, uint64_t len, int elem_kind, double* vertices, uint64_t* num_vertices,
+                uint64_t* connectivity, uint64_t* num_elements);
+const char* fh_msh_last_error(void);
 /* cuthill_mckee on a square sparsity pattern (src/mesh/reorder.rs:171-233): perm_out[target] = source.  The
  * reference orders equal-degree neighbours with an unstable sort (unspecified); ties are broken by ascending index. */
 int fh_cuthill_mckee(uint64_t num_rows, const uint64_t* row_offsets, const uint64_t* col_indices, uint64_t* perm_out);

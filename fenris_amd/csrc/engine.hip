@@ -57,6 +57,8 @@ const double HEX_SIGN[27][3] = {
     {0, -1, 1}, {-1, 0, 1}, {1, 0, 1}, {0, 1, 1},
     {0, 0, -1}, {0, -1, 0}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
 const double QUAD_SIGN[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+const double QUAD9_SIGN[9][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}, {0, -1}, {1, 0}, {0, 1}, {-1, 0}, {0, 0}};
+void ref_basis(int kind, const double* xi, double* out);
 
 inline double lin(double al, double x) { return (1.0 + al * x) / 2.0; }
 inline double dlin(double al) { return al / 2.0; }
@@ -99,6 +101,33 @@ void ref_gradients(int kind, const double* xi, double* out) {
             std::memcpy(out, G, sizeof G);
             break;
         }
+        case FH_TET10:
+        case FH_TRI6: {
+            // vertex node i: g_i (4 psi_i - 1); edge node (i, j): 4 (g_i psi_j + g_j psi_i), psi / g of the linear
+            // simplex (tetrahedron.rs:198-224, triangle.rs:228-252)
+            const int lin_kind = (kind == FH_TET10) ? FH_TET4 : FH_TRI3;
+            const int d = (kind == FH_TET10) ? 3 : 2, nv = d + 1;
+            static const int E3[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+            static const int E2[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+            double psi[4], g[12];
+            ref_basis(lin_kind, xi, psi);
+            ref_gradients(lin_kind, xi, g);
+            for (int i = 0; i < nv; ++i)
+                for (int k = 0; k < d; ++k) out[d * i + k] = g[d * i + k] * (4.0 * psi[i] - 1.0);
+            const int ne = (kind == FH_TET10) ? 6 : 3;
+            for (int m = 0; m < ne; ++m) {
+                const int i = (kind == FH_TET10) ? E3[m][0] : E2[m][0], j = (kind == FH_TET10) ? E3[m][1] : E2[m][1];
+                for (int k = 0; k < d; ++k) out[d * (nv + m) + k] = g[d * i + k] * (4.0 * psi[j]) + g[d * j + k] * (4.0 * psi[i]);
+            }
+            break;
+        }
+        case FH_QUAD9:
+            for (int n = 0; n < 9; ++n) {  // quadrilateral.rs:280-313
+                const double al = QUAD9_SIGN[n][0], be = QUAD9_SIGN[n][1];
+                out[2 * n] = quad(be, xi[1]) * dquad(al, xi[0]);
+                out[2 * n + 1] = quad(al, xi[0]) * dquad(be, xi[1]);
+            }
+            break;
     }
 }
 
@@ -126,6 +155,24 @@ void ref_basis(int kind, const double* xi, double* out) {
             out[1] = 0.5 * xi[0] + 0.5;
             out[2] = 0.5 * xi[1] + 0.5;
             break;
+        case FH_TET10: {  // tetrahedron.rs:179-195
+            double p[4];
+            ref_basis(FH_TET4, xi, p);
+            for (int i = 0; i < 4; ++i) out[i] = p[i] * (2.0 * p[i] - 1.0);
+            out[4] = 4.0 * p[0] * p[1]; out[5] = 4.0 * p[1] * p[2]; out[6] = 4.0 * p[0] * p[2];
+            out[7] = 4.0 * p[0] * p[3]; out[8] = 4.0 * p[2] * p[3]; out[9] = 4.0 * p[1] * p[3];
+            break;
+        }
+        case FH_TRI6: {  // triangle.rs:211-224
+            double p[3];
+            ref_basis(FH_TRI3, xi, p);
+            for (int i = 0; i < 3; ++i) out[i] = p[i] * (2.0 * p[i] - 1.0);
+            out[3] = 4.0 * p[0] * p[1]; out[4] = 4.0 * p[1] * p[2]; out[5] = 4.0 * p[0] * p[2];
+            break;
+        }
+        case FH_QUAD9:  // quadrilateral.rs:247-277
+            for (int n = 0; n < 9; ++n) out[n] = quad(QUAD9_SIGN[n][0], xi[0]) * quad(QUAD9_SIGN[n][1], xi[1]);
+            break;
     }
 }
 
@@ -137,6 +184,9 @@ bool elem_info(int kind, ElemInfo& e) {
         case FH_TET4: e = {3, 4, 4, FH_TET4}; return true;
         case FH_HEX27: e = {3, 27, 8, FH_HEX8}; return true;
         case FH_TRI3: e = {2, 3, 3, FH_TRI3}; return true;
+        case FH_TET10: e = {3, 10, 4, FH_TET4}; return true;
+        case FH_QUAD9: e = {2, 9, 4, FH_QUAD4}; return true;
+        case FH_TRI6: e = {2, 6, 3, FH_TRI3}; return true;
         default: return false;
     }
 }
@@ -398,6 +448,9 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         case FH_TET4: FH_FOR_OP(FH_TET4, OPV, CALL); break;                        \
         case FH_HEX27: FH_FOR_OP(FH_HEX27, OPV, CALL); break;                      \
         case FH_TRI3: FH_FOR_OP(FH_TRI3, OPV, CALL); break;                        \
+        case FH_TET10: FH_FOR_OP(FH_TET10, OPV, CALL); break;                      \
+        case FH_QUAD9: FH_FOR_OP(FH_QUAD9, OPV, CALL); break;                      \
+        case FH_TRI6: FH_FOR_OP(FH_TRI6, OPV, CALL); break;                        \
         default: break;                                                            \
     }
 #define FH_FOR_OP(EKC, OPV, CALL)                                   \

@@ -429,6 +429,89 @@ int fh_hex8_to_hex27(const double* v, uint64_t nv, const uint64_t* hex8, uint64_
     hex8_to_hex27(v, hex8, ncells, out_v, out_nv, out_c);
     return FH_OK;
 }
+// p-refinement of linear meshes to their quadratic counterparts (src/mesh_convert.rs)
+int fh_refine_to_quadratic(int from_kind, const double* v, uint64_t nv, const uint64_t* conn, uint64_t ncells, double* out_v,
+                           uint64_t* out_nv, uint64_t* out_c) {
+    if (!v || !conn || !out_v || !out_nv || !out_c) return FH_BAD_ARGUMENT;
+    const int n0 = (from_kind == FH_TET4) ? 4 : (from_kind == FH_TRI3) ? 3 : (from_kind == FH_QUAD4) ? 4 : 0;
+    if (!n0) return FH_BAD_ARGUMENT;
+    for (uint64_t i = 0; i < (uint64_t)n0 * ncells; ++i)
+        if (conn[i] >= nv) return FH_BAD_ARGUMENT;
+    if (from_kind == FH_TET4) {
+        // Tet10Mesh::from(&tet4): RefineFrom (mesh_convert.rs:42-83) through the generic relabelling of :227-330 -- every
+        // node (vertex nodes first, then the six edge nodes) is identified by its sorted parent vertices and labelled in
+        // order of first occurrence, so the old vertex indices are NOT kept
+        static const int EDGE[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+        const uint64_t NONE = ~0ull;
+        std::unordered_map<ParentKey, uint64_t, ParentKeyHash> label;
+        label.reserve(static_cast<size_t>(ncells) * 4);
+        uint64_t next = 0;
+        for (uint64_t e = 0; e < ncells; ++e) {
+            const uint64_t* g = conn + 4 * e;
+            double pos[10][3];
+            ParentKey key[10];
+            for (auto& k : key) k.p.fill(NONE);
+            for (int a = 0; a < 4; ++a) {
+                for (int r = 0; r < 3; ++r) pos[a][r] = v[3 * g[a] + r];
+                key[a].p[0] = g[a];
+            }
+            for (int m = 0; m < 6; ++m) {
+                const int b = EDGE[m][0], en = EDGE[m][1];
+                // nalgebra lerp: self * (1 - t) + rhs * t
+                for (int r = 0; r < 3; ++r) pos[4 + m][r] = v[3 * g[b] + r] * (1.0 - 0.5) + v[3 * g[en] + r] * 0.5;
+                key[4 + m].p[0] = g[b];
+                key[4 + m].p[1] = g[en];
+            }
+            for (int a = 0; a < 10; ++a) {
+                std::sort(key[a].p.begin(), key[a].p.end());
+                auto it = label.find(key[a]);
+                if (it == label.end()) {
+                    label.emplace(key[a], next);
+                    std::memcpy(out_v + 3 * next, pos[a], sizeof(double) * 3);
+                    out_c[10 * e + a] = next++;
+                } else {
+                    out_c[10 * e + a] = it->second;
+                }
+            }
+        }
+        *out_nv = next;
+        return FH_OK;
+    }
+    // Tri6 from Tri3 (mesh_convert.rs:332-383) and Quad9 from Quad4 (:385-442): the vertices are kept, the midpoint of
+    // every edge (a, b) -- consecutive vertices of the element, cyclically -- is appended at its first occurrence
+    // ((v_a + v_b) / 2), Quad9 then appends the image of the reference origin
+    const int n1 = (from_kind == FH_TRI3) ? 6 : 9;
+    std::memcpy(out_v, v, sizeof(double) * 2 * nv);
+    uint64_t next = nv;
+    std::map<std::pair<uint64_t, uint64_t>, uint64_t> edge_index;
+    for (uint64_t e = 0; e < ncells; ++e) {
+        const uint64_t* g = conn + (uint64_t)n0 * e;
+        uint64_t* o = out_c + (uint64_t)n1 * e;
+        for (int a = 0; a < n0; ++a) o[a] = g[a];
+        for (int m = 0; m < n0; ++m) {
+            const uint64_t a = g[m], b = g[(m + 1) % n0];
+            const auto key = std::make_pair(std::min(a, b), std::max(a, b));
+            auto it = edge_index.find(key);
+            if (it == edge_index.end()) {
+                for (int r = 0; r < 2; ++r) out_v[2 * next + r] = (out_v[2 * a + r] + out_v[2 * b + r]) / 2.0;
+                it = edge_index.emplace(key, next++).first;
+            }
+            o[n0 + m] = it->second;
+        }
+        if (from_kind == FH_QUAD4) {
+            // map_reference_coords(origin) = X N^T with N_k = (1 + 0)(1 + 0) / 4 (quadrilateral.rs:117-122), k ascending
+            for (int r = 0; r < 2; ++r) {
+                double sacc = v[2 * g[0] + r] * 0.25;
+                for (int k = 1; k < 4; ++k) sacc = sacc + v[2 * g[k] + r] * 0.25;
+                out_v[2 * next + r] = sacc;
+            }
+            o[8] = next++;
+        }
+    }
+    *out_nv = next;
+    return FH_OK;
+}
+
 // cuthill_mckee (src/mesh/reorder.rs:171-233): breadth-first search from the first unvisited vertex of least degree,
 // neighbours visited by ascending degree.  The reference sorts the neighbours with sort_unstable_by_key, which leaves
 // the order of equal-degree neighbours unspecified; ties are resolved here by ascending vertex index (a stable sort
@@ -566,6 +649,9 @@ int fh_load_msh(const char* bytes, uint64_t len, int elem_kind, double* vertices
         case FH_TET4: want_type = 4; want_dim = 3; gdim = 3; nper = 4; break;
         case FH_HEX8: want_type = 5; want_dim = 3; gdim = 3; nper = 8; break;
         case FH_HEX27: want_type = 12; want_dim = 3; gdim = 3; nper = 27; break;
+        case FH_TET10: want_type = 11; want_dim = 3; gdim = 3; nper = 10; break;
+        case FH_QUAD9: want_type = 10; want_dim = 2; gdim = 2; nper = 9; break;
+        case FH_TRI6: want_type = 9; want_dim = 2; gdim = 2; nper = 6; break;
         default: return msh_fail("unsupported element kind");
     }
     MshCursor c{bytes, bytes + len};

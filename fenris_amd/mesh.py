@@ -60,6 +60,15 @@ class procedural:
         return procedural.create_rectangular_uniform_quad_mesh_2d(1.0, 1, 1, cells_per_dim, (0.0, 1.0))
 
     @staticmethod
+    def create_unit_square_uniform_tri_mesh_2d(cells_per_dim):
+        """procedural.rs:22-28: the quad mesh with every (convex) cell split into the triangles [0, 1, 2] and [0, 2, 3]
+        (split_into_triangles, src/mesh.rs:276-293; fenris-geometry/src/primitives/quad.rs:76-88)"""
+        q = procedural.create_unit_square_uniform_quad_mesh_2d(cells_per_dim)
+        c = q.connectivity
+        tri = np.stack([c[:, [0, 1, 2]], c[:, [0, 2, 3]]], axis=1).reshape(-1, 3)
+        return Mesh(q.vertices, np.ascontiguousarray(tri, dtype=np.uint64), _ffi.TRI3)
+
+    @staticmethod
     def create_rectangular_uniform_hex_mesh(unit_length, units_x, units_y, units_z, cells_per_unit):
         """procedural.rs:216-277"""
         return _gen(_ffi.lib().fh_hex_mesh, 3, 8, _ffi.HEX8, float(unit_length), units_x, units_y, units_z,
@@ -94,3 +103,31 @@ def hex27_mesh_from_hex8(mesh: Mesh) -> Mesh:
     if rc:
         raise _ffi.FenrisError(rc, "hex8_to_hex27")
     return Mesh(out_v[: nv.value].copy(), out_c, _ffi.HEX27)
+
+
+def _refine(mesh: Mesh, from_kind, to_kind) -> Mesh:
+    assert mesh.elem_kind == from_kind
+    E, d, n1 = mesh.num_elements(), _ffi.ELEM_DIM[to_kind], _ffi.ELEM_NODES[to_kind]
+    out_v = np.zeros((max(mesh.num_nodes() + n1 * E, 1), d))
+    out_c = np.zeros((E, n1), dtype=np.uint64)
+    nv = C.c_uint64()
+    rc = _ffi.lib().fh_refine_to_quadratic(from_kind, _ffi.fp(mesh.vertices), mesh.num_nodes(), _ffi.up(mesh.connectivity), E,
+                                           _ffi.fp(out_v), C.byref(nv), _ffi.up(out_c))
+    if rc:
+        raise _ffi.FenrisError(rc, "refine_to_quadratic")
+    return Mesh(out_v[: nv.value].copy(), out_c, to_kind)
+
+
+def tet10_mesh_from_tet4(mesh: Mesh) -> Mesh:
+    """Tet10Mesh::from(&tet4_mesh) (src/mesh_convert.rs:42-83, 227-330, 444-452)"""
+    return _refine(mesh, _ffi.TET4, _ffi.TET10)
+
+
+def tri6_mesh_from_tri3(mesh: Mesh) -> Mesh:
+    """Mesh2d<Tri6d2Connectivity>::from(tri3_mesh) (src/mesh_convert.rs:332-383)"""
+    return _refine(mesh, _ffi.TRI3, _ffi.TRI6)
+
+
+def quad9_mesh_from_quad4(mesh: Mesh) -> Mesh:
+    """Mesh2d<Quad9d2Connectivity>::from(quad4_mesh) (src/mesh_convert.rs:385-442)"""
+    return _refine(mesh, _ffi.QUAD4, _ffi.QUAD9)

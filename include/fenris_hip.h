@@ -52,7 +52,11 @@ enum {
 /* element kinds: Quad4d2Element (src/element/quadrilateral.rs:70-142), Hex8Element
  * (src/element/hexahedron.rs:34-117), Tet4Element (src/element/tetrahedron.rs:543-608),
  * Hex27Element (hexahedron.rs:157-335), Tri3d2Element (src/element/triangle.rs:63-110) */
-enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4 };
+enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4,
+       /* quadratic elements, sub-parametric like Hex27 -- the geometry map is the embedded linear element's:
+        * Tet10Element (src/element/tetrahedron.rs:92-246), Quad9d2Element (quadrilateral.rs:150-330),
+        * Tri6d2Element (triangle.rs:130-260) */
+       FH_TET10 = 5, FH_QUAD9 = 6, FH_TRI6 = 7 };
 
 /* operator kinds: LaplaceOperator (src/assembly/operators/laplace.rs), MaterialEllipticOperator over
  * LinearElasticMaterial / NeoHookeanMaterial / StVKMaterial (fenris-solid/src/lib.rs:412-508,
@@ -211,6 +215,13 @@ int fh_tet_mesh(double unit_length, uint64_t units_x, uint64_t units_y, uint64_t
  * 27*num_cells*3 doubles, out_connectivity 27*num_cells. */
 int fh_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64_t* hex8, uint64_t num_cells,
                      double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
+/* p-refinement of the linear meshes (src/mesh_convert.rs): Tet10Mesh::from(&tet4) (:42-83, 444-452: vertex nodes then
+ * the edge nodes (0,1) (1,2) (0,2) (0,3) (2,3) (1,3), labels in order of first occurrence), Tri6 from Tri3 (:332-383)
+ * and Quad9 from Quad4 (:385-442): the old vertices keep their indices, edge midpoints are appended in order of first
+ * occurrence, Quad9 also appends the cell midpoint.  from_kind is FH_TET4 / FH_TRI3 / FH_QUAD4; out_vertices capacity
+ * (nodes per refined element) * num_cells * d doubles. */
+int fh_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* connectivity,
+                           uint64_t num_cells, double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
 /* load_msh_from_bytes (src/io/msh.rs:47-111), Gmsh MSH 4.1 ASCII: vertices of all node blocks in file order (x, y for the
  * 2-D kinds), the elements of every block whose (Gmsh element type, entity dimension) matches elem_kind, node tags
  * minus one, no reordering.  Two-phase: call with vertices = connectivity = NULL for the sizes.  Blocks with

@@ -126,13 +126,16 @@ int fo_element_num_nodes(int k) {
         case FO_TET4: return 4;
         case FO_HEX27: return 27;
         case FO_TRI3: return 3;
+        case FO_TET10: return 10;
+        case FO_QUAD9: return 9;
+        case FO_TRI6: return 6;
         default: return -1;
     }
 }
 int fo_element_dim(int k) {
     switch (k) {
-        case FO_QUAD4: case FO_TRI3: return 2;
-        case FO_HEX8: case FO_TET4: case FO_HEX27: return 3;
+        case FO_QUAD4: case FO_TRI3: case FO_QUAD9: case FO_TRI6: return 2;
+        case FO_HEX8: case FO_TET4: case FO_HEX27: case FO_TET10: return 3;
         default: return -1;
     }
 }
@@ -153,6 +156,8 @@ static double phi_quadratic_1d_grad(double alpha, double xi) {
 
 /* node sign tables: src/element/quadrilateral.rs:84-89, hexahedron.rs:49-58, :229-264 */
 static const double QUAD4_SIGNS[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+/* quadrilateral.rs:212-228: corners, edge midpoints (0,1) (1,2) (2,3) (3,0), centre */
+static const double QUAD9_SIGNS[9][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}, {0, -1}, {1, 0}, {0, 1}, {-1, 0}, {0, 0}};
 static const double HEX27_SIGNS[27][3] = {
     {-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1},
     /* edge nodes */
@@ -194,6 +199,36 @@ int fo_element_basis(int kind, const double* xi, double* phi) {
             phi[1] = 0.5 * xi[0] + 0.5;
             phi[2] = 0.5 * xi[1] + 0.5;
             return FO_OK;
+        case FO_TET10: { /* tetrahedron.rs:179-195: products of the Tet4 basis */
+            double psi[4];
+            fo_element_basis(FO_TET4, xi, psi);
+            phi[0] = psi[0] * (2.0 * psi[0] - 1.0);
+            phi[1] = psi[1] * (2.0 * psi[1] - 1.0);
+            phi[2] = psi[2] * (2.0 * psi[2] - 1.0);
+            phi[3] = psi[3] * (2.0 * psi[3] - 1.0);
+            phi[4] = 4.0 * psi[0] * psi[1];
+            phi[5] = 4.0 * psi[1] * psi[2];
+            phi[6] = 4.0 * psi[0] * psi[2];
+            phi[7] = 4.0 * psi[0] * psi[3];
+            phi[8] = 4.0 * psi[2] * psi[3];
+            phi[9] = 4.0 * psi[1] * psi[3];
+            return FO_OK;
+        }
+        case FO_TRI6: { /* triangle.rs:211-224 */
+            double psi[3];
+            fo_element_basis(FO_TRI3, xi, psi);
+            phi[0] = psi[0] * (2.0 * psi[0] - 1.0);
+            phi[1] = psi[1] * (2.0 * psi[1] - 1.0);
+            phi[2] = psi[2] * (2.0 * psi[2] - 1.0);
+            phi[3] = 4.0 * psi[0] * psi[1];
+            phi[4] = 4.0 * psi[1] * psi[2];
+            phi[5] = 4.0 * psi[0] * psi[2];
+            return FO_OK;
+        }
+        case FO_QUAD9: /* quadrilateral.rs:233-277: N_ab(xi, eta) = phi_a(xi) phi_b(eta), 1-D quadratic factors */
+            for (int n = 0; n < 9; ++n)
+                phi[n] = phi_quadratic_1d(QUAD9_SIGNS[n][0], xi[0]) * phi_quadratic_1d(QUAD9_SIGNS[n][1], xi[1]);
+            return FO_OK;
         default: return FO_BAD_ARGUMENT;
     }
 }
@@ -233,14 +268,53 @@ int fo_element_gradients(int kind, const double* xi, double* g) {
             memcpy(g, G, sizeof G);
             return FO_OK;
         }
+        case FO_TET10:
+        case FO_TRI6: {
+            /* tetrahedron.rs:198-224, triangle.rs:228-252: vertex node i: g_i (4 psi_i - 1);
+             * edge node (i, j): g_i (4 psi_j) + g_j (4 psi_i) */
+            static const int E3[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+            static const int E2[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+            int lin = (kind == FO_TET10) ? FO_TET4 : FO_TRI3, d = (kind == FO_TET10) ? 3 : 2, nv = d + 1;
+            int ne = (kind == FO_TET10) ? 6 : 3;
+            double psi[4], gl[12];
+            fo_element_basis(lin, xi, psi);
+            fo_element_gradients(lin, xi, gl);
+            for (int i = 0; i < nv; ++i)
+                for (int k = 0; k < d; ++k) g[CM(k, i, d)] = gl[CM(k, i, d)] * (4.0 * psi[i] - 1.0);
+            for (int m = 0; m < ne; ++m) {
+                int i = (kind == FO_TET10) ? E3[m][0] : E2[m][0], j = (kind == FO_TET10) ? E3[m][1] : E2[m][1];
+                for (int k = 0; k < d; ++k)
+                    g[CM(k, nv + m, d)] = gl[CM(k, i, d)] * (4.0 * psi[j]) + gl[CM(k, j, d)] * (4.0 * psi[i]);
+            }
+            return FO_OK;
+        }
+        case FO_QUAD9: /* quadrilateral.rs:280-313 */
+            for (int n = 0; n < 9; ++n) {
+                double alpha = QUAD9_SIGNS[n][0], beta = QUAD9_SIGNS[n][1];
+                g[CM(0, n, 2)] = phi_quadratic_1d(beta, xi[1]) * phi_quadratic_1d_grad(alpha, xi[0]);
+                g[CM(1, n, 2)] = phi_quadratic_1d(alpha, xi[0]) * phi_quadratic_1d_grad(beta, xi[1]);
+            }
+            return FO_OK;
         default: return FO_BAD_ARGUMENT;
     }
 }
 
 /* J = X * G^T, X[i][j] = vertex_j[i]  (hexahedron.rs:101-107, tetrahedron.rs:584-590,
  * quadrilateral.rs:125-132).  Hex27 delegates to its embedded Hex8 (hexahedron.rs:324-326). */
+/* the quadratic elements take their geometry from the embedded linear element (hexahedron.rs:324-326,
+ * tetrahedron.rs:233-240, quadrilateral.rs:316-323, triangle.rs:254-262) */
+static int geometry_kind(int kind) {
+    switch (kind) {
+        case FO_HEX27: return FO_HEX8;
+        case FO_TET10: return FO_TET4;
+        case FO_QUAD9: return FO_QUAD4;
+        case FO_TRI6: return FO_TRI3;
+        default: return kind;
+    }
+}
+
 int fo_element_reference_jacobian(int kind, const double* ev, const double* xi, double* J) {
-    int gkind = (kind == FO_HEX27) ? FO_HEX8 : kind;
+    int gkind = geometry_kind(kind);
     int n = fo_element_num_nodes(gkind), d = fo_element_dim(gkind);
     if (n < 0) return FO_BAD_ARGUMENT;
     double G[MAXD * 8];
@@ -257,7 +331,7 @@ int fo_element_reference_jacobian(int kind, const double* ev, const double* xi, 
 
 /* map_reference_coords: x = X * N^T (hexahedron.rs:92-98) ; Hex27 uses the Hex8 map */
 static void map_reference_coords(int kind, const double* ev, const double* xi, double* x) {
-    int gkind = (kind == FO_HEX27) ? FO_HEX8 : kind;
+    int gkind = geometry_kind(kind);
     int n = fo_element_num_nodes(gkind), d = fo_element_dim(gkind);
     double N[8];
     fo_element_basis(gkind, xi, N);
@@ -650,6 +724,105 @@ int fo_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64
                 }
                 h = (h + 1) & (cap - 1);
             }
+        }
+    }
+    free(table);
+    *out_vertices = fv; *out_num_vertices = next; *out_connectivity = conn;
+    return FO_OK;
+}
+
+/* p-refinement to the quadratic meshes (src/mesh_convert.rs).
+ * Tet4 -> Tet10: RefineFrom :42-83 (vertex nodes, then the edge nodes (0,1) (1,2) (0,2) (0,3) (2,3) (1,3) at
+ *   lerp(begin, end, 0.5)) through the first-occurrence relabelling of :227-330, like Hex8 -> Hex27.
+ * Tri3 -> Tri6 (:332-383), Quad4 -> Quad9 (:385-442): the vertices are kept; for every element the midpoints of its
+ *   edges (consecutive vertices, cyclically), keyed by (min, max), are appended at first occurrence as
+ *   (v_a + v_b) / 2; Quad9 then appends map_reference_coords(origin) of the cell. */
+int fo_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* conn_in,
+                           uint64_t num_cells, double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity) {
+    if (from_kind == FO_TET4) {
+        static const int EDGES[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+        size_t cap = 1;
+        while (cap < (size_t)num_cells * 10 * 2 + 16) cap <<= 1;
+        parent_slot* table = calloc(cap, sizeof(parent_slot));
+        double* fv = malloc(sizeof(double) * 3 * ((size_t)num_cells * 10 + 1));
+        uint64_t* conn = malloc(sizeof(uint64_t) * ((size_t)num_cells * 10 + 1));
+        if (!table || !fv || !conn) return FO_BAD_ARGUMENT;
+        uint64_t next = 0;
+        for (uint64_t e = 0; e < num_cells; ++e) {
+            const uint64_t* gi = conn_in + 4 * e;
+            double lv[10][3];
+            uint64_t par[10][2];
+            int npar[10];
+            for (int n = 0; n < 4; ++n) {
+                for (int c = 0; c < 3; ++c) lv[n][c] = vertices[3 * gi[n] + c];
+                par[n][0] = gi[n]; npar[n] = 1;
+            }
+            for (int ed = 0; ed < 6; ++ed) {
+                int b = EDGES[ed][0], en = EDGES[ed][1];
+                for (int c = 0; c < 3; ++c) lv[4 + ed][c] = vertices[3 * gi[b] + c] * (1.0 - 0.5) + vertices[3 * gi[en] + c] * 0.5;
+                par[4 + ed][0] = gi[b]; par[4 + ed][1] = gi[en]; npar[4 + ed] = 2;
+            }
+            for (int n = 0; n < 10; ++n) {
+                qsort(par[n], (size_t)npar[n], sizeof(uint64_t), cmp_u64);
+                uint64_t h = hash_parents(par[n], npar[n]) & (cap - 1);
+                for (;;) {
+                    parent_slot* sl = &table[h];
+                    if (!sl->used) {
+                        sl->used = 1; sl->nkey = (uint8_t)npar[n];
+                        memcpy(sl->key, par[n], sizeof(uint64_t) * (size_t)npar[n]);
+                        sl->value = next;
+                        for (int c = 0; c < 3; ++c) fv[3 * next + c] = lv[n][c];
+                        conn[10 * e + n] = next++;
+                        break;
+                    }
+                    if (sl->nkey == npar[n] && memcmp(sl->key, par[n], sizeof(uint64_t) * (size_t)npar[n]) == 0) {
+                        conn[10 * e + n] = sl->value;
+                        break;
+                    }
+                    h = (h + 1) & (cap - 1);
+                }
+            }
+        }
+        free(table);
+        *out_vertices = fv; *out_num_vertices = next; *out_connectivity = conn;
+        return FO_OK;
+    }
+    if (from_kind != FO_TRI3 && from_kind != FO_QUAD4) return FO_BAD_ARGUMENT;
+    int n0 = (from_kind == FO_TRI3) ? 3 : 4, n1 = (from_kind == FO_TRI3) ? 6 : 9;
+    size_t cap = 1;
+    while (cap < (size_t)num_cells * n0 * 2 + 16) cap <<= 1;
+    parent_slot* table = calloc(cap, sizeof(parent_slot));
+    double* fv = malloc(sizeof(double) * 2 * ((size_t)num_vertices + (size_t)num_cells * (n0 + 1) + 1));
+    uint64_t* conn = malloc(sizeof(uint64_t) * ((size_t)num_cells * n1 + 1));
+    if (!table || !fv || !conn) return FO_BAD_ARGUMENT;
+    memcpy(fv, vertices, sizeof(double) * 2 * (size_t)num_vertices);
+    uint64_t next = num_vertices;
+    for (uint64_t e = 0; e < num_cells; ++e) {
+        const uint64_t* gi = conn_in + (uint64_t)n0 * e;
+        uint64_t* o = conn + (uint64_t)n1 * e;
+        for (int a = 0; a < n0; ++a) o[a] = gi[a];
+        for (int m = 0; m < n0; ++m) {
+            uint64_t a = gi[m], b = gi[(m + 1) % n0];
+            uint64_t key[2] = {a < b ? a : b, a < b ? b : a};
+            uint64_t h = hash_parents(key, 2) & (cap - 1);
+            for (;;) {
+                parent_slot* sl = &table[h];
+                if (!sl->used) {
+                    sl->used = 1; sl->nkey = 2; sl->key[0] = key[0]; sl->key[1] = key[1]; sl->value = next;
+                    for (int c = 0; c < 2; ++c) fv[2 * next + c] = (fv[2 * a + c] + fv[2 * b + c]) / 2.0;
+                    o[n0 + m] = next++;
+                    break;
+                }
+                if (sl->key[0] == key[0] && sl->key[1] == key[1]) { o[n0 + m] = sl->value; break; }
+                h = (h + 1) & (cap - 1);
+            }
+        }
+        if (from_kind == FO_QUAD4) {
+            double ev[8], origin[2] = {0, 0};
+            for (int n = 0; n < 4; ++n)
+                for (int c = 0; c < 2; ++c) ev[2 * n + c] = vertices[2 * gi[n] + c];
+            map_reference_coords(FO_QUAD4, ev, origin, fv + 2 * next);
+            o[8] = next++;
         }
     }
     free(table);

@@ -39,7 +39,9 @@ extern "C" {
 #endif
 
 /* element kinds (node orders: SURVEY Appendix A.2) */
-enum { FO_QUAD4 = 0, FO_HEX8 = 1, FO_TET4 = 2, FO_HEX27 = 3, FO_TRI3 = 4 };
+enum { FO_QUAD4 = 0, FO_HEX8 = 1, FO_TET4 = 2, FO_HEX27 = 3, FO_TRI3 = 4,
+       /* quadratic, sub-parametric: tetrahedron.rs:92-246, quadrilateral.rs:150-330, triangle.rs:130-260 */
+       FO_TET10 = 5, FO_QUAD9 = 6, FO_TRI6 = 7 };
 /* operator kinds */
 enum { FO_LAPLACE = 0, FO_LINEAR_ELASTIC = 1, FO_NEO_HOOKEAN = 2, FO_STVK = 3,
        /* ElementMassAssembler (src/assembly/local/mass.rs) with solution_dim 1 / geometry dim; q_params[2q] = density */
@@ -76,6 +78,10 @@ int fo_create_rectangular_uniform_tet_mesh(double unit_length, uint64_t units_x,
 /* Hex8 -> Hex27 (src/mesh_convert.rs:85-166,227-330) */
 int fo_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64_t* hex8, uint64_t num_cells,
                      double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity);
+
+/* p-refinement Tet4 -> Tet10, Tri3 -> Tri6, Quad4 -> Quad9 (src/mesh_convert.rs:42-83, 332-452); outputs malloc'ed */
+int fo_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* connectivity,
+                           uint64_t num_cells, double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity);
 
 /* ---- elements (src/element/ *.rs) */
 /* reference gradients, d x n column-major (column per node) */

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfenris_oracle.so")
 
-QUAD4, HEX8, TET4, HEX27, TRI3 = 0, 1, 2, 3, 4
+QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6 = 0, 1, 2, 3, 4, 5, 6, 7
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 OK, SINGULAR_JACOBIAN, BAD_ARGUMENT, COLUMN_NOT_FOUND = 0, 1, 2, 4
 
@@ -75,6 +75,8 @@ def lib():
         for f in (_lib.fo_create_rectangular_uniform_hex_mesh, _lib.fo_create_rectangular_uniform_tet_mesh):
             f.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_f64p), _u64p,
                           C.POINTER(_u64p), _u64p]
+        _lib.fo_refine_to_quadratic.argtypes = [C.c_int, _f64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(_f64p), _u64p,
+                                                C.POINTER(_u64p)]
         _lib.fo_hex8_to_hex27.argtypes = [_f64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(_f64p), _u64p,
                                           C.POINTER(_u64p)]
         _lib.fo_assemble_pattern.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p, _u64p, _u64p]
@@ -217,6 +219,18 @@ def hex8_to_hex27(vertices, conn):
                                 C.byref(cp))
     assert st == 0
     return _take(vp, nv, cp, C.c_uint64(len(conn)), 3, 27)
+
+
+def refine_to_quadratic(from_kind, vertices, conn):
+    """Tet4 -> Tet10, Tri3 -> Tri6, Quad4 -> Quad9 (src/mesh_convert.rs:42-83, 332-452)"""
+    d, n1 = {TET4: (3, 10), TRI3: (2, 6), QUAD4: (2, 9)}[from_kind]
+    vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+    conn = np.ascontiguousarray(conn, dtype=np.uint64)
+    vp, cp, nv = _f64p(), _u64p(), C.c_uint64()
+    st = lib().fo_refine_to_quadratic(from_kind, _f(vertices), len(vertices), _u(conn), len(conn), C.byref(vp), C.byref(nv),
+                                      C.byref(cp))
+    assert st == 0
+    return _take(vp, nv, cp, C.c_uint64(len(conn)), d, n1)
 
 
 # ---------------------------------------------------------------- materials

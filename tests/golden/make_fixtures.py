@@ -28,6 +28,14 @@ SNAPS = {
     "cube_hex8_8": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_cube_hex8.snap",
     "cube_hex27_8": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_cube_hex27.snap",
     "square_quad4_79": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_square_quad4d2_large.snap",
+    # msh loader snapshots of the remaining assets (tests/test_msh.py)
+    "cube_tet4_24": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_cube_tet4.snap",
+    "cube_tet10_24": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_cube_tet10.snap",
+    "rectangle_tri3_110": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_rect_tri3d2_large.snap",
+    "square_quad4_4": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_square_quad4d2.snap",
+    "square_quad9_4": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_square_quad9d2.snap",
+    "square_tri3_4": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_square_tri3d2.snap",
+    "square_tri6_4": "tests/unit_tests/io/snapshots/unit__unit_tests__io__msh__load_msh_square_tri6d2.snap",
 }
 
 NUM = re.compile(r"-?(?:\d+\.\d*(?:e-?\d+)?|\d+(?:e-?\d+)?)")
@@ -69,6 +77,12 @@ def main():
     with open(os.path.join(OUT, "tet_rule_6_24.json"), "w") as f:
         json.dump({"source": "fenris-quadrature/rules/polyquad/expanded/tet/6-24.txt",
                    "points": [r[:3] for r in rows], "weights": [r[3] for r in rows]}, f)
+    # ... and of the Tri3 / Tri6 MMS tests (poisson_2d_mms.rs:103, 112)
+    rows = [[float(x) for x in line.split()]
+            for line in open(os.path.join(REF, "fenris-quadrature/rules/polyquad/expanded/tri/6-12.txt")) if line.strip()]
+    with open(os.path.join(OUT, "tri_rule_6_12.json"), "w") as f:
+        json.dump({"source": "fenris-quadrature/rules/polyquad/expanded/tri/6-12.txt",
+                   "points": [r[:2] for r in rows], "weights": [r[2] for r in rows]}, f)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,9 @@ MSH = os.path.join(GOLDEN, "msh")
 
 
 @pytest.mark.parametrize("name,kind", [("sphere_tet4_593", fa.TET4), ("cube_hex8_8", fa.HEX8), ("cube_hex27_8", fa.HEX27),
-                                       ("square_quad4_79", fa.QUAD4)])
+                                       ("square_quad4_79", fa.QUAD4), ("cube_tet4_24", fa.TET4), ("cube_tet10_24", fa.TET10),
+                                       ("rectangle_tri3_110", fa.TRI3), ("square_quad4_4", fa.QUAD4), ("square_quad9_4", fa.QUAD9),
+                                       ("square_tri3_4", fa.TRI3), ("square_tri6_4", fa.TRI6)])
 def test_load_msh_matches_reference_snapshots(name, kind):
     """tests/unit_tests/io/msh.rs: load_msh_* snapshot tests (vertices and connectivity, bit for bit)"""
     mesh = io.load_msh_from_file(os.path.join(MSH, name + ".msh"), kind)

@@ -1142,7 +1142,8 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
                             // diagonal block: the lower triangle mirrors the upper one (util.rs:46-50); compile-time
                             // register indices only (a runtime index would push Gr to scratch)
                             const double v = (i > j && diag) ? val[j][i] : val[i][j];
-                            atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
+                            if (a.ablate & 32) base[(i % S) * S * cnt + (j % S)] = v;  // experiment: plain stores (wrong sums)
+                            else atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
                         }
                 }
             }

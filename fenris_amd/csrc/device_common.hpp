@@ -77,7 +77,8 @@ struct KArgs {
     int num_nodes;
     // quadrature tables (device)
     int nq;
-    int ablate;            // profiling only (FENRIS_HIP_ABLATE bitmask): 1 skip phase B, 2 skip phase C, 4 skip finalize, 8 skip phase D
+    int ablate;            // profiling only (FENRIS_HIP_ABLATE bitmask): 1 skip phase B, 2 skip phase C, 4 skip finalize, 8 skip phase D,
+                           // 16 write-out behind the barrier instead of overlapped, 32 plain LDS stores instead of atomics (wrong sums)
     int fast;              // uniform parameters and non-negative weights: sqrt-scaled gradients
     double mu, lambda;     // uniform Lame parameters (fast path)
     const double* qw;      // nq

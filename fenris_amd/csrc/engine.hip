@@ -121,6 +121,28 @@ void ref_gradients(int kind, const double* xi, double* out) {
             }
             break;
         }
+        case FH_HEX20:
+            for (int n = 0; n < 20; ++n) {  // hexahedron.rs:465-543: phi = s f g (corners) / s h g (edges), product rule
+                const double al = HEX_SIGN[n][0], be = HEX_SIGN[n][1], ga = HEX_SIGN[n][2];
+                const double ax = 1.0 + al * xi[0], by = 1.0 + be * xi[1], cz = 1.0 + ga * xi[2];
+                const double g = ax * by * cz;
+                if (n < 8) {
+                    const double f = al * xi[0] + be * xi[1] + ga * xi[2] - 2.0, s = 1.0 / 8.0;
+                    out[3 * n] = s * (al * g + f * al * by * cz);
+                    out[3 * n + 1] = s * (be * g + f * be * ax * cz);
+                    out[3 * n + 2] = s * (ga * g + f * ga * ax * by);
+                } else {
+                    const double a2 = al * al, b2 = be * be, c2 = ga * ga, s = 1.0 / 4.0;
+                    const double hx = 1.0 - (1.0 - a2) * xi[0] * xi[0], hy = 1.0 - (1.0 - b2) * xi[1] * xi[1], hz = 1.0 - (1.0 - c2) * xi[2] * xi[2];
+                    const double h = hx * hy * hz;
+                    const double dh0 = -2.0 * (1.0 - a2) * xi[0] * hy * hz, dh1 = -2.0 * (1.0 - b2) * xi[1] * hx * hz,
+                                 dh2 = -2.0 * (1.0 - c2) * xi[2] * hx * hy;
+                    out[3 * n] = s * (dh0 * g + h * al * by * cz);
+                    out[3 * n + 1] = s * (dh1 * g + h * be * ax * cz);
+                    out[3 * n + 2] = s * (dh2 * g + h * ga * ax * by);
+                }
+            }
+            break;
         case FH_QUAD9:
             for (int n = 0; n < 9; ++n) {  // quadrilateral.rs:280-313
                 const double al = QUAD9_SIGN[n][0], be = QUAD9_SIGN[n][1];
@@ -170,6 +192,15 @@ void ref_basis(int kind, const double* xi, double* out) {
             out[3] = 4.0 * p[0] * p[1]; out[4] = 4.0 * p[1] * p[2]; out[5] = 4.0 * p[0] * p[2];
             break;
         }
+        case FH_HEX20:  // hexahedron.rs:413-462
+            for (int n = 0; n < 20; ++n) {
+                const double al = HEX_SIGN[n][0], be = HEX_SIGN[n][1], ga = HEX_SIGN[n][2];
+                const double g = (1.0 + al * xi[0]) * (1.0 + be * xi[1]) * (1.0 + ga * xi[2]);
+                if (n < 8) out[n] = (1.0 / 8.0) * g * (al * xi[0] + be * xi[1] + ga * xi[2] - 2.0);
+                else out[n] = (1.0 / 4.0) * (1.0 - (1.0 - al * al) * xi[0] * xi[0]) * (1.0 - (1.0 - be * be) * xi[1] * xi[1]) *
+                              (1.0 - (1.0 - ga * ga) * xi[2] * xi[2]) * g;
+            }
+            break;
         case FH_QUAD9:  // quadrilateral.rs:247-277
             for (int n = 0; n < 9; ++n) out[n] = quad(QUAD9_SIGN[n][0], xi[0]) * quad(QUAD9_SIGN[n][1], xi[1]);
             break;
@@ -187,6 +218,7 @@ bool elem_info(int kind, ElemInfo& e) {
         case FH_TET10: e = {3, 10, 4, FH_TET4}; return true;
         case FH_QUAD9: e = {2, 9, 4, FH_QUAD4}; return true;
         case FH_TRI6: e = {2, 6, 3, FH_TRI3}; return true;
+        case FH_HEX20: e = {3, 20, 8, FH_HEX8}; return true;
         default: return false;
     }
 }
@@ -451,6 +483,7 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         case FH_TET10: FH_FOR_OP(FH_TET10, OPV, CALL); break;                      \
         case FH_QUAD9: FH_FOR_OP(FH_QUAD9, OPV, CALL); break;                      \
         case FH_TRI6: FH_FOR_OP(FH_TRI6, OPV, CALL); break;                        \
+        case FH_HEX20: FH_FOR_OP(FH_HEX20, OPV, CALL); break;                      \
         default: break;                                                            \
     }
 #define FH_FOR_OP(EKC, OPV, CALL)                                   \

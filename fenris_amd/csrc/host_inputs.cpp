@@ -433,44 +433,48 @@ int fh_hex8_to_hex27(const double* v, uint64_t nv, const uint64_t* hex8, uint64_
 int fh_refine_to_quadratic(int from_kind, const double* v, uint64_t nv, const uint64_t* conn, uint64_t ncells, double* out_v,
                            uint64_t* out_nv, uint64_t* out_c) {
     if (!v || !conn || !out_v || !out_nv || !out_c) return FH_BAD_ARGUMENT;
-    const int n0 = (from_kind == FH_TET4) ? 4 : (from_kind == FH_TRI3) ? 3 : (from_kind == FH_QUAD4) ? 4 : 0;
+    const int n0 = (from_kind == FH_TET4) ? 4 : (from_kind == FH_TRI3) ? 3 : (from_kind == FH_QUAD4) ? 4 : (from_kind == FH_HEX8) ? 8 : 0;
     if (!n0) return FH_BAD_ARGUMENT;
     for (uint64_t i = 0; i < (uint64_t)n0 * ncells; ++i)
         if (conn[i] >= nv) return FH_BAD_ARGUMENT;
-    if (from_kind == FH_TET4) {
-        // Tet10Mesh::from(&tet4): RefineFrom (mesh_convert.rs:42-83) through the generic relabelling of :227-330 -- every
-        // node (vertex nodes first, then the six edge nodes) is identified by its sorted parent vertices and labelled in
-        // order of first occurrence, so the old vertex indices are NOT kept
-        static const int EDGE[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+    if (from_kind == FH_TET4 || from_kind == FH_HEX8) {
+        // Tet10Mesh::from(&tet4) / Hex20Mesh::from(&hex8): RefineFrom (mesh_convert.rs:42-83, 168-217) through the generic
+        // relabelling of :227-330 -- every node (vertex nodes first, then the edge nodes) is identified by its sorted
+        // parent vertices and labelled in order of first occurrence, so the old vertex indices are NOT kept
+        static const int EDGE_T[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+        static const int EDGE_H[12][2] = {{0, 1}, {0, 3}, {0, 4}, {1, 2}, {1, 5}, {2, 3}, {2, 6}, {3, 7}, {4, 5}, {4, 7}, {5, 6}, {6, 7}};
+        const bool hex = (from_kind == FH_HEX8);
+        const int nv0 = hex ? 8 : 4, ne = hex ? 12 : 6, n1 = nv0 + ne;
+        const int (*EDGE)[2] = hex ? EDGE_H : EDGE_T;
         const uint64_t NONE = ~0ull;
         std::unordered_map<ParentKey, uint64_t, ParentKeyHash> label;
         label.reserve(static_cast<size_t>(ncells) * 4);
         uint64_t next = 0;
         for (uint64_t e = 0; e < ncells; ++e) {
-            const uint64_t* g = conn + 4 * e;
-            double pos[10][3];
-            ParentKey key[10];
+            const uint64_t* g = conn + (uint64_t)nv0 * e;
+            double pos[20][3];
+            ParentKey key[20];
             for (auto& k : key) k.p.fill(NONE);
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < nv0; ++a) {
                 for (int r = 0; r < 3; ++r) pos[a][r] = v[3 * g[a] + r];
                 key[a].p[0] = g[a];
             }
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < ne; ++m) {
                 const int b = EDGE[m][0], en = EDGE[m][1];
                 // nalgebra lerp: self * (1 - t) + rhs * t
-                for (int r = 0; r < 3; ++r) pos[4 + m][r] = v[3 * g[b] + r] * (1.0 - 0.5) + v[3 * g[en] + r] * 0.5;
-                key[4 + m].p[0] = g[b];
-                key[4 + m].p[1] = g[en];
+                for (int r = 0; r < 3; ++r) pos[nv0 + m][r] = v[3 * g[b] + r] * (1.0 - 0.5) + v[3 * g[en] + r] * 0.5;
+                key[nv0 + m].p[0] = g[b];
+                key[nv0 + m].p[1] = g[en];
             }
-            for (int a = 0; a < 10; ++a) {
+            for (int a = 0; a < n1; ++a) {
                 std::sort(key[a].p.begin(), key[a].p.end());
                 auto it = label.find(key[a]);
                 if (it == label.end()) {
                     label.emplace(key[a], next);
                     std::memcpy(out_v + 3 * next, pos[a], sizeof(double) * 3);
-                    out_c[10 * e + a] = next++;
+                    out_c[(uint64_t)n1 * e + a] = next++;
                 } else {
-                    out_c[10 * e + a] = it->second;
+                    out_c[(uint64_t)n1 * e + a] = it->second;
                 }
             }
         }

@@ -131,3 +131,8 @@ def tri6_mesh_from_tri3(mesh: Mesh) -> Mesh:
 def quad9_mesh_from_quad4(mesh: Mesh) -> Mesh:
     """Mesh2d<Quad9d2Connectivity>::from(quad4_mesh) (src/mesh_convert.rs:385-442)"""
     return _refine(mesh, _ffi.QUAD4, _ffi.QUAD9)
+
+
+def hex20_mesh_from_hex8(mesh: Mesh) -> Mesh:
+    """Hex20Mesh::from(&hex8_mesh) (src/mesh_convert.rs:168-217, 227-330, 481-490)"""
+    return _refine(mesh, _ffi.HEX8, _ffi.HEX20)

@@ -129,13 +129,14 @@ int fo_element_num_nodes(int k) {
         case FO_TET10: return 10;
         case FO_QUAD9: return 9;
         case FO_TRI6: return 6;
+        case FO_HEX20: return 20;
         default: return -1;
     }
 }
 int fo_element_dim(int k) {
     switch (k) {
         case FO_QUAD4: case FO_TRI3: case FO_QUAD9: case FO_TRI6: return 2;
-        case FO_HEX8: case FO_TET4: case FO_HEX27: case FO_TET10: return 3;
+        case FO_HEX8: case FO_TET4: case FO_HEX27: case FO_TET10: case FO_HEX20: return 3;
         default: return -1;
     }
 }
@@ -225,6 +226,20 @@ int fo_element_basis(int kind, const double* xi, double* phi) {
             phi[5] = 4.0 * psi[0] * psi[2];
             return FO_OK;
         }
+        case FO_HEX20: /* hexahedron.rs:413-462: corner and edge functions; nodes = the first 20 of Hex27 */
+            for (int n = 0; n < 20; ++n) {
+                double alpha = HEX27_SIGNS[n][0], beta = HEX27_SIGNS[n][1], gamma = HEX27_SIGNS[n][2];
+                if (n < 8) {
+                    phi[n] = (1.0 / 8.0) * (1.0 + alpha * xi[0]) * (1.0 + beta * xi[1]) * (1.0 + gamma * xi[2]) *
+                             (alpha * xi[0] + beta * xi[1] + gamma * xi[2] - 2.0);
+                } else {
+                    double alpha2 = alpha * alpha, beta2 = beta * beta, gamma2 = gamma * gamma;
+                    phi[n] = (1.0 / 4.0) * (1.0 - (1.0 - alpha2) * xi[0] * xi[0]) * (1.0 - (1.0 - beta2) * xi[1] * xi[1]) *
+                             (1.0 - (1.0 - gamma2) * xi[2] * xi[2]) * (1.0 + alpha * xi[0]) * (1.0 + beta * xi[1]) *
+                             (1.0 + gamma * xi[2]);
+                }
+            }
+            return FO_OK;
         case FO_QUAD9: /* quadrilateral.rs:233-277: N_ab(xi, eta) = phi_a(xi) phi_b(eta), 1-D quadratic factors */
             for (int n = 0; n < 9; ++n)
                 phi[n] = phi_quadratic_1d(QUAD9_SIGNS[n][0], xi[0]) * phi_quadratic_1d(QUAD9_SIGNS[n][1], xi[1]);
@@ -288,6 +303,28 @@ int fo_element_gradients(int kind, const double* xi, double* g) {
             }
             return FO_OK;
         }
+        case FO_HEX20: /* hexahedron.rs:465-543 */
+            for (int n = 0; n < 20; ++n) {
+                double alpha = HEX27_SIGNS[n][0], beta = HEX27_SIGNS[n][1], gamma = HEX27_SIGNS[n][2];
+                double gg = (1.0 + alpha * xi[0]) * (1.0 + beta * xi[1]) * (1.0 + gamma * xi[2]);
+                if (n < 8) {
+                    double f = alpha * xi[0] + beta * xi[1] + gamma * xi[2] - 2.0, sc = 1.0 / 8.0;
+                    g[CM(0, n, 3)] = sc * (alpha * gg + f * alpha * (1.0 + beta * xi[1]) * (1.0 + gamma * xi[2]));
+                    g[CM(1, n, 3)] = sc * (beta * gg + f * beta * (1.0 + alpha * xi[0]) * (1.0 + gamma * xi[2]));
+                    g[CM(2, n, 3)] = sc * (gamma * gg + f * gamma * (1.0 + alpha * xi[0]) * (1.0 + beta * xi[1]));
+                } else {
+                    double alpha2 = alpha * alpha, beta2 = beta * beta, gamma2 = gamma * gamma, sc = 1.0 / 4.0;
+                    double h = (1.0 - (1.0 - alpha2) * xi[0] * xi[0]) * (1.0 - (1.0 - beta2) * xi[1] * xi[1]) *
+                               (1.0 - (1.0 - gamma2) * xi[2] * xi[2]);
+                    double dh0 = -2.0 * (1.0 - alpha2) * xi[0] * (1.0 - (1.0 - beta2) * xi[1] * xi[1]) * (1.0 - (1.0 - gamma2) * xi[2] * xi[2]);
+                    double dh1 = -2.0 * (1.0 - beta2) * xi[1] * (1.0 - (1.0 - alpha2) * xi[0] * xi[0]) * (1.0 - (1.0 - gamma2) * xi[2] * xi[2]);
+                    double dh2 = -2.0 * (1.0 - gamma2) * xi[2] * (1.0 - (1.0 - alpha2) * xi[0] * xi[0]) * (1.0 - (1.0 - beta2) * xi[1] * xi[1]);
+                    g[CM(0, n, 3)] = sc * (dh0 * gg + h * alpha * (1.0 + beta * xi[1]) * (1.0 + gamma * xi[2]));
+                    g[CM(1, n, 3)] = sc * (dh1 * gg + h * beta * (1.0 + alpha * xi[0]) * (1.0 + gamma * xi[2]));
+                    g[CM(2, n, 3)] = sc * (dh2 * gg + h * gamma * (1.0 + alpha * xi[0]) * (1.0 + beta * xi[1]));
+                }
+            }
+            return FO_OK;
         case FO_QUAD9: /* quadrilateral.rs:280-313 */
             for (int n = 0; n < 9; ++n) {
                 double alpha = QUAD9_SIGNS[n][0], beta = QUAD9_SIGNS[n][1];
@@ -306,6 +343,7 @@ int fo_element_gradients(int kind, const double* xi, double* g) {
 static int geometry_kind(int kind) {
     switch (kind) {
         case FO_HEX27: return FO_HEX8;
+        case FO_HEX20: return FO_HEX8;
         case FO_TET10: return FO_TET4;
         case FO_QUAD9: return FO_QUAD4;
         case FO_TRI6: return FO_TRI3;
@@ -739,30 +777,34 @@ int fo_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64
  *   (v_a + v_b) / 2; Quad9 then appends map_reference_coords(origin) of the cell. */
 int fo_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* conn_in,
                            uint64_t num_cells, double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity) {
-    if (from_kind == FO_TET4) {
-        static const int EDGES[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+    if (from_kind == FO_TET4 || from_kind == FO_HEX8) {
+        /* Hex8 -> Hex20 (mesh_convert.rs:168-217): the vertex and edge nodes of the Hex27 refinement */
+        static const int EDGES_T[6][2] = {{0, 1}, {1, 2}, {0, 2}, {0, 3}, {2, 3}, {1, 3}};
+        static const int EDGES_H[12][2] = {{0, 1}, {0, 3}, {0, 4}, {1, 2}, {1, 5}, {2, 3}, {2, 6}, {3, 7}, {4, 5}, {4, 7}, {5, 6}, {6, 7}};
+        const int (*EDGES)[2] = (from_kind == FO_HEX8) ? EDGES_H : EDGES_T;
+        const int NV0 = (from_kind == FO_HEX8) ? 8 : 4, NE = (from_kind == FO_HEX8) ? 12 : 6, N1 = NV0 + NE;
         size_t cap = 1;
-        while (cap < (size_t)num_cells * 10 * 2 + 16) cap <<= 1;
+        while (cap < (size_t)num_cells * 20 * 2 + 16) cap <<= 1;
         parent_slot* table = calloc(cap, sizeof(parent_slot));
-        double* fv = malloc(sizeof(double) * 3 * ((size_t)num_cells * 10 + 1));
-        uint64_t* conn = malloc(sizeof(uint64_t) * ((size_t)num_cells * 10 + 1));
+        double* fv = malloc(sizeof(double) * 3 * ((size_t)num_cells * 20 + 1));
+        uint64_t* conn = malloc(sizeof(uint64_t) * ((size_t)num_cells * 20 + 1));
         if (!table || !fv || !conn) return FO_BAD_ARGUMENT;
         uint64_t next = 0;
         for (uint64_t e = 0; e < num_cells; ++e) {
-            const uint64_t* gi = conn_in + 4 * e;
-            double lv[10][3];
-            uint64_t par[10][2];
-            int npar[10];
-            for (int n = 0; n < 4; ++n) {
+            const uint64_t* gi = conn_in + (uint64_t)NV0 * e;
+            double lv[20][3];
+            uint64_t par[20][2];
+            int npar[20];
+            for (int n = 0; n < NV0; ++n) {
                 for (int c = 0; c < 3; ++c) lv[n][c] = vertices[3 * gi[n] + c];
                 par[n][0] = gi[n]; npar[n] = 1;
             }
-            for (int ed = 0; ed < 6; ++ed) {
+            for (int ed = 0; ed < NE; ++ed) {
                 int b = EDGES[ed][0], en = EDGES[ed][1];
-                for (int c = 0; c < 3; ++c) lv[4 + ed][c] = vertices[3 * gi[b] + c] * (1.0 - 0.5) + vertices[3 * gi[en] + c] * 0.5;
-                par[4 + ed][0] = gi[b]; par[4 + ed][1] = gi[en]; npar[4 + ed] = 2;
+                for (int c = 0; c < 3; ++c) lv[NV0 + ed][c] = vertices[3 * gi[b] + c] * (1.0 - 0.5) + vertices[3 * gi[en] + c] * 0.5;
+                par[NV0 + ed][0] = gi[b]; par[NV0 + ed][1] = gi[en]; npar[NV0 + ed] = 2;
             }
-            for (int n = 0; n < 10; ++n) {
+            for (int n = 0; n < N1; ++n) {
                 qsort(par[n], (size_t)npar[n], sizeof(uint64_t), cmp_u64);
                 uint64_t h = hash_parents(par[n], npar[n]) & (cap - 1);
                 for (;;) {
@@ -772,11 +814,11 @@ int fo_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_v
                         memcpy(sl->key, par[n], sizeof(uint64_t) * (size_t)npar[n]);
                         sl->value = next;
                         for (int c = 0; c < 3; ++c) fv[3 * next + c] = lv[n][c];
-                        conn[10 * e + n] = next++;
+                        conn[(uint64_t)N1 * e + n] = next++;
                         break;
                     }
                     if (sl->nkey == npar[n] && memcmp(sl->key, par[n], sizeof(uint64_t) * (size_t)npar[n]) == 0) {
-                        conn[10 * e + n] = sl->value;
+                        conn[(uint64_t)N1 * e + n] = sl->value;
                         break;
                     }
                     h = (h + 1) & (cap - 1);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfenris_oracle.so")
 
-QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6 = 0, 1, 2, 3, 4, 5, 6, 7
+QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 OK, SINGULAR_JACOBIAN, BAD_ARGUMENT, COLUMN_NOT_FOUND = 0, 1, 2, 4
 
@@ -223,7 +223,7 @@ def hex8_to_hex27(vertices, conn):
 
 def refine_to_quadratic(from_kind, vertices, conn):
     """Tet4 -> Tet10, Tri3 -> Tri6, Quad4 -> Quad9 (src/mesh_convert.rs:42-83, 332-452)"""
-    d, n1 = {TET4: (3, 10), TRI3: (2, 6), QUAD4: (2, 9)}[from_kind]
+    d, n1 = {TET4: (3, 10), TRI3: (2, 6), QUAD4: (2, 9), HEX8: (3, 20)}[from_kind]
     vertices = np.ascontiguousarray(vertices, dtype=np.float64)
     conn = np.ascontiguousarray(conn, dtype=np.uint64)
     vp, cp, nv = _f64p(), _u64p(), C.c_uint64()

@@ -1,4 +1,4 @@
-"""Tet10 / Quad9 / Tri6 (sub-parametric quadratic elements): oracle pins on the CPU, HIP parity and the reference's
+"""Tet10 / Quad9 / Tri6 / Hex20 (sub-parametric quadratic elements): oracle pins on the CPU, HIP parity and the reference's
 MMS error JSONs on the GPU."""
 import json
 import os
@@ -10,7 +10,7 @@ import fenris_amd as fa
 from fenris_amd import quadrature
 from conftest import GOLDEN
 
-KIND = {"TET10": fa.TET10, "QUAD9": fa.QUAD9, "TRI6": fa.TRI6}
+KIND = {"TET10": fa.TET10, "QUAD9": fa.QUAD9, "TRI6": fa.TRI6, "HEX20": fa.HEX20}
 LAME = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
 OPS = {"LAPLACE": lambda: fa.LaplaceOperator(), "LINEAR_ELASTIC": lambda: fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
        "NEO_HOOKEAN": lambda: fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()), "STVK": lambda: fa.MaterialEllipticOperator(fa.StVKMaterial())}
@@ -18,6 +18,10 @@ REF_NODES = {  # reference elements: tetrahedron.rs:153-168, quadrilateral.rs:21
     "TET10": [[-1, -1, -1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1], [0, -1, -1], [0, 0, -1], [-1, 0, -1], [-1, -1, 0], [-1, 0, 0], [0, -1, 0]],
     "QUAD9": [[-1, -1], [1, -1], [1, 1], [-1, 1], [0, -1], [1, 0], [0, 1], [-1, 0], [0, 0]],
     "TRI6": [[-1, -1], [1, -1], [-1, 1], [0, -1], [0, 0], [-1, 0]],
+    # hexahedron.rs:376-402: corners, then the edge nodes in the order of Hex27
+    "HEX20": [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
+              [0, -1, -1], [-1, 0, -1], [-1, -1, 0], [1, 0, -1], [1, -1, 0], [0, 1, -1], [1, 1, 0], [-1, 1, 0],
+              [0, -1, 1], [-1, 0, 1], [1, 0, 1], [0, 1, 1]],
 }
 
 
@@ -37,10 +41,13 @@ def _mesh(kind, seed=0, distort=0.04):
         base = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
     elif kind == "QUAD9":
         base = fa.procedural.create_unit_square_uniform_quad_mesh_2d(3)
+    elif kind == "HEX20":
+        base = fa.procedural.create_unit_box_uniform_hex_mesh_3d(2)
     else:
         base = fa.procedural.create_unit_square_uniform_tri_mesh_2d(3)
     base = fa.Mesh(base.vertices + rng.uniform(-distort, distort, base.vertices.shape), base.connectivity, base.elem_kind)
-    return {"TET10": fa.tet10_mesh_from_tet4, "QUAD9": fa.quad9_mesh_from_quad4, "TRI6": fa.tri6_mesh_from_tri3}[kind](base), base
+    return {"TET10": fa.tet10_mesh_from_tet4, "QUAD9": fa.quad9_mesh_from_quad4, "TRI6": fa.tri6_mesh_from_tri3,
+            "HEX20": fa.hex20_mesh_from_hex8}[kind](base), base
 
 
 def _rule(kind):
@@ -48,11 +55,13 @@ def _rule(kind):
         return quadrature.total_order.tetrahedron(3)
     if kind == "QUAD9":
         return quadrature.tensor.quadrilateral_gauss(3)
+    if kind == "HEX20":
+        return quadrature.tensor.hexahedron_gauss(3)
     return _tri_rule6()
 
 
 # ------------------------------------------------------------------------------------------- CPU: oracle pins
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
 def test_oracle_basis_is_nodal_and_a_partition_of_unity(oracle, kind):
     """the properties the reference's element tests check (partition of unity, Lagrange property at the reference
     nodes, gradients consistent with finite differences)"""
@@ -73,18 +82,19 @@ def test_oracle_basis_is_nodal_and_a_partition_of_unity(oracle, kind):
             assert np.abs(fd - g[:, c]).max() < 1e-8
 
 
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
 def test_refinement_product_equals_oracle_and_is_consistent(oracle, kind):
     mesh, base = _mesh(kind, seed=1)
-    ov, oc = oracle.refine_to_quadratic(getattr(oracle, {"TET10": "TET4", "QUAD9": "QUAD4", "TRI6": "TRI3"}[kind]), base.vertices,
+    ov, oc = oracle.refine_to_quadratic(getattr(oracle, {"TET10": "TET4", "QUAD9": "QUAD4", "TRI6": "TRI3", "HEX20": "HEX8"}[kind]), base.vertices,
                                         base.connectivity)
     assert np.array_equal(mesh.vertices, ov) and np.array_equal(mesh.connectivity, oc)  # bit-exact
     # edge nodes are the midpoints of their end vertices, shared edges share their node
     c = mesh.connectivity.astype(int)
     edges = {"TET10": [(0, 1), (1, 2), (0, 2), (0, 3), (2, 3), (1, 3)], "QUAD9": [(0, 1), (1, 2), (2, 3), (3, 0)],
-             "TRI6": [(0, 1), (1, 2), (2, 0)]}[kind]
+             "TRI6": [(0, 1), (1, 2), (2, 0)],
+             "HEX20": [(0, 1), (0, 3), (0, 4), (1, 2), (1, 5), (2, 3), (2, 6), (3, 7), (4, 5), (4, 7), (5, 6), (6, 7)]}[kind]
     nv = len(edges) + (0 if kind == "QUAD9" else 0)
-    first = {"TET10": 4, "QUAD9": 4, "TRI6": 3}[kind]
+    first = {"TET10": 4, "QUAD9": 4, "TRI6": 3, "HEX20": 8}[kind]
     for m, (a, b) in enumerate(edges):
         mid = 0.5 * (mesh.vertices[c[:, a]] + mesh.vertices[c[:, b]])
         assert np.abs(mesh.vertices[c[:, first + m]] - mid).max() < 1e-15
@@ -94,7 +104,7 @@ def test_refinement_product_equals_oracle_and_is_consistent(oracle, kind):
 
 
 @pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad9_summary", "QUAD9", 3), ("poisson2d_mms_tri6_summary", "TRI6", 3),
-                                            ("poisson3d_mms_tet10_summary", "TET10", 2)])
+                                            ("poisson3d_mms_tet10_summary", "TET10", 2), ("poisson3d_mms_hex20_summary", "HEX20", 2)])
 def test_oracle_mms_errors(oracle, name, kind, nres):
     """tests/convergence_tests/poisson_{2d,3d}_mms.rs with the oracle end to end (assembly, source, Dirichlet, CG, error
     norms) against the reference's error JSONs (1 %)"""
@@ -109,6 +119,9 @@ def _mms(name, kind, nres, engines, oracle):
     elif kind == "TRI6":
         gen = lambda r: fa.tri6_mesh_from_tri3(fa.procedural.create_unit_square_uniform_tri_mesh_2d(r))
         rule, err_rule = quadrature.total_order.triangle(2), _tri_rule6()
+    elif kind == "HEX20":  # poisson_3d_mms.rs:91-98
+        gen = lambda r: fa.hex20_mesh_from_hex8(fa.procedural.create_unit_box_uniform_hex_mesh_3d(r))
+        rule, err_rule = quadrature.tensor.hexahedron_gauss(4), quadrature.tensor.hexahedron_gauss(6)
     else:
         gen = lambda r: fa.tet10_mesh_from_tet4(fa.procedural.create_unit_box_uniform_tet_mesh_3d(r))
         rule, err_rule = quadrature.total_order.tetrahedron(2), _tet_rule6()
@@ -184,7 +197,7 @@ def engine():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
 @pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK"])
 def test_matrix_vector_scalar_match_oracle(engine, oracle, kind, op):
     mesh, _ = _mesh(kind, seed=2)
@@ -220,7 +233,7 @@ def test_matrix_vector_scalar_match_oracle(engine, oracle, kind, op):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
 def test_mass_and_source_match_oracle(engine, oracle, kind):
     mesh, _ = _mesh(kind, seed=4)
     w, p = _rule(kind)
@@ -241,7 +254,7 @@ def test_mass_and_source_match_oracle(engine, oracle, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad9_summary", "QUAD9", 4), ("poisson2d_mms_tri6_summary", "TRI6", 4),
-                                            ("poisson3d_mms_tet10_summary", "TET10", 3)])
+                                            ("poisson3d_mms_tet10_summary", "TET10", 3), ("poisson3d_mms_hex20_summary", "HEX20", 3)])
 def test_mms_loop_on_device(oracle, name, kind, nres):
     engines = (fa.Engine(0), fa.Engine(0), fa.Engine(0))
     try:

@@ -5,7 +5,7 @@ fenris -- global stiffness / residual assembly -- lives here; see DESIGN.md.
 """
 from . import _ffi, assembly, io, mesh, operators, quadrature, reorder
 from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
-                   SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, TET10, QUAD9, TRI6, HEX20, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
+                   SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, TET10, QUAD9, TRI6, HEX20, TET20, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,
                        ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,
                        MockElementAssembler, UniformQuadratureTable, CompactQuadratureTable,
@@ -13,7 +13,7 @@ from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsets
                        apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes, CgSolveError, ConjugateGradient,
                        IdentityOperator, JacobiPreconditioner, RelativeResidualCriterion, estimate_H1_seminorm_error,
                        estimate_H1_seminorm_error_squared, estimate_L2_error, estimate_L2_error_squared)
-from .mesh import Mesh, hex20_mesh_from_hex8, hex27_mesh_from_hex8, procedural, quad9_mesh_from_quad4, tet10_mesh_from_tet4, tri6_mesh_from_tri3
+from .mesh import Mesh, hex20_mesh_from_hex8, hex27_mesh_from_hex8, procedural, quad9_mesh_from_quad4, tet10_mesh_from_tet4, tet20_mesh_from_tet4, tri6_mesh_from_tri3
 from .operators import (Density, GravitySource, SourceFunction, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
                         NeoHookeanMaterial, StVKMaterial, YoungPoisson)
 

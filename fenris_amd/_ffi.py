@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfenris_hip.so")
 
 FH_OK, FH_SINGULAR_JACOBIAN, FH_BAD_ARGUMENT, FH_HIP_ERROR, FH_INVALID_STATE, FH_UNSUPPORTED = 0, 1, 2, 3, 5, 6
-QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER = 0, 1, 2
 ASSEMBLE_OVERWRITE = 0x100
 
-ELEM_NODES = {QUAD4: 4, HEX8: 8, TET4: 4, HEX27: 27, TRI3: 3, TET10: 10, QUAD9: 9, TRI6: 6, HEX20: 20}
-ELEM_DIM = {QUAD4: 2, HEX8: 3, TET4: 3, HEX27: 3, TRI3: 2, TET10: 3, QUAD9: 2, TRI6: 2, HEX20: 3}
+ELEM_NODES = {QUAD4: 4, HEX8: 8, TET4: 4, HEX27: 27, TRI3: 3, TET10: 10, QUAD9: 9, TRI6: 6, HEX20: 20, TET20: 20}
+ELEM_DIM = {QUAD4: 2, HEX8: 3, TET4: 3, HEX27: 3, TRI3: 2, TET10: 3, QUAD9: 2, TRI6: 2, HEX20: 3, TET20: 3}
 
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
@@ -103,6 +103,7 @@ _SIGS = {
     "fh_hex8_to_hex27": (C.c_int, [f64p, C.c_uint64, u64p, C.c_uint64, f64p, u64p, u64p]),
     "fh_load_msh": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, f64p, u64p, u64p, u64p]),
     "fh_msh_last_error": (C.c_char_p, []),
+    "fh_tet4_to_tet20": (C.c_int, [f64p, C.c_uint64, u64p, C.c_uint64, f64p, u64p, u64p]),
     "fh_refine_to_quadratic": (C.c_int, [C.c_int, f64p, C.c_uint64, u64p, C.c_uint64, f64p, u64p, u64p]),
     "fh_cuthill_mckee": (C.c_int, [C.c_uint64, u64p, u64p, u64p]),
     "fh_reorder_mesh": (C.c_int, [C.c_uint64, C.c_uint64, u64p, C.c_uint64, u64p, u64p]),

@@ -20,6 +20,7 @@ template <> struct ElemT<FH_TET10> { static constexpr int D = 3, N = 10, NG = 4;
 template <> struct ElemT<FH_QUAD9> { static constexpr int D = 2, N = 9, NG = 4; };
 template <> struct ElemT<FH_TRI6>  { static constexpr int D = 2, N = 6, NG = 3; };
 template <> struct ElemT<FH_HEX20> { static constexpr int D = 3, N = 20, NG = 8; };
+template <> struct ElemT<FH_TET20> { static constexpr int D = 3, N = 20, NG = 4; };
 
 // ------------------------------------------------------------------------------------ operator traits
 // Per (element, quadrature point) the prologue leaves in LDS:  NVEC vectors per node (physical

@@ -121,6 +121,28 @@ void ref_gradients(int kind, const double* xi, double* out) {
             }
             break;
         }
+        case FH_TET20: {  // tetrahedron.rs:404-466: products of the Tet4 basis psi and its gradients g
+            static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+            static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+            double psi[4], g[12];
+            ref_basis(FH_TET4, xi, psi);
+            ref_gradients(FH_TET4, xi, g);
+            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 3; ++k) out[3 * i + k] = g[3 * i + k] * 0.5 * (27.0 * psi[i] * psi[i] - 18.0 * psi[i] + 2.0);
+            for (int m = 0; m < 6; ++m)
+                for (int half = 0; half < 2; ++half) {  // edge_gradient(a, b): the node closer to a
+                    const int a = half ? ED[m][1] : ED[m][0], b = half ? ED[m][0] : ED[m][1];
+                    const double pa = psi[a], pb = psi[b];
+                    for (int k = 0; k < 3; ++k)
+                        out[3 * (4 + 2 * m + half) + k] = (g[3 * a + k] * (pb * (6.0 * pa - 1.0)) + g[3 * b + k] * (pa * (3.0 * pa - 1.0))) * (9.0 / 2.0);
+                }
+            for (int f = 0; f < 4; ++f) {
+                const int a = FA[f][0], b = FA[f][1], c = FA[f][2];
+                for (int k = 0; k < 3; ++k)
+                    out[3 * (16 + f) + k] = (g[3 * a + k] * psi[b] * psi[c] + g[3 * b + k] * psi[a] * psi[c] + g[3 * c + k] * psi[a] * psi[b]) * 27.0;
+            }
+            break;
+        }
         case FH_HEX20:
             for (int n = 0; n < 20; ++n) {  // hexahedron.rs:465-543: phi = s f g (corners) / s h g (edges), product rule
                 const double al = HEX_SIGN[n][0], be = HEX_SIGN[n][1], ga = HEX_SIGN[n][2];
@@ -192,6 +214,20 @@ void ref_basis(int kind, const double* xi, double* out) {
             out[3] = 4.0 * p[0] * p[1]; out[4] = 4.0 * p[1] * p[2]; out[5] = 4.0 * p[0] * p[2];
             break;
         }
+        case FH_TET20: {  // tetrahedron.rs:346-401
+            static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+            static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+            double psi[4];
+            ref_basis(FH_TET4, xi, psi);
+            for (int i = 0; i < 4; ++i) out[i] = 0.5 * psi[i] * (3.0 * psi[i] - 1.0) * (3.0 * psi[i] - 2.0);
+            for (int m = 0; m < 6; ++m)
+                for (int half = 0; half < 2; ++half) {  // phi_edge(closest, other)
+                    const int cl = half ? ED[m][1] : ED[m][0], ot = half ? ED[m][0] : ED[m][1];
+                    out[4 + 2 * m + half] = (9.0 / 2.0) * psi[cl] * psi[ot] * (3.0 * psi[cl] - 1.0);
+                }
+            for (int f = 0; f < 4; ++f) out[16 + f] = 27.0 * psi[FA[f][0]] * psi[FA[f][1]] * psi[FA[f][2]];
+            break;
+        }
         case FH_HEX20:  // hexahedron.rs:413-462
             for (int n = 0; n < 20; ++n) {
                 const double al = HEX_SIGN[n][0], be = HEX_SIGN[n][1], ga = HEX_SIGN[n][2];
@@ -219,6 +255,7 @@ bool elem_info(int kind, ElemInfo& e) {
         case FH_QUAD9: e = {2, 9, 4, FH_QUAD4}; return true;
         case FH_TRI6: e = {2, 6, 3, FH_TRI3}; return true;
         case FH_HEX20: e = {3, 20, 8, FH_HEX8}; return true;
+        case FH_TET20: e = {3, 20, 4, FH_TET4}; return true;
         default: return false;
     }
 }
@@ -484,6 +521,7 @@ size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int 
         case FH_QUAD9: FH_FOR_OP(FH_QUAD9, OPV, CALL); break;                      \
         case FH_TRI6: FH_FOR_OP(FH_TRI6, OPV, CALL); break;                        \
         case FH_HEX20: FH_FOR_OP(FH_HEX20, OPV, CALL); break;                      \
+        case FH_TET20: FH_FOR_OP(FH_TET20, OPV, CALL); break;                      \
         default: break;                                                            \
     }
 #define FH_FOR_OP(EKC, OPV, CALL)                                   \

@@ -87,29 +87,19 @@ bool tensor_rule(unsigned dim, unsigned n, double* w_out, double* p_out) {
 }
 
 // Witherden-Vincent tables as decimal strings, converted with strtod like Rust's str::parse::<f64>
-// (polyquad-parse/src/lib.rs:48-51).  Row = coordinates..., weight.
+// (polyquad-parse/src/lib.rs:48-51).  Row = coordinates..., weight.  Tabulated: tet 1, 2, 3, 5, 6; tri 1, 2, 4, 5, 6.
 struct TableRule { unsigned strength, npts; const char* const* rows; };
-static const char* const TET_1[] = {"-0.5", "-0.5", "-0.5", "1.3333333333333333333333333333333333333"};
-#define A2 "-0.72360679774997896964091736687312762354"
-#define B2 "0.17082039324993690892275210061938287063"
-#define W2 "0.33333333333333333333333333333333333333"
-static const char* const TET_2[] = {A2, A2, B2, W2, A2, B2, A2, W2, B2, A2, A2, W2, A2, A2, A2, W2};
-#define A3 "-0.34367339496723662642072827083693243093"
-#define B3 "-0.9689798150982901207378151874892027072"
-#define W3A "0.18162379004944980942342872025562069427"
-#define C3 "-0.78390550020314279176487322158837338344"
-#define D3 "0.35171650060942837529461966476512015033"
-#define W3B "0.15170954328388352390990461307771263906"
-static const char* const TET_3[] = {A3, A3, B3, W3A, A3, B3, A3, W3A, B3, A3, A3, W3A, A3, A3, A3, W3A,
-                                    C3, C3, D3, W3B, C3, D3, C3, W3B, D3, C3, C3, W3B, C3, C3, C3, W3B};
-static const TableRule TET_RULES[] = {{1, 1, TET_1}, {2, 4, TET_2}, {3, 8, TET_3}};
-#define T13 "-0.33333333333333333333333333333333333333"
-static const char* const TRI_1[] = {T13, T13, "2"};
-#define T23 "-0.66666666666666666666666666666666666667"
-#define T13P "0.33333333333333333333333333333333333333"
-#define T23P "0.66666666666666666666666666666666666667"
-static const char* const TRI_2[] = {T23, T13P, T23P, T13P, T23, T23P, T23, T23, T23P};
-static const TableRule TRI_RULES[] = {{1, 1, TRI_1}, {2, 3, TRI_2}};
+#include "polyquad_tables.inc"
+static const TableRule TET_RULES[] = {{FH_PQ_TET_TABLES[0].strength, FH_PQ_TET_TABLES[0].npts, FH_PQ_TET_TABLES[0].rows},
+                                      {FH_PQ_TET_TABLES[1].strength, FH_PQ_TET_TABLES[1].npts, FH_PQ_TET_TABLES[1].rows},
+                                      {FH_PQ_TET_TABLES[2].strength, FH_PQ_TET_TABLES[2].npts, FH_PQ_TET_TABLES[2].rows},
+                                      {FH_PQ_TET_TABLES[3].strength, FH_PQ_TET_TABLES[3].npts, FH_PQ_TET_TABLES[3].rows},
+                                      {FH_PQ_TET_TABLES[4].strength, FH_PQ_TET_TABLES[4].npts, FH_PQ_TET_TABLES[4].rows}};
+static const TableRule TRI_RULES[] = {{FH_PQ_TRI_TABLES[0].strength, FH_PQ_TRI_TABLES[0].npts, FH_PQ_TRI_TABLES[0].rows},
+                                      {FH_PQ_TRI_TABLES[1].strength, FH_PQ_TRI_TABLES[1].npts, FH_PQ_TRI_TABLES[1].rows},
+                                      {FH_PQ_TRI_TABLES[2].strength, FH_PQ_TRI_TABLES[2].npts, FH_PQ_TRI_TABLES[2].rows},
+                                      {FH_PQ_TRI_TABLES[3].strength, FH_PQ_TRI_TABLES[3].npts, FH_PQ_TRI_TABLES[3].rows},
+                                      {FH_PQ_TRI_TABLES[4].strength, FH_PQ_TRI_TABLES[4].npts, FH_PQ_TRI_TABLES[4].rows}};
 
 // select_minimum (fenris-quadrature/build.rs:172-194): smallest tabulated strength >= requested
 template <size_t K>
@@ -429,6 +419,62 @@ int fh_hex8_to_hex27(const double* v, uint64_t nv, const uint64_t* hex8, uint64_
     hex8_to_hex27(v, hex8, ncells, out_v, out_nv, out_c);
     return FH_OK;
 }
+// Tet20Mesh::from(&tet4_mesh), src/mesh_convert.rs:658-775
+int fh_tet4_to_tet20(const double* v, uint64_t nv, const uint64_t* tet4, uint64_t ncells, double* out_v, uint64_t* out_nv,
+                     uint64_t* out_c) {
+    if (!v || !tet4 || !out_v || !out_nv || !out_c) return FH_BAD_ARGUMENT;
+    for (uint64_t i = 0; i < 4 * ncells; ++i)
+        if (tet4[i] >= nv) return FH_BAD_ARGUMENT;
+    using Key = std::array<uint64_t, 4>;
+    static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+    static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+    auto element_keys = [&](const uint64_t* g, Key (&k)[20]) {
+        for (int a = 0; a < 4; ++a) k[a] = Key{g[a], 0, 0, 0};
+        for (int m = 0; m < 6; ++m)
+            for (uint64_t local = 0; local < 2; ++local) {
+                uint64_t s0 = g[ED[m][0]], e0 = g[ED[m][1]], l = local;
+                if (s0 > e0) { std::swap(s0, e0); l = (l + 1) % 2; }  // normalized_edge :685-692
+                k[4 + 2 * m + (int)local] = Key{s0, e0, l, 1};
+            }
+        for (int f = 0; f < 4; ++f) {
+            std::array<uint64_t, 3> t{g[FA[f][0]], g[FA[f][1]], g[FA[f][2]]};
+            std::sort(t.begin(), t.end());
+            k[16 + f] = Key{t[0], t[1], t[2], 2};
+        }
+    };
+    std::vector<Key> all;
+    all.reserve((size_t)ncells * 20);
+    Key k[20];
+    for (uint64_t e = 0; e < ncells; ++e) {
+        element_keys(tet4 + 4 * e, k);
+        all.insert(all.end(), k, k + 20);
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (uint64_t e = 0; e < ncells; ++e) {
+        element_keys(tet4 + 4 * e, k);
+        for (int a = 0; a < 20; ++a) out_c[20 * e + a] = (uint64_t)(std::lower_bound(all.begin(), all.end(), k[a]) - all.begin());
+    }
+    for (size_t i = 0; i < all.size(); ++i) {
+        const Key& q = all[i];
+        for (int r = 0; r < 3; ++r) {
+            double x;
+            if (q[3] == 0) {
+                x = v[3 * q[0] + r];
+            } else if (q[3] == 1) {  // start + (end - start) * ((local + 1) / 3)
+                const double st = v[3 * q[0] + r], en = v[3 * q[1] + r];
+                const double alpha = (double)(q[2] + 1) / 3.0;
+                x = st + (en - st) * alpha;
+            } else {                 // (a + b + c) / 3
+                x = ((v[3 * q[0] + r] + v[3 * q[1] + r]) + v[3 * q[2] + r]) / 3.0;
+            }
+            out_v[3 * i + r] = x;
+        }
+    }
+    *out_nv = all.size();
+    return FH_OK;
+}
+
 // p-refinement of linear meshes to their quadratic counterparts (src/mesh_convert.rs)
 int fh_refine_to_quadratic(int from_kind, const double* v, uint64_t nv, const uint64_t* conn, uint64_t ncells, double* out_v,
                            uint64_t* out_nv, uint64_t* out_c) {

@@ -136,3 +136,17 @@ def quad9_mesh_from_quad4(mesh: Mesh) -> Mesh:
 def hex20_mesh_from_hex8(mesh: Mesh) -> Mesh:
     """Hex20Mesh::from(&hex8_mesh) (src/mesh_convert.rs:168-217, 227-330, 481-490)"""
     return _refine(mesh, _ffi.HEX8, _ffi.HEX20)
+
+
+def tet20_mesh_from_tet4(mesh: Mesh) -> Mesh:
+    """Tet20Mesh::from(&tet4_mesh) (src/mesh_convert.rs:658-775)"""
+    assert mesh.elem_kind == _ffi.TET4
+    E = mesh.num_elements()
+    out_v = np.zeros((max(20 * E, 1), 3))
+    out_c = np.zeros((E, 20), dtype=np.uint64)
+    nv = C.c_uint64()
+    rc = _ffi.lib().fh_tet4_to_tet20(_ffi.fp(mesh.vertices), mesh.num_nodes(), _ffi.up(mesh.connectivity), E, _ffi.fp(out_v),
+                                     C.byref(nv), _ffi.up(out_c))
+    if rc:
+        raise _ffi.FenrisError(rc, "tet4_to_tet20")
+    return Mesh(out_v[: nv.value].copy(), out_c, _ffi.TET20)

@@ -58,7 +58,9 @@ enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4,
         * Tri6d2Element (triangle.rs:130-260) */
        FH_TET10 = 5, FH_QUAD9 = 6, FH_TRI6 = 7,
        /* Hex20Element, 20-node serendipity (src/element/hexahedron.rs:357-563), geometry from the embedded Hex8 */
-       FH_HEX20 = 8 };
+       FH_HEX20 = 8,
+       /* Tet20Element, cubic (src/element/tetrahedron.rs:248-470), geometry from the embedded Tet4 */
+       FH_TET20 = 9 };
 
 /* operator kinds: LaplaceOperator (src/assembly/operators/laplace.rs), MaterialEllipticOperator over
  * LinearElasticMaterial / NeoHookeanMaterial / StVKMaterial (fenris-solid/src/lib.rs:412-508,
@@ -220,9 +222,14 @@ int fh_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64
 /* p-refinement of the linear meshes (src/mesh_convert.rs): Tet10Mesh::from(&tet4) (:42-83, 444-452: vertex nodes then
  * the edge nodes (0,1) (1,2) (0,2) (0,3) (2,3) (1,3), labels in order of first occurrence), Tri6 from Tri3 (:332-383)
  * and Quad9 from Quad4 (:385-442): the old vertices keep their indices, edge midpoints are appended in order of first
- * occurrence, Quad9 also appends the cell midpoint.  from_kind is FH_TET4 / FH_TRI3 / FH_QUAD4, or FH_HEX8 for
+ * occurrence, Quad9 also appends the cell midpoint.  from_kind is FH_TET4 / FH_TRI3 / FH_QUAD4, FH_HEX8 for
  * Hex20Mesh::from(&hex8) (:168-217: the 8 vertex nodes and the 12 edge nodes of Hex27, same labelling); out_vertices capacity
  * (nodes per refined element) * num_cells * d doubles. */
+/* Tet20Mesh::from(&tet4) (src/mesh_convert.rs:658-775): new vertices = the sorted, deduplicated 4-tuples [idx,0,0,0]
+ * (vertex), [min,max,local,1] (two nodes per edge, local counted from min), [a,b,c,2] (face centroid); the label of a
+ * vertex is its rank in that order.  out_vertices capacity 20 * num_cells * 3 doubles. */
+int fh_tet4_to_tet20(const double* vertices, uint64_t num_vertices, const uint64_t* tet4, uint64_t num_cells,
+                     double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
 int fh_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* connectivity,
                            uint64_t num_cells, double* out_vertices, uint64_t* out_num_vertices, uint64_t* out_connectivity);
 /* load_msh_from_bytes (src/io/msh.rs:47-111), Gmsh MSH 4.1 ASCII: vertices of all node blocks in file order (x, y for the

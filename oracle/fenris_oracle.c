@@ -130,13 +130,14 @@ int fo_element_num_nodes(int k) {
         case FO_QUAD9: return 9;
         case FO_TRI6: return 6;
         case FO_HEX20: return 20;
+        case FO_TET20: return 20;
         default: return -1;
     }
 }
 int fo_element_dim(int k) {
     switch (k) {
         case FO_QUAD4: case FO_TRI3: case FO_QUAD9: case FO_TRI6: return 2;
-        case FO_HEX8: case FO_TET4: case FO_HEX27: case FO_TET10: case FO_HEX20: return 3;
+        case FO_HEX8: case FO_TET4: case FO_HEX27: case FO_TET10: case FO_HEX20: case FO_TET20: return 3;
         default: return -1;
     }
 }
@@ -226,6 +227,20 @@ int fo_element_basis(int kind, const double* xi, double* phi) {
             phi[5] = 4.0 * psi[0] * psi[2];
             return FO_OK;
         }
+        case FO_TET20: { /* tetrahedron.rs:346-401 (Zienkiewicz): products of the Tet4 basis */
+            static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+            static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+            double psi[4];
+            fo_element_basis(FO_TET4, xi, psi);
+            for (int i = 0; i < 4; ++i) phi[i] = 0.5 * psi[i] * (3.0 * psi[i] - 1.0) * (3.0 * psi[i] - 2.0);
+            for (int m = 0; m < 6; ++m) {
+                int a = ED[m][0], b = ED[m][1];
+                phi[4 + 2 * m] = (9.0 / 2.0) * psi[a] * psi[b] * (3.0 * psi[a] - 1.0);      /* phi_edge(a, b) */
+                phi[4 + 2 * m + 1] = (9.0 / 2.0) * psi[b] * psi[a] * (3.0 * psi[b] - 1.0);  /* phi_edge(b, a) */
+            }
+            for (int f = 0; f < 4; ++f) phi[16 + f] = 27.0 * psi[FA[f][0]] * psi[FA[f][1]] * psi[FA[f][2]];
+            return FO_OK;
+        }
         case FO_HEX20: /* hexahedron.rs:413-462: corner and edge functions; nodes = the first 20 of Hex27 */
             for (int n = 0; n < 20; ++n) {
                 double alpha = HEX27_SIGNS[n][0], beta = HEX27_SIGNS[n][1], gamma = HEX27_SIGNS[n][2];
@@ -303,6 +318,32 @@ int fo_element_gradients(int kind, const double* xi, double* g) {
             }
             return FO_OK;
         }
+        case FO_TET20: { /* tetrahedron.rs:404-466 */
+            static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+            static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+            double psi[4], gl[12];
+            fo_element_basis(FO_TET4, xi, psi);
+            fo_element_gradients(FO_TET4, xi, gl);
+            for (int i = 0; i < 4; ++i) {
+                double pp = psi[i];
+                for (int k = 0; k < 3; ++k) g[CM(k, i, 3)] = gl[CM(k, i, 3)] * 0.5 * (27.0 * pp * pp - 18.0 * pp + 2.0);
+            }
+            for (int m = 0; m < 6; ++m)
+                for (int half = 0; half < 2; ++half) {
+                    int a = half ? ED[m][1] : ED[m][0], b = half ? ED[m][0] : ED[m][1];
+                    double pa = psi[a], pb = psi[b];
+                    for (int k = 0; k < 3; ++k)
+                        g[CM(k, 4 + 2 * m + half, 3)] =
+                            (gl[CM(k, a, 3)] * (pb * (6.0 * pa - 1.0)) + gl[CM(k, b, 3)] * (pa * (3.0 * pa - 1.0))) * (9.0 / 2.0);
+                }
+            for (int f = 0; f < 4; ++f) {
+                int a = FA[f][0], b = FA[f][1], c = FA[f][2];
+                for (int k = 0; k < 3; ++k)
+                    g[CM(k, 16 + f, 3)] = (gl[CM(k, a, 3)] * psi[b] * psi[c] + gl[CM(k, b, 3)] * psi[a] * psi[c] +
+                                           gl[CM(k, c, 3)] * psi[a] * psi[b]) * 27.0;
+            }
+            return FO_OK;
+        }
         case FO_HEX20: /* hexahedron.rs:465-543 */
             for (int n = 0; n < 20; ++n) {
                 double alpha = HEX27_SIGNS[n][0], beta = HEX27_SIGNS[n][1], gamma = HEX27_SIGNS[n][2];
@@ -345,6 +386,7 @@ static int geometry_kind(int kind) {
         case FO_HEX27: return FO_HEX8;
         case FO_HEX20: return FO_HEX8;
         case FO_TET10: return FO_TET4;
+        case FO_TET20: return FO_TET4;
         case FO_QUAD9: return FO_QUAD4;
         case FO_TRI6: return FO_TRI3;
         default: return kind;
@@ -459,54 +501,34 @@ int fo_hexahedron_gauss(int n, double* w3, double* p3) {
     return FO_OK;
 }
 
-/* Witherden-Vincent tables, fenris-quadrature/rules/polyquad/expanded/tet/{1-1,2-4,3-8}.txt, parsed
- * like Rust str::parse::<f64> (correctly rounded) -> strtod. select_minimum: build.rs:172-194 */
+/* Witherden-Vincent tables, fenris-quadrature/rules/polyquad/expanded/{tet,tri}/ *.txt (data, generated into
+ * polyquad_tables.inc), parsed like Rust str::parse::<f64> (correctly rounded) -> strtod.
+ * select_minimum (build.rs:172-194): the smallest tabulated strength >= the requested one. */
+#include "polyquad_tables.inc"
 int fo_tetrahedron_rule(int strength, double* w, double* p) {
-    static const char* T1[] = {"-0.5", "-0.5", "-0.5", "1.3333333333333333333333333333333333333"};
-    static const char* T2[] = {
-        "-0.72360679774997896964091736687312762354", "-0.72360679774997896964091736687312762354", "0.17082039324993690892275210061938287063", "0.33333333333333333333333333333333333333",
-        "-0.72360679774997896964091736687312762354", "0.17082039324993690892275210061938287063", "-0.72360679774997896964091736687312762354", "0.33333333333333333333333333333333333333",
-        "0.17082039324993690892275210061938287063", "-0.72360679774997896964091736687312762354", "-0.72360679774997896964091736687312762354", "0.33333333333333333333333333333333333333",
-        "-0.72360679774997896964091736687312762354", "-0.72360679774997896964091736687312762354", "-0.72360679774997896964091736687312762354", "0.33333333333333333333333333333333333333"};
-    static const char* T3[] = {
-        "-0.34367339496723662642072827083693243093", "-0.34367339496723662642072827083693243093", "-0.9689798150982901207378151874892027072", "0.18162379004944980942342872025562069427",
-        "-0.34367339496723662642072827083693243093", "-0.9689798150982901207378151874892027072", "-0.34367339496723662642072827083693243093", "0.18162379004944980942342872025562069427",
-        "-0.9689798150982901207378151874892027072", "-0.34367339496723662642072827083693243093", "-0.34367339496723662642072827083693243093", "0.18162379004944980942342872025562069427",
-        "-0.34367339496723662642072827083693243093", "-0.34367339496723662642072827083693243093", "-0.34367339496723662642072827083693243093", "0.18162379004944980942342872025562069427",
-        "-0.78390550020314279176487322158837338344", "-0.78390550020314279176487322158837338344", "0.35171650060942837529461966476512015033", "0.15170954328388352390990461307771263906",
-        "-0.78390550020314279176487322158837338344", "0.35171650060942837529461966476512015033", "-0.78390550020314279176487322158837338344", "0.15170954328388352390990461307771263906",
-        "0.35171650060942837529461966476512015033", "-0.78390550020314279176487322158837338344", "-0.78390550020314279176487322158837338344", "0.15170954328388352390990461307771263906",
-        "-0.78390550020314279176487322158837338344", "-0.78390550020314279176487322158837338344", "-0.78390550020314279176487322158837338344", "0.15170954328388352390990461307771263906"};
-    const char** T;
-    int np;
-    if (strength <= 1) { T = T1; np = 1; }
-    else if (strength == 2) { T = T2; np = 4; }
-    else if (strength == 3) { T = T3; np = 8; }
-    else return -1;
-    for (int i = 0; i < np; ++i) {
-        for (int c = 0; c < 3; ++c) p[3 * i + c] = strtod(T[4 * i + c], NULL);
-        w[i] = strtod(T[4 * i + 3], NULL);
+    for (size_t t = 0; t < sizeof FO_PQ_TET_TABLES / sizeof FO_PQ_TET_TABLES[0]; ++t) {
+        if ((int)FO_PQ_TET_TABLES[t].strength < strength) continue;
+        int np = (int)FO_PQ_TET_TABLES[t].npts;
+        for (int i = 0; i < np; ++i) {
+            for (int c = 0; c < 3; ++c) p[3 * i + c] = strtod(FO_PQ_TET_TABLES[t].rows[4 * i + c], NULL);
+            w[i] = strtod(FO_PQ_TET_TABLES[t].rows[4 * i + 3], NULL);
+        }
+        return np;
     }
-    return np;
+    return -1;
 }
 
-/* rules/polyquad/expanded/tri/{1-1,2-3}.txt */
 int fo_triangle_rule(int strength, double* w, double* p) {
-    static const char* T1[] = {"-0.33333333333333333333333333333333333333", "-0.33333333333333333333333333333333333333", "2"};
-    static const char* T2[] = {
-        "-0.66666666666666666666666666666666666667", "0.33333333333333333333333333333333333333", "0.66666666666666666666666666666666666667",
-        "0.33333333333333333333333333333333333333", "-0.66666666666666666666666666666666666667", "0.66666666666666666666666666666666666667",
-        "-0.66666666666666666666666666666666666667", "-0.66666666666666666666666666666666666667", "0.66666666666666666666666666666666666667"};
-    const char** T;
-    int np;
-    if (strength <= 1) { T = T1; np = 1; }
-    else if (strength == 2) { T = T2; np = 3; }
-    else return -1;
-    for (int i = 0; i < np; ++i) {
-        for (int c = 0; c < 2; ++c) p[2 * i + c] = strtod(T[3 * i + c], NULL);
-        w[i] = strtod(T[3 * i + 2], NULL);
+    for (size_t t = 0; t < sizeof FO_PQ_TRI_TABLES / sizeof FO_PQ_TRI_TABLES[0]; ++t) {
+        if ((int)FO_PQ_TRI_TABLES[t].strength < strength) continue;
+        int np = (int)FO_PQ_TRI_TABLES[t].npts;
+        for (int i = 0; i < np; ++i) {
+            for (int c = 0; c < 2; ++c) p[2 * i + c] = strtod(FO_PQ_TRI_TABLES[t].rows[3 * i + c], NULL);
+            w[i] = strtod(FO_PQ_TRI_TABLES[t].rows[3 * i + 2], NULL);
+        }
+        return np;
     }
-    return np;
+    return -1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -766,6 +788,76 @@ int fo_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64
     }
     free(table);
     *out_vertices = fv; *out_num_vertices = next; *out_connectivity = conn;
+    return FO_OK;
+}
+
+/* Tet20Mesh::from(&tet4_mesh), src/mesh_convert.rs:658-775: every new vertex is a 4-tuple -- [idx,0,0,0] (vertex),
+ * [min,max,local,1] (edge node, local counted from min), [a,b,c,2] sorted (face) -- the tuples are sorted and
+ * deduplicated, and a vertex is labelled by its rank. */
+static int cmp_key4(const void* a, const void* b) {
+    const uint64_t* x = a;
+    const uint64_t* y = b;
+    for (int i = 0; i < 4; ++i)
+        if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+    return 0;
+}
+static void tet20_keys(const uint64_t* g, uint64_t (*k)[4]) {
+    static const int ED[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+    static const int FA[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+    for (int a = 0; a < 4; ++a) { k[a][0] = g[a]; k[a][1] = 0; k[a][2] = 0; k[a][3] = 0; }
+    for (int m = 0; m < 6; ++m)
+        for (uint64_t local = 0; local < 2; ++local) {
+            uint64_t st = g[ED[m][0]], en = g[ED[m][1]], l = local;
+            if (st > en) { uint64_t t = st; st = en; en = t; l = (l + 1) % 2; }
+            uint64_t* q = k[4 + 2 * m + (int)local];
+            q[0] = st; q[1] = en; q[2] = l; q[3] = 1;
+        }
+    for (int f = 0; f < 4; ++f) {
+        uint64_t t[3] = {g[FA[f][0]], g[FA[f][1]], g[FA[f][2]]};
+        qsort(t, 3, sizeof(uint64_t), cmp_u64);
+        uint64_t* q = k[16 + f];
+        q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = 2;
+    }
+}
+int fo_tet4_to_tet20(const double* vertices, uint64_t num_vertices, const uint64_t* tet4, uint64_t num_cells,
+                     double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity) {
+    (void)num_vertices;
+    size_t total = (size_t)num_cells * 20;
+    uint64_t (*all)[4] = malloc(sizeof(uint64_t[4]) * (total + 1));
+    uint64_t* conn = malloc(sizeof(uint64_t) * (total + 1));
+    if (!all || !conn) return FO_BAD_ARGUMENT;
+    for (uint64_t e = 0; e < num_cells; ++e) tet20_keys(tet4 + 4 * e, all + 20 * e);
+    qsort(all, total, sizeof(uint64_t[4]), cmp_key4);
+    size_t nu = 0;
+    for (size_t i = 0; i < total; ++i)
+        if (nu == 0 || cmp_key4(all[nu - 1], all[i]) != 0) { memcpy(all[nu], all[i], sizeof(uint64_t[4])); ++nu; }
+    for (uint64_t e = 0; e < num_cells; ++e) {
+        uint64_t k[20][4];
+        tet20_keys(tet4 + 4 * e, k);
+        for (int a = 0; a < 20; ++a) {
+            size_t lo = 0, hi = nu;  /* binary_search :740-742 */
+            while (lo < hi) {
+                size_t mid = (lo + hi) / 2;
+                if (cmp_key4(all[mid], k[a]) < 0) lo = mid + 1; else hi = mid;
+            }
+            conn[20 * e + a] = lo;
+        }
+    }
+    double* fv = malloc(sizeof(double) * 3 * (nu + 1));
+    for (size_t i = 0; i < nu; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const uint64_t* q = all[i];
+            if (q[3] == 0) fv[3 * i + c] = vertices[3 * q[0] + c];
+            else if (q[3] == 1) {
+                double st = vertices[3 * q[0] + c], en = vertices[3 * q[1] + c];
+                double alpha = (double)(q[2] + 1) / 3.0;
+                fv[3 * i + c] = st + (en - st) * alpha;
+            } else {
+                fv[3 * i + c] = ((vertices[3 * q[0] + c] + vertices[3 * q[1] + c]) + vertices[3 * q[2] + c]) / 3.0;
+            }
+        }
+    free(all);
+    *out_vertices = fv; *out_num_vertices = nu; *out_connectivity = conn;
     return FO_OK;
 }
 

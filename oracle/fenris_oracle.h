@@ -43,7 +43,9 @@ enum { FO_QUAD4 = 0, FO_HEX8 = 1, FO_TET4 = 2, FO_HEX27 = 3, FO_TRI3 = 4,
        /* quadratic, sub-parametric: tetrahedron.rs:92-246, quadrilateral.rs:150-330, triangle.rs:130-260 */
        FO_TET10 = 5, FO_QUAD9 = 6, FO_TRI6 = 7,
        /* 20-node serendipity hexahedron, hexahedron.rs:357-563 */
-       FO_HEX20 = 8 };
+       FO_HEX20 = 8,
+       /* cubic tetrahedron, tetrahedron.rs:248-470 */
+       FO_TET20 = 9 };
 /* operator kinds */
 enum { FO_LAPLACE = 0, FO_LINEAR_ELASTIC = 1, FO_NEO_HOOKEAN = 2, FO_STVK = 3,
        /* ElementMassAssembler (src/assembly/local/mass.rs) with solution_dim 1 / geometry dim; q_params[2q] = density */
@@ -83,6 +85,9 @@ int fo_hex8_to_hex27(const double* vertices, uint64_t num_vertices, const uint64
 
 /* p-refinement Tet4 -> Tet10, Hex8 -> Hex20, Tri3 -> Tri6, Quad4 -> Quad9 (src/mesh_convert.rs:42-83, 168-217, 332-452);
  * outputs malloc'ed */
+/* Tet20Mesh::from(&tet4) (src/mesh_convert.rs:658-775); outputs malloc'ed */
+int fo_tet4_to_tet20(const double* vertices, uint64_t num_vertices, const uint64_t* tet4, uint64_t num_cells,
+                     double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity);
 int fo_refine_to_quadratic(int from_kind, const double* vertices, uint64_t num_vertices, const uint64_t* connectivity,
                            uint64_t num_cells, double** out_vertices, uint64_t* out_num_vertices, uint64_t** out_connectivity);
 

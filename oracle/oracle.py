@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfenris_oracle.so")
 
-QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 OK, SINGULAR_JACOBIAN, BAD_ARGUMENT, COLUMN_NOT_FOUND = 0, 1, 2, 4
 
@@ -75,6 +75,7 @@ def lib():
         for f in (_lib.fo_create_rectangular_uniform_hex_mesh, _lib.fo_create_rectangular_uniform_tet_mesh):
             f.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_f64p), _u64p,
                           C.POINTER(_u64p), _u64p]
+        _lib.fo_tet4_to_tet20.argtypes = [_f64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(_f64p), _u64p, C.POINTER(_u64p)]
         _lib.fo_refine_to_quadratic.argtypes = [C.c_int, _f64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(_f64p), _u64p,
                                                 C.POINTER(_u64p)]
         _lib.fo_hex8_to_hex27.argtypes = [_f64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(_f64p), _u64p,
@@ -219,6 +220,16 @@ def hex8_to_hex27(vertices, conn):
                                 C.byref(cp))
     assert st == 0
     return _take(vp, nv, cp, C.c_uint64(len(conn)), 3, 27)
+
+
+def tet4_to_tet20(vertices, conn):
+    """Tet20Mesh::from(&tet4_mesh) (src/mesh_convert.rs:658-775)"""
+    vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+    conn = np.ascontiguousarray(conn, dtype=np.uint64)
+    vp, cp, nv = _f64p(), _u64p(), C.c_uint64()
+    st = lib().fo_tet4_to_tet20(_f(vertices), len(vertices), _u(conn), len(conn), C.byref(vp), C.byref(nv), C.byref(cp))
+    assert st == 0
+    return _take(vp, nv, cp, C.c_uint64(len(conn)), 3, 20)
 
 
 def refine_to_quadratic(from_kind, vertices, conn):

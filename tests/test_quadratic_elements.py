@@ -1,4 +1,4 @@
-"""Tet10 / Quad9 / Tri6 / Hex20 (sub-parametric quadratic elements): oracle pins on the CPU, HIP parity and the reference's
+"""Tet10 / Quad9 / Tri6 / Hex20 / Tet20 (sub-parametric higher-order elements): oracle pins on the CPU, HIP parity and the reference's
 MMS error JSONs on the GPU."""
 import json
 import os
@@ -10,10 +10,11 @@ import fenris_amd as fa
 from fenris_amd import quadrature
 from conftest import GOLDEN
 
-KIND = {"TET10": fa.TET10, "QUAD9": fa.QUAD9, "TRI6": fa.TRI6, "HEX20": fa.HEX20}
+KIND = {"TET10": fa.TET10, "QUAD9": fa.QUAD9, "TRI6": fa.TRI6, "HEX20": fa.HEX20, "TET20": fa.TET20}
 LAME = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
 OPS = {"LAPLACE": lambda: fa.LaplaceOperator(), "LINEAR_ELASTIC": lambda: fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
        "NEO_HOOKEAN": lambda: fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()), "STVK": lambda: fa.MaterialEllipticOperator(fa.StVKMaterial())}
+T = 1.0 / 3.0
 REF_NODES = {  # reference elements: tetrahedron.rs:153-168, quadrilateral.rs:212-228, triangle.rs:196-206
     "TET10": [[-1, -1, -1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1], [0, -1, -1], [0, 0, -1], [-1, 0, -1], [-1, -1, 0], [-1, 0, 0], [0, -1, 0]],
     "QUAD9": [[-1, -1], [1, -1], [1, 1], [-1, 1], [0, -1], [1, 0], [0, 1], [-1, 0], [0, 0]],
@@ -22,6 +23,11 @@ REF_NODES = {  # reference elements: tetrahedron.rs:153-168, quadrilateral.rs:21
     "HEX20": [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
               [0, -1, -1], [-1, 0, -1], [-1, -1, 0], [1, 0, -1], [1, -1, 0], [0, 1, -1], [1, 1, 0], [-1, 1, 0],
               [0, -1, 1], [-1, 0, 1], [1, 0, 1], [0, 1, 1]],
+    # tetrahedron.rs:296-340: vertices, two nodes per edge (01, 02, 03, 12, 13, 23), face nodes (012, 013, 023, 123)
+    "TET20": [[-1, -1, -1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1],
+              [-T, -1, -1], [T, -1, -1], [-1, -T, -1], [-1, T, -1], [-1, -1, -T], [-1, -1, T],
+              [T, -T, -1], [-T, T, -1], [T, -1, -T], [-T, -1, T], [-1, T, -T], [-1, -T, T],
+              [-T, -T, -1], [-T, -1, -T], [-1, -T, -T], [-T, -T, -T]],
 }
 
 
@@ -43,16 +49,20 @@ def _mesh(kind, seed=0, distort=0.04):
         base = fa.procedural.create_unit_square_uniform_quad_mesh_2d(3)
     elif kind == "HEX20":
         base = fa.procedural.create_unit_box_uniform_hex_mesh_3d(2)
+    elif kind == "TET20":
+        base = fa.procedural.create_unit_box_uniform_tet_mesh_3d(1)
     else:
         base = fa.procedural.create_unit_square_uniform_tri_mesh_2d(3)
     base = fa.Mesh(base.vertices + rng.uniform(-distort, distort, base.vertices.shape), base.connectivity, base.elem_kind)
     return {"TET10": fa.tet10_mesh_from_tet4, "QUAD9": fa.quad9_mesh_from_quad4, "TRI6": fa.tri6_mesh_from_tri3,
-            "HEX20": fa.hex20_mesh_from_hex8}[kind](base), base
+            "HEX20": fa.hex20_mesh_from_hex8, "TET20": fa.tet20_mesh_from_tet4}[kind](base), base
 
 
 def _rule(kind):
     if kind == "TET10":
         return quadrature.total_order.tetrahedron(3)
+    if kind == "TET20":
+        return quadrature.total_order.tetrahedron(5)
     if kind == "QUAD9":
         return quadrature.tensor.quadrilateral_gauss(3)
     if kind == "HEX20":
@@ -61,7 +71,7 @@ def _rule(kind):
 
 
 # ------------------------------------------------------------------------------------------- CPU: oracle pins
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20", "TET20"])
 def test_oracle_basis_is_nodal_and_a_partition_of_unity(oracle, kind):
     """the properties the reference's element tests check (partition of unity, Lagrange property at the reference
     nodes, gradients consistent with finite differences)"""
@@ -80,6 +90,28 @@ def test_oracle_basis_is_nodal_and_a_partition_of_unity(oracle, kind):
             e = np.zeros(nodes.shape[1]); e[c] = h
             fd = (oracle.element_basis(k, xi + e) - oracle.element_basis(k, xi - e)) / (2 * h)
             assert np.abs(fd - g[:, c]).max() < 1e-8
+
+
+def test_tet20_conversion_product_equals_oracle_and_is_consistent(oracle):
+    base = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
+    rng = np.random.default_rng(5)
+    base = fa.Mesh(base.vertices + rng.uniform(-0.03, 0.03, base.vertices.shape), base.connectivity, base.elem_kind)
+    mesh = fa.tet20_mesh_from_tet4(base)
+    ov, oc = oracle.tet4_to_tet20(base.vertices, base.connectivity)
+    assert np.array_equal(mesh.vertices, ov) and np.array_equal(mesh.connectivity, oc)
+    c, b = mesh.connectivity.astype(int), base.connectivity.astype(int)
+    assert np.array_equal(mesh.vertices[c[:, :4]], base.vertices[b])  # the vertex nodes are the Tet4 vertices
+    edges = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    for m, (i, j) in enumerate(edges):  # thirds of the edges, the first node next to vertex i
+        vi, vj = mesh.vertices[c[:, i]], mesh.vertices[c[:, j]]
+        assert np.abs(mesh.vertices[c[:, 4 + 2 * m]] - (vi + (vj - vi) / 3)).max() < 1e-14
+        assert np.abs(mesh.vertices[c[:, 5 + 2 * m]] - (vi + 2 * (vj - vi) / 3)).max() < 1e-14
+    for f, tri in enumerate([(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3)]):
+        cen = sum(mesh.vertices[c[:, k]] for k in tri) / 3
+        assert np.abs(mesh.vertices[c[:, 16 + f]] - cen).max() < 1e-14
+    n_edges = len({tuple(sorted((r[i], r[j]))) for r in b for i, j in edges})
+    n_faces = len({tuple(sorted((r[i], r[j], r[k]))) for r in b for i, j, k in [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3)]})
+    assert mesh.num_nodes() == base.num_nodes() + 2 * n_edges + n_faces
 
 
 @pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
@@ -104,7 +136,8 @@ def test_refinement_product_equals_oracle_and_is_consistent(oracle, kind):
 
 
 @pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad9_summary", "QUAD9", 3), ("poisson2d_mms_tri6_summary", "TRI6", 3),
-                                            ("poisson3d_mms_tet10_summary", "TET10", 2), ("poisson3d_mms_hex20_summary", "HEX20", 2)])
+                                            ("poisson3d_mms_tet10_summary", "TET10", 2), ("poisson3d_mms_hex20_summary", "HEX20", 2),
+                                            ("poisson3d_mms_tet20_summary", "TET20", 2)])
 def test_oracle_mms_errors(oracle, name, kind, nres):
     """tests/convergence_tests/poisson_{2d,3d}_mms.rs with the oracle end to end (assembly, source, Dirichlet, CG, error
     norms) against the reference's error JSONs (1 %)"""
@@ -119,6 +152,9 @@ def _mms(name, kind, nres, engines, oracle):
     elif kind == "TRI6":
         gen = lambda r: fa.tri6_mesh_from_tri3(fa.procedural.create_unit_square_uniform_tri_mesh_2d(r))
         rule, err_rule = quadrature.total_order.triangle(2), _tri_rule6()
+    elif kind == "TET20":  # poisson_3d_mms.rs:131-138 (resolutions 1, 2, 4, 6, ...)
+        gen = lambda r: fa.tet20_mesh_from_tet4(fa.procedural.create_unit_box_uniform_tet_mesh_3d(r))
+        rule, err_rule = quadrature.total_order.tetrahedron(4), _tet_rule6()
     elif kind == "HEX20":  # poisson_3d_mms.rs:91-98
         gen = lambda r: fa.hex20_mesh_from_hex8(fa.procedural.create_unit_box_uniform_hex_mesh_3d(r))
         rule, err_rule = quadrature.tensor.hexahedron_gauss(4), quadrature.tensor.hexahedron_gauss(6)
@@ -197,7 +233,7 @@ def engine():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20", "TET20"])
 @pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK"])
 def test_matrix_vector_scalar_match_oracle(engine, oracle, kind, op):
     mesh, _ = _mesh(kind, seed=2)
@@ -233,7 +269,7 @@ def test_matrix_vector_scalar_match_oracle(engine, oracle, kind, op):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20"])
+@pytest.mark.parametrize("kind", ["TET10", "QUAD9", "TRI6", "HEX20", "TET20"])
 def test_mass_and_source_match_oracle(engine, oracle, kind):
     mesh, _ = _mesh(kind, seed=4)
     w, p = _rule(kind)
@@ -254,7 +290,8 @@ def test_mass_and_source_match_oracle(engine, oracle, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad9_summary", "QUAD9", 4), ("poisson2d_mms_tri6_summary", "TRI6", 4),
-                                            ("poisson3d_mms_tet10_summary", "TET10", 3), ("poisson3d_mms_hex20_summary", "HEX20", 3)])
+                                            ("poisson3d_mms_tet10_summary", "TET10", 3), ("poisson3d_mms_hex20_summary", "HEX20", 3),
+                                            ("poisson3d_mms_tet20_summary", "TET20", 3)])
 def test_mms_loop_on_device(oracle, name, kind, nres):
     engines = (fa.Engine(0), fa.Engine(0), fa.Engine(0))
     try:

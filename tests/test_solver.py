@@ -245,7 +245,8 @@ def test_h1_error_reports_singular_jacobian(engine):
 @pytest.mark.parametrize("name,kind,nres", [("poisson2d_mms_quad4_summary", "QUAD4", 5),
                                             ("poisson3d_mms_hex8_summary", "HEX8", 4),
                                             ("poisson3d_mms_tet4_summary", "TET4", 3),
-                                            ("poisson3d_mms_hex27_summary", "HEX27", 3)])
+                                            ("poisson3d_mms_hex27_summary", "HEX27", 3),
+                                            ("poisson2d_mms_tri3_summary", "TRI3", 5)])
 def test_mms_loop_on_device_matches_reference_errors(name, kind, nres):
     """tests/convergence_tests/poisson_{2d,3d}_mms.rs against reference_values/*.json (1 %,
     poisson_mms_common.rs:40-65): K, b, Dirichlet conditions, Jacobi-PCG (max_iter 10000, tol 1e-9 as in
@@ -262,6 +263,9 @@ def test_mms_loop_on_device_matches_reference_errors(name, kind, nres):
     elif kind == "HEX27":
         gen = lambda r: fa.hex27_mesh_from_hex8(fa.procedural.create_unit_box_uniform_hex_mesh_3d(r))
         rule, err_rule = quadrature.tensor.hexahedron_gauss(4), quadrature.tensor.hexahedron_gauss(6)
+    elif kind == "TRI3":  # poisson_2d_mms.rs:99-105
+        gen, rule, err_rule = (fa.procedural.create_unit_square_uniform_tri_mesh_2d, quadrature.total_order.triangle(0),
+                               quadrature.total_order.triangle(6))
     else:
         t = json.load(open(os.path.join(GOLDEN, "tet_rule_6_24.json")))
         # poisson_3d_mms.rs:111-118: the reference assembles Tet4 with tetrahedron(0), errors with tetrahedron(6)

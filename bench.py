@@ -121,12 +121,13 @@ def main():
 
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
     slab_asm = None
-    t0 = time.perf_counter()
     if world == 1:
         mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
         eng = fa.Engine(local_rank, stream=stream)
         configure(eng, mesh)
-        nnz = eng.build_pattern()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nnz = eng.build_pattern()  # assemble_pattern on the device (secondary metric)
         E = mesh.num_elements()
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
     else:
@@ -134,6 +135,7 @@ def main():
 
         slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world, args.partition)
         mesh = slab.mesh
+        t0 = time.perf_counter()  # N > 1: engines, masks and patterns of this rank
         # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
         slab_asm = fd.SlabAssembly(slab, configure, device=local_rank, overlap=(args.scatter == "gather" and not args.no_overlap),
                                    stream=stream)

@@ -64,6 +64,34 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
     const int lane = threadIdx.x;
     for (int node = blockIdx.x; node < num_nodes; node += gridDim.x) {
         const unsigned b = n2e_off[node], en = n2e_off[node + 1];
+        if (!c.eoff && (en - b) * (unsigned)c.n <= 64u) {
+            // fast path (fixed-n meshes, at most 64 candidates -- e.g. the 8 x 8 of a hexahedral mesh): one candidate per
+            // lane, bitonic sort across the wavefront in registers, no LDS and no barriers.  A degenerate element that
+            // lists the node twice only duplicates candidates, which the unique step removes.
+            const unsigned C = (en - b) * (unsigned)c.n;
+            unsigned v = 0xffffffffu;
+            if ((unsigned)lane < C) {
+                const unsigned e = n2e[b + (unsigned)lane / (unsigned)c.n] / (unsigned)c.n;
+                v = (unsigned)c.nodes[(size_t)e * c.n + (unsigned)lane % (unsigned)c.n];
+            }
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const unsigned other = (unsigned)__shfl_xor((int)v, stride, 64);
+                    const bool up = ((lane & size) == 0), lower = ((lane & stride) == 0);
+                    v = (lower == up) ? min(v, other) : max(v, other);
+                }
+            const unsigned prev = (unsigned)__shfl_up((int)v, 1, 64);
+            const bool keep = (v != 0xffffffffu) && (lane == 0 || v != prev);
+            const unsigned long long mask = __ballot(keep);
+            if (FILL) {
+                if (keep) ncols[noff[node] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+            } else if (lane == 0) {
+                cnt[node] = (unsigned)__popcll(mask);
+            }
+            continue;
+        }
         // collect candidates; consecutive entries of the same element (degenerate elements) are skipped
         __syncthreads();
         unsigned C = 0;

@@ -893,8 +893,12 @@ struct PipeTables {
 
 __host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs) { return 8 + us / 4 + ms + ms * N / 4 + nbs + 1; }
 
-template <int EK, int OP, int QC, int JT>
+// DBG: the profiling hooks (FENRIS_HIP_TRACE phase stamps, FENRIS_HIP_ABLATE switches) exist only in the DBG instantiation;
+// the production kernel carries none of their scalar branches.
+template <int EK, int OP, int QC, int JT, bool DBG = false>
 __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
+    const int ablate = DBG ? a.ablate : 0;
+    unsigned long long* const trace = DBG ? a.trace : nullptr;
     // JT = local nodes J handled per lane in phase C
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
@@ -960,7 +964,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     auto write_out = [&](double* out, int nacc, int nth) {
         const int rt = nt - 1 - tid;
         if (rt >= nth) return;
-        if (a.ablate & 8) {
+        if (ablate & 8) {
             for (int i = rt; i < nacc; i += nth) acc[i] = 0.0;
         } else if (a.overwrite) {
             int i = rt;
@@ -991,9 +995,9 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
 
     // optional phase timing (FENRIS_HIP_TRACE): lane 0 of every wave accumulates s_memtime deltas per phase
     unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tr_t = a.trace ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long tr_t = trace ? __builtin_amdgcn_s_memtime() : 0;
 #define FH_STAMP(K)                                              \
-    if (a.trace) {                                               \
+    if (trace) {                                               \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         tr_acc[K] += now_ - tr_t;                                \
         tr_t = now_;                                             \
@@ -1041,7 +1045,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             if (qc > 0) lds_barrier();  // the previous chunk's phase C is done with the staged points
             FH_STAMP(0)  // top of block: prefetch issue, header, item decode
             // phase B for quadrature points [qc, qc + QC)
-            if (!(a.ablate & 1))
+            if (!(ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
                 const int u = (int)slot_b[i / QC], qs = i % QC;
                 if (qc + qs < a.nq)
@@ -1050,14 +1054,14 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             // phase D of the previous block, overlapped with phase B: its accumulators are complete (barrier at the
             // end of the last iteration) and are not touched again before the barrier below
             // (phase B fills half of the waves: the other half writes out; a smaller phase B is not worth idling for)
-            if (qc == 0 && prev_nacc > 0 && !(a.ablate & 16))
+            if (qc == 0 && prev_nacc > 0 && !(ablate & 16))
                 write_out(prev_out, prev_nacc, (U * QC > nt / 4 && U * QC <= nt / 2) ? nt / 2 : nt);
             FH_STAMP(1)  // phase B (+ write-out of the previous block)
             lds_barrier();
             FH_STAMP(2)  // barrier after B
             // phase C (accumulate)
             const int nqc = min(QC, a.nq - qc);
-            if (has_item && !(a.ablate & 2)) {
+            if (has_item && !(ablate & 2)) {
                 const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
                 // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours
                 // into ds_read2_b64, which costs 8 cycles for the same 16 bytes (MI355X_MICROARCH.md, LDS
@@ -1108,7 +1112,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         }
         FH_STAMP(3)  // phase C
         // finalize: s x s block from G, mirrored like clone_upper_to_lower, then row accumulators
-        if (has_item && !(a.ablate & 4)) {
+        if (has_item && !(ablate & 4)) {
             const int rb = noff_l[il], cnt = noff_l[il + 1] - rb;
 #pragma unroll
             for (int r = 0; r < JT; ++r) {
@@ -1142,7 +1146,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
                             // diagonal block: the lower triangle mirrors the upper one (util.rs:46-50); compile-time
                             // register indices only (a runtime index would push Gr to scratch)
                             const double v = (i > j && diag) ? val[j][i] : val[i][j];
-                            if (a.ablate & 32) base[(i % S) * S * cnt + (j % S)] = v;  // experiment: plain stores (wrong sums)
+                            if (ablate & 32) base[(i % S) * S * cnt + (j % S)] = v;  // experiment: plain stores (wrong sums)
                             else atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
                         }
                 }
@@ -1158,7 +1162,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         prev_nacc = nacc;
         FH_STAMP(4)  // finalize + park
         lds_barrier();
-        if (a.ablate & 16) {  // experiment: write-out by all threads behind the barrier instead of overlapped
+        if (ablate & 16) {  // experiment: write-out by all threads behind the barrier instead of overlapped
             write_out(prev_out, prev_nacc, nt);
             prev_nacc = 0;
             lds_barrier();
@@ -1167,8 +1171,8 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     }
     write_out(prev_out, prev_nacc, nt);
 #undef FH_STAMP
-    if (a.trace && (tid & 63) == 0) {  // one row of 7 counters per wave index
-        unsigned long long* row = a.trace + 7 * (tid >> 6);
+    if (trace && (tid & 63) == 0) {  // one row of 7 counters per wave index
+        unsigned long long* row = trace + 7 * (tid >> 6);
         for (int k = 0; k < 6; ++k) atomicAdd(row + k, tr_acc[k]);
         atomicAdd(row + 6, 1ull);
     }

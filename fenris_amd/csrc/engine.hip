@@ -858,7 +858,12 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int wgs = std::max(1, env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     const int grid = std::min(c->nblk, dev_cus * wgs);
-    auto kern = k_gather_pipelined<EK, OP, QC, JT>;
+    // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
+    const bool dbg = (std::getenv("FENRIS_HIP_TRACE") || std::getenv("FENRIS_HIP_ABLATE") || std::getenv("FENRIS_HIP_DBG_KERNEL"));
+    void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
+    if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
+        if (dbg) kern = k_gather_pipelined<EK, OP, QC, JT, true>;
+    }
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("FENRIS_HIP_VERBOSE"))

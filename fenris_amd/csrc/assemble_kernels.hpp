@@ -895,9 +895,11 @@ __host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs)
 
 // DBG: the profiling hooks (FENRIS_HIP_TRACE phase stamps, FENRIS_HIP_ABLATE switches) exist only in the DBG instantiation;
 // the production kernel carries none of their scalar branches.
-template <int EK, int OP, int QC, int JT, bool DBG = false>
+// FULLQ: the rule has exactly QC points (one chunk): the chunk loop and its bounds are compile-time.
+template <int EK, int OP, int QC, int JT, bool DBG = false, bool FULLQ = false>
 __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
     const int ablate = DBG ? a.ablate : 0;
+    const int nq_rt = FULLQ ? QC : a.nq;
     unsigned long long* const trace = DBG ? a.trace : nullptr;
     // JT = local nodes J handled per lane in phase C
     using E = ElemT<EK>;
@@ -1022,7 +1024,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         load_rec(p + 2, nn);
         // slots to (re)compute: only the new ones, except at the start of this workgroup's range where nothing
         // is staged yet (the slot list holds the new slots first, then the retained ones)
-        const int U = (p == p_begin || QC < a.nq) ? hc.U : hc.k0;  // chunked staging keeps nothing across blocks
+        const int U = (p == p_begin || QC < nq_rt) ? hc.U : hc.k0;  // chunked staging keeps nothing across blocks
         const int m = hc.m, nrow = hc.nrow;
         const int nacc = S * S * nrow;
         // G = sum_q h_I h_J^T accumulated in registers across chunks of QC quadrature points; all unique
@@ -1041,14 +1043,14 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         const int u_item = (int)(packed >> 16);
         const int an = (int)((packed >> 8) & 0xffu);
         const int il = (int)(packed & 0xffu);
-        for (int qc = 0; qc < a.nq; qc += QC) {
+        for (int qc = 0; qc < nq_rt; qc += QC) {
             if (qc > 0) lds_barrier();  // the previous chunk's phase C is done with the staged points
             FH_STAMP(0)  // top of block: prefetch issue, header, item decode
             // phase B for quadrature points [qc, qc + QC)
             if (!(ablate & 1))
             for (int i = tid; i < U * QC; i += nt) {
                 const int u = (int)slot_b[i / QC], qs = i % QC;
-                if (qc + qs < a.nq)
+                if (qc + qs < nq_rt)
                     prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
             }
             // phase D of the previous block, overlapped with phase B: its accumulators are complete (barrier at the
@@ -1060,7 +1062,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             lds_barrier();
             FH_STAMP(2)  // barrier after B
             // phase C (accumulate)
-            const int nqc = min(QC, a.nq - qc);
+            const int nqc = FULLQ ? QC : min(QC, nq_rt - qc);
             if (has_item && !(ablate & 2)) {
                 const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
                 // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours

@@ -602,6 +602,30 @@ def test_full_size_hex27_neo_hookean_properties(engine, oracle):
     v2 = torch.zeros_like(vals)
     eng.assemble_matrix(v2, fa.SCATTER_ATOMIC)
     assert float((vals - v2).abs().max()) <= 1e-12 * float(vals.abs().max())
+    # the production path for high-order elements: two-pass owner-computes, element matrices on the fp64 matrix cores
+    v3 = torch.empty_like(vals).fill_(float("nan"))
+    eng.assemble_matrix(v3, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+    assert float((vals - v3).abs().max()) <= 1e-12 * float(vals.abs().max())
+    # size-independent properties through the blocked-CSR SpMV: a rigid translation carries no force (every elastic
+    # tangent annihilates constant displacement fields), and K is symmetric: x.(K y) == y.(K x)
+    n = 3 * mesh.num_nodes()
+    scale = float(vals.abs().max())
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for comp in range(3):
+        t = torch.zeros(n, dtype=torch.float64, device="cuda")
+        t[comp::3] = 1.0
+        eng.spmv(v3, t, y)
+        assert float(y.abs().max()) <= 1e-10 * scale
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x1 = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    x2 = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    eng.spmv(v3, x2, y)
+    a12 = float(torch.dot(x1, y))
+    eng.spmv(v3, x1, y)
+    a21 = float(torch.dot(x2, y))
+    assert abs(a12 - a21) <= 1e-10 * abs(a12)
+    del v3, x1, x2, y
     # one element matrix against the oracle (same inputs)
     ref = oracle.ElementAssembler(oracle.HEX27, oracle.NEO_HOOKEAN, mesh.vertices, mesh.connectivity[:3], w, p,
                                   params=LAME.as_pair(), u=u)

@@ -8,7 +8,8 @@ from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO
                    SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, TET10, QUAD9, TRI6, HEX20, TET20, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,
                        ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,
-                       MockElementAssembler, UniformQuadratureTable, CompactQuadratureTable,
+                       MockElementAssembler, UniformQuadratureTable, CompactQuadratureTable, GeneralQuadratureTable,
+                       compact_quadrature_table,
                        VectorAssembler, VectorParAssembler, apply_homogeneous_dirichlet_bc_csr,
                        apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes, CgSolveError, ConjugateGradient,
                        IdentityOperator, JacobiPreconditioner, RelativeResidualCriterion, estimate_H1_seminorm_error,

@@ -91,7 +91,10 @@ class Engine:
 
     def set_quadrature_table(self, qtable):
         """UniformQuadratureTable or CompactQuadratureTable"""
-        if hasattr(qtable, "rule_params"):
+        if hasattr(qtable, "rules"):  # walked rule by rule by the global assemblers; stage the first rule for now
+            w, p, d = qtable.rules[0]
+            self.set_quadrature_uniform(w, p, d)
+        elif hasattr(qtable, "rule_params"):
             w, p = _ffi.as_f64(qtable.weights), _ffi.as_f64(qtable.points)
             self._keep_q = (w, p, qtable.rule_params, qtable.element_to_rule_map)
             self._check(self._lib.fh_set_quadrature_compact(self._h, _ffi.fp(w), _ffi.fp(p), len(w), len(qtable.rule_params),
@@ -337,6 +340,72 @@ class CompactQuadratureTable:
         return cls(points, weights, data, element_to_rule_map)
 
 
+class _RuleSetTable:
+    """Quadrature tables whose rules differ in their POINTS (GeneralQuadratureTable, and CompactQuadratureTable with
+    different point sets; quadrature_table.rs:57-210, 300-439).  The device kernels stage one rule per launch, so the
+    global assemblers walk the distinct rules: uniform table of rule r + the element mask of the elements that use it
+    (fh_set_active_elements), accumulating into the same output.  Identical rules are merged."""
+
+    def __init__(self, rules, element_to_rule_map):
+        self.rules = rules  # list of (weights, points, data (nq, 2) or None)
+        self.element_to_rule_map = _ffi.as_u64(element_to_rule_map)
+        self.weights, self.points, self.data = rules[0]
+
+    @staticmethod
+    def _norm(points, weights, data):
+        w, p = _ffi.as_f64(weights), _ffi.as_f64(points)
+        if data is None:
+            d = None
+        else:
+            d = np.array([x.as_pair() if hasattr(x, "as_pair") else tuple(x) for x in data], dtype=np.float64).reshape(len(w), 2)
+        if len(p) != len(w):
+            raise ValueError("Rules must have an equal number of points and weights.")  # check_rules_consistency
+        return w, p, d
+
+    @classmethod
+    def build(cls, per_entry_rules, entry_of_element):
+        """dedupe identical (points, weights, data) triples"""
+        keys, rules, remap = {}, [], []
+        for w, p, d in per_entry_rules:
+            key = (w.tobytes(), p.tobytes(), None if d is None else d.tobytes())
+            if key not in keys:
+                keys[key] = len(rules)
+                rules.append((w, p, d))
+            remap.append(keys[key])
+        remap = np.asarray(remap, dtype=np.uint64)
+        return cls(rules, remap[np.asarray(entry_of_element, dtype=np.int64)])
+
+
+class GeneralQuadratureTable(_RuleSetTable):
+    """src/assembly/local/quadrature_table.rs:57-210: one rule (points, weights, data) per element"""
+
+    @classmethod
+    def from_points_and_weights(cls, points, weights):
+        return cls.from_points_weights_and_data(points, weights, None)
+
+    @classmethod
+    def from_points_weights_and_data(cls, points, weights, data):
+        n = len(weights)
+        if len(points) != n or (data is not None and len(data) != n):
+            raise ValueError("Quadrature point arrays must have the same number of rules.")
+        rules = [cls._norm(points[e], weights[e], None if data is None else data[e]) for e in range(n)]
+        return cls.build(rules, np.arange(n))
+
+
+def compact_quadrature_table(points, weights, data, element_to_rule_map):
+    """CompactQuadratureTable::from_quadrature_rules_and_map (quadrature_table.rs:357-383) for NestedVec inputs: rules
+    that share points and weights take the single-launch device table (CompactQuadratureTable), anything else is walked
+    rule by rule."""
+    rules = [_RuleSetTable._norm(points[r], weights[r], None if data is None else data[r]) for r in range(len(weights))]
+    emap = _ffi.as_u64(element_to_rule_map)
+    if len(emap) and int(emap.max()) >= len(rules):
+        raise ValueError("Each rule index must correspond to a provided quadrature rule.")
+    same = all(np.array_equal(r[0], rules[0][0]) and np.array_equal(r[1], rules[0][1]) for r in rules)
+    if same and all(r[2] is not None for r in rules):
+        return CompactQuadratureTable(rules[0][1], rules[0][0], [r[2] for r in rules], emap)
+    return _RuleSetTable.build(rules, emap)
+
+
 @dataclass
 class DisjointSubsetsColors:
     """Vec<DisjointSubsets> (fenris-paradis/src/lib.rs:171-181) flattened: elements of colour c are
@@ -569,6 +638,27 @@ class MockElementAssembler:
 
 
 # ------------------------------------------------------------------------------------------ global
+def _for_each_rule(element_assembler, fn):
+    """Runs ``fn()`` once per distinct rule of a rule-set table (uniform tables: once), with the rule staged and the
+    element mask restricted to the elements that use it; every fn must ACCUMULATE into its output."""
+    qt = getattr(element_assembler, "qtable", None)
+    if qt is None or not hasattr(qt, "rules"):
+        return [fn()]
+    eng = element_assembler.engine
+    out = []
+    try:
+        for r, (w, p, d) in enumerate(qt.rules):
+            mask = (qt.element_to_rule_map == r).astype(np.uint8)
+            if not mask.any():
+                continue
+            eng.set_quadrature_uniform(w, p, d)
+            eng.set_active_elements(mask)
+            out.append(fn())
+    finally:
+        eng.set_active_elements(None)
+    return out
+
+
 class CsrAssembler:
     """src/assembly/global.rs:24-183.  ``scatter`` picks the device strategy (default: atomic adds)."""
 
@@ -601,9 +691,13 @@ class CsrAssembler:
         if len(csr.values) != eng.nnz():
             raise ValueError("CSR matrix does not have the pattern of this element assembler")
         flags = self.scatter
-        if flags == SCATTER_COLORED:
-            eng.color()
-        eng.assemble_matrix(csr.values, flags)
+
+        def run():
+            if flags == SCATTER_COLORED:
+                eng.color()
+            eng.assemble_matrix(csr.values, flags)
+
+        _for_each_rule(element_assembler, run)
 
 
 class CsrParAssembler:
@@ -623,8 +717,11 @@ class CsrParAssembler:
         eng = element_assembler.engine
         if len(csr.values) != eng.nnz():
             raise ValueError("CSR matrix does not have the pattern of this element assembler")
-        eng.set_colors(colors)
-        eng.assemble_matrix(csr.values, SCATTER_COLORED)
+        def run():
+            eng.set_colors(colors)
+            eng.assemble_matrix(csr.values, SCATTER_COLORED)
+
+        _for_each_rule(element_assembler, run)
 
 
 class VectorAssembler:
@@ -642,7 +739,7 @@ class VectorAssembler:
         if hasattr(element_assembler, "assemble_vector_into_engine"):  # ElementSourceAssembler
             element_assembler.assemble_vector_into_engine(output)
         else:
-            element_assembler.engine.assemble_vector(output)
+            _for_each_rule(element_assembler, lambda: element_assembler.engine.assemble_vector(output))
 
 
 class VectorParAssembler(VectorAssembler):
@@ -654,7 +751,7 @@ class VectorParAssembler(VectorAssembler):
 
 def assemble_scalar(element_assembler):
     """global.rs:697-711"""
-    return element_assembler.engine.assemble_scalar()
+    return float(sum(_for_each_rule(element_assembler, element_assembler.engine.assemble_scalar)))
 
 
 def color_nodes(mesh_or_assembler, engine: Optional[Engine] = None) -> DisjointSubsetsColors:

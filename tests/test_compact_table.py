@@ -138,3 +138,70 @@ def test_uniform_table_after_compact_restores_fast_path(engine, oracle):
     oasm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=RULES[0])
     vals = oracle.assemble(oasm)[4]
     assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+# ------------------------------------------------------------------------------------------- rules with different points
+def _mixed_rules(kind="HEX8"):
+    """two rules with different point sets (Gauss 2 and Gauss 3) and different data"""
+    w2, p2 = quadrature.tensor.hexahedron_gauss(2)
+    w3, p3 = quadrature.tensor.hexahedron_gauss(3)
+    d2 = [fa.LameParameters(*RULES[0])] * len(w2)
+    d3 = [fa.LameParameters(RULES[1][0] * (1 + 0.01 * q), RULES[1][1]) for q in range(len(w3))]
+    return [(w2, p2, d2), (w3, p3, d3)]
+
+
+def _oracle_sum_over_rules(oracle, mesh, op, rules, emap, u):
+    w, p, _ = rules[0]
+    full = oracle.ElementAssembler(oracle.HEX8, op, mesh.vertices, mesh.connectivity, w, p, params=[1.0, 1.0])
+    ro, ci = oracle.pattern_for(full)
+    vals, f, e = np.zeros(len(ci)), np.zeros(3 * mesh.num_nodes()), 0.0
+    for r, (w, p, d) in enumerate(rules):
+        params = np.array([x.as_pair() for x in d])
+        sub = oracle.ElementAssembler(oracle.HEX8, op, mesh.vertices, mesh.connectivity[emap == r], w, p, params=params, u=u)
+        st, _ = oracle.assemble_into_csr(sub, ro, ci, vals)
+        assert st == 0
+        st, _, f = oracle.assemble_vector(sub, out=f)
+        assert st == 0
+        st, _, er = oracle.assemble_scalar(sub)
+        e += er
+    return ro, ci, vals, f, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("table", ["compact", "general"])
+def test_rules_with_different_points_are_walked_rule_by_rule(engine, oracle, table):
+    """CompactQuadratureTable / GeneralQuadratureTable in full generality (quadrature_table.rs:57-210, 300-439): elements
+    with a 2-point and a 3-point Gauss rule in one mesh"""
+    m, _, _, _, _ = _setup("HEX8", seed=8)
+    rules = _mixed_rules()
+    emap = (np.arange(m.num_elements()) % 3 == 0).astype(np.uint64)
+    u = 0.01 * np.random.default_rng(9).standard_normal(3 * m.num_nodes())
+    if table == "compact":
+        qt = fa.compact_quadrature_table([r[1] for r in rules], [r[0] for r in rules], [r[2] for r in rules], emap)
+    else:
+        qt = fa.GeneralQuadratureTable.from_points_weights_and_data([rules[int(r)][1] for r in emap], [rules[int(r)][0] for r in emap],
+                                                                     [rules[int(r)][2] for r in emap])
+        assert len(qt.rules) == 2  # identical per-element rules are merged
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m)
+           .with_operator(fa.MaterialEllipticOperator(fa.NeoHookeanMaterial())).with_quadrature_table(qt).with_u(u).build())
+    ro, ci, vals, fo, eo = _oracle_sum_over_rules(oracle, m, oracle.NEO_HOOKEAN, rules, emap, u)
+    for scatter in (fa.SCATTER_GATHER, fa.SCATTER_ATOMIC):
+        k = fa.CsrAssembler(scatter).assemble(asm)
+        assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+        assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    k = fa.CsrParAssembler().assemble(fa.color_nodes(asm), asm)
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    f = fa.VectorAssembler().assemble_vector(asm)
+    assert np.abs(f - fo).max() <= 1e-12 * np.abs(fo).max()
+    assert abs(fa.assemble_scalar(asm) - eo) <= 1e-12 * abs(eo)
+
+
+def test_compact_table_helper_picks_the_single_launch_form():
+    m, w, p, emap, rp = _setup("HEX8")
+    qt = fa.compact_quadrature_table([p] * len(rp), [w] * len(rp), [[fa.LameParameters(*x) for x in r] for r in rp], emap)
+    assert isinstance(qt, fa.CompactQuadratureTable)
+    rules = _mixed_rules()
+    qt2 = fa.compact_quadrature_table([r[1] for r in rules], [r[0] for r in rules], [r[2] for r in rules], emap % 2)
+    assert hasattr(qt2, "rules") and len(qt2.rules) == 2
+    with pytest.raises(ValueError):
+        fa.compact_quadrature_table([p], [w], [[fa.LameParameters(1, 1)] * len(w)], np.array([0, 1]))

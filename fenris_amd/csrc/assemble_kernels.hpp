@@ -895,7 +895,8 @@ __host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs)
 
 // DBG: the profiling hooks (FENRIS_HIP_TRACE phase stamps, FENRIS_HIP_ABLATE switches) exist only in the DBG instantiation;
 // the production kernel carries none of their scalar branches.
-// FULLQ: the rule has exactly QC points (one chunk): the chunk loop and its bounds are compile-time.
+// FULLQ: the rule has exactly QC points (one chunk): the chunk loop and its bounds are compile-time; the host also
+// guarantees cs <= 256 and rw <= 256, so one geometry-node slot and one record word per thread suffice.
 template <int EK, int OP, int QC, int JT, bool DBG = false, bool FULLQ = false>
 __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
     const int ablate = DBG ? a.ablate : 0;
@@ -905,7 +906,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
-    constexpr int SLOTS = 2;  // geometry-node slots per thread: U * NG <= 512
+    constexpr int SLOTS = FULLQ ? 1 : 2;  // geometry-node slots per thread: U * NG <= 512 (<= 256 with FULLQ)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC);
     double* lds = reinterpret_cast<double*>(smem);
@@ -918,7 +919,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     // Prefetch state per thread: one header word (threads 0..7), SLOTS geometry-node indices, one packed entry,
     // one word of column slots, one relative row offset.  Headers are parked in LDS (double-buffered by block
     // parity) and read back as wave-uniform values, so they cost one VGPR instead of eight.
-    constexpr int RL = 2;  // record words per thread: rw <= 512 (checked by the host)
+    constexpr int RL = FULLQ ? 1 : 2;  // record words per thread: rw <= 512 (checked by the host; <= 256 with FULLQ)
     struct Rec { int w[RL]; int conn[SLOTS]; };
     const int npos = T.npos;
     // contiguous range of positions per workgroup: consecutive positions are chain neighbours
@@ -935,7 +936,8 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     };
     // pins the record in registers: the compiler places the vmcnt wait for its loads here
     auto land_rec = [&](Rec& r) {
-        asm volatile("" : "+v"(r.w[0]), "+v"(r.w[1]), "+v"(r.conn[0]), "+v"(r.conn[1]));
+        if constexpr (FULLQ) asm volatile("" : "+v"(r.w[0]), "+v"(r.conn[0]));
+        else asm volatile("" : "+v"(r.w[0]), "+v"(r.w[RL - 1]), "+v"(r.conn[0]), "+v"(r.conn[SLOTS - 1]));
     };
     double V[SLOTS][D];
     auto load_verts = [&](const Rec& r) {

@@ -863,7 +863,8 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
     if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
         if (dbg) kern = k_gather_pipelined<EK, OP, QC, JT, true>;
-        else if (a.nq == QC && !std::getenv("FENRIS_HIP_NO_FULLQ")) kern = k_gather_pipelined<EK, OP, QC, JT, false, true>;
+        else if (a.nq == QC && T.cs <= 256 && T.rw <= 256 && !std::getenv("FENRIS_HIP_NO_FULLQ"))
+            kern = k_gather_pipelined<EK, OP, QC, JT, false, true>;
     }
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1049,11 +1049,17 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             if (qc > 0) lds_barrier();  // the previous chunk's phase C is done with the staged points
             FH_STAMP(0)  // top of block: prefetch issue, header, item decode
             // phase B for quadrature points [qc, qc + QC)
-            if (!(ablate & 1))
-            for (int i = tid; i < U * QC; i += nt) {
-                const int u = (int)slot_b[i / QC], qs = i % QC;
-                if (qc + qs < nq_rt)
-                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
+            if constexpr (FULLQ) {  // U <= 32 slots x 8 points: at most one item per thread
+                if (tid < U * QC && !(ablate & 1)) {
+                    const int u = (int)slot_b[tid / QC];
+                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC);
+                }
+            } else if (!(ablate & 1)) {
+                for (int i = tid; i < U * QC; i += nt) {
+                    const int u = (int)slot_b[i / QC], qs = i % QC;
+                    if (qc + qs < nq_rt)
+                        prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, qc + qs, T.elem + (size_t)p * T.us + u, qs);
+                }
             }
             // phase D of the previous block, overlapped with phase B: its accumulators are complete (barrier at the
             // end of the last iteration) and are not touched again before the barrier below

@@ -15,6 +15,7 @@
 // The block of a pair (I <= J) is always computed with roles (a = grad phi_I, b = grad phi_J) and the
 // (J, I) block is its transpose -- the same values clone_upper_to_lower produces (src/util.rs:38-51).
 #pragma once
+#include <type_traits>
 #include "device_common.hpp"
 
 namespace fenris_hip {
@@ -140,6 +141,15 @@ __device__ __forceinline__ void lds_wait() {
 __device__ __forceinline__ void lds_wait_all() { lds_wait<0>(); }
 
 
+// compile-time loop 0..N-1: f(std::integral_constant<int, k>) -- the explicit LDS waits need immediate operands
+template <int N, int D, int K = 0, typename F>
+__device__ __forceinline__ void pipeline_consume(F&& f) {
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        pipeline_consume<N, D, K + 1>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ phase B
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
 template <int EK, int OP, int WHAT>
@@ -167,17 +177,39 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     // physical gradients below (a quarter of phase B's LDS traffic)
     constexpr bool KEEP_G = EXPLICIT_LDS && NG == N && !IS_MASS;
     double gkeep[KEEP_G ? N : 1][D];
-    if (EXPLICIT_LDS) {
+    if (EXPLICIT_LDS && KEEP_G) {
+        // software-pipelined two nodes ahead: 4 D fetches (<= 12 of the 15 LDS operations the lgkm counter can track)
+        // are in flight while node g is accumulated; LDS returns in order
+        double xall[NG][D];
+        constexpr int AHEAD = (NG > 2) ? 2 : 1;
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) {
+            lds_read_vec<D>(X + g * D, xall[g]);
+            lds_read_vec<D>(gg + g * D, gkeep[KEEP_G ? g : 0]);
+        }
+        pipeline_consume<NG, D>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + AHEAD < NG) {
+                lds_read_vec<D>(X + (g + AHEAD) * D, xall[g + AHEAD]);
+                lds_read_vec<D>(gg + (g + AHEAD) * D, gkeep[KEEP_G ? g + AHEAD : 0]);
+            }
+            constexpr int pending = ((NG - 1 - g) < AHEAD ? (NG - 1 - g) : AHEAD) * 2 * D;
+            lds_wait<pending>();
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) J[i][j] = fma(xall[g][i], gkeep[KEEP_G ? g : 0][j], J[i][j]);
+        });
+    } else if (EXPLICIT_LDS) {
         // software-pipelined: the fetches of node g+1 are in flight while node g is accumulated
         double xb[2][D], gb[2][D];
         lds_read_vec<D>(X, xb[0]);
-        if (KEEP_G) lds_read_vec<D>(gg, gkeep[0]); else lds_read_vec<D>(gg, gb[0]);
+        lds_read_vec<D>(gg, gb[0]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) {
                 lds_read_vec<D>(X + (g + 1) * D, xb[(g + 1) & 1]);
-                if (KEEP_G) lds_read_vec<D>(gg + (g + 1) * D, gkeep[KEEP_G ? g + 1 : 0]);
-                else lds_read_vec<D>(gg + (g + 1) * D, gb[(g + 1) & 1]);
+                lds_read_vec<D>(gg + (g + 1) * D, gb[(g + 1) & 1]);
                 lds_wait<2 * D>();
             } else {
                 lds_wait<0>();
@@ -185,8 +217,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int j = 0; j < D; ++j)
-                    J[i][j] = fma(xb[g & 1][i], KEEP_G ? gkeep[KEEP_G ? g : 0][j] : gb[g & 1][j], J[i][j]);
+                for (int j = 0; j < D; ++j) J[i][j] = fma(xb[g & 1][i], gb[g & 1][j], J[i][j]);
         }
     } else {
         for (int g = 0; g < NG; ++g)

@@ -28,6 +28,8 @@ struct Layout {
     int fast;  // 1: gradients stored pre-scaled by sqrt(w |det J|), no per-point coefficients
     int o_pos; // gather: per (entry, local node) column slot, bytes
     int nqs;   // quadrature points staged per element at a time (== nq unless chunked)
+    int qss;   // doubles per staged element (nqs * qpd, plus padding in the planar form)
+    int planar;  // 1: gradients of a point stored component-major ([c][node], 16-byte aligned rows) for ds_read_b128
     // strides in doubles, rounded up to odd counts: phase B runs one lane per (element, point), so lanes differ
     // in the element (X, U) or in the point (gradient tables); an even stride such as 24 maps eight of them onto
     // two LDS bank pairs (4-way conflicts on three quarters of phase B's LDS traffic)
@@ -39,7 +41,7 @@ enum { WHAT_MATRIX = 0, WHAT_VECTOR = 1, WHAT_SCALAR = 2 };
 
 template <int EK, int OP, int WHAT>
 __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int nb_max, bool gather, int mb = 0, int fast = 0,
-                                               int nq_stage = 0, int nc_row = 0) {
+                                               int nq_stage = 0, int nc_row = 0, int planar = 0) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     Layout L;
@@ -61,7 +63,18 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     else L.qpd = 1;
     if (WHAT != WHAT_SCALAR && (L.qpd & 1) == 0) L.qpd += 1;
     L.nqs = nq_stage > 0 ? nq_stage : nq;  // quadrature points staged at a time
-    L.o_QP = o;    o += ub * L.nqs * L.qpd;
+    L.planar = (planar && L.fast) ? 1 : 0;
+    L.qss = L.nqs * L.qpd;
+    if (L.planar) {
+        // rows of 2 (N D / 2 + 1) doubles: even (16-byte alignment of every row), and 8 consecutive points of a slot
+        // land on disjoint bank quads for phase B's ds_write_b128; slot stride = 8 (mod 16) doubles: the 64-byte
+        // footprints that phase C's 16-lane ds_read_b128 groups fetch from four different slots cover all 64 banks
+        L.qpd = E::N * E::D + 2;
+        L.qss = L.nqs * L.qpd;
+        L.qss += (8 - L.qss % 16 + 16) % 16;
+        o += o & 1;
+    }
+    L.o_QP = o;    o += ub * L.qss;
     L.o_ACC = o;   o += gather ? acc_max : 0;
     L.n_doubles = o;
     int i = 0;
@@ -119,6 +132,21 @@ __device__ __forceinline__ double lds_read_f64(const double* p) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
     return v;
 }
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// ds_read_b128 of two adjacent doubles (16-byte aligned): 4 LDS cycles per wave for 16 bytes per lane, and -- unlike
+// the 8-byte form -- the rate is reached with one wave per SIMD (MI355X_MICROARCH.md, LDS table)
+template <int OFF_BYTES>
+__device__ __forceinline__ f64x2 lds_read_f64x2(unsigned addr) {
+    f64x2 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ double lds_read_f64_at(unsigned addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF_BYTES));
+    return v;
+}
 template <int D>
 __device__ __forceinline__ void lds_read_vec(const double* p, double (&v)[D]) {
     v[0] = lds_read_f64<0>(p);
@@ -152,7 +180,7 @@ __device__ __forceinline__ void pipeline_consume(F&& f) {
 
 // ------------------------------------------------------------------------------------------ phase B
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
-template <int EK, int OP, int WHAT>
+template <int EK, int OP, int WHAT, bool PLANAR = false>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
                                          const int* elem_id, int qslot = -1) {
     using E = ElemT<EK>;
@@ -162,7 +190,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     const double* X = lds + L.o_X + u * L.xs;
     const double* gg = lds + L.o_ggeom + q * L.ggs;
     const double* gr = lds + L.o_gref + q * L.gs;
-    double* qp = lds + L.o_QP + (size_t)(u * L.nqs + (qslot < 0 ? q : qslot)) * L.qpd;
+    double* qp = lds + L.o_QP + (size_t)u * L.qss + (size_t)(qslot < 0 ? q : qslot) * L.qpd;
     (void)lds_i;
 
     // J = X G^T  (hexahedron.rs:101-107): J[i][j] = sum_g x_g[i] dN_g/dxi_j
@@ -267,6 +295,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         return;
     }
     double rb[2][D];
+    double gpair[D];  // PLANAR: the even node of a pair waits here for its odd neighbour
     if (EXPLICIT_LDS && !KEEP_G) lds_read_vec<D>(gr, rb[0]);
 #pragma unroll UNR
     for (int n = 0; n < N; ++n) {
@@ -294,7 +323,21 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
             for (int k = 0; k < D; ++k) t = fma(Ji[k][i], rv[k], t);
             g[i] = t;
         }
-        if (WHAT != WHAT_SCALAR) {
+        if (PLANAR) {
+            // component-major rows [c][node]: the values of nodes (n - 1, n) leave as one ds_write_b128 per component
+            if (n & 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    f64x2 pr;
+                    pr.x = gpair[i];
+                    pr.y = fast_scale * g[i];
+                    *reinterpret_cast<f64x2*>(gout + i * N + (n - 1)) = pr;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) gpair[i] = fast_scale * g[i];
+            }
+        } else if (WHAT != WHAT_SCALAR) {
 #pragma unroll
             for (int i = 0; i < D; ++i) gout[n * D + i] = fast_scale * g[i];
         }
@@ -938,8 +981,11 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
     constexpr int SLOTS = FULLQ ? 1 : 2;  // geometry-node slots per thread: U * NG <= 512 (<= 256 with FULLQ)
+    // PLANAR: component-major gradient rows, phase C fetches the two column nodes of a lane with one ds_read_b128
+    // per component (pipelined_planar() in engine.hip makes the same choice for the LDS size)
+    constexpr bool PLANAR = FULLQ && N == 8 && D == 3 && JT == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC);
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC, 0, PLANAR ? 1 : 0);
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
     double* acc = lds + L.o_ACC;
@@ -1083,7 +1129,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             if constexpr (FULLQ) {  // U <= 32 slots x 8 points: at most one item per thread
                 if (tid < U * QC && !(ablate & 1)) {
                     const int u = (int)slot_b[tid / QC];
-                    prologue<EK, OP, WHAT_MATRIX>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC);
+                    prologue<EK, OP, WHAT_MATRIX, PLANAR>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC);
                 }
             } else if (!(ablate & 1)) {
                 for (int i = tid; i < U * QC; i += nt) {
@@ -1102,8 +1148,46 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             FH_STAMP(2)  // barrier after B
             // phase C (accumulate)
             const int nqc = FULLQ ? QC : min(QC, nq_rt - qc);
-            if (has_item && !(ablate & 2)) {
-                const double* pq = lds + L.o_QP + (size_t)u_item * QC * L.qpd;
+            if constexpr (PLANAR) {
+                if (has_item && !(ablate & 2)) {
+                    // straight-line, all strides compile-time: two address registers and immediate offsets.  Per
+                    // point 3 ds_read_b64 (row node, one per component) + 3 ds_read_b128 (the two column nodes);
+                    // two points (12 operations, the lgkm counter tracks 15) are in flight while one is multiplied.
+                    constexpr int QPD = N * D + 2, AHEAD = 2, NB = AHEAD + 1;
+                    const double* pq = lds + L.o_QP + (size_t)u_item * L.qss;
+                    const unsigned pa = (unsigned)(unsigned long long)(pq + an), pb = (unsigned)(unsigned long long)(pq + j0);
+                    double av[NB][D];
+                    f64x2 bv[NB][D];
+                    auto fetchq = [&](auto qk) {
+                        constexpr int qq = decltype(qk)::value, sl = qq % NB;
+                        av[sl][0] = lds_read_f64_at<(qq * QPD) * 8>(pa);
+                        av[sl][1] = lds_read_f64_at<(qq * QPD + N) * 8>(pa);
+                        av[sl][2] = lds_read_f64_at<(qq * QPD + 2 * N) * 8>(pa);
+                        bv[sl][0] = lds_read_f64x2<(qq * QPD) * 8>(pb);
+                        bv[sl][1] = lds_read_f64x2<(qq * QPD + N) * 8>(pb);
+                        bv[sl][2] = lds_read_f64x2<(qq * QPD + 2 * N) * 8>(pb);
+                    };
+                    fetchq(std::integral_constant<int, 0>{});
+                    fetchq(std::integral_constant<int, 1>{});
+                    pipeline_consume<QC, D>([&](auto qk) {
+                        constexpr int qq = decltype(qk)::value, sl = qq % NB;
+                        // wait for point qq first (point qq + 1 may stay in flight), then issue point qq + AHEAD: never
+                        // more than 12 operations outstanding
+                        constexpr int ahead = (QC - 1 - qq) < (AHEAD - 1) ? (QC - 1 - qq) : (AHEAD - 1);
+                        lds_wait<ahead * 2 * D>();
+                        if constexpr (qq + AHEAD < QC) fetchq(std::integral_constant<int, qq + AHEAD>{});
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                Gr[0][i][j] = fma(av[sl][i], bv[sl][j].x, Gr[0][i][j]);
+                                Gr[1][i][j] = fma(av[sl][i], bv[sl][j].y, Gr[1][i][j]);
+                            }
+                    });
+                }
+            } else if (has_item && !(ablate & 2)) {
+                const double* pq = lds + L.o_QP + (size_t)u_item * L.qss;
                 // every fetch is an explicit ds_read_b64 (2 LDS cycles per wave): hipcc would merge neighbours
                 // into ds_read2_b64, which costs 8 cycles for the same 16 bytes (MI355X_MICROARCH.md, LDS
                 // table), and the LDS pipe -- shared by the CU's four SIMDs -- is what bounds this loop.

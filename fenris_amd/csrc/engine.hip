@@ -851,8 +851,17 @@ int build_partition(fh_ctx* c) {
 
 template <int EK, int OP, int QC, int JT>
 int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
-    const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC).bytes();
+    size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC).bytes();
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "pipelined gather: LDS footprint too large");
+    // the compile-time-rule instantiation (Hex8, rule of exactly QC points) stages planar gradient rows, which are
+    // longer: taken only while two workgroups still share a CU
+    bool fullq = false;
+    if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
+        const size_t lds_planar = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC, 0, 1).bytes();
+        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 && !std::getenv("FENRIS_HIP_NO_FULLQ") &&
+                (2 * lds_planar + 1024 <= LDS_LIMIT || 2 * lds + 1024 > LDS_LIMIT);
+        if (fullq) lds = lds_planar;
+    }
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
@@ -862,8 +871,10 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     const bool dbg = (std::getenv("FENRIS_HIP_TRACE") || std::getenv("FENRIS_HIP_ABLATE") || std::getenv("FENRIS_HIP_DBG_KERNEL"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
     if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
-        if (dbg) kern = k_gather_pipelined<EK, OP, QC, JT, true>;
-        else if (a.nq == QC && T.cs <= 256 && T.rw <= 256 && !std::getenv("FENRIS_HIP_NO_FULLQ"))
+        if (dbg) {  // the instrumented twin of whichever instantiation production would take
+            if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, true, true>;
+            else kern = k_gather_pipelined<EK, OP, QC, JT, true>;
+        } else if (fullq)
             kern = k_gather_pipelined<EK, OP, QC, JT, false, true>;
     }
     if (lds > 48 * 1024)

@@ -46,24 +46,32 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     using O = OpT<OP, E::D>;
     Layout L;
     int o = 0;
+    L.fast = (WHAT == WHAT_MATRIX && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC)) ? fast : 0;
+    L.planar = (planar && L.fast) ? 1 : 0;
     L.xs = (E::NG * E::D) | 1;
     L.us = (E::N * O::S) | 1;
     L.gs = (E::N * E::D) | 1;
     L.ggs = (E::NG * E::D) | 1;
+    if (L.planar) {
+        // phase B reads whole rows as ds_read_b128 pairs: even strides (16-byte aligned rows); 2 (n + 1) doubles per
+        // row puts the rows of eight points, and of nearby slots, on different bank quads
+        L.xs = E::NG * E::D + 2;
+        L.gs = E::N * E::D + 2;
+        L.ggs = E::NG * E::D + 2;
+    }
     L.o_gref = o;  o += nq * L.gs;
     if (E::NG == E::N) L.o_ggeom = L.o_gref;  // iso-parametric: one table
     else { L.o_ggeom = o; o += nq * L.ggs; }
     L.o_qw = o;    o += nq;
     L.o_qpar = o;  o += 2 * nq;
+    if (L.planar) o += o & 1;
     L.o_X = o;     o += ub * L.xs;
     L.o_U = o;     o += (O::NEEDS_U || WHAT != WHAT_MATRIX) ? ub * L.us : 0;
-    L.fast = (WHAT == WHAT_MATRIX && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC)) ? fast : 0;
     if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + (L.fast ? 0 : O::NCOEF);
     else if (WHAT == WHAT_VECTOR) L.qpd = E::N * E::D + O::S * E::D;
     else L.qpd = 1;
     if (WHAT != WHAT_SCALAR && (L.qpd & 1) == 0) L.qpd += 1;
     L.nqs = nq_stage > 0 ? nq_stage : nq;  // quadrature points staged at a time
-    L.planar = (planar && L.fast) ? 1 : 0;
     L.qss = L.nqs * L.qpd;
     if (L.planar) {
         // rows of 2 (N D / 2 + 1) doubles: even (16-byte alignment of every row), and 8 consecutive points of a slot
@@ -205,7 +213,41 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     // physical gradients below (a quarter of phase B's LDS traffic)
     constexpr bool KEEP_G = EXPLICIT_LDS && NG == N && !IS_MASS;
     double gkeep[KEEP_G ? N : 1][D];
-    if (EXPLICIT_LDS && KEEP_G) {
+    if constexpr (PLANAR) {
+        // rows of X and of the gradient table as ds_read_b128 pairs (flat index 3 g + c), two nodes (3 + 3 fetches)
+        // per step, two steps in flight: 24 wide fetches instead of 48 narrow ones
+        static_assert(!PLANAR || (NG == N && N % 2 == 0 && D == 3), "planar phase B: iso-parametric, even node count, 3D");
+        const unsigned xa = (unsigned)(unsigned long long)X, ga = (unsigned)(unsigned long long)gg;
+        constexpr int NS = N / 2;  // steps
+        f64x2 xf[NS][3], gf[NS][3];
+        auto fetch2 = [&](auto sk) {
+            constexpr int st = decltype(sk)::value;
+            xf[st][0] = lds_read_f64x2<(6 * st) * 8>(xa);
+            xf[st][1] = lds_read_f64x2<(6 * st + 2) * 8>(xa);
+            xf[st][2] = lds_read_f64x2<(6 * st + 4) * 8>(xa);
+            gf[st][0] = lds_read_f64x2<(6 * st) * 8>(ga);
+            gf[st][1] = lds_read_f64x2<(6 * st + 2) * 8>(ga);
+            gf[st][2] = lds_read_f64x2<(6 * st + 4) * 8>(ga);
+        };
+        fetch2(std::integral_constant<int, 0>{});
+        fetch2(std::integral_constant<int, 1>{});
+        pipeline_consume<NS, D>([&](auto sk) {
+            constexpr int st = decltype(sk)::value;
+            lds_wait<(st + 1 < NS) ? 6 : 0>();
+            if constexpr (st + 2 < NS) fetch2(std::integral_constant<int, st + 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const double xe[2][3] = {{xf[st][0].x, xf[st][0].y, xf[st][1].x}, {xf[st][1].y, xf[st][2].x, xf[st][2].y}};
+            const double ge[2][3] = {{gf[st][0].x, gf[st][0].y, gf[st][1].x}, {gf[st][1].y, gf[st][2].x, gf[st][2].y}};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    gkeep[KEEP_G ? 2 * st + h : 0][i] = ge[h][i];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) J[i][j] = fma(xe[h][i], ge[h][j], J[i][j]);
+                }
+        });
+    } else if (EXPLICIT_LDS && KEEP_G) {
         // software-pipelined two nodes ahead: 4 D fetches (<= 12 of the 15 LDS operations the lgkm counter can track)
         // are in flight while node g is accumulated; LDS returns in order
         double xall[NG][D];
@@ -294,6 +336,12 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         }
         return;
     }
+    if constexpr (PLANAR) {  // fold sqrt(s) into J^-1 once (9 products) instead of scaling the 3 N gradient components
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Ji[i][j] *= fast_scale;
+    }
     double rb[2][D];
     double gpair[D];  // PLANAR: the even node of a pair waits here for its odd neighbour
     if (EXPLICIT_LDS && !KEEP_G) lds_read_vec<D>(gr, rb[0]);
@@ -330,12 +378,12 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
                 for (int i = 0; i < D; ++i) {
                     f64x2 pr;
                     pr.x = gpair[i];
-                    pr.y = fast_scale * g[i];
+                    pr.y = g[i];
                     *reinterpret_cast<f64x2*>(gout + i * N + (n - 1)) = pr;
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < D; ++i) gpair[i] = fast_scale * g[i];
+                for (int i = 0; i < D; ++i) gpair[i] = g[i];
             }
         } else if (WHAT != WHAT_SCALAR) {
 #pragma unroll
@@ -1047,6 +1095,22 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         if (rt >= nth) return;
         if (ablate & 8) {
             for (int i = rt; i < nacc; i += nth) acc[i] = 0.0;
+        } else if (PLANAR && a.overwrite) {
+            // pairs: ds_read_b128 / global_store_dwordx4 / ds_write_b128 (the accumulators start 16-byte aligned;
+            // the rows in global memory are 8-byte aligned, which the vector-memory path accepts)
+            typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+            f64x2* acc2 = reinterpret_cast<f64x2*>(acc);
+            f64x2_u* out2 = reinterpret_cast<f64x2_u*>(out);
+            const int npair = nacc >> 1;
+            const f64x2 zero2 = {0.0, 0.0};
+            int i = rt;
+            for (; i + nth < npair; i += 2 * nth) {
+                const f64x2 v0 = acc2[i], v1 = acc2[i + nth];
+                out2[i] = v0; out2[i + nth] = v1;
+                acc2[i] = zero2; acc2[i + nth] = zero2;
+            }
+            for (; i < npair; i += nth) { out2[i] = acc2[i]; acc2[i] = zero2; }
+            if ((nacc & 1) && rt == 0) { out[nacc - 1] = acc[nacc - 1]; acc[nacc - 1] = 0.0; }
         } else if (a.overwrite) {
             int i = rt;
             for (; i + 3 * nth < nacc; i += 4 * nth) {  // batches of four: the LDS reads overlap
@@ -1271,8 +1335,10 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
                             // diagonal block: the lower triangle mirrors the upper one (util.rs:46-50); compile-time
                             // register indices only (a runtime index would push Gr to scratch)
                             const double v = (i > j && diag) ? val[j][i] : val[i][j];
-                            if (ablate & 32) base[(i % S) * S * cnt + (j % S)] = v;  // experiment: plain stores (wrong sums)
-                            else atomic_add_f64(base + (i % S) * S * cnt + (j % S), v);
+                            // experiments (wrong sums): 64 = lane-private, conflict-free targets; 32 = plain stores
+                            double* dst = (ablate & 64) ? lds + L.o_QP + tid * 17 + r * 9 + i * 3 + j : base + (i % S) * S * cnt + (j % S);
+                            if (ablate & 32) *dst = v;
+                            else atomic_add_f64(dst, v);
                         }
                 }
             }

@@ -112,14 +112,27 @@ template <> __device__ __forceinline__ double det_small<3>(const double (&m)[3][
     return m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) - m[0][1] * (m[1][0] * m[2][2] - m[2][0] * m[1][2]) +
            m[0][2] * (m[1][0] * m[2][1] - m[2][0] * m[1][1]);
 }
-// inverse by cofactors / det (what nalgebra's try_inverse does for 2x2 / 3x3)
-__device__ __forceinline__ void inv_small(const double (&m)[2][2], double det, double (&o)[2][2]) {
-    const double r = 1.0 / det;
+// adjugate times r: the inverse by cofactors / det (what nalgebra's try_inverse does for 2x2 / 3x3) for r = 1 / det
+__device__ __forceinline__ void adj_scaled(const double (&m)[2][2], double r, double (&o)[2][2]) {
     o[0][0] = m[1][1] * r;  o[0][1] = -m[0][1] * r;
     o[1][0] = -m[1][0] * r; o[1][1] = m[0][0] * r;
 }
-__device__ __forceinline__ void inv_small(const double (&m)[3][3], double det, double (&o)[3][3]) {
-    const double r = 1.0 / det;
+__device__ __forceinline__ void adj_scaled(const double (&m)[3][3], double r, double (&o)[3][3]);
+template <int D>
+__device__ __forceinline__ void inv_small(const double (&m)[D][D], double det, double (&o)[D][D]) {
+    adj_scaled(m, 1.0 / det, o);
+}
+// 1 / sqrt(x) for x > 0 to double precision: v_rsq_f64 seed + two Newton steps (the seed is good to ~2^-26)
+__device__ __forceinline__ double rsqrt_newton(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double h = fma(-x * y, y, 1.0);  // 1 - x y^2
+        y = fma(0.5 * y, h, y);
+    }
+    return y;
+}
+__device__ __forceinline__ void adj_scaled(const double (&m)[3][3], double r, double (&o)[3][3]) {
     o[0][0] = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * r;
     o[0][1] = (m[0][2] * m[2][1] - m[2][2] * m[0][1]) * r;
     o[0][2] = (m[0][1] * m[1][2] - m[1][1] * m[0][2]) * r;
@@ -190,7 +203,7 @@ __device__ __forceinline__ void pipeline_consume(F&& f) {
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
 template <int EK, int OP, int WHAT, bool PLANAR = false>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
-                                         const int* elem_id, int qslot = -1) {
+                                         const int* elem_id, int qslot = -1, double sqw = 0.0) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
@@ -305,6 +318,10 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j < D; ++j) Ji[i][j] = 0.0;
+    } else if constexpr (PLANAR) {
+        // sqrt(w |det J|) J^-1 = sign(det J) sqrt(w) / sqrt(|det J|) adj(J): one reciprocal square root instead of a
+        // division, a square root and the scaling of the gradients (sqw = sqrt(w_q), constant per lane)
+        adj_scaled(J, copysign(sqw, detJ) * rsqrt_newton(fabs(detJ)), Ji);
     } else {
         inv_small(J, detJ, Ji);
     }
@@ -323,7 +340,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
     double* gout = qp;  // first node-vector block: physical gradients
     // FAST path (Laplace / uniform linear elasticity, non-negative weights): store sqrt(s) g_n so that
     // sum_q s g_I g_J^T = sum_q h_I h_J^T needs no per-point coefficient in phase C
-    const double fast_scale = (WHAT == WHAT_MATRIX && L.fast) ? sqrt(s) : 1.0;
+    const double fast_scale = (WHAT == WHAT_MATRIX && L.fast && !PLANAR) ? sqrt(s) : 1.0;
     if (IS_MASS) {
         // mass.rs:243-270: only |det J|, the density and the basis values enter; phi_n goes to the first component
         if (WHAT == WHAT_MATRIX) {
@@ -335,12 +352,6 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
             qp[O::NVEC * N * D] = s * (a.rule_map ? a.rparams[((size_t)a.rule_map[*elem_id] * a.nq + q) * 2] : lds[L.o_qpar + 2 * q]);
         }
         return;
-    }
-    if constexpr (PLANAR) {  // fold sqrt(s) into J^-1 once (9 products) instead of scaling the 3 N gradient components
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) Ji[i][j] *= fast_scale;
     }
     double rb[2][D];
     double gpair[D];  // PLANAR: the even node of a pair waits here for its odd neighbour
@@ -1124,6 +1135,8 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         }
     };
 
+    // FULLQ: a lane always works on point tid % QC in phase B
+    const double sqw = PLANAR ? sqrt(a.qw[tid % QC]) : 0.0;
     int p = p_begin;
     if (p >= p_end) return;
     Rec nxt;
@@ -1193,7 +1206,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
             if constexpr (FULLQ) {  // U <= 32 slots x 8 points: at most one item per thread
                 if (tid < U * QC && !(ablate & 1)) {
                     const int u = (int)slot_b[tid / QC];
-                    prologue<EK, OP, WHAT_MATRIX, PLANAR>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC);
+                    prologue<EK, OP, WHAT_MATRIX, PLANAR>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC, sqw);
                 }
             } else if (!(ablate & 1)) {
                 for (int i = tid; i < U * QC; i += nt) {

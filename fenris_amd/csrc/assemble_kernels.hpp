@@ -1340,14 +1340,14 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
                         for (int j = 0; j < D; ++j)
                             val[i][j] = (i == j) ? fma(a.mu, tr + Gr[r][i][i], a.lambda * Gr[r][i][i])
                                                  : fma(a.mu, Gr[r][j][i], a.lambda * Gr[r][i][j]);
-                    const bool diag = (an == Jn);
+                    // diagonal block (an == Jn): the lower triangle mirrors the upper one (util.rs:46-50).  Both
+                    // operand vectors are then the same LDS values, so G[i][j] and G[j][i] are the same products summed
+                    // in the same order -- val is symmetric bit for bit and needs no explicit mirroring.
 #pragma unroll
                     for (int i = 0; i < D; ++i)
 #pragma unroll
                         for (int j = 0; j < D; ++j) {
-                            // diagonal block: the lower triangle mirrors the upper one (util.rs:46-50); compile-time
-                            // register indices only (a runtime index would push Gr to scratch)
-                            const double v = (i > j && diag) ? val[j][i] : val[i][j];
+                            const double v = val[i][j];
                             // experiments (wrong sums): 64 = lane-private, conflict-free targets; 32 = plain stores
                             double* dst = (ablate & 64) ? lds + L.o_QP + tid * 17 + r * 9 + i * 3 + j : base + (i % S) * S * cnt + (j % S);
                             if (ablate & 32) *dst = v;

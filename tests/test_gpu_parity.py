@@ -526,6 +526,34 @@ def test_pipelined_kernel_is_the_one_measured(engine, oracle):
             assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), (kind, op)
 
 
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_pipelined_kernel_mirrored_and_permuted_hex8(engine, oracle, op):
+    """The planar instantiation folds sign(det J) sqrt(w) / sqrt(|det J|) into the adjugate: elements with a negative
+    Jacobian determinant (mirrored node order), a random vertex / element numbering and widely varying element
+    sizes must come out like the oracle's."""
+    base = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 2, 1, 1, 5)
+    rng = np.random.default_rng(7)
+    v = base.vertices.copy()
+    v += 0.03 * rng.standard_normal(v.shape)
+    v[:, 0] = np.sign(v[:, 0]) * np.abs(v[:, 0]) ** 2.5      # graded: element sizes over two orders of magnitude
+    conn = base.connectivity.copy()
+    flip = rng.random(len(conn)) < 0.5
+    conn[flip] = conn[flip][:, [4, 5, 6, 7, 0, 1, 2, 3]]     # swap bottom and top face: det J < 0
+    perm = rng.permutation(len(v))
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(v))
+    mesh = fa.Mesh(v[perm], inv[conn][rng.permutation(len(conn))], fa.HEX8)
+    asm, ref = _pair(engine, oracle, "HEX8", op, mesh=mesh)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert asm.engine.last_kernel_name() == "k_gather_pipelined"
+    assert np.array_equal(k.row_offsets, oro) and np.array_equal(k.col_indices, oci)
+    assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+    ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
+    assert np.abs(k.values - ka.values).max() <= TOL * np.abs(ovals).max()
+
+
 def test_full_size_tet4_elasticity_properties(engine, oracle):
     """BASELINE config C3 (Tet4 linear elasticity, BCC res 75, vertices and elements permuted) at full size:
     closed-form nnz, owner-computes == atomic == coloured, rigid translations in the null space, and the row

@@ -1019,6 +1019,8 @@ struct PipeTables {
     const int* rec;             // [npos][rw]
     const int* conn;            // [npos][cs]   geometry-node indices per LDS slot (padded with 0)
     const int* elem;            // [npos][us]   element id per slot (error reporting)
+    const double* slotpar;      // [npos][us][2] (mu, lambda) of the element in each slot -- compact table whose rules are
+                                //              constant over the points (piecewise-constant material); else null
     int rw;                     // words per record
     int cs, ms, nbs, us;        // strides: cs = us * NG
     int npos;
@@ -1030,7 +1032,9 @@ __host__ __device__ inline int pipe_record_words(int us, int ms, int N, int nbs)
 // the production kernel carries none of their scalar branches.
 // FULLQ: the rule has exactly QC points (one chunk): the chunk loop and its bounds are compile-time; the host also
 // guarantees cs <= 256 and rw <= 256, so one geometry-node slot and one record word per thread suffice.
-template <int EK, int OP, int QC, int JT, bool DBG = false, bool FULLQ = false>
+// ELEMPAR: (mu, lambda) per element (T.slotpar) instead of one uniform pair: the gradients are still stored pre-scaled
+// by sqrt(w |det J|), the parameters only enter the finalize of a lane, whose two blocks belong to one element.
+template <int EK, int OP, int QC, int JT, bool DBG = false, bool FULLQ = false, bool ELEMPAR = false>
 __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(const KArgs a, const PipeTables T) {
     const int ablate = DBG ? a.ablate : 0;
     const int nq_rt = FULLQ ? QC : a.nq;
@@ -1197,6 +1201,13 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         const bool has_item = tid < m * NGRP;
         const unsigned packed = has_item ? packed_raw : 0u;
         const int u_item = (int)(packed >> 16);
+        // material of this lane's element: fetched now, used by the finalize a whole block later
+        double mu_i = a.mu, lambda_i = a.lambda;
+        if constexpr (ELEMPAR) {
+            const double* sp = T.slotpar + 2 * ((size_t)p * T.us + u_item);
+            mu_i = sp[0];
+            lambda_i = sp[1];
+        }
         const int an = (int)((packed >> 8) & 0xffu);
         const int il = (int)(packed & 0xffu);
         for (int qc = 0; qc < nq_rt; qc += QC) {
@@ -1338,8 +1349,8 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
                     for (int i = 0; i < D; ++i)
 #pragma unroll
                         for (int j = 0; j < D; ++j)
-                            val[i][j] = (i == j) ? fma(a.mu, tr + Gr[r][i][i], a.lambda * Gr[r][i][i])
-                                                 : fma(a.mu, Gr[r][j][i], a.lambda * Gr[r][i][j]);
+                            val[i][j] = (i == j) ? fma(mu_i, tr + Gr[r][i][i], lambda_i * Gr[r][i][i])
+                                                 : fma(mu_i, Gr[r][j][i], lambda_i * Gr[r][i][j]);
                     // diagonal block (an == Jn): the lower triangle mirrors the upper one (util.rs:46-50).  Both
                     // operand vectors are then the same LDS values, so G[i][j] and G[j][i] are the same products summed
                     // in the same order -- val is symmetric bit for bit and needs no explicit mirroring.
@@ -1380,6 +1391,23 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
         for (int k = 0; k < 6; ++k) atomicAdd(row + k, tr_acc[k]);
         atomicAdd(row + 6, 1ull);
     }
+}
+
+// (mu, lambda) of the element staged in every slot of every position, for compact tables whose rules are constant over
+// their points: out[2 i] = rparams[rule_map[elem[i]]][point 0]
+__global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size_t n, const unsigned* rule_map, const double* rparams,
+                                                           int nq, double* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = elem[i];
+    double mu = 0.0, lambda = 0.0;
+    if (e >= 0) {
+        const double* par = rparams + (size_t)rule_map[e] * nq * 2;
+        mu = par[0];
+        lambda = par[1];
+    }
+    out[2 * i] = mu;
+    out[2 * i + 1] = lambda;
 }
 
 // successor of a block in the sweep order: the block that owns most of the nodes (with an index beyond this

@@ -290,7 +290,10 @@ struct fh_ctx {
     DevBuf<unsigned> rule_map;
     bool has_rules = false;
     bool has_params = false, has_u = false;
-    bool fast_ok = false;       // uniform parameters and non-negative weights
+    bool fast_ok = false;       // uniform parameters (or rules constant over their points, elem_par) and non-negative weights
+    bool elem_par = false;      // compact table whose rules are constant over the points: pipelined kernel with per-slot data
+    DevBuf<double> p_slotpar;
+    bool has_slotpar = false;
     double uni_mu = 0.0, uni_lambda = 0.0;
     std::vector<double> h_points;
     // optional element mask: pattern from all elements, numerics from the active ones only
@@ -556,6 +559,10 @@ int check_ready(fh_ctx* c, const char* who, bool need_pattern) {
     return FH_OK;
 }
 
+// the pre-scaled-gradient ("fast") form of every kernel but the pipelined gather needs ONE uniform parameter pair;
+// with a compact table only the pipelined kernel knows per-element data (fh_ctx::elem_par)
+static bool generic_fast(const fh_ctx* c) { return c->fast_ok && (!c->has_rules || c->op == FH_LAPLACE); }
+
 void fill_common(fh_ctx* c, KArgs& a) {
     std::memset(&a, 0, sizeof a);
     a.verts = c->verts.p;
@@ -571,7 +578,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.rule_map = c->has_rules ? c->rule_map.p : nullptr;
     a.rparams = c->has_rules ? c->rparams.p : nullptr;
     a.u = c->has_u ? c->u.p : nullptr;
-    a.fast = (c->fast_ok && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) ? 1 : 0;
+    a.fast = (generic_fast(c) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) ? 1 : 0;
     a.mu = c->uni_mu;
     a.lambda = c->uni_lambda;
     a.noff = c->noff.p;
@@ -610,7 +617,7 @@ int read_status(fh_ctx* c, uint64_t* failed) {
 int choose_epb(fh_ctx* c, int what) {
     int best = 1;
     for (int epb = 1; epb <= 64; ++epb) {
-        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false, 0, c->fast_ok);
+        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false, 0, generic_fast(c));
         if (b <= LDS_TARGET) best = epb; else break;
     }
     return best;
@@ -840,6 +847,13 @@ int build_partition(fh_ctx* c) {
                 std::fprintf(stderr, "[fenris_hip] sweep order: %d blocks in %d chains (us=%d ms=%d)\n", nblk, nchains, us, ms);
         }
     }
+    c->has_slotpar = false;
+    if (c->has_rules && c->fast_ok && c->op != FH_LAPLACE && !c->has_pipe) {
+        // per-element data without the pipelined tables: the generic kernels need the per-point-coefficient layout
+        c->fast_ok = false;
+        c->elem_par = false;
+        return build_partition(c);
+    }
     c->g_ub = ub;
     c->g_umax = umax;
     c->g_mb = mb;
@@ -870,7 +884,17 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
     const bool dbg = (std::getenv("FENRIS_HIP_TRACE") || std::getenv("FENRIS_HIP_ABLATE") || std::getenv("FENRIS_HIP_DBG_KERNEL"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
-    if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
+    constexpr int N_ = ElemT<EK>::N;
+    constexpr bool DEFAULT_JT = JT == ((N_ % 2 == 0) ? 2 : N_);  // per-element data: the default tiling only
+    if (T.slotpar) {
+        if constexpr (OP == FH_LINEAR_ELASTIC && DEFAULT_JT) {
+            kern = k_gather_pipelined<EK, OP, QC, JT, false, false, true>;
+            if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2)
+                if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, false, true, true>;
+        } else {
+            return c->fail(FH_UNSUPPORTED, "pipelined gather with per-element parameters: default FENRIS_HIP_PIPE_JT only");
+        }
+    } else if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
         if (dbg) {  // the instrumented twin of whichever instantiation production would take
             if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, true, true>;
             else kern = k_gather_pipelined<EK, OP, QC, JT, true>;
@@ -1081,8 +1105,18 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         a.acc_max = c->g_acc;
         a.nb_max = c->g_nb;
         const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
-        if (c->has_pipe && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
-            PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, c->p_rw,
+        const bool pipe_rules = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
+        if (pipe_rules && !c->has_slotpar) {
+            const size_t n = (size_t)c->nblk * c->p_us;
+            HIP_TRY(c, c->p_slotpar.alloc(2 * n));
+            hipLaunchKernelGGL(k_build_slot_params, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->p_elem.p, n,
+                               c->rule_map.p, c->rparams.p, c->nq, c->p_slotpar.p);
+            HIP_TRY(c, hipGetLastError());
+            c->has_slotpar = true;
+        }
+        if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+            a.fast = 1;
+            PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr, c->p_rw,
                          c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->nblk};
             a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
             a.mb = c->p_ms;  // the LDS layout is sized by the table strides
@@ -1450,6 +1484,7 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     if (std::getenv("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
     c->has_rules = false;
+    c->elem_par = false;
     c->has_partition = false; c->has_tp_pos = false;
     return FH_OK;
 }
@@ -1471,7 +1506,17 @@ int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uin
     HIP_TRY(c, hipMemcpy(c->rule_map.p, map.data(), sizeof(unsigned) * map.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->rparams.p, rule_params, sizeof(double) * (size_t)num_rules * nq * 2, hipMemcpyHostToDevice));
     c->has_rules = true;
-    c->fast_ok = false;  // per-element data: per-point coefficients, generic kernels
+    // rules that are constant over their points (piecewise-constant material) keep the pre-scaled-gradient form: the
+    // pipelined kernel reads (mu, lambda) per element; anything else takes the per-point-coefficient kernels
+    bool weights_ok = true, rules_const = true;
+    for (uint32_t q = 0; q < nq; ++q) weights_ok = weights_ok && (w[q] >= 0.0);
+    for (uint64_t r = 0; r < num_rules && rules_const; ++r)
+        for (uint32_t q = 1; q < nq; ++q)
+            rules_const = rules_const && rule_params[(r * nq + q) * 2] == rule_params[r * nq * 2] &&
+                          rule_params[(r * nq + q) * 2 + 1] == rule_params[r * nq * 2 + 1];
+    c->elem_par = weights_ok && rules_const && !std::getenv("FENRIS_HIP_NO_FAST") && !std::getenv("FENRIS_HIP_NO_ELEM_PAR");
+    c->fast_ok = c->elem_par;
+    c->has_slotpar = false;
     c->has_partition = false; c->has_tp_pos = false;
     return FH_OK;
 }

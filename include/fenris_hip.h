@@ -128,7 +128,9 @@ int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* poin
  * that share points and weights and differ in their per-point data -- piecewise material parameters: element e
  * uses rule_params[elem_to_rule[e]] (num_rules x nq x 2, same pair layout as the uniform table).  A rule index out
  * of bounds is FH_BAD_ARGUMENT (the reference panics).  Rules with different point sets are not expressible here:
- * assemble them rule by rule with fh_set_active_elements. */
+ * assemble them rule by rule with fh_set_active_elements.  Rules whose data are the same at every point (one
+ * LameParameters pair per element: the multi-material case) keep the fastest LinearElastic stiffness kernel, which then
+ * reads the pair per element; rules that vary over their points take the per-point-coefficient kernels. */
 int fh_set_quadrature_compact(fh_ctx*, const double* weights, const double* points, uint32_t nq, uint64_t num_rules,
                               const double* rule_params, const uint64_t* elem_to_rule);
 /* .with_u(&u) (elliptic.rs:123-137); u has s*N entries; NULL = zeros */

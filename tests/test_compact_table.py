@@ -125,6 +125,51 @@ def test_compact_table_mass_and_gravity_match_oracle(engine, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["HEX8", "TET4", "QUAD4"])
+def test_piecewise_constant_material_takes_the_pipelined_kernel(engine, oracle, kind):
+    """Rules that are constant over their points (one LameParameters pair per element -- the multi-material case) keep the
+    owner-computes pipelined kernel, which then reads (mu, lambda) per element; values as the oracle's."""
+    m, w, p, emap, rp = _setup(kind, seed=9)
+    rp = np.ascontiguousarray(np.broadcast_to(RULES[:, None, :], rp.shape))
+    op = fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(op)
+           .with_quadrature_table(_table(p, w, rp, emap)).with_u(None).build())
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() == "k_gather_pipelined"
+    oasm = oracle.ElementAssembler(getattr(oracle, kind), oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=rp[0],
+                                   elem_to_rule=emap, rule_params=rp)
+    st, _, ro, ci, vals = oracle.assemble(oasm)
+    assert st == 0 and np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+    assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    # the element-centric kernels and the residual see the same per-element data
+    ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
+    assert np.abs(ka.values - vals).max() <= 1e-12 * np.abs(vals).max()
+    # accumulate mode, twice: 2 K on top of the first result
+    fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
+    assert np.abs(k.values - 2.0 * vals).max() <= 2e-12 * np.abs(vals).max()
+    # a different map on the same pattern: the per-slot parameters are rebuilt
+    emap2 = ((emap + 1) % len(RULES)).astype(np.uint64)
+    asm2 = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(op)
+            .with_quadrature_table(_table(p, w, rp, emap2)).with_u(None).build())
+    k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm2)
+    assert engine.last_kernel_name() == "k_gather_pipelined"
+    oasm2 = oracle.ElementAssembler(getattr(oracle, kind), oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=rp[0],
+                                    elem_to_rule=emap2, rule_params=rp)
+    vals2 = oracle.assemble(oasm2)[4]
+    assert np.abs(k3.values - vals2).max() <= 1e-12 * np.abs(vals2).max()
+
+
+@pytest.mark.gpu
+def test_rules_varying_over_points_take_the_generic_kernel(engine, oracle):
+    m, w, p, emap, rp = _setup("HEX8", seed=10)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m)
+           .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial()))
+           .with_quadrature_table(_table(p, w, rp, emap)).with_u(None).build())
+    fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() == "k_assemble_matrix<gather>"
+
+
+@pytest.mark.gpu
 def test_uniform_table_after_compact_restores_fast_path(engine, oracle):
     m, w, p, emap, rp = _setup("HEX8", seed=6)
     lame = fa.LameParameters(*RULES[0])

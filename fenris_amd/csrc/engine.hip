@@ -894,6 +894,8 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
         } else {
             return c->fail(FH_UNSUPPORTED, "pipelined gather with per-element parameters: default FENRIS_HIP_PIPE_JT only");
         }
+    } else if constexpr (EK == FH_TET4 && QC == 1 && JT == 2) {
+        if (dbg) kern = k_gather_pipelined<EK, OP, QC, JT, true>;
     } else if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
         if (dbg) {  // the instrumented twin of whichever instantiation production would take
             if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, true, true>;

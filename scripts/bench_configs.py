@@ -47,6 +47,8 @@ def run(name, mesh, op, rule, params, u, n, d, s, scatters=("gather", "atomic", 
     E, N = mesh.num_elements(), mesh.num_nodes()
     abytes = E * n * 4 + N * d * 8 + (s * N * 8 if u is not None else 0) + nnz * 12 + (s * N + 1) * 8
     out = {"config": name, "elements": E, "nodes": N, "nnz": nnz, "pattern_s": tp, "algorithmic_bytes": abytes, "modes": {}}
+    if os.environ.get("BENCH_GATHER_ONLY"):
+        scatters = ("gather",)
     for sc in scatters:
         flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[sc] | fa.ASSEMBLE_OVERWRITE
         try:
@@ -80,6 +82,8 @@ def main():
         conn = inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64)
         run("C3 Tet4 linear elasticity BCC res 75, vertices+elements permuted (seed 12345)", fa.Mesh(verts, conn, fa.TET4),
             fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), quadrature.total_order.tetrahedron(1), lame, None, 4, 3, 3)
+        if os.environ.get("BENCH_GATHER_ONLY"):
+            return
         from fenris_amd import reorder
         t0 = time.perf_counter()
         mp = reorder.reorder_mesh_par(fa.Mesh(verts, conn, fa.TET4))

@@ -73,7 +73,14 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     if (WHAT != WHAT_SCALAR && (L.qpd & 1) == 0) L.qpd += 1;
     L.nqs = nq_stage > 0 ? nq_stage : nq;  // quadrature points staged at a time
     L.qss = L.nqs * L.qpd;
-    if (L.planar) {
+    if (L.planar && planar == 2) {
+        // node-major rows padded to 4 doubles per node ([x y | z 0]: two ds_read_b128 per vector) for the row-owner
+        // kernel (rows_kernel.hpp); 4 N + 2 doubles per row: the 8 points of a slot land on disjoint bank quads for
+        // phase B's ds_write_b128
+        L.qpd = 4 * E::N + 2;
+        L.qss = L.nqs * L.qpd;
+        o += o & 1;
+    } else if (L.planar) {
         // rows of 2 (N D / 2 + 1) doubles: even (16-byte alignment of every row), and 8 consecutive points of a slot
         // land on disjoint bank quads for phase B's ds_write_b128; slot stride = 8 (mod 16) doubles: the 64-byte
         // footprints that phase C's 16-lane ds_read_b128 groups fetch from four different slots cover all 64 banks
@@ -201,7 +208,7 @@ __device__ __forceinline__ void pipeline_consume(F&& f) {
 
 // ------------------------------------------------------------------------------------------ phase B
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
-template <int EK, int OP, int WHAT, bool PLANAR = false>
+template <int EK, int OP, int WHAT, bool PLANAR = false, bool NODEMAJOR = false>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
                                          const int* elem_id, int qslot = -1, double sqw = 0.0) {
     using E = ElemT<EK>;
@@ -382,7 +389,14 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
             for (int k = 0; k < D; ++k) t = fma(Ji[k][i], rv[k], t);
             g[i] = t;
         }
-        if (PLANAR) {
+        if (PLANAR && NODEMAJOR) {
+            // node-major rows padded to four doubles: [x y | z 0]
+            f64x2 lo, hi;
+            lo.x = g[0]; lo.y = g[1 % D];
+            hi.x = g[2 % D]; hi.y = 0.0;
+            *reinterpret_cast<f64x2*>(gout + 4 * n) = lo;
+            *reinterpret_cast<f64x2*>(gout + 4 * n + 2) = hi;
+        } else if (PLANAR) {
             // component-major rows [c][node]: the values of nodes (n - 1, n) leave as one ds_write_b128 per component
             if (n & 1) {
 #pragma unroll

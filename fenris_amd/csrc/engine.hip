@@ -15,6 +15,7 @@
 #include "assemble_kernels.hpp"
 #include "solver_kernels.hpp"
 #include "hex27_mfma.hpp"
+#include "rows_kernel.hpp"
 #include "device_common.hpp"
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
@@ -315,6 +316,10 @@ struct fh_ctx {
     bool has_pos = false;
     // fixed-stride tables of the pipelined gather kernel
     DevBuf<int> p_conn, p_rec, p_elem;
+    DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
+    DevBuf<uint2> r_lanes;      //                                     lanes per position
+    int r_rw = 0;
+    bool has_rows = false;
     int p_rw = 0;
     int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1, p_us = 0;
     bool has_pipe = false;
@@ -777,6 +782,7 @@ int build_partition(fh_ctx* c) {
                      layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, ub, acc, 64, true, mb, c->fast_ok));
     // position-indexed tables for the pipelined kernel (elements with few geometry nodes, pos table present)
     c->has_pipe = false;
+    c->has_rows = false;
     if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
         const int n = c->ei.n;
         const int ms = (mmax + 3) / 4 * 4;
@@ -845,6 +851,25 @@ int build_partition(fh_ctx* c) {
             c->has_pipe = true;
             if (std::getenv("FENRIS_HIP_VERBOSE"))
                 std::fprintf(stderr, "[fenris_hip] sweep order: %d blocks in %d chains (us=%d ms=%d)\n", nblk, nchains, us, ms);
+            // row-owner lanes (Hex8; opt-in while it is being measured)
+            c->has_rows = false;
+            if (c->elem_kind == FH_HEX8 && us * 8 <= 256 && nb_target <= 8 && std::getenv("FENRIS_HIP_ROWS")) {
+                c->r_rw = 8 + us / 4 + nb_target + 1;
+                DevBuf<int> st;
+                HIP_TRY(c, st.alloc(1));
+                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                HIP_TRY(c, c->r_rec.alloc((size_t)nblk * c->r_rw));
+                HIP_TRY(c, c->r_lanes.alloc((size_t)nblk * 256));
+                hipLaunchKernelGGL(k_build_row_lanes, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target, nblk,
+                                   c->r_rw, c->r_rec.p, c->r_lanes.p, st.p);
+                HIP_TRY(c, hipGetLastError());
+                int bad = 0;
+                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->has_rows = bad == 0;
+                if (std::getenv("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] row-owner lanes: %s\n", c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
+            }
         }
     }
     c->has_slotpar = false;
@@ -860,6 +885,24 @@ int build_partition(fh_ctx* c) {
     c->g_acc = acc;
     c->g_nb = 64;
     c->has_partition = true;
+    return FH_OK;
+}
+
+template <int OP>
+int launch_rows(fh_ctx* c, KArgs& a, const RowTables& T) {
+    const size_t lds = make_layout<FH_HEX8, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 8, 0, 2).bytes();
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int grid = std::min(c->nblk, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    auto kern = k_gather_rows<OP>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (std::getenv("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] row-owner gather: lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }
 
@@ -1115,6 +1158,14 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
                                c->rule_map.p, c->rparams.p, c->nq, c->p_slotpar.p);
             HIP_TRY(c, hipGetLastError());
             c->has_slotpar = true;
+        }
+        if (c->has_pipe && c->has_rows && a.fast && !pipe_rules && c->nq == 8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+            !std::getenv("FENRIS_HIP_TRACE")) {
+            RowTables T{c->r_rec.p, c->r_lanes.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
+            a.ub = c->p_us;
+            a.nb_max = c->p_nbs;
+            c->last_kernel = "k_gather_rows";
+            return c->op == FH_LAPLACE ? launch_rows<FH_LAPLACE>(c, a, T) : launch_rows<FH_LINEAR_ELASTIC>(c, a, T);
         }
         if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
             a.fast = 1;

@@ -317,7 +317,8 @@ struct fh_ctx {
     // fixed-stride tables of the pipelined gather kernel
     DevBuf<int> p_conn, p_rec, p_elem;
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
-    DevBuf<uint2> r_lanes;      //                                     lanes per position
+    DevBuf<uint2> r_lanes;      //                                     lanes per position (Hex8)
+    DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
     int r_rw = 0;
     bool has_rows = false;
     int p_rw = 0;
@@ -870,6 +871,25 @@ int build_partition(fh_ctx* c) {
                 if (std::getenv("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] row-owner lanes: %s\n", c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
+            // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
+            // the pipelined kernel
+            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && !std::getenv("FENRIS_HIP_NO_ROWS")) {
+                c->r_rw = 8 + us / 4 + nb_target + 1;
+                DevBuf<int> st;
+                HIP_TRY(c, st.alloc(1));
+                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                HIP_TRY(c, c->r_rec.alloc((size_t)nblk * c->r_rw));
+                HIP_TRY(c, c->r_lanes4.alloc((size_t)nblk * 256));
+                hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target,
+                                   nblk, c->r_rw, c->r_rec.p, c->r_lanes4.p, st.p);
+                HIP_TRY(c, hipGetLastError());
+                int bad = 0;
+                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->has_rows = bad == 0;
+                if (std::getenv("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4): %s\n", c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
+            }
         }
     }
     c->has_slotpar = false;
@@ -901,6 +921,24 @@ int launch_rows(fh_ctx* c, KArgs& a, const RowTables& T) {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] row-owner gather: lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int OP>
+int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
+    const size_t lds = make_layout<FH_TET4, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 1, 0, 2).bytes();
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
+    const int grid = std::min(c->nblk, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    auto kern = k_gather_rows_tet4<OP>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (std::getenv("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] row-owner gather (Tet4): lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
     HIP_TRY(c, hipGetLastError());
     return FH_OK;
@@ -1159,8 +1197,16 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             HIP_TRY(c, hipGetLastError());
             c->has_slotpar = true;
         }
-        if (c->has_pipe && c->has_rows && a.fast && !pipe_rules && c->nq == 8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
-            !std::getenv("FENRIS_HIP_TRACE")) {
+        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && a.fast && !pipe_rules && c->nq == 1 &&
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
+            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
+            a.ub = c->p_us;
+            a.nb_max = c->p_nbs;
+            c->last_kernel = "k_gather_rows";
+            return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
+        }
+        if (c->has_pipe && c->has_rows && c->elem_kind == FH_HEX8 && a.fast && !pipe_rules && c->nq == 8 &&
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
             RowTables T{c->r_rec.p, c->r_lanes.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;

@@ -38,6 +38,16 @@ __device__ __forceinline__ double dpp_quad(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
 }
 
+// value of lane ^ 4 (row_shl:4 into the lanes with bit 2 clear, row_shr:4 into the others)
+__device__ __forceinline__ double dpp_xor4(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x104, 0xF, 0x5, false);
+    lo = __builtin_amdgcn_update_dpp(lo, (int)b, 0x114, 0xF, 0xA, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x104, 0xF, 0x5, false);
+    hi = __builtin_amdgcn_update_dpp(hi, (int)(b >> 32), 0x114, 0xF, 0xA, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256, 2) k_gather_rows(const KArgs a, const RowTables T) {
     constexpr int EK = FH_HEX8, QC = 8;
@@ -316,6 +326,312 @@ __global__ void __launch_bounds__(64) k_build_row_lanes(const int* p_rec, int rw
     }
     __syncthreads();
     for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
+}
+
+}  // namespace fenris_hip
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tet4 (one-point rule): six terms per lane.  A node of a tetrahedral mesh has ~24 elements and ~15 columns: the diagonal
+// block takes 4 lanes (24 terms), everything else one lane.  Lane record (uint4):
+//   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 | nterms << 10 | log2(group) << 13 | store << 15
+namespace fenris_hip {
+
+struct RowTablesS {
+    const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets (nbs + 1 words)
+    const uint4* lanes;  // [npos][256]
+    const int* conn;     // [npos][cs]
+    const int* elem;     // [npos][us]
+    int rw, cs, us, nbs, npos;
+};
+
+template <int OP>
+__global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, const RowTablesS T) {
+    constexpr int EK = FH_TET4, QC = 1, TL = 6, SLOTS = 4;
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
+    static_assert(D == 3 && N == 4 && NG == 4, "row-owner kernel: Tet4");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, QC, 0, 2);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    const int tid = threadIdx.x, nt = 256;
+    const int G = gridDim.x;
+    stage_tables<EK>(a, L, lds);
+
+    struct Rec { int w; int conn[SLOTS]; };
+    const int npos = T.npos;
+    const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
+    auto load_rec = [&](int p, Rec& r) {
+        p = min(p, npos - 1);
+        r.w = T.rec[(size_t)p * T.rw + min(tid, T.rw - 1)];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) r.conn[k] = T.conn[(size_t)p * T.cs + min(tid + k * nt, T.cs - 1)];
+    };
+    auto load_lane = [&](int p) { return T.lanes[(size_t)min(p, npos - 1) * 256 + tid]; };
+    double V[SLOTS][D];
+    auto load_verts = [&](const Rec& r) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+#pragma unroll
+            for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
+    };
+    auto rec_base = [&](int parity) { return lds_i + parity * T.rw; };
+    auto park = [&](const Rec& r, int parity) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int sidx = tid + k * nt;
+            if (sidx < T.cs)
+#pragma unroll
+                for (int c = 0; c < D; ++c) lds[L.o_X + (sidx / NG) * L.xs + (sidx % NG) * D + c] = V[k][c];
+        }
+        if (tid < T.rw) rec_base(parity)[tid] = r.w;
+    };
+    const double sqw = sqrt(a.qw[0]);
+    int p = p_begin;
+    if (p >= p_end) return;
+    Rec nxt;
+    uint4 lane_cur;
+    {
+        Rec cur;
+        load_rec(p, cur);
+        load_verts(cur);
+        lane_cur = load_lane(p);
+        load_rec(p + 1, nxt);
+        park(cur, 0);
+        asm volatile("" : "+v"(nxt.w), "+v"(nxt.conn[0]), "+v"(nxt.conn[SLOTS - 1]), "+v"(lane_cur.x), "+v"(lane_cur.w));
+    }
+    __syncthreads();
+
+    int parity = 0;
+    for (; p < p_end; ++p, parity ^= 1) {
+        const bool have_next = (p + 1) < p_end;
+        const int* rec = rec_base(parity);
+        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(rec);
+        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(rec + 8);
+        const int* noff_l = rec + 8 + T.us / 4;
+        load_verts(nxt);
+        Rec nn;
+        load_rec(p + 2, nn);
+        uint4 lane_nxt = load_lane(p + 1);
+        const int U = (p == p_begin) ? hc.U : hc.k0;
+        // phase B: one lane per new slot (one quadrature point)
+        if (tid < U) {
+            const int u = (int)slot_b[tid];
+            prologue<EK, OP, WHAT_MATRIX, true, true>(a, L, lds, lds_i, u, 0, T.elem + (size_t)p * T.us + u, 0, sqw);
+        }
+        lds_barrier();
+
+        // phase C: G = sum over the lane's terms of h_a h_j^T
+        const unsigned wl = lane_cur.w;
+        const int nterms = (int)((wl >> 10) & 7u), grp = (int)((wl >> 13) & 3u);
+        const unsigned tw[3] = {lane_cur.x, lane_cur.y, lane_cur.z};
+        double Gm[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Gm[i][j] = 0.0;
+        unsigned pa[TL], pj[TL];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) {
+            const unsigned term = (tw[t / 2] >> (16 * (t % 2))) & 0xffffu;
+            const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
+            pa[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 3u));
+            pj[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 10) & 3u));
+        }
+        // [x y] by ds_read_b128, z by ds_read_b64 (see k_gather_rows); two terms in flight while one is multiplied
+        constexpr int AHEAD = 2, NB = AHEAD + 1;
+        f64x2 av[NB], bv[NB];
+        double az[NB], bz[NB];
+        auto fetcht = [&](auto tk) {
+            constexpr int tt = decltype(tk)::value, sl = tt % NB;
+            av[sl] = lds_read_f64x2<0>(pa[tt]);
+            az[sl] = lds_read_f64_at<16>(pa[tt]);
+            bv[sl] = lds_read_f64x2<0>(pj[tt]);
+            bz[sl] = lds_read_f64_at<16>(pj[tt]);
+        };
+        fetcht(std::integral_constant<int, 0>{});
+        fetcht(std::integral_constant<int, 1>{});
+        pipeline_consume<TL, D>([&](auto tk) {
+            constexpr int tt = decltype(tk)::value, sl = tt % NB;
+            constexpr int ahead = (TL - 1 - tt) < (AHEAD - 1) ? (TL - 1 - tt) : (AHEAD - 1);
+            lds_wait<ahead * 4>();
+            asm volatile("" : "+v"(av[sl]), "+v"(az[sl]), "+v"(bv[sl]), "+v"(bz[sl]));
+            if constexpr (tt + AHEAD < TL) fetcht(std::integral_constant<int, tt + AHEAD>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt < nterms) {  // unused terms read slot 0: never let their values in
+                const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
+                const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Gm[i][j] = fma(ai[i], bj[j], Gm[i][j]);
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double t1 = dpp_quad<0xB1>(Gm[i][j]);
+                if (grp >= 1) Gm[i][j] += t1;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double t2 = dpp_quad<0x4E>(Gm[i][j]);
+                if (grp >= 2) Gm[i][j] += t2;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double t3 = dpp_xor4(Gm[i][j]);
+                if (grp >= 3) Gm[i][j] += t3;
+            }
+        if ((wl >> 15) & 1u) {
+            const int il = (int)((wl >> 7) & 7u), pos = (int)(wl & 127u);
+            const int rb = noff_l[il], cnt = noff_l[il + 1] - rb;
+            double* base = a.vals + (size_t)S * S * ((size_t)hc.r0 + rb) + S * pos;
+            double tr = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) tr += Gm[i][i];
+            if (OP == FH_LAPLACE) {
+                if (a.overwrite) base[0] = tr; else base[0] += tr;
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double* row = base + (size_t)(i % S) * S * cnt;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const double v = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
+                        if (a.overwrite) row[j % S] = v; else row[j % S] += v;
+                    }
+                }
+            }
+        }
+        if (have_next) park(nxt, parity ^ 1);
+        asm volatile("" : "+v"(nn.w), "+v"(nn.conn[0]), "+v"(nn.conn[SLOTS - 1]), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
+        nxt = nn;
+        lane_cur = lane_nxt;
+        lds_barrier();
+    }
+}
+
+// lanes of every position for the Tet4 kernel (see k_build_row_lanes).  Terms are kept in one compact array (a block has
+// at most ms N of them) behind per-column offsets; blocks with up to 48 terms (a node of an unstructured mesh easily has
+// 30-40 elements) take groups of up to 8 lanes.
+__global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
+                                                             int* rec_new, uint4* lanes, int* status) {
+    constexpr int N = 4, NKEY = 8 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;
+    __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
+    __shared__ unsigned short terms[MAXTERMS];
+    __shared__ unsigned lw[256][4];
+    __shared__ int wave_tot[64];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int* rec = p_rec + (size_t)p * rw_old;
+    const GatherHdr h = *reinterpret_cast<const GatherHdr*>(rec);
+    const unsigned* ent = reinterpret_cast<const unsigned*>(rec + 8 + us / 4);
+    const unsigned char* posb = reinterpret_cast<const unsigned char*>(rec + 8 + us / 4 + ms);
+    const int* noff_old = rec + 8 + us / 4 + ms + ms * N / 4;
+    int* out = rec_new + (size_t)p * rw_new;
+    for (int i = lane; i < 8 + us / 4; i += 64) out[i] = rec[i];
+    for (int i = lane; i <= nbs; i += 64) out[8 + us / 4 + i] = noff_old[i];
+    for (int i = lane; i < NKEY; i += 64) { cnt[i] = 0; fill[i] = 0; }
+    for (int i = lane; i < 256 * 4; i += 64) lw[i / 4][i % 4] = 0u;
+    __syncthreads();
+    bool bad = h.m * N > MAXTERMS;
+    for (int idx = lane; idx < h.m * N && !bad; idx += 64) {
+        const int t = idx / N, j = idx % N;
+        const unsigned e = ent[t];
+        const unsigned il = e & 0xffu, pos = posb[t * N + j];
+        if (il >= 8u || pos >= 128u || (e >> 16) >= 256u || ((e >> 8) & 0xffu) >= 4u) { bad = true; break; }
+        atomicAdd(&cnt[(int)(il * 128u + pos)], 1);
+    }
+    __syncthreads();
+    // exclusive prefix sum of the counts: 16 consecutive keys per lane, then across the lanes
+    {
+        int local = 0;
+        for (int k = 0; k < NKEY / 64; ++k) local += cnt[lane * (NKEY / 64) + k];
+        wave_tot[lane] = local;
+        __syncthreads();
+        int before = 0;
+        for (int l = 0; l < lane; ++l) before += wave_tot[l];
+        for (int k = 0; k < NKEY / 64; ++k) {
+            off[lane * (NKEY / 64) + k] = before;
+            before += cnt[lane * (NKEY / 64) + k];
+        }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < h.m * N && !bad; idx += 64) {
+        const int t = idx / N, j = idx % N;
+        const unsigned e = ent[t];
+        const unsigned slot = e >> 16, a_loc = (e >> 8) & 0xffu, il = e & 0xffu, pos = posb[t * N + j];
+        const int key = (int)(il * 128u + pos);
+        const int s_ = atomicAdd(&fill[key], 1);
+        terms[off[key] + s_] = (unsigned short)(slot | (a_loc << 8) | ((unsigned)j << 10));
+    }
+    __syncthreads();
+    for (int key = lane; key < NKEY; key += 64) {  // fixed term order
+        const int Tn = cnt[key];
+        if (Tn > TMAX) bad = true;
+        unsigned short* b = terms + off[key];
+        for (int i = 1; i < Tn && !bad; ++i) {
+            const unsigned short v = b[i];
+            int k = i - 1;
+            while (k >= 0 && b[k] > v) { b[k + 1] = b[k]; --k; }
+            b[k + 1] = v;
+        }
+    }
+    __syncthreads();
+    // classes by lanes needed: 25..48 terms -> 8 lanes, 13..24 -> 4, 7..12 -> 2, 1..6 -> 1
+    int n8 = 0, n4 = 0, n2 = 0, n1 = 0;
+    for (int base = 0; base < NKEY; base += 64) {
+        const int Tn = cnt[base + lane];
+        n8 += __popcll(__ballot(Tn > 4 * TL));
+        n4 += __popcll(__ballot(Tn > 2 * TL && Tn <= 4 * TL));
+        n2 += __popcll(__ballot(Tn > TL && Tn <= 2 * TL));
+        n1 += __popcll(__ballot(Tn >= 1 && Tn <= TL));
+    }
+    const int base4 = 8 * n8, base2 = base4 + 4 * n4, base1 = base2 + 2 * n2;
+    if (base1 + n1 > 256) bad = true;
+    if (__ballot(bad)) {
+        if (lane == 0) atomicOr(status, 1);
+        for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    int r8 = 0, r4 = 0, r2 = 0, r1 = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < NKEY; base += 64) {
+        const int key = base + lane;
+        const int Tn = cnt[key];
+        const unsigned il = (unsigned)key >> 7, pos = (unsigned)key & 127u;
+        const unsigned short* b = terms + off[key];
+        const unsigned long long m8 = __ballot(Tn > 4 * TL), m4 = __ballot(Tn > 2 * TL && Tn <= 4 * TL),
+                                 m2 = __ballot(Tn > TL && Tn <= 2 * TL), m1 = __ballot(Tn >= 1 && Tn <= TL);
+        auto lane_words = [&](int first, int Lidx, unsigned grp, bool leader) {
+            const int n = max(0, min(TL, Tn - first));
+            unsigned w3[3] = {0u, 0u, 0u};
+            for (int t = 0; t < n; ++t) w3[t / 2] |= (unsigned)b[first + t] << (16 * (t % 2));
+            lw[Lidx][0] = w3[0]; lw[Lidx][1] = w3[1]; lw[Lidx][2] = w3[2];
+            lw[Lidx][3] = pos | (il << 7) | ((unsigned)n << 10) | (grp << 13) | (leader ? (1u << 15) : 0u);
+        };
+        if (Tn > 4 * TL) {
+            const int L0 = 8 * (r8 + __popcll(m8 & below));
+            for (int g = 0; g < 8; ++g) lane_words(TL * g, L0 + g, 3u, g == 0);
+        } else if (Tn > 2 * TL) {
+            const int L0 = base4 + 4 * (r4 + __popcll(m4 & below));
+            for (int g = 0; g < 4; ++g) lane_words(TL * g, L0 + g, 2u, g == 0);
+        } else if (Tn > TL) {
+            const int L0 = base2 + 2 * (r2 + __popcll(m2 & below));
+            for (int g = 0; g < 2; ++g) lane_words(TL * g, L0 + g, 1u, g == 0);
+        } else if (Tn >= 1) {
+            lane_words(0, base1 + r1 + __popcll(m1 & below), 0u, true);
+        }
+        r8 += __popcll(m8); r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
 }
 
 }  // namespace fenris_hip

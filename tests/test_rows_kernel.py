@@ -1,5 +1,6 @@
-"""Row-owner form of the Hex8 stiffness kernel (fenris_amd/csrc/rows_kernel.hpp; opt-in through FENRIS_HIP_ROWS while it is
-being measured): parity against the oracle on structured, distorted, mirrored / permuted and masked meshes."""
+"""Row-owner (atomics-free) forms of the stiffness kernel (fenris_amd/csrc/rows_kernel.hpp): the Tet4 / one-point-rule
+kernel, which is the default there, and the Hex8 kernel, opt-in through FENRIS_HIP_ROWS (measured slower than the pipelined
+kernel).  Parity against the oracle on structured, distorted, mirrored / permuted, unstructured and masked meshes."""
 import os
 
 import numpy as np
@@ -76,3 +77,38 @@ def test_rows_kernel_matches_oracle(rows_engine, oracle, name, op):
     assert np.abs(km.values - ka.values).max() <= TOL * max(np.abs(ka.values).max(), 1e-300)
     assert np.abs(ka.values).max() < np.abs(vals).max() * 1.0000001 and not np.array_equal(ka.values, vals)
     rows_engine.set_active_elements(None)
+
+
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
+@pytest.mark.parametrize("name", ["bcc3", "bcc2_distorted", "sphere_permuted"])
+def test_rows_kernel_tet4_matches_oracle(rows_engine, oracle, name, op):
+    from conftest import load_golden_mesh
+
+    rng = np.random.default_rng(11)
+    if name == "bcc3":
+        mesh = fa.procedural.create_unit_box_uniform_tet_mesh_3d(3)
+    elif name == "bcc2_distorted":
+        b = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
+        mesh = fa.Mesh(b.vertices + 0.02 * rng.standard_normal(b.vertices.shape), b.connectivity, fa.TET4)
+    else:
+        v, c = load_golden_mesh("sphere_tet4_593")
+        mesh = fa.Mesh(v, c[rng.permutation(len(c))], fa.TET4)
+    w, p = quadrature.total_order.tetrahedron(1)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if op == "LAPLACE":
+        oper, oparams, oop = fa.LaplaceOperator(), None, oracle.LAPLACE
+    else:
+        qt = qt.with_uniform_data(LAME)
+        oper, oparams, oop = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), LAME.as_pair(), oracle.LINEAR_ELASTIC
+    asm = (fa.ElementEllipticAssemblerBuilder(rows_engine).with_finite_element_space(mesh).with_operator(oper)
+           .with_quadrature_table(qt).with_u(None).build())
+    ref = oracle.ElementAssembler(oracle.TET4, oop, mesh.vertices, mesh.connectivity, w, p, params=oparams)
+    st, _, ro, ci, vals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    # the unstructured sphere has nodes with up to 40 elements: diagonal blocks of 8 lanes
+    assert rows_engine.last_kernel_name() == "k_gather_rows"
+    assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+    assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+    fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
+    assert np.abs(k.values - 2.0 * vals).max() <= 2 * TOL * np.abs(vals).max()

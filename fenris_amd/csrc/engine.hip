@@ -1197,8 +1197,14 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             HIP_TRY(c, hipGetLastError());
             c->has_slotpar = true;
         }
-        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && a.fast && !pipe_rules && c->nq == 1 &&
+        // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
+        // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
+        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && a.fast && !pipe_rules &&
             (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
+            if (c->nq > 1) {
+                a.qw = c->qw.p + c->nq;
+                a.nq = 1;
+            }
             RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;
@@ -1562,11 +1568,16 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     HIP_TRY(c, c->phiref.alloc(phiref.size()));
     HIP_TRY(c, hipMemcpy(c->phiref.p, phiref.data(), sizeof(double) * phiref.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, c->qw.alloc(nq));
+    HIP_TRY(c, c->qw.alloc(nq + 1));  // [nq]: sum of the weights (collapsed rule of the affine simplices, see dispatch)
     HIP_TRY(c, c->gref.alloc(gref.size()));
     HIP_TRY(c, c->ggeom.alloc(ggeom.size()));
     HIP_TRY(c, c->qparams.alloc(2 * (size_t)nq));
     HIP_TRY(c, hipMemcpy(c->qw.p, w, sizeof(double) * nq, hipMemcpyHostToDevice));
+    {
+        double wsum = 0.0;
+        for (uint32_t q = 0; q < nq; ++q) wsum += w[q];
+        HIP_TRY(c, hipMemcpy(c->qw.p + nq, &wsum, sizeof(double), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemcpy(c->gref.p, gref.data(), sizeof(double) * gref.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->ggeom.p, ggeom.data(), sizeof(double) * ggeom.size(), hipMemcpyHostToDevice));
     c->has_params = params != nullptr;

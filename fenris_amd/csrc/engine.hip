@@ -319,7 +319,7 @@ struct fh_ctx {
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
     DevBuf<uint2> r_lanes;      //                                     lanes per position (Hex8)
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
-    int r_rw = 0;
+    int r_rw = 0, r_ls = 256;
     bool has_rows = false;
     int p_rw = 0;
     int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1, p_us = 0;
@@ -879,16 +879,22 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                 HIP_TRY(c, c->r_rec.alloc((size_t)nblk * c->r_rw));
-                HIP_TRY(c, c->r_lanes4.alloc((size_t)nblk * 256));
-                hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target,
-                                   nblk, c->r_rw, c->r_rec.p, c->r_lanes4.p, st.p);
-                HIP_TRY(c, hipGetLastError());
                 int bad = 0;
-                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                for (int ls : {128, 256}) {  // half the table (and its traffic) when no block needs more than 128 lanes
+                    c->r_ls = ls;
+                    HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                    HIP_TRY(c, c->r_lanes4.alloc((size_t)nblk * ls));
+                    hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms,
+                                       nb_target, nblk, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p);
+                    HIP_TRY(c, hipGetLastError());
+                    HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (bad != 2) break;  // 2: only the stride was too small
+                }
                 c->has_rows = bad == 0;
                 if (std::getenv("FENRIS_HIP_VERBOSE"))
-                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4): %s\n", c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
+                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, stride %d): %s\n", c->r_ls,
+                                 c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
         }
     }
@@ -1205,7 +1211,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
                 a.qw = c->qw.p + c->nq;
                 a.nq = 1;
             }
-            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
+            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk, c->r_ls};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;
             c->last_kernel = "k_gather_rows";

@@ -338,10 +338,10 @@ namespace fenris_hip {
 
 struct RowTablesS {
     const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets (nbs + 1 words)
-    const uint4* lanes;  // [npos][256]
+    const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256
     const int* conn;     // [npos][cs]
     const int* elem;     // [npos][us]
-    int rw, cs, us, nbs, npos;
+    int rw, cs, us, nbs, npos, ls;
 };
 
 template <int OP>
@@ -368,7 +368,12 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) r.conn[k] = T.conn[(size_t)p * T.cs + min(tid + k * nt, T.cs - 1)];
     };
-    auto load_lane = [&](int p) { return T.lanes[(size_t)min(p, npos - 1) * 256 + tid]; };
+    // lanes beyond the table's stride re-read its last record and switch themselves off
+    auto load_lane = [&](int p) {
+        uint4 r = T.lanes[(size_t)min(p, npos - 1) * T.ls + min(tid, T.ls - 1)];
+        if (tid >= T.ls) r.w = 0u;
+        return r;
+    };
     double V[SLOTS][D];
     auto load_verts = [&](const Rec& r) {
 #pragma unroll
@@ -522,7 +527,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 // at most ms N of them) behind per-column offsets; blocks with up to 48 terms (a node of an unstructured mesh easily has
 // 30-40 elements) take groups of up to 8 lanes.
 __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
-                                                             int* rec_new, uint4* lanes, int* status) {
+                                                             int* rec_new, uint4* lanes, int ls, int* status) {
     constexpr int N = 4, NKEY = 8 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
     __shared__ unsigned short terms[MAXTERMS];
@@ -594,10 +599,11 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
         n1 += __popcll(__ballot(Tn >= 1 && Tn <= TL));
     }
     const int base4 = 8 * n8, base2 = base4 + 4 * n4, base1 = base2 + 2 * n2;
+    const bool too_many = base1 + n1 > ls;  // status bit 1: the lane stride is too small (the host retries with 256)
     if (base1 + n1 > 256) bad = true;
-    if (__ballot(bad)) {
-        if (lane == 0) atomicOr(status, 1);
-        for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint4(0u, 0u, 0u, 0u);
+    if (__ballot(bad || too_many)) {
+        if (lane == 0) atomicOr(status, __ballot(bad) ? 1 : 2);
+        for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     int r8 = 0, r4 = 0, r2 = 0, r1 = 0;
@@ -631,7 +637,7 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
         r8 += __popcll(m8); r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
     }
     __syncthreads();
-    for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
+    for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
 }
 
 }  // namespace fenris_hip

@@ -932,7 +932,7 @@ int launch_rows(fh_ctx* c, KArgs& a, const RowTables& T) {
     return FH_OK;
 }
 
-template <int OP>
+template <int OP, bool ELEMPAR = false>
 int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     const size_t lds = make_layout<FH_TET4, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 1, 0, 2).bytes();
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
@@ -940,7 +940,7 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
     const int grid = std::min(c->nblk, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
-    auto kern = k_gather_rows_tet4<OP>;
+    auto kern = k_gather_rows_tet4<OP, ELEMPAR>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("FENRIS_HIP_VERBOSE"))
@@ -1205,16 +1205,19 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         }
         // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
         // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
-        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && a.fast && !pipe_rules &&
+        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pipe_rules) &&
             (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
+            a.fast = 1;
             if (c->nq > 1) {
                 a.qw = c->qw.p + c->nq;
                 a.nq = 1;
             }
-            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk, c->r_ls};
+            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
+                         c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk, c->r_ls};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;
             c->last_kernel = "k_gather_rows";
+            if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
         }
         if (c->has_pipe && c->has_rows && c->elem_kind == FH_HEX8 && a.fast && !pipe_rules && c->nq == 8 &&

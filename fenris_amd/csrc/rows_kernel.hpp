@@ -341,10 +341,13 @@ struct RowTablesS {
     const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256
     const int* conn;     // [npos][cs]
     const int* elem;     // [npos][us]
+    const double* slotpar;  // [npos][us][2] (mu, lambda) of the element in each slot (piecewise-constant material), or null
     int rw, cs, us, nbs, npos, ls;
 };
 
-template <int OP>
+// ELEMPAR: (mu, lambda) per element: every term carries its element's pair, the block is
+//   sum_e mu_e (tr G_e I + G_e^T) + lambda_e G_e  =  tr(Gmu) I + Gmu^T + Gla   with Gmu = sum mu_e G_e, Gla = sum lambda_e G_e
+template <int OP, bool ELEMPAR = false>
 __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, const RowTablesS T) {
     constexpr int EK = FH_TET4, QC = 1, TL = 6, SLOTS = 4;
     using E = ElemT<EK>;
@@ -431,18 +434,27 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         const unsigned wl = lane_cur.w;
         const int nterms = (int)((wl >> 10) & 7u), grp = (int)((wl >> 13) & 3u);
         const unsigned tw[3] = {lane_cur.x, lane_cur.y, lane_cur.z};
-        double Gm[D][D];
+        double Gm[D][D], Gl[ELEMPAR ? D : 1][ELEMPAR ? D : 1];
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) Gm[i][j] = 0.0;
+            for (int j = 0; j < D; ++j) {
+                Gm[i][j] = 0.0;
+                if (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] = 0.0;
+            }
         unsigned pa[TL], pj[TL];
+        double mu_t[ELEMPAR ? TL : 1], la_t[ELEMPAR ? TL : 1];
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
             const unsigned term = (tw[t / 2] >> (16 * (t % 2))) & 0xffffu;
             const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
             pa[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 3u));
             pj[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 10) & 3u));
+            if constexpr (ELEMPAR) {  // fetched now (global memory), used after phase B
+                const double* sp = T.slotpar + 2 * ((size_t)p * T.us + (term & 255u));
+                mu_t[t] = sp[0];
+                la_t[t] = sp[1];
+            }
         }
         // [x y] by ds_read_b128, z by ds_read_b64 (see k_gather_rows); two terms in flight while one is multiplied
         constexpr int AHEAD = 2, NB = AHEAD + 1;
@@ -468,9 +480,15 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                 const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
                 const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
 #pragma unroll
-                for (int i = 0; i < D; ++i)
+                for (int i = 0; i < D; ++i) {
+                    const double am = ELEMPAR ? mu_t[ELEMPAR ? tt : 0] * ai[i] : ai[i];
+                    const double al = ELEMPAR ? la_t[ELEMPAR ? tt : 0] * ai[i] : 0.0;
 #pragma unroll
-                    for (int j = 0; j < D; ++j) Gm[i][j] = fma(ai[i], bj[j], Gm[i][j]);
+                    for (int j = 0; j < D; ++j) {
+                        Gm[i][j] = fma(am, bj[j], Gm[i][j]);
+                        if (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] = fma(al, bj[j], Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    }
+                }
             }
         });
 #pragma unroll
@@ -479,6 +497,10 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             for (int j = 0; j < D; ++j) {
                 const double t1 = dpp_quad<0xB1>(Gm[i][j]);
                 if (grp >= 1) Gm[i][j] += t1;
+                if constexpr (ELEMPAR) {
+                    const double t1l = dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    if (grp >= 1) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t1l;
+                }
             }
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -486,6 +508,10 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             for (int j = 0; j < D; ++j) {
                 const double t2 = dpp_quad<0x4E>(Gm[i][j]);
                 if (grp >= 2) Gm[i][j] += t2;
+                if constexpr (ELEMPAR) {
+                    const double t2l = dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    if (grp >= 2) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t2l;
+                }
             }
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -493,6 +519,10 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             for (int j = 0; j < D; ++j) {
                 const double t3 = dpp_xor4(Gm[i][j]);
                 if (grp >= 3) Gm[i][j] += t3;
+                if constexpr (ELEMPAR) {
+                    const double t3l = dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    if (grp >= 3) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t3l;
+                }
             }
         if ((wl >> 15) & 1u) {
             const int il = (int)((wl >> 7) & 7u), pos = (int)(wl & 127u);
@@ -509,7 +539,9 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                     double* row = base + (size_t)(i % S) * S * cnt;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        const double v = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
+                        double v;
+                        if constexpr (ELEMPAR) v = ((i == j) ? tr : 0.0) + Gm[j][i] + Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)];
+                        else v = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
                         if (a.overwrite) row[j % S] = v; else row[j % S] += v;
                     }
                 }

@@ -112,3 +112,19 @@ def test_rows_kernel_tet4_matches_oracle(rows_engine, oracle, name, op):
     assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
     fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
     assert np.abs(k.values - 2.0 * vals).max() <= 2 * TOL * np.abs(vals).max()
+    # element mask and a row range (what one rank of the slab partition assembles)
+    active = (np.arange(mesh.num_elements()) % 4 != 2)
+    rows_engine.set_active_elements(active)
+    km = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert rows_engine.last_kernel_name() == "k_gather_rows"
+    ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
+    assert np.abs(km.values - ka.values).max() <= TOL * np.abs(ka.values).max()
+    rows_engine.set_active_elements(None)
+    n = mesh.num_nodes()
+    rows_engine.set_row_range(n // 3, 2 * n // 3)
+    kr = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    s_dim = 1 if op == "LAPLACE" else 3
+    lo, hi = int(ro[s_dim * (n // 3)]), int(ro[s_dim * (2 * n // 3)])
+    assert np.abs(kr.values[lo:hi] - vals[lo:hi]).max() <= TOL * np.abs(vals).max()
+    assert not kr.values[:lo].any() and not kr.values[hi:].any()
+    rows_engine.set_row_range(0, n)

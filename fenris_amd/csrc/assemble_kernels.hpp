@@ -1798,6 +1798,85 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
 // of J enters: no singular-Jacobian error on this path), then one lane per (element, node) sums over the points.
 // The source is either density_q * g (GravitySource, fenris-solid/src/gravity_source.rs:57-65; density_q is the
 // first parameter of the quadrature table) or values sampled by the caller at the physical points.
+// Persistent form of k_assemble_vector for the iso-parametric elements with 4 or 8 nodes: a workgroup walks batches of
+// 256 / N consecutive elements and prefetches like k_gather_pipelined -- node indices two batches ahead, vertex
+// coordinates and u one batch ahead, in registers, parked in LDS behind the contraction -- so that the dependent
+// connectivity -> vertex fetches of a batch no longer stand between its phases (they were a third of the kernel).  One
+// thread per (element of the batch, local node) throughout: it fetches that node's data and scatters that node's row.
+// NT threads: 256, or 128 when the point records of 256 / N elements do not leave room for two workgroups per CU
+template <int EK, int OP, int NT>
+__global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S, EPB = NT / N;
+    static_assert(E::NG == N && NT % N == 0, "streamed residual kernel: iso-parametric, 4 or 8 nodes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout L = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false);
+    double* lds = reinterpret_cast<double*>(smem);
+    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
+    const int tid = threadIdx.x, G = gridDim.x;
+    const int u = tid / N, I = tid % N;
+    stage_tables<EK>(a, L, lds);
+    const long long total = a.work_end - a.work_begin;
+    const long long nbatch = (total + EPB - 1) / EPB;
+    // element of this thread's slot in batch b, clamped into the work range (branch-free prefetch)
+    auto elem_of = [&](long long b) { return a.work_begin + min(b * EPB + u, total - 1); };
+    auto load_node = [&](long long b) { return a.conn[(size_t)elem_of(min(b, nbatch - 1)) * N + I]; };
+    double V[D], Uv[S];
+    auto load_data = [&](int node) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) V[c] = a.verts[(size_t)node * D + c];
+#pragma unroll
+        for (int c = 0; c < S; ++c) Uv[c] = a.u ? a.u[(size_t)node * S + c] : 0.0;
+    };
+    auto park = [&](long long b) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) lds[L.o_X + u * L.xs + I * D + c] = V[c];
+#pragma unroll
+        for (int c = 0; c < S; ++c) lds[L.o_U + u * L.us + I * S + c] = Uv[c];
+        if (I == 0) lds_i[L.o_uniq + u] = (int)elem_of(min(b, nbatch - 1));
+    };
+    long long b = blockIdx.x;
+    if (b >= nbatch) return;
+    int node_cur = load_node(b);
+    load_data(node_cur);
+    int node_n1 = load_node(b + G);
+    park(b);
+    asm volatile("" : "+v"(node_n1));
+    __syncthreads();
+    for (; b < nbatch; b += G) {
+        load_data(node_n1);                    // lands while this batch is computed
+        int node_n2 = load_node(b + 2LL * G);
+        // phase B: one lane per (element, point)
+        for (int i = tid; i < EPB * a.nq; i += NT)
+            prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
+        lds_barrier();
+        // contraction: this thread's node row of the element vector, scattered with fp64 atomics
+        {
+            double f[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) f[i] = 0.0;
+            const double* qp = lds + L.o_QP + (size_t)u * a.nq * L.qpd;
+            for (int q = 0; q < a.nq; ++q, qp += L.qpd) {
+                const double* g = qp + I * D;
+                const double* sp = qp + N * D;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) f[i] = fma(sp[i * D + k], g[k], f[i]);
+            }
+            if (b * EPB + u < total)
+#pragma unroll
+                for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node_cur * S + i, f[i]);
+        }
+        park(b + G);  // X / U are read by phase B only, which lies behind the barrier above
+        asm volatile("" : "+v"(node_n2));
+        node_cur = node_n1;
+        node_n1 = node_n2;
+        lds_barrier();
+    }
+}
+
 struct SourceArgs {
     int N, NG;                 // nodes per element (solution / geometry; the geometry nodes come first)
     const double* phigeom;     // nq x NG  basis values of the geometry map

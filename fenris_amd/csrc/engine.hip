@@ -1300,6 +1300,33 @@ static int launch_vector(fh_ctx* c, KArgs& a, size_t lds, int grid) {
     HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }
+template <int EK, int OP, int NT>
+static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
+    constexpr int EPB = NT / ElemT<EK>::N;
+    const size_t lds = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false).bytes();
+    if (lds > LDS_TARGET + 8 * 1024) return -1;
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const long long nbatch = (a.work_end - a.work_begin + EPB - 1) / EPB;
+    const int per_cu = std::max(1, (int)std::min<size_t>(env_int("FENRIS_HIP_VEC_WGS_PER_CU", 3), (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int grid = (int)std::min<long long>(nbatch, (long long)dev_cus * per_cu);
+    auto kern = k_assemble_vector_stream<EK, OP, NT>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+template <int EK, int OP>
+static int launch_vector_stream(fh_ctx* c, KArgs& a) {
+    if constexpr (ElemT<EK>::NG == ElemT<EK>::N && (ElemT<EK>::N == 4 || ElemT<EK>::N == 8)) {
+        int rs = env_int("FENRIS_HIP_VEC_NT", 256) == 256 ? launch_vector_stream_nt<EK, OP, 256>(c, a) : -1;
+        if (rs < 0) rs = launch_vector_stream_nt<EK, OP, 128>(c, a);
+        return rs;
+    } else {
+        return -1;
+    }
+}
 template <int EK, int OP>
 static int launch_scalar(fh_ctx* c, KArgs& a, size_t lds, int grid) {
     auto kern = k_assemble_scalar<EK, OP>;
@@ -1820,6 +1847,15 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return read_status(c, failed);
+    // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel)
+    if (!a.labels && !std::getenv("FENRIS_HIP_NO_VECTOR_STREAM")) {
+        int rs = -1;
+#define CALL(EKC, OPC) rs = launch_vector_stream<EKC, OPC>(c, a)
+        FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+        if (rs == FH_OK) return read_status(c, failed);
+        if (rs > 0) return rs;
+    }
     a.epb = choose_epb(c, WHAT_VECTOR);
     a.ub = a.epb;
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_VECTOR, c->nq, a.ub, 0, 0, false);

@@ -68,7 +68,7 @@ __host__ __device__ inline Layout make_layout(int nq, int ub, int acc_max, int n
     L.o_X = o;     o += ub * L.xs;
     L.o_U = o;     o += (O::NEEDS_U || WHAT != WHAT_MATRIX) ? ub * L.us : 0;
     if (WHAT == WHAT_MATRIX) L.qpd = O::NVEC * E::N * E::D + (L.fast ? 0 : O::NCOEF);
-    else if (WHAT == WHAT_VECTOR) L.qpd = E::N * E::D + O::S * E::D;
+    else if (WHAT == WHAT_VECTOR) L.qpd = (fast ? 0 : E::N * E::D) + O::S * E::D;  // fast: the VCOMPACT record of prologue()
     else L.qpd = 1;
     if (WHAT != WHAT_SCALAR && (L.qpd & 1) == 0) L.qpd += 1;
     L.nqs = nq_stage > 0 ? nq_stage : nq;  // quadrature points staged at a time
@@ -208,7 +208,10 @@ __device__ __forceinline__ void pipeline_consume(F&& f) {
 
 // ------------------------------------------------------------------------------------------ phase B
 // One lane per (staged element u, quadrature point q).  Writes the LDS record qp[] described by OpT.
-template <int EK, int OP, int WHAT, bool PLANAR = false, bool NODEMAJOR = false>
+// VCOMPACT (WHAT_VECTOR only): the point record is the 3 x 3 matrix  M = s P J^-T  instead of the N physical gradients and
+// s P -- the element vector is  f_n = sum_q M_q grad_ref_n(xi_q)  with the reference gradients from the (constant) table;
+// grad u comes from  J^-T (sum_n grad_ref_n u_n^T), so the physical gradients are never formed
+template <int EK, int OP, int WHAT, bool PLANAR = false, bool NODEMAJOR = false, bool VCOMPACT = false>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
                                          const int* elem_id, int qslot = -1, double sqw = 0.0) {
     using E = ElemT<EK>;
@@ -361,6 +364,13 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         return;
     }
     double rb[2][D];
+    double Rm[VCOMPACT ? D : 1][VCOMPACT ? S : 1];  // VCOMPACT: sum_n grad_ref_n u_n^T
+    if (VCOMPACT) {
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+#pragma unroll
+            for (int k = 0; k < S; ++k) Rm[m % (VCOMPACT ? D : 1)][k % (VCOMPACT ? S : 1)] = 0.0;
+    }
     double gpair[D];  // PLANAR: the even node of a pair waits here for its odd neighbour
     if (EXPLICIT_LDS && !KEEP_G) lds_read_vec<D>(gr, rb[0]);
 #pragma unroll UNR
@@ -381,6 +391,13 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         } else {
 #pragma unroll
             for (int k = 0; k < D; ++k) rv[k] = gr[n * D + k];
+        }
+        if constexpr (VCOMPACT) {
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+#pragma unroll
+                for (int k = 0; k < S; ++k) Rm[m][k] = fma(rv[m], Ue[n * S + k], Rm[m][k]);
+            continue;
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -420,6 +437,17 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
 #pragma unroll
                 for (int k = 0; k < S; ++k) gu[i][k] = fma(g[i], Ue[n * S + k], gu[i][k]);
         }
+    }
+    if constexpr (VCOMPACT) {  // grad u = J^-T R
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                double t = 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) t = fma(Ji[m][i], Rm[m % (VCOMPACT ? D : 1)][k % (VCOMPACT ? S : 1)], t);
+                gu[i][k] = t;
+            }
     }
     double mu = 0.0, lambda = 0.0;
     if (OP != FH_LAPLACE) {
@@ -619,7 +647,17 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
                 }
             psi = mu * ee + 0.5 * lambda * (trE * trE);
         }
-        if (WHAT == WHAT_VECTOR) {
+        if (WHAT == WHAT_VECTOR && VCOMPACT) {
+#pragma unroll
+            for (int i = 0; i < S; ++i)
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(P[i][k], Ji[m][k], t);
+                    qp[i * D + m] = s * t;
+                }
+        } else if (WHAT == WHAT_VECTOR) {
             double* sp = qp + N * D;
 #pragma unroll
             for (int i = 0; i < S; ++i)
@@ -1811,7 +1849,7 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
     constexpr int D = E::D, N = E::N, S = O::S, EPB = NT / N;
     static_assert(E::NG == N && NT % N == 0, "streamed residual kernel: iso-parametric, 4 or 8 nodes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Layout L = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false);
+    const Layout L = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false, 0, 1);  // compact point records
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
     const int tid = threadIdx.x, G = gridDim.x;
@@ -1849,7 +1887,7 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
         int node_n2 = load_node(b + 2LL * G);
         // phase B: one lane per (element, point)
         for (int i = tid; i < EPB * a.nq; i += NT)
-            prologue<EK, OP, WHAT_VECTOR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
+            prologue<EK, OP, WHAT_VECTOR, false, false, true>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
         lds_barrier();
         // contraction: this thread's node row of the element vector, scattered with fp64 atomics
         {
@@ -1857,13 +1895,12 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < S; ++i) f[i] = 0.0;
             const double* qp = lds + L.o_QP + (size_t)u * a.nq * L.qpd;
-            for (int q = 0; q < a.nq; ++q, qp += L.qpd) {
-                const double* g = qp + I * D;
-                const double* sp = qp + N * D;
+            const double* r = lds + L.o_gref + I * D;  // reference gradient of this node, one table row per point
+            for (int q = 0; q < a.nq; ++q, qp += L.qpd, r += L.gs) {
 #pragma unroll
                 for (int i = 0; i < S; ++i)
 #pragma unroll
-                    for (int k = 0; k < D; ++k) f[i] = fma(sp[i * D + k], g[k], f[i]);
+                    for (int m = 0; m < D; ++m) f[i] = fma(qp[i * D + m], r[m], f[i]);
             }
             if (b * EPB + u < total)
 #pragma unroll

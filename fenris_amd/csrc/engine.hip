@@ -1303,7 +1303,7 @@ static int launch_vector(fh_ctx* c, KArgs& a, size_t lds, int grid) {
 template <int EK, int OP, int NT>
 static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
     constexpr int EPB = NT / ElemT<EK>::N;
-    const size_t lds = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false).bytes();
+    const size_t lds = make_layout<EK, OP, WHAT_VECTOR>(a.nq, EPB, 0, 0, false, 0, 1).bytes();
     if (lds > LDS_TARGET + 8 * 1024) return -1;
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);

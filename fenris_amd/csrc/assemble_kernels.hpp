@@ -1902,9 +1902,16 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
 #pragma unroll
                     for (int m = 0; m < D; ++m) f[i] = fma(qp[i * D + m], r[m], f[i]);
             }
-            if (b * EPB + u < total)
+            if (b * EPB + u < total) {
+                if (a.ke_out) {  // two-pass form: the element vectors, (element, local node, component); k_vector_from_elements sums
+                    double* dst = a.ke_out + ((size_t)elem_of(b) * N + I) * S;
 #pragma unroll
-                for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node_cur * S + i, f[i]);
+                    for (int i = 0; i < S; ++i) dst[i] = f[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node_cur * S + i, f[i]);
+                }
+            }
         }
         park(b + G);  // X / U are read by phase B only, which lies behind the barrier above
         asm volatile("" : "+v"(node_n2));
@@ -1912,6 +1919,19 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
         node_n1 = node_n2;
         lds_barrier();
     }
+}
+
+// second pass of the atomics-free residual: out[s node + c] += sum over the node's (element, local node) entries, in ascending
+// entry order (n2e is sorted: element-major like the reference's sequential loop) -- bitwise reproducible
+template <int S>
+__global__ void __launch_bounds__(256) k_vector_from_elements(int num_nodes, const unsigned* n2e_off, const unsigned* n2e, const double* fe,
+                                                              double* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)num_nodes * S) return;
+    const int node = (int)(i / S), c = (int)(i % S);
+    double acc = 0.0;
+    for (unsigned k = n2e_off[node]; k < n2e_off[node + 1]; ++k) acc += fe[(size_t)n2e[k] * S + c];
+    out[i] += acc;
 }
 
 struct SourceArgs {

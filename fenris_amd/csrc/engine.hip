@@ -337,6 +337,7 @@ struct fh_ctx {
     DevBuf<DevStatus> status;
     DevBuf<double> scratch;
     DevBuf<double> ke_dense;  // two-pass assembly of high-order elements: E dense element matrices
+    DevBuf<double> fe_scratch;  // two-pass residual: E element vectors
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
@@ -1847,14 +1848,34 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return read_status(c, failed);
-    // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel)
+    // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel).
+    // Two passes by default: element vectors to a scratch buffer, then one thread per row sums its node's entries in
+    // ascending element order -- no atomics, bitwise reproducible (FENRIS_HIP_VECTOR_ATOMICS keeps the one-pass scatter)
     if (!a.labels && !std::getenv("FENRIS_HIP_NO_VECTOR_STREAM")) {
+        const bool two_pass = !std::getenv("FENRIS_HIP_VECTOR_ATOMICS") && !c->ragged &&
+                              (c->elem_kind == FH_HEX8 || c->elem_kind == FH_TET4 || c->elem_kind == FH_QUAD4);
+        if (two_pass) {
+            rc = build_pattern(c);  // the node -> (element, local node) adjacency comes with the pattern
+            if (rc) return rc;
+            const size_t need = (size_t)c->E * c->ei.n * c->S();
+            if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
+            a.ke_out = c->fe_scratch.p;
+        }
         int rs = -1;
 #define CALL(EKC, OPC) rs = launch_vector_stream<EKC, OPC>(c, a)
         FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
 #undef CALL
+        if (rs == FH_OK && two_pass) {
+            const long long rows = (long long)c->N * c->S();
+            const int grid = (int)((rows + 255) / 256);
+            if (c->S() == 1) hipLaunchKernelGGL(k_vector_from_elements<1>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+            else if (c->S() == 2) hipLaunchKernelGGL(k_vector_from_elements<2>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+            else hipLaunchKernelGGL(k_vector_from_elements<3>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+            HIP_TRY(c, hipGetLastError());
+        }
         if (rs == FH_OK) return read_status(c, failed);
         if (rs > 0) return rs;
+        a.ke_out = nullptr;
     }
     a.epb = choose_epb(c, WHAT_VECTOR);
     a.ub = a.epb;

@@ -337,6 +337,9 @@ def test_vector_and_scalar_match_oracle(engine, oracle, kind, op):
     out = f.copy()
     fa.VectorAssembler().assemble_vector_into(out, asm)
     assert np.abs(out - 2 * f).max() <= 1e-15 * np.abs(f).max() * 8
+    if kind in ("HEX8", "TET4", "QUAD4"):
+        # two-pass residual (element vectors, then a per-row sum in ascending element order): no atomics, same bits every run
+        assert np.array_equal(fa.VectorAssembler().assemble_vector(asm), f)
 
 
 def test_residual_is_K_times_u_for_linear_operators(engine, oracle):

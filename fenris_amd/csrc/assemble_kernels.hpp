@@ -1995,9 +1995,15 @@ __global__ void __launch_bounds__(256) k_assemble_source(const KArgs a, const So
                 f[c] = fma(t, fc, f[c]);
             }
         }
-        const int node = a.conn[(size_t)e * sa.N + I];
+        if (a.ke_out) {  // two-pass form (see k_vector_from_elements): element vectors to scratch
+            double* dst = a.ke_out + ((size_t)e * sa.N + I) * S;
 #pragma unroll
-        for (int c = 0; c < S; ++c) atomic_add_f64(a.vec_out + (size_t)node * S + c, f[c]);
+            for (int c = 0; c < S; ++c) dst[c] = f[c];
+        } else {
+            const int node = a.conn[(size_t)e * sa.N + I];
+#pragma unroll
+            for (int c = 0; c < S; ++c) atomic_add_f64(a.vec_out + (size_t)node * S + c, f[c]);
+        }
     }
 }
 

@@ -1941,6 +1941,15 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return FH_OK;
+    // two passes without atomics where the node adjacency is available (it comes with the pattern, which needs an operator
+    // for the solution dimension): element vectors to scratch, then a per-row sum in element order
+    bool two_pass = !a.labels && !c->ragged && c->op >= 0 && !std::getenv("FENRIS_HIP_VECTOR_ATOMICS");
+    if (two_pass && build_pattern(c) != FH_OK) two_pass = false;
+    if (two_pass) {
+        const size_t need = (size_t)c->E * c->ei.n * sdim;
+        if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
+        a.ke_out = c->fe_scratch.p;
+    }
     a.epb = std::max(1, 256 / std::max(c->nq, c->ei.n));
     const size_t lds = sizeof(double) * (size_t)a.epb * c->nq;
     const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
@@ -1950,6 +1959,14 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     else if (sdim == 1) hipLaunchKernelGGL((k_assemble_source<3, 1>), dim3(grid), dim3(256), lds, c->stream, a, sa);
     else hipLaunchKernelGGL((k_assemble_source<3, 3>), dim3(grid), dim3(256), lds, c->stream, a, sa);
     HIP_TRY(c, hipGetLastError());
+    if (two_pass) {
+        const long long rows = (long long)c->N * sdim;
+        const int g2 = (int)((rows + 255) / 256);
+        if (sdim == 1) hipLaunchKernelGGL(k_vector_from_elements<1>, dim3(g2), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+        else if (sdim == 2) hipLaunchKernelGGL(k_vector_from_elements<2>, dim3(g2), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+        else hipLaunchKernelGGL(k_vector_from_elements<3>, dim3(g2), dim3(256), 0, c->stream, (int)c->N, c->n2e_off.p, c->n2e.p, c->fe_scratch.p, out_dev);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // gd is released on return
     return FH_OK;
 }

@@ -2038,11 +2038,17 @@ __global__ void __launch_bounds__(256) k_assemble_scalar(const KArgs a) {
     for (int i = tid; i < U * a.nq; i += nt)
         prologue<EK, OP, WHAT_SCALAR>(a, L, lds, lds_i, i / a.nq, i % a.nq, lds_i + L.o_uniq + i / a.nq);
     __syncthreads();
-    // per-element energies in element order, then one partial per block (summed on the host in block
-    // order => deterministic)
+    // element energies (sum over the points, like compute_element_elliptic_energy), then one partial per block summed in
+    // element order; the host adds the partials in block order => deterministic
+    if (tid < U) {
+        double t = 0.0;
+        for (int q = 0; q < a.nq; ++q) t += lds[L.o_QP + tid * a.nq + q];
+        lds[L.o_QP + tid * a.nq] = t;
+    }
+    __syncthreads();
     if (tid == 0) {
         double tot = 0.0;
-        for (int i = 0; i < U * a.nq; ++i) tot += lds[L.o_QP + i];
+        for (int i = 0; i < U; ++i) tot += lds[L.o_QP + i * a.nq];
         a.scalar_out[blockIdx.x] = tot;
     }
 }

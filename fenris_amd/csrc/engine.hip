@@ -2043,10 +2043,12 @@ int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return FH_OK;
-    a.epb = 1;  // one partial per element, summed in element order on the host (global.rs:703-709)
-    a.ub = 1;
+    // a batch of elements per workgroup: element energies summed in element order inside the batch, the batch partials in
+    // order on the host (global.rs:703-709 sums element by element; same terms, fixed association)
+    a.epb = std::max(1, std::min(choose_epb(c, WHAT_SCALAR), std::max(1, 256 / std::max(c->nq, 1))));
+    a.ub = a.epb;
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_SCALAR, c->nq, a.ub, 0, 0, false);
-    const int grid = (int)a.work_end;
+    const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
     DevBuf<double> partial;
     HIP_TRY(c, partial.alloc((size_t)grid));
     a.scalar_out = partial.p;

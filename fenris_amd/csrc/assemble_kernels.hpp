@@ -1773,6 +1773,56 @@ __global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsign
 
 // PLANAR: the dense matrices are stored as S x S planes ke[e][r][c][I][J] (what the MFMA kernel writes) instead of one
 // column-major (S n) x (S n) matrix; a lane then walks (c, J) with J fastest so that its reads stay contiguous.
+// k_rows_from_dense for small column-major element matrices (S n <= P <= 32, P a power of two): a row of K_e fills less
+// than half a wavefront, so 64 / P entries of the node share one load instruction (lane / P picks the entry) and all
+// EB groups of a node are in flight together -- Hex8: the 8 entries of a node in one round (the one-entry-per-load
+// form ran this pass at 2.7 TB/s with 24 of 64 lanes busy).
+template <int S, typename PT, int P>
+__global__ void __launch_bounds__(256) k_rows_from_dense_small(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
+                                                               const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
+                                                               int overwrite, int max_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
+    const int ld = S * n;
+    constexpr int G = 64 / P, EB = 4;
+    const int sub = lane / P, idx = min(lane % P, ld - 1);
+    const bool lane_in_row = (lane % P) < ld;
+    for (int i = blockIdx.x * 4 + wave; i < num_nodes; i += gridDim.x * 4) {
+        const unsigned r0 = noff[i];
+        const int cnt = (int)(noff[i + 1] - r0);
+        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
+        const unsigned t0 = adj_off[i], t1 = adj_off[i + 1];
+        for (unsigned t = t0; t < t1; t += EB * G) {
+            double v[EB][S];
+            int pos[EB];
+            bool ok[EB];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const unsigned tk = t + (unsigned)(k * G + sub);
+                ok[k] = tk < t1 && lane_in_row;
+                const unsigned tc = min(tk, t1 - 1);
+                const unsigned ent = adj[tc];
+                const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
+                const double* kb = ke + (size_t)e * ld * ld + (size_t)S * a * ld;  // column S a + r of the symmetric K_e
+                pos[k] = (int)pos_tab[(size_t)tc * n + idx / S];
+#pragma unroll
+                for (int r = 0; r < S; ++r) v[k][r] = kb[(size_t)r * ld + idx];
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k)
+                if (ok[k]) {
+                    double* dst = acc + S * pos[k] + idx % S;
+#pragma unroll
+                    for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][r]);
+                }
+        }
+        double* out = vals + (size_t)S * S * r0;
+        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
+        else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
+    }
+}
+
 template <int S, typename PT, bool PLANAR>
 __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
                                                          const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,

@@ -1142,7 +1142,14 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     } while (0)
 #define ROWS2(SS, PT, PTR, PL)                                                                                                \
     do {                                                                                                                       \
-        auto kern = k_rows_from_dense<SS, PT, PL>;                                                                                 \
+        void (*kern)(int, int, const unsigned*, const unsigned*, const unsigned*, const PT*, const double*, double*, int, int) = \
+            k_rows_from_dense<SS, PT, PL>;                                                                                     \
+        if (!PL && !std::getenv("FENRIS_HIP_NO_ROWS_SMALL")) {                                                                 \
+            const int ld_ = SS * (int)c->ei.n;                                                                                 \
+            if (ld_ <= 8) kern = k_rows_from_dense_small<SS, PT, 8>;                                                           \
+            else if (ld_ <= 16) kern = k_rows_from_dense_small<SS, PT, 16>;                                                    \
+            else if (ld_ <= 32) kern = k_rows_from_dense_small<SS, PT, 32>;                                                    \
+        }                                                                                                                      \
         if (lds > 48 * 1024)                                                                                                   \
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (int)c->N, c->ei.n, c->noff.p, adj_off, adj, PTR,         \

@@ -942,13 +942,33 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             if (MODE == MODE_DUMP) {
                 // K_e column-major (s n) x (s n), both triangles
                 double* ke = a.ke_out + (size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * (S * N) * (S * N);
+                // runs of S contiguous values: column (J, j) rows (I, 0..S), and column (I, i) rows (J, 0..S)
 #pragma unroll
-                for (int i = 0; i < S; ++i)
+                for (int j = 0; j < S; ++j) {
+                    double* col = ke + (size_t)(S * J + j) * (S * N) + S * I;
+                    if (S == 3) {
+                        typedef double f64x2_u8 __attribute__((ext_vector_type(2), aligned(8)));
+                        f64x2_u8 p2; p2.x = blk[0][j]; p2.y = blk[1 % S][j];
+                        *reinterpret_cast<f64x2_u8*>(col) = p2;
+                        col[2 % S] = blk[2 % S][j];
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < S; ++j) {
-                        ke[(size_t)(S * J + j) * (S * N) + (S * I + i)] = blk[i][j];
-                        ke[(size_t)(S * I + i) * (S * N) + (S * J + j)] = blk[i][j];
+                        for (int i = 0; i < S; ++i) col[i] = blk[i][j];
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    double* col = ke + (size_t)(S * I + i) * (S * N) + S * J;
+                    if (S == 3) {
+                        typedef double f64x2_u8 __attribute__((ext_vector_type(2), aligned(8)));
+                        f64x2_u8 p2; p2.x = blk[i][0]; p2.y = blk[i][1 % S];
+                        *reinterpret_cast<f64x2_u8*>(col) = p2;
+                        col[2 % S] = blk[i][2 % S];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < S; ++j) col[j] = blk[i][j];
+                    }
+                }
             } else {
                 const unsigned ni = (unsigned)lds_i[L.o_cn + u * N + I], nj = (unsigned)lds_i[L.o_cn + u * N + J];
                 {

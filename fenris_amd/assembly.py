@@ -132,6 +132,16 @@ class Engine:
     def synchronize(self):
         self._check(self._lib.fh_synchronize(self._h))
 
+    def set_affine_tolerance(self, rel_tol: float):
+        """fh_set_affine_tolerance: 0 switches the affine-element fast path off."""
+        self._check(self._lib.fh_set_affine_tolerance(self._h, float(rel_tol)))
+
+    def affine_stats(self):
+        """(elements found affine, node blocks on the affine kernel, node blocks on the general kernels)"""
+        a, b, g = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.fh_affine_stats(self._h, C.byref(a), C.byref(b), C.byref(g)))
+        return int(a.value), int(b.value), int(g.value)
+
     # pattern
     def pattern(self, want_cols=True):
         R = self.num_rows()

@@ -1494,8 +1494,9 @@ __global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size
 // successor of a block in the sweep order: the block that owns most of the nodes (with an index beyond this
 // block) touched by this block's elements -- i.e. the neighbouring block sharing the most elements.  One
 // wavefront per block.
+// cls (optional): class of every block; only blocks of the same class are candidates (chains never mix classes).
 __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
-                                                        const int* node2blk, int nblk, int* succ) {
+                                                        const int* node2blk, int nblk, const unsigned char* cls, int* succ) {
     __shared__ int cand[1024];
     __shared__ int best_blk, best_cnt;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1504,7 +1505,9 @@ __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, co
     const int total = min(h.U * N, 1024);
     for (int i = lane; i < total; i += 64) {
         const int node = conn[(size_t)gt_elems[h.u_off + i / N] * N + i % N];
-        cand[i] = (node > last) ? node2blk[node] : -1;
+        int cb = (node > last) ? node2blk[node] : -1;
+        if (cls && cb >= 0 && cls[cb] != cls[b]) cb = -1;
+        cand[i] = cb;
     }
     if (lane == 0) { best_blk = -1; best_cnt = 0; }
     __syncthreads();

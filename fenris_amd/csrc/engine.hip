@@ -16,6 +16,7 @@
 #include "solver_kernels.hpp"
 #include "hex27_mfma.hpp"
 #include "rows_kernel.hpp"
+#include "affine_kernel.hpp"
 #include "device_common.hpp"
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
@@ -327,6 +328,19 @@ struct fh_ctx {
     DevBuf<GatherHdr> gt_hdr;
     int nblk = 0, g_ub = 0, g_mb = 0, g_acc = 0, g_nb = 0, g_umax = 0;
     bool has_partition = false;
+    // affine-element fast path (affine_kernel.hpp): per-element flags, reference blocks, and the sweep positions of the
+    // node blocks all of whose elements are affine (the position-indexed tables above then cover the other blocks only)
+    double affine_tol = 0x1p-46;
+    bool has_aff = false;
+    DevBuf<unsigned char> elem_aff;
+    uint64_t num_aff = 0;
+    DevBuf<double> ghat;            // [64][10] LinearElastic blocks | [64][6] Laplace blocks
+    bool has_ghat = false;
+    DevBuf<int> a_rec, a_conn, a_elem;
+    DevBuf<uint2> a_lanes;
+    int a_rw = 0, a_cs = 0, a_us = 0, a_npos = 0;
+    int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
+    bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
     // colours
     bool has_colors = false;
@@ -785,6 +799,8 @@ int build_partition(fh_ctx* c) {
     // position-indexed tables for the pipelined kernel (elements with few geometry nodes, pos table present)
     c->has_pipe = false;
     c->has_rows = false;
+    c->a_npos = 0;
+    c->npos_gen = c->nblk;
     if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
         const int n = c->ei.n;
         const int ms = (mmax + 3) / 4 * 4;
@@ -797,9 +813,25 @@ int build_partition(fh_ctx* c) {
         if (us * c->ei.ng <= 512 && us <= 252 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb &&
             nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
             const int nblk = c->nblk;
+            // Block classes: 1 = every adjacent element is affine, the block runs on k_gather_affine; 0 = general kernels.
+            // Chains never mix classes, so each class gets its own sweep order and its own position-indexed tables.
+            std::vector<unsigned char> cls((size_t)nblk, 0);
+            DevBuf<unsigned char> cls_d;
+            const bool want_aff = c->elem_kind == FH_HEX8 && c->has_aff && c->has_ghat && c->num_aff > 0 && !c->has_rules &&
+                                  !c->aff_failed && c->affine_tol > 0.0 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+                                  us <= 32 && nb_target <= 8 && !std::getenv("FENRIS_HIP_NO_AFFINE");
+            if (want_aff) {
+                HIP_TRY(c, cls_d.alloc((size_t)nblk));
+                hipLaunchKernelGGL(k_block_class, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, c->gt_elems.p,
+                                   c->elem_aff.p, nblk, 32, cls_d.p);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipMemcpyAsync(cls.data(), cls_d.p, (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
             // sweep order: chains of blocks whose consecutive members share elements (their staged data is reused)
-            std::vector<int> order, chain_off(1, 0);
-            order.reserve(nblk);
+            std::vector<int> order[2], chain_off[2];
+            chain_off[0].push_back(0);
+            chain_off[1].push_back(0);
             if (!std::getenv("FENRIS_HIP_NO_SWEEP")) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
@@ -807,63 +839,107 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, succ_d.alloc((size_t)nblk));
                 hipLaunchKernelGGL(k_node_to_block, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->blk_off.p, nblk, node2blk.p);
                 hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
-                                   node2blk.p, nblk, succ_d.p);
+                                   node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p);
                 std::vector<int> succ((size_t)nblk);
                 HIP_TRY(c, hipMemcpyAsync(succ.data(), succ_d.p, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 std::vector<unsigned char> visited((size_t)nblk, 0);
                 for (int b = 0; b < nblk; ++b) {
                     if (visited[b]) continue;
-                    for (int cur = b; cur >= 0 && cur < nblk && !visited[cur]; cur = succ[cur]) {
+                    const int k = cls[b];
+                    for (int cur = b; cur >= 0 && cur < nblk && !visited[cur] && cls[cur] == k; cur = succ[cur]) {
                         visited[cur] = 1;
-                        order.push_back(cur);
+                        order[k].push_back(cur);
                     }
-                    chain_off.push_back((int)order.size());
+                    chain_off[k].push_back((int)order[k].size());
                 }
             } else {
-                for (int b = 0; b < nblk; ++b) { order.push_back(b); chain_off.push_back(b + 1); }
+                for (int b = 0; b < nblk; ++b) { order[cls[b]].push_back(b); chain_off[cls[b]].push_back((int)order[cls[b]].size()); }
             }
-            const int nchains = (int)chain_off.size() - 1;
-            DevBuf<int> order_d, chain_d;
-            HIP_TRY(c, order_d.alloc(order.size()));
-            HIP_TRY(c, chain_d.alloc(chain_off.size()));
-            HIP_TRY(c, hipMemcpyAsync(order_d.p, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(chain_d.p, chain_off.data(), sizeof(int) * chain_off.size(), hipMemcpyHostToDevice, c->stream));
             c->p_cs = us * c->ei.ng;
             c->p_ms = ms;
             c->p_nbs = nb_target;
             c->p_us = us;
             c->p_rw = pipe_record_words(us, ms, n, nb_target);
-            HIP_TRY(c, c->p_rec.alloc((size_t)nblk * c->p_rw));
-            HIP_TRY(c, c->p_conn.alloc((size_t)nblk * c->p_cs));
-            HIP_TRY(c, c->p_elem.alloc((size_t)nblk * us));
+            // position-indexed tables of one class
+            auto build_set = [&](const std::vector<int>& ord, const std::vector<int>& choff, DevBuf<int>& rec, DevBuf<int>& conn,
+                                 DevBuf<int>& elem) -> int {
+                const int npos = (int)ord.size(), nchains = (int)choff.size() - 1;
+                DevBuf<int> order_d, chain_d;
+                HIP_TRY(c, order_d.alloc(ord.size()));
+                HIP_TRY(c, chain_d.alloc(choff.size()));
+                HIP_TRY(c, hipMemcpyAsync(order_d.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(chain_d.p, choff.data(), sizeof(int) * choff.size(), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, rec.alloc((size_t)npos * c->p_rw));
+                HIP_TRY(c, conn.alloc((size_t)npos * c->p_cs));
+                HIP_TRY(c, elem.alloc((size_t)npos * us));
 #define PT_LAUNCH(NGV)                                                                                                           \
     hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(nchains), dim3(64), 0, c->stream, order_d.p, chain_d.p, c->gt_hdr.p,        \
                        c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_rw,     \
-                       c->p_rec.p, c->p_conn.p, c->p_elem.p)
-            switch (c->ei.ng) {
-                case 3: PT_LAUNCH(3); break;
-                case 4: PT_LAUNCH(4); break;
-                case 8: PT_LAUNCH(8); break;
-                default: break;
-            }
+                       rec.p, conn.p, elem.p)
+                switch (c->ei.ng) {
+                    case 3: PT_LAUNCH(3); break;
+                    case 4: PT_LAUNCH(4); break;
+                    case 8: PT_LAUNCH(8); break;
+                    default: break;
+                }
 #undef PT_LAUNCH
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipStreamSynchronize(c->stream));  // order_d / chain_d are released on return
+                return FH_OK;
+            };
+            c->a_npos = 0;
+            if (!order[1].empty()) {
+                // the affine kernel keeps nothing staged from one block to the next, and its write-out carries incomplete
+                // 128-byte lines from a block to its successor in memory: positions in CSR order, every position its own chain
+                std::sort(order[1].begin(), order[1].end());
+                chain_off[1].resize(order[1].size() + 1);
+                for (size_t k = 0; k <= order[1].size(); ++k) chain_off[1][k] = (int)k;
+                DevBuf<int> tmp_rec;  // the pipelined kernel's records: input of the lane builder only
+                int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem);
+                if (rs) return rs;
+                const int npos = (int)order[1].size();
+                c->a_rw = 8 + us / 4 + nb_target + 1;
+                c->a_cs = c->p_cs;
+                c->a_us = us;
+                DevBuf<int> st;
+                HIP_TRY(c, st.alloc(1));
+                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                HIP_TRY(c, c->a_rec.alloc((size_t)npos * c->a_rw));
+                HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
+                hipLaunchKernelGGL(k_build_row_lanes, dim3(npos), dim3(64), 0, c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos,
+                                   c->a_rw, c->a_rec.p, c->a_lanes.p, st.p, c->a_elem.p);
+                HIP_TRY(c, hipGetLastError());
+                int bad = 0;
+                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (bad) {  // a block the lane tables cannot express: everything on the general kernels
+                    c->aff_failed = true;
+                    return build_partition(c);
+                }
+                c->a_npos = npos;
+            }
+            c->npos_gen = (int)order[0].size();
+            if (!order[0].empty()) {
+                int rs = build_set(order[0], chain_off[0], c->p_rec, c->p_conn, c->p_elem);
+                if (rs) return rs;
+            }
             c->has_pipe = true;
             if (std::getenv("FENRIS_HIP_VERBOSE"))
-                std::fprintf(stderr, "[fenris_hip] sweep order: %d blocks in %d chains (us=%d ms=%d)\n", nblk, nchains, us, ms);
+                std::fprintf(stderr, "[fenris_hip] sweep order: %d general blocks in %d chains, %d affine blocks in %d chains (us=%d ms=%d)\n",
+                             c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, (int)chain_off[1].size() - 1, us, ms);
             // row-owner lanes (Hex8; opt-in while it is being measured)
             c->has_rows = false;
-            if (c->elem_kind == FH_HEX8 && us * 8 <= 256 && nb_target <= 8 && std::getenv("FENRIS_HIP_ROWS")) {
+            const int npg = c->npos_gen;
+            if (c->elem_kind == FH_HEX8 && us * 8 <= 256 && nb_target <= 8 && npg > 0 && std::getenv("FENRIS_HIP_ROWS")) {
                 c->r_rw = 8 + us / 4 + nb_target + 1;
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                HIP_TRY(c, c->r_rec.alloc((size_t)nblk * c->r_rw));
-                HIP_TRY(c, c->r_lanes.alloc((size_t)nblk * 256));
-                hipLaunchKernelGGL(k_build_row_lanes, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target, nblk,
-                                   c->r_rw, c->r_rec.p, c->r_lanes.p, st.p);
+                HIP_TRY(c, c->r_rec.alloc((size_t)npg * c->r_rw));
+                HIP_TRY(c, c->r_lanes.alloc((size_t)npg * 256));
+                hipLaunchKernelGGL(k_build_row_lanes, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target, npg,
+                                   c->r_rw, c->r_rec.p, c->r_lanes.p, st.p, (const int*)nullptr);
                 HIP_TRY(c, hipGetLastError());
                 int bad = 0;
                 HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -874,19 +950,19 @@ int build_partition(fh_ctx* c) {
             }
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
-            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && !std::getenv("FENRIS_HIP_NO_ROWS")) {
+            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !std::getenv("FENRIS_HIP_NO_ROWS")) {
                 c->r_rw = 8 + us / 4 + nb_target + 1;
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                HIP_TRY(c, c->r_rec.alloc((size_t)nblk * c->r_rw));
+                HIP_TRY(c, c->r_rec.alloc((size_t)npg * c->r_rw));
                 int bad = 0;
                 for (int ls : {128, 256}) {  // half the table (and its traffic) when no block needs more than 128 lanes
                     c->r_ls = ls;
                     HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                    HIP_TRY(c, c->r_lanes4.alloc((size_t)nblk * ls));
-                    hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(nblk), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms,
-                                       nb_target, nblk, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p);
+                    HIP_TRY(c, c->r_lanes4.alloc((size_t)npg * ls));
+                    hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms,
+                                       nb_target, npg, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p);
                     HIP_TRY(c, hipGetLastError());
                     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -922,7 +998,7 @@ int launch_rows(fh_ctx* c, KArgs& a, const RowTables& T) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int grid = std::min(c->nblk, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int grid = std::min(c->npos_gen, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     auto kern = k_gather_rows<OP>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -940,7 +1016,7 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
-    const int grid = std::min(c->nblk, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int grid = std::min(c->npos_gen, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     auto kern = k_gather_rows_tet4<OP, ELEMPAR>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -968,7 +1044,7 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int wgs = std::max(1, env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
-    const int grid = std::min(c->nblk, dev_cus * wgs);
+    const int grid = std::min(c->npos_gen, dev_cus * wgs);
     // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
     const bool dbg = (std::getenv("FENRIS_HIP_TRACE") || std::getenv("FENRIS_HIP_ABLATE") || std::getenv("FENRIS_HIP_DBG_KERNEL"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
@@ -1043,6 +1119,26 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
                                  : launch_pipelined_t<FH_TRI3, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
         default: return c->fail(FH_UNSUPPORTED, "pipelined gather: unsupported element");
     }
+}
+
+// node blocks all of whose elements are affine: k_gather_affine over its own position tables
+int launch_affine(fh_ctx* c, KArgs& a) {
+    AffineTables T{c->a_rec.p, c->a_lanes.p, c->a_conn.p, c->a_elem.p,
+                   c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_rw, c->a_cs, c->a_us, c->p_nbs, c->a_npos, c->g_acc};
+    const size_t lds = affine_lds_bytes(c->op, c->a_us, c->g_acc, c->a_rw);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+    void (*kern)(const KArgs, const AffineTables) = (c->op == FH_LAPLACE) ? k_gather_affine<FH_LAPLACE> : k_gather_affine<FH_LINEAR_ELASTIC>;
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (std::getenv("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] affine gather: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
 }
 
 // dense element matrices of the elements [first, first + count) into device memory (no status read-back)
@@ -1191,6 +1287,15 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         rc = build_partition(c);
         if (rc) return rc;
         if (c->nblk == 0) return FH_OK;  // empty row range
+        c->last_kernel.clear();
+        if (c->a_npos > 0) {
+            // node blocks whose elements are all affine (affine_kernel.hpp); the remaining positions follow below
+            rc = launch_affine(c, a);
+            if (rc) return rc;
+            c->last_kernel = "k_gather_affine";
+            if (c->npos_gen == 0) return FH_OK;
+            c->last_kernel += " + ";
+        }
         a.blk_off = c->blk_off.p;
         a.gt_hdr = c->gt_hdr.p;
         a.gt_elems = c->gt_elems.p;
@@ -1204,7 +1309,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
         const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
         const bool pipe_rules = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
         if (pipe_rules && !c->has_slotpar) {
-            const size_t n = (size_t)c->nblk * c->p_us;
+            const size_t n = (size_t)c->npos_gen * c->p_us;
             HIP_TRY(c, c->p_slotpar.alloc(2 * n));
             hipLaunchKernelGGL(k_build_slot_params, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->p_elem.p, n,
                                c->rule_map.p, c->rparams.p, c->nq, c->p_slotpar.p);
@@ -1221,32 +1326,32 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
                 a.nq = 1;
             }
             RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
-                         c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk, c->r_ls};
+                         c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;
-            c->last_kernel = "k_gather_rows";
+            c->last_kernel += "k_gather_rows";
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
         }
         if (c->has_pipe && c->has_rows && c->elem_kind == FH_HEX8 && a.fast && !pipe_rules && c->nq == 8 &&
             (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
-            RowTables T{c->r_rec.p, c->r_lanes.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->nblk};
+            RowTables T{c->r_rec.p, c->r_lanes.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->npos_gen};
             a.ub = c->p_us;
             a.nb_max = c->p_nbs;
-            c->last_kernel = "k_gather_rows";
+            c->last_kernel += "k_gather_rows";
             return c->op == FH_LAPLACE ? launch_rows<FH_LAPLACE>(c, a, T) : launch_rows<FH_LINEAR_ELASTIC>(c, a, T);
         }
         if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
             a.fast = 1;
             PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr, c->p_rw,
-                         c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->nblk};
+                         c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->npos_gen};
             a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
             a.mb = c->p_ms;  // the LDS layout is sized by the table strides
             a.nb_max = c->p_nbs;
-            c->last_kernel = "k_gather_pipelined";
+            c->last_kernel += "k_gather_pipelined";
             return launch_pipelined(c, a, T, 0, 0);
         }
-        c->last_kernel = "k_assemble_matrix<gather>";
+        c->last_kernel += "k_assemble_matrix<gather>";
 #define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_GATHER, lds, c->nblk)
         FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
 #undef CALL
@@ -1426,6 +1531,50 @@ uint64_t fh_num_nodes(const fh_ctx* c) { return c ? c->N : 0; }
 uint64_t fh_num_rows(const fh_ctx* c) { return c ? (uint64_t)c->S() * c->N : 0; }
 uint64_t fh_nnz(const fh_ctx* c) { return (c && c->has_pattern) ? (uint64_t)c->S() * c->S() * c->nnz_nodes : 0; }
 
+// per-element affine flags from the current vertex coordinates (Hex8; affine_kernel.hpp).  The owner-computes partition
+// depends on them: it is rebuilt when they change.
+static int classify_affine(fh_ctx* c) {
+    const bool had = c->has_aff;
+    const uint64_t old_count = c->num_aff;
+    c->has_aff = false;
+    c->num_aff = 0;
+    if (c->elem_kind != FH_HEX8 || c->E == 0 || !(c->affine_tol > 0.0)) {
+        if (had) c->has_partition = false;
+        return FH_OK;
+    }
+    DevBuf<unsigned char> flags;
+    DevBuf<unsigned long long> cnt;
+    HIP_TRY(c, flags.alloc((size_t)c->E));
+    HIP_TRY(c, cnt.alloc(1));
+    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_classify_affine_hex8, dim3((unsigned)((c->E + 255) / 256)), dim3(256), 0, c->stream, c->verts.p, c->conn.p,
+                       (long long)c->E, c->affine_tol, flags.p, cnt.p);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // same flags as before (the usual case of fh_update_vertices on a moving mesh: none before, none now; or a rigid motion):
+    // keep the partition.  Equal counts with different members are told apart by comparing the arrays.
+    bool same = had && old_count == h && c->elem_aff.n >= c->E;
+    if (same && h != 0 && h != c->E) {
+        DevBuf<int> diff;
+        HIP_TRY(c, diff.alloc(1));
+        HIP_TRY(c, hipMemsetAsync(diff.p, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_bytes_differ, dim3((unsigned)((c->E + 255) / 256)), dim3(256), 0, c->stream, flags.p, c->elem_aff.p,
+                           (long long)c->E, diff.p);
+        int hd = 0;
+        HIP_TRY(c, hipMemcpyAsync(&hd, diff.p, sizeof hd, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        same = hd == 0;
+    }
+    std::swap(c->elem_aff.p, flags.p);
+    std::swap(c->elem_aff.n, flags.n);
+    c->num_aff = h;
+    c->has_aff = true;
+    if (!same) { c->has_partition = false; c->aff_failed = false; }
+    return FH_OK;
+}
+
 static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     ElemInfo ei;
     if (!elem_info(elem_kind, ei)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh: unknown element kind");
@@ -1442,6 +1591,11 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->flat_len = E * (uint64_t)ei.n;
     c->has_u = false;
     c->has_mask = false;
+    c->has_aff = false;
+    c->aff_failed = false;
+    c->has_ghat = false;
+    c->row_lo = 0;   // the row range is per-mesh state
+    c->row_hi = -1;
     c->nq = 0;  // reference gradient tables depend on the element kind
     HIP_TRY(c, c->verts.alloc((size_t)N * ei.d));
     HIP_TRY(c, c->conn.alloc((size_t)c->flat_len));
@@ -1478,7 +1632,7 @@ int fh_set_mesh(fh_ctx* c, int elem_kind, const double* vertices, uint64_t N, co
     c->h_eoff.clear();
     c->has_host_conn = true;
     c->has_mesh = true;
-    return FH_OK;
+    return classify_affine(c);
 }
 
 int fh_set_mesh_dev(fh_ctx* c, int elem_kind, const double* vertices_dev, uint64_t N, const uint64_t* conn_dev, uint64_t E) {
@@ -1492,7 +1646,7 @@ int fh_set_mesh_dev(fh_ctx* c, int elem_kind, const double* vertices_dev, uint64
     c->h_nodes.clear();
     c->has_host_conn = false;
     c->has_mesh = true;
-    return FH_OK;
+    return classify_affine(c);
 }
 
 int fh_update_vertices(fh_ctx* c, const double* vertices) {
@@ -1501,7 +1655,7 @@ int fh_update_vertices(fh_ctx* c, const double* vertices) {
     if (!vertices) return c->fail(FH_BAD_ARGUMENT, "fh_update_vertices: null pointer");
     HIP_TRY(c, hipMemcpyAsync(c->verts.p, vertices, sizeof(double) * c->N * c->ei.d, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FH_OK;
+    return classify_affine(c);
 }
 
 int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint64_t* eoff, const uint64_t* nodes, uint64_t E) {
@@ -1514,6 +1668,9 @@ int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint6
     invalidate_pattern(c);
     c->has_mesh = false;
     c->ragged = true;
+    c->has_aff = false;
+    c->row_lo = 0;
+    c->row_hi = -1;
     c->elem_kind = -1;
     c->ei = ElemInfo{0, 0, 0, -1};
     c->N = N;
@@ -1585,13 +1742,32 @@ int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
     return FH_OK;
 }
 
+int fh_set_affine_tolerance(fh_ctx* c, double rel_tol) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!(rel_tol >= 0.0) || rel_tol > 1e-6) return c->fail(FH_BAD_ARGUMENT, "fh_set_affine_tolerance: tolerance must be in [0, 1e-6]");
+    if (rel_tol == c->affine_tol) return FH_OK;
+    c->affine_tol = rel_tol;
+    if (c->has_mesh && !c->ragged) return classify_affine(c);
+    return FH_OK;
+}
+
+int fh_affine_stats(const fh_ctx* c, uint64_t* affine_elements, uint64_t* affine_blocks, uint64_t* general_blocks) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (affine_elements) *affine_elements = c->has_aff ? c->num_aff : 0;
+    if (affine_blocks) *affine_blocks = c->has_partition ? (uint64_t)c->a_npos : 0;
+    if (general_blocks) *general_blocks = c->has_partition ? (uint64_t)c->npos_gen : 0;
+    return FH_OK;
+}
+
 int fh_set_operator(fh_ctx* c, int op_kind) {
     if (!c) return FH_BAD_ARGUMENT;
     if (op_kind < FH_LAPLACE || op_kind > FH_MASS_VECTOR) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
     if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
-    const int old_s = c->S();
+    const int old_s = c->S(), old_op = c->op;
     c->op = op_kind;
-    if (c->S() != old_s) { c->has_u = false; c->has_partition = false; c->has_tp_pos = false; }
+    if (c->S() != old_s) { c->has_u = false; c->has_tp_pos = false; }
+    // the owner-computes partition (LDS budgets, kernel classes, slot parameters) is built for one operator
+    if (op_kind != old_op) { c->has_partition = false; c->has_slotpar = false; }
     return FH_OK;
 }
 
@@ -1624,6 +1800,32 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     HIP_TRY(c, hipMemcpy(c->gref.p, gref.data(), sizeof(double) * gref.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->ggeom.p, ggeom.data(), sizeof(double) * ggeom.size(), hipMemcpyHostToDevice));
+    c->has_ghat = false;
+    if (c->elem_kind == FH_HEX8) {
+        // reference blocks of the affine-element kernel: Ghat_ab[c][d] = sum_q w_q ghat_a(xi_q)[c] ghat_b(xi_q)[d], summed in
+        // table order; Ghat_ba is the exact transpose of Ghat_ab (the factors of each product commute)
+        std::vector<double> gh((size_t)64 * (AFFINE_GW_LE + AFFINE_GW_LAP), 0.0);
+        double* le = gh.data();
+        double* lap = gh.data() + 64 * AFFINE_GW_LE;
+        for (int a = 0; a < 8; ++a)
+            for (int b = 0; b < 8; ++b) {
+                double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                for (uint32_t q = 0; q < nq; ++q) {
+                    const double* ga = gref.data() + ((size_t)q * 8 + a) * 3;
+                    const double* gb = gref.data() + ((size_t)q * 8 + b) * 3;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) G[i][j] += w[q] * (ga[i] * gb[j]);
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) le[(a * 8 + b) * AFFINE_GW_LE + 3 * i + j] = G[i][j];
+                double* l6 = lap + (a * 8 + b) * AFFINE_GW_LAP;
+                l6[0] = G[0][0]; l6[1] = G[0][1] + G[1][0]; l6[2] = G[0][2] + G[2][0];
+                l6[3] = G[1][1]; l6[4] = G[1][2] + G[2][1]; l6[5] = G[2][2];
+            }
+        HIP_TRY(c, c->ghat.alloc(gh.size()));
+        HIP_TRY(c, hipMemcpy(c->ghat.p, gh.data(), sizeof(double) * gh.size(), hipMemcpyHostToDevice));
+        c->has_ghat = true;
+    }
     c->has_params = params != nullptr;
     if (params) HIP_TRY(c, hipMemcpy(c->qparams.p, params, sizeof(double) * 2 * nq, hipMemcpyHostToDevice));
     c->h_points.assign(pts, pts + (size_t)nq * ei.d);

@@ -228,8 +228,11 @@ __global__ void __launch_bounds__(256, 2) k_gather_rows(const KArgs a, const Row
 
 // Lanes of every position from the pipelined kernel's records (p_rec: GatherHdr | slots | entries | column slots | row
 // offsets).  One wavefront per position.  status |= 1 when a block cannot be expressed (see the header comment).
+// p_elem (optional, [npos][us] element id per slot): the terms of a block are ordered by element id instead of by slot, so
+// that the blocks (I, J) and (J, I) -- owned by different lanes, possibly at different positions -- add their elements'
+// contributions in the same order (k_gather_affine's bitwise symmetry).
 __global__ void __launch_bounds__(64) k_build_row_lanes(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
-                                                        int* rec_new, uint2* lanes, int* status) {
+                                                        int* rec_new, uint2* lanes, int* status, const int* p_elem) {
     constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
     __shared__ int cnt[NKEY];
     __shared__ unsigned short bucket[NKEY * TMAX];
@@ -260,13 +263,18 @@ __global__ void __launch_bounds__(64) k_build_row_lanes(const int* p_rec, int rw
     }
     __syncthreads();
     // fixed order of the terms of a block (the atomics above hand out positions in arbitrary order)
+    const int* el = p_elem ? p_elem + (size_t)p * us : nullptr;
+    auto term_key = [&](unsigned short v) -> long long {  // an element meets a block once: the element id alone orders the terms
+        return el ? (((long long)el[v & 255u] << 16) | v) : (long long)v;
+    };
     for (int key = lane; key < NKEY; key += 64) {
         const int Tn = min(cnt[key], TMAX);
         unsigned short* b = bucket + key * TMAX;
         for (int i = 1; i < Tn; ++i) {
             const unsigned short v = b[i];
+            const long long kv = term_key(v);
             int k = i - 1;
-            while (k >= 0 && b[k] > v) { b[k + 1] = b[k]; --k; }
+            while (k >= 0 && term_key(b[k]) > kv) { b[k + 1] = b[k]; --k; }
             b[k + 1] = v;
         }
     }

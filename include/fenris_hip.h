@@ -133,6 +133,18 @@ int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* poin
  * reads the pair per element; rules that vary over their points take the per-point-coefficient kernels. */
 int fh_set_quadrature_compact(fh_ctx*, const double* weights, const double* points, uint32_t nq, uint64_t num_rules,
                               const double* rule_params, const uint64_t* elem_to_rule);
+/* Affine-element fast path of FH_SCATTER_GATHER (Hex8; Laplace / LinearElastic with uniform parameters).  On an element
+ * whose geometry map is affine the Jacobian of elliptic.rs:399 is the same at every quadrature point, so
+ * K_ab = |det J| C(J^-T Ghat_ab J^-1) with Ghat_ab = sum_q w_q ghat_a ghat_b^T depending on the rule only -- the engine
+ * detects such elements from the vertex coordinates and runs the node blocks whose elements all qualify on a kernel
+ * without a quadrature loop; every other block keeps the general kernels.  An element qualifies when the four mixed
+ * coefficients of its trilinear map are at most rel_tol times its shortest edge-direction coefficient.  Results change
+ * by O(rel_tol) relative at most (exactly affine elements -- every generated box mesh -- agree to rounding).
+ * Default 2^-46 (1.4e-14); 0 switches the path off.  No reference counterpart (the reference has one code path). */
+int fh_set_affine_tolerance(fh_ctx*, double rel_tol);
+/* how the last FH_SCATTER_GATHER assembly was split: elements found affine, node blocks on the affine kernel, node blocks on
+ * the general kernels (any pointer may be NULL; zeros before the first assembly) */
+int fh_affine_stats(const fh_ctx*, uint64_t* affine_elements, uint64_t* affine_blocks, uint64_t* general_blocks);
 /* .with_u(&u) (elliptic.rs:123-137); u has s*N entries; NULL = zeros */
 int fh_set_u(fh_ctx*, const double* u);
 int fh_set_u_dev(fh_ctx*, const double* u_dev);

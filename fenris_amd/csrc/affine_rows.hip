@@ -1,0 +1,490 @@
+// Affine-element form of the owner-computes stiffness kernel (Hex8; Laplace / uniform LinearElastic), second version.
+//
+// On an element whose trilinear map is affine (a parallelepiped) the Jacobian is constant, so the quadrature loop of
+// elliptic.rs:398-432 collapses: with  Ghat_ab = sum_q w_q ghat_a(xi_q) ghat_b(xi_q)^T  (reference gradients only, built once
+// per quadrature table on the host) the block of the node pair (a, b) of an element is
+//     H_ab = R^T Ghat_ab R,  R = sqrt(|det J|) J^-1      (= |det J| J^-T Ghat_ab J^-1)
+//     K_ab = mu (tr H_ab I + H_ab^T) + lambda H_ab       (materials.rs:108-118 summed over the points)
+//     K_ab = tr H_ab = <Ghat_ab, R R^T>                   (laplace.rs:60-68)
+// -- no per-point Jacobians, no physical gradients, no q-loop.  Which elements qualify is decided per element from the
+// vertex coordinates (k_classify_affine_hex8 in affine_kernel.hpp); node blocks all of whose elements qualify run here, the
+// others keep the general kernels.
+//
+// Work distribution (one workgroup = 4 row waves + 1 store wave, persistent over a contiguous range of positions):
+//  * row lanes: a lane owns an output block (owned node I, column node J) and evaluates up to two of its terms
+//    (element slot, local a, local b); blocks with more terms are split over 2 / 4 adjacent lanes whose partial sums meet by
+//    DPP quad permutes (self block of a structured mesh: 8 terms, face 4, edge 2, corner 1: 36 lanes per node, 252 per 7-node
+//    block).  The finished 3 x 3 block goes to a staging buffer in LDS laid out like the CSR rows.  No LDS atomics.
+//  * one lane per element slot (in row wave 3) computes R of the NEXT position's elements from four vertices.
+//  * the store wave streams the staged rows of the PREVIOUS position to global memory as 16-byte stores, whole 128-byte
+//    lines only (an incomplete last line is carried into the next position's buffer).  It never loads from global memory
+//    and the row waves never store to it, so no wave ever waits for its stores to drain (loads and stores share vmcnt):
+//    the stores of several positions stay in flight.
+// One barrier per position; staging buffers and slot records are double-buffered by position parity.
+//
+// Exact symmetry (util.rs:38-51 mirrors the upper triangle): the owners of (I, J) and (J, I) both evaluate the block of
+// the pair with the smaller global node first (gidx below), the terms of a block are ordered by element id, the split over
+// lanes and the DPP tree depend only on the number of terms, and the owner of the larger node stores the transpose -- so
+// both add bitwise identical numbers in the same order.  Diagonal blocks mirror their upper triangle.  Run-to-run
+// reproducible for the same reason.
+#include <hip/hip_runtime.h>
+
+#include "affine_rows.hpp"
+#include "small_ops.hpp"
+
+namespace fenris_hip {
+
+// lane record:  x = slot0 | gidx0 << 5 | slot1 << 12 | gidx1 << 17 | log2(group) << 24 | transpose << 26 | diagonal << 27 | store << 28
+//               y = byte offset of the block's first value in the staged rows | byte stride between its rows << 16
+// gidx = 8 a + b selects Ghat_ab; gidx 64 is a block of zeros (absent term).
+constexpr unsigned AR_ZERO_G = 64u;
+
+size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
+    const int gw = (op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    const size_t accp = (size_t)((acc_max + 16 + 1) & ~1);
+    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4);
+}
+
+template <int OP, bool OVERWRITE, bool DBG>
+__global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
+    constexpr bool LAP = (OP == FH_LAPLACE);
+    constexpr int S = LAP ? 1 : 3, SS = S * S;
+    constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    const int ablate = DBG ? ablate_arg : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* GH = reinterpret_cast<double*>(smem);   // [65][GW]
+    double* JS = GH + 65 * GW;                      // [2][us][GW]
+    const int accp = (T.acc_max + 16 + 1) & ~1;
+    double* OUT = JS + 2 * T.us * GW;               // [2][accp]
+    int4* HDR = reinterpret_cast<int4*>(OUT + 2 * accp);  // [4] ring of position headers, slot q & 3 holds hdr[q]: the row waves
+                                                    // fetch them from global memory, every wave reads them here
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, npos = T.npos;
+    const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
+    if (p_begin >= p_end) return;
+    for (int i = tid; i < 65 * GW; i += AFFINE_ROWS_THREADS) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
+    for (int i = tid; i < 2 * accp; i += AFFINE_ROWS_THREADS) OUT[i] = 0.0;
+    const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
+    auto head_of = [&](int r0) { return (int)((vals_w + (size_t)SS * (size_t)r0) & 15); };
+
+    if (wave == 4) {
+        // ------------------------------------------------------------------------------------------ store wave
+        const int lane = tid - 256;
+        // Rows of a finished position: LDS -> global memory.  The write path wants whole, aligned 128-byte lines (16-byte
+        // stores that start a wave off a line boundary reach 4.3 TB/s instead of 6.2, and a line written in two parts costs
+        // about ten full ones: scripts/ubench_fill.hip), but a block's rows start and end anywhere.  So the staging buffer is
+        // laid out from the line boundary below the block's first value (`head` doubles in), only complete lines are stored,
+        // and when the next position continues these rows (positions are in CSR order) the incomplete last line is carried
+        // into the head of the other buffer instead of being written.
+        auto write_out = [&](const int4 h, double* buf, double* other, bool carry_in, bool carry_out) {
+            const int head = h.w;
+            double* line0 = a.vals + (size_t)SS * (size_t)h.x - head;
+            const int lo = carry_in ? 0 : head, hi = head + SS * h.y;
+            const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
+            const bool zero = !(h.z & 1);
+            f64x2* buf2 = reinterpret_cast<f64x2*>(buf);
+            f64x2* out2 = reinterpret_cast<f64x2*>(line0);
+            const f64x2 zero2 = {0.0, 0.0};
+            const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces
+            auto piece = [&](int k, f64x2 v) {
+                if (DBG && (ablate & 1)) return;
+                if constexpr (OVERWRITE) out2[k] = v;
+                else { const f64x2 o = out2[k]; f64x2 r; r.x = o.x + v.x; r.y = o.y + v.y; out2[k] = r; }
+            };
+            int k = k0 + lane;
+            for (; k + 192 < k1; k += 256) {
+                const f64x2 v0 = buf2[k], v1 = buf2[k + 64], v2 = buf2[k + 128], v3 = buf2[k + 192];
+                piece(k, v0); piece(k + 64, v1); piece(k + 128, v2); piece(k + 192, v3);
+                if (zero) { buf2[k] = zero2; buf2[k + 64] = zero2; buf2[k + 128] = zero2; buf2[k + 192] = zero2; }
+            }
+            for (; k < k1; k += 64) {
+                const f64x2 v = buf2[k];
+                piece(k, v);
+                if (zero) buf2[k] = zero2;
+            }
+            if (lane == 0 && !(DBG && (ablate & 1))) {           // the ends of a run of positions: single doubles
+                if ((lo & 1) && lo < L) { if (OVERWRITE) line0[lo] = buf[lo]; else line0[lo] += buf[lo]; }
+                if ((L & 1) && L - 1 >= lo) { if (OVERWRITE) line0[L - 1] = buf[L - 1]; else line0[L - 1] += buf[L - 1]; }
+            }
+            if (zero && lane == 0) {
+                if ((lo & 1) && lo < L) buf[lo] = 0.0;
+                if ((L & 1) && L - 1 >= lo) buf[L - 1] = 0.0;
+            }
+            if (carry_out && lane < hi - L) {
+                other[lane] = buf[L + lane];
+                if (zero) buf[L + lane] = 0.0;
+            }
+        };
+        lds_barrier();  // B0
+        bool carry_in = false;
+        int par = 0;
+        for (int p = p_begin; p < p_end; ++p, par ^= 1) {
+            if (p > p_begin) {
+                const int4 h_prev = HDR[(p - 1) & 3], h_cur = HDR[p & 3];
+                const bool carry_out = h_cur.x == h_prev.x + h_prev.y;
+                write_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
+                carry_in = carry_out;
+            }
+            lds_barrier();
+        }
+        const int4 h_prev = HDR[(p_end - 1) & 3];
+        write_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- row waves
+    const bool hwave = wave == 0;                     // fetches the position headers
+    // Jacobian role: four lanes per element slot (one quad), lane k holds vertex k of (node 0, node 1, node 3, node 4)
+    const int jbase = 256 - 4 * T.us;
+    const bool jwave = wave >= (jbase >> 6);          // wave-uniform: the wave holds Jacobian lanes
+    const int jl = tid - jbase;                       // >= 0 on Jacobian lanes
+    const int jl_c = max(jl, 0);
+    const int jk = jl_c & 3, jslot = jl_c >> 2;
+    auto load_lane = [&](int p) { return T.lanes[(size_t)((unsigned)min(p, npos - 1) * 256u + (unsigned)tid)]; };
+    auto load_vidx = [&](int p) { return T.slotv[(size_t)((unsigned)min(p, npos - 1) * (unsigned)(4 * T.us) + (unsigned)jl_c)]; };
+    double X[3];
+    auto load_vert = [&](int v) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[c] = a.verts[(size_t)(unsigned)v * 3 + c];
+    };
+    // Records of the slots of position p from the vertices in registers.  The edges from node 0 to nodes 1, 3, 4 are twice
+    // the columns c0, c1, c2 of J (hexahedron.rs:49-58: nodes (---), (+--), (-+-), (--+); exact for a parallelepiped).  Lane
+    // k = 1, 2, 3 of a quad holds column k - 1, fetches the other two by quad permutes and forms row k - 1 of the adjugate,
+    // c_k x c_(k+1) (indices mod 3), and det J = c_(k-1) . row.  LinearElastic: R = sqrt(|det J|) J^-1 =
+    // sign(det J) rsqrt(|det J|) adj(J) (nine doubles); Laplace: M = R R^T (six).
+    auto slot_record = [&](int p, int parity) {
+        double E[3], A[3], B[3], row[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) E[c] = 0.5 * (X[c] - dpp_quad_full<0x00>(X[c]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { A[c] = dpp_quad_full<0x78>(E[c]); B[c] = dpp_quad_full<0x9C>(E[c]); }
+        row[0] = A[1] * B[2] - A[2] * B[1];
+        row[1] = A[2] * B[0] - A[0] * B[2];
+        row[2] = A[0] * B[1] - A[1] * B[0];
+        const double detJ = fma(E[2], row[2], fma(E[1], row[1], E[0] * row[0]));
+        const bool mine = jl >= 0 && jk >= 1;
+        double sc = 0.0;
+        if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404); empty slots are degenerate too
+            if (mine) {
+                const int e = T.elem[(size_t)p * T.us + jslot];
+                if (e >= 0) report_singular(a.status, (long long)e);
+            }
+        } else {
+            sc = copysign(rsqrt_newton(fabs(detJ)), detJ);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] *= sc;
+        double* o = JS + ((size_t)parity * T.us + jslot) * GW;
+        if constexpr (LAP) {
+            double nb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nb[c] = dpp_quad_full<0x78>(row[c]);   // row of the next lane (cyclic over lanes 1, 2, 3)
+            const double dd = fma(row[2], row[2], fma(row[1], row[1], row[0] * row[0]));
+            const double od = fma(row[2], nb[2], fma(row[1], nb[1], row[0] * nb[0]));
+            // [M00, M01, M02, M11, M12, M22]: lane 1 holds M00, M01; lane 2 M11, M12; lane 3 M22, M20
+            if (mine) {
+                o[jk == 1 ? 0 : jk == 2 ? 3 : 5] = dd;
+                o[jk == 1 ? 1 : jk == 2 ? 4 : 2] = od;
+            }
+        } else {
+            if (mine) {
+                double* r = o + 3 * (jk - 1);
+                r[0] = row[0]; r[1] = row[1]; r[2] = row[2];
+            }
+        }
+    };
+
+    uint2 lane_cur = load_lane(p_begin);
+    int4 h_nxt = {0, 0, 0, 0};
+    auto with_head = [&](int4 h) { h.w = head_of(h.x); return h; };
+    if (hwave) {
+        const int4 h0 = with_head(T.hdr[p_begin]);
+        h_nxt = T.hdr[min(p_begin + 1, npos - 1)];
+        if (tid == 0) HDR[p_begin & 3] = h0;
+    }
+    int vi_nxt = 0;
+    if (jwave) {
+        load_vert(load_vidx(p_begin));
+        vi_nxt = load_vidx(p_begin + 1);
+        slot_record(p_begin, 0);
+    }
+    // everything the prologue fetched has landed before the loop is entered: otherwise the waits the compiler derives for the
+    // entry path (a prologue fetch older than the loop's own prefetches) are executed on every trip -- vmcnt(1) right behind the
+    // issue of the prefetches
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    lds_barrier();  // B0
+
+    const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 12u;  // .w: head of the position
+    int par = 0;
+    for (int p = p_begin; p < p_end; ++p, par ^= 1) {
+        const bool have_next = (p + 1) < p_end;
+        // head of this position's rows (vector fetch: a scalar one would have to be waited for right here)
+        int head;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(head) : "v"(hdr_addr + 16u * (unsigned)(p & 3)));
+        // prefetch: lane record of p + 1, vertices of p + 1 (their indices arrived during the previous position), indices and
+        // header of p + 2
+        uint2 lane_nxt = lane_cur;
+        if (!(DBG && (ablate & 8))) lane_nxt = load_lane(p + 1);
+        int vi_nn = vi_nxt;
+        if (jwave && !(DBG && (ablate & 4))) {
+            load_vert(vi_nxt);
+            vi_nn = load_vidx(p + 2);
+        }
+        int4 h_nn = h_nxt;
+        if (hwave) h_nn = T.hdr[min(p + 2, npos - 1)];
+
+        const unsigned x = lane_cur.x, y = lane_cur.y;
+        const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
+        const char* gh = reinterpret_cast<const char*>(GH);
+        const unsigned oR0 = (x & 31u) * (GW * 8), oG0 = ((x >> 5) & 127u) * (GW * 8);
+        const unsigned oR1 = ((x >> 12) & 31u) * (GW * 8), oG1 = ((x >> 17) & 127u) * (GW * 8);
+        const int grp = (int)((x >> 24) & 3u);
+        char* out_par = reinterpret_cast<char*>(OUT + (size_t)par * accp);
+        if constexpr (LAP) {
+            const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
+            const f64x2* g0 = reinterpret_cast<const f64x2*>(gh + oG0);
+            const f64x2* m1 = reinterpret_cast<const f64x2*>(js + oR1);
+            const f64x2* g1 = reinterpret_cast<const f64x2*>(gh + oG1);
+            double s = 0.0;
+            if (!(DBG && (ablate & 2))) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) { const f64x2 m = m0[h], g = g0[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
+#pragma unroll
+                for (int h = 0; h < 3; ++h) { const f64x2 m = m1[h], g = g1[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
+            }
+            if (grp >= 1) s += dpp_quad_full<0xB1>(s);
+            if (grp >= 2) s += dpp_quad_full<0x4E>(s);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(head));
+            if ((x >> 28) & 1u) *reinterpret_cast<double*>(out_par + 8 * head + (y & 0xffffu)) = s;
+        } else {
+            double H[3][3];
+            if (!(DBG && (ablate & 2))) {
+                auto load33 = [&](const char* p_, double (&M)[3][3]) {
+                    const f64x2* q = reinterpret_cast<const f64x2*>(p_);
+                    const f64x2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];
+                    M[0][0] = v0.x; M[0][1] = v0.y; M[0][2] = v1.x; M[1][0] = v1.y; M[1][1] = v2.x; M[1][2] = v2.y;
+                    M[2][0] = v3.x; M[2][1] = v3.y; M[2][2] = v4.x;
+                };
+                // one term after the other (the second term's operands are fetched while the first is multiplied): H stays
+                // one chain of six products per entry
+                auto term = [&](const char* pr, const char* pg, bool first) {
+                    double R[3][3], Gm[3][3], Tm[3][3];
+                    load33(pr, R);
+                    load33(pg, Gm);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) Tm[c][s_] = fma(Gm[c][2], R[2][s_], fma(Gm[c][1], R[1][s_], Gm[c][0] * R[0][s_]));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) {
+                            double h = first ? R[0][i] * Tm[0][s_] : fma(R[0][i], Tm[0][s_], H[i][s_]);
+                            h = fma(R[1][i], Tm[1][s_], h);
+                            H[i][s_] = fma(R[2][i], Tm[2][s_], h);
+                        }
+                };
+                term(js + oR0, gh + oG0, true);
+                term(js + oR1, gh + oG1, false);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] = (double)(x + 3 * i + s_);
+            }
+            if (grp >= 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] += dpp_quad_full<0xB1>(H[i][s_]);
+            }
+            if (grp >= 2) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] += dpp_quad_full<0x4E>(H[i][s_]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(head));
+            if ((x >> 28) & 1u) {
+                const bool tr = (x >> 26) & 1u, dg = (x >> 27) & 1u;
+                const double mu_tr = a.mu * (H[0][0] + H[1][1] + H[2][2]);
+                const double mpl = a.mu + a.lambda;
+                double v[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i][i] = fma(mpl, H[i][i], mu_tr);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < 3; ++j) {
+                        const double up = fma(a.mu, H[j][i], a.lambda * H[i][j]);   // (i, j)
+                        const double lw = fma(a.mu, H[i][j], a.lambda * H[j][i]);   // (j, i)
+                        v[i][j] = tr ? lw : up;
+                        v[j][i] = (tr || dg) ? up : lw;
+                    }
+                const unsigned rs = y >> 16;
+                char* stage = out_par + 8 * head + (y & 0xffffu);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double* row = reinterpret_cast<double*>(stage + i * rs);
+                    row[0] = v[i][0]; row[1] = v[i][1]; row[2] = v[i][2];
+                }
+            }
+        }
+
+        // records of the next position's slots (its vertices have landed by now)
+        if (jwave && have_next && !(DBG && (ablate & 4))) slot_record(p + 1, par ^ 1);
+        if (hwave && tid == 0) HDR[(p + 1) & 3] = with_head(h_nxt);
+        h_nxt = h_nn;
+        vi_nxt = vi_nn;
+        lane_cur = lane_nxt;
+        lds_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ table builder
+// One workgroup (one wave) per position.  Input: the position record of k_build_pipe_tables (header, entries
+// slot << 16 | local a << 8 | block-local node, per (entry, local node) the column slot in the owner's row, relative row
+// offsets).  Terms are grouped by output block (node, column slot), ordered by element id, and dealt two per lane.
+__global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
+                                                          const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
+                                                          int4* hdr_out, uint2* lanes, int* slotv, int* status) {
+    constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
+    __shared__ int cnt[NKEY];
+    __shared__ unsigned short bucket[NKEY * TMAX];
+    __shared__ unsigned lw0[256], lw1[256];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int* rec = p_rec + (size_t)p * rw_old;
+    const GatherHdr h = *reinterpret_cast<const GatherHdr*>(rec);
+    const unsigned* ent = reinterpret_cast<const unsigned*>(rec + 8 + us / 4);
+    const unsigned char* posb = reinterpret_cast<const unsigned char*>(rec + 8 + us / 4 + ms);
+    const int* noff_old = rec + 8 + us / 4 + ms + ms * N / 4;
+    const int* el = p_elem + (size_t)p * us;
+    for (int s = lane; s < us; s += 64) {
+        const int* c = p_conn + (size_t)p * cs + (size_t)s * N;
+        reinterpret_cast<int4*>(slotv)[(size_t)p * us + s] = make_int4(c[0], c[1], c[3], c[4]);
+    }
+    for (int i = lane; i < NKEY; i += 64) cnt[i] = 0;
+    const unsigned idle = (AR_ZERO_G << 5) | (AR_ZERO_G << 17);
+    for (int i = lane; i < 256; i += 64) { lw0[i] = idle; lw1[i] = 0u; }
+    __syncthreads();
+    bool bad = false;
+    for (int idx = lane; idx < h.m * N; idx += 64) {
+        const int t = idx / N, j = idx % N;
+        const unsigned e = ent[t];
+        const unsigned slot = e >> 16, a_loc = (e >> 8) & 0xffu, il = e & 0xffu, pos = posb[t * N + j];
+        if (il >= 8u || pos >= 128u || slot >= 32u || a_loc >= 8u) { bad = true; continue; }
+        const int key = (int)(il * 128u + pos);
+        const int s_ = atomicAdd(&cnt[key], 1);
+        if (s_ < TMAX) bucket[key * TMAX + s_] = (unsigned short)(slot | (a_loc << 8) | ((unsigned)j << 11));
+        else bad = true;
+    }
+    __syncthreads();
+    // fixed order of the terms of a block (the atomics above hand out positions in arbitrary order): an element meets a
+    // block once, so the element id alone orders them -- the same order for the owners of (I, J) and (J, I)
+    for (int key = lane; key < NKEY; key += 64) {
+        const int Tn = min(cnt[key], TMAX);
+        unsigned short* b = bucket + key * TMAX;
+        for (int i = 1; i < Tn; ++i) {
+            const unsigned short v = b[i];
+            const int kv = el[v & 255u];
+            int k = i - 1;
+            while (k >= 0 && el[b[k] & 255u] > kv) { b[k + 1] = b[k]; --k; }
+            b[k + 1] = v;
+        }
+    }
+    __syncthreads();
+    // classes: 5..8 terms -> 4 lanes, 3..4 -> 2 lanes, 1..2 -> one lane
+    int n4 = 0, n2 = 0, n1 = 0;
+    for (int base = 0; base < NKEY; base += 64) {
+        const int Tn = min(cnt[base + lane], TMAX);
+        n4 += __popcll(__ballot(Tn >= 5));
+        n2 += __popcll(__ballot(Tn == 3 || Tn == 4));
+        n1 += __popcll(__ballot(Tn == 1 || Tn == 2));
+    }
+    const int base4 = 0, base2 = 4 * n4, base1 = base2 + 2 * n2;
+    if (base1 + n1 > 256) bad = true;
+    if ((size_t)8 * S * S * (size_t)h.nrow >= 65536u) bad = true;
+    if (__ballot(bad)) {
+        if (lane == 0) {
+            atomicOr(status, 1);
+            hdr_out[p] = make_int4(h.r0, h.nrow, 0, h.U);
+        }
+        for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(idle, 0u);
+        return;
+    }
+    int r4 = 0, r2 = 0, r1 = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < NKEY; base += 64) {
+        const int key = base + lane;
+        const int Tn = min(cnt[key], TMAX);
+        const unsigned il = (unsigned)key >> 7, pos = (unsigned)key & 127u;
+        const unsigned short* b = bucket + key * TMAX;
+        const unsigned long long m4 = __ballot(Tn >= 5), m2 = __ballot(Tn == 3 || Tn == 4), m1 = __ballot(Tn == 1 || Tn == 2);
+        if (Tn >= 1) {
+            const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
+            const unsigned I = (unsigned)h.i0 + il, J = ncols[(size_t)h.r0 + rb + pos];
+            const unsigned trf = I > J ? 1u : 0u, dgf = I == J ? 1u : 0u;
+            const unsigned yw = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+            auto lane_words = [&](int first, int Lidx, unsigned grp, bool leader) {
+                unsigned xw = (grp << 24) | (trf << 26) | (dgf << 27) | (leader ? (1u << 28) : 0u);
+                for (int t = 0; t < 2; ++t) {
+                    unsigned slot = b[0] & 255u, gidx = AR_ZERO_G;
+                    if (first + t < Tn) {
+                        const unsigned v = b[first + t], a_loc = (v >> 8) & 7u, j_loc = (v >> 11) & 7u;
+                        slot = v & 255u;
+                        gidx = trf ? (j_loc * 8u + a_loc) : (a_loc * 8u + j_loc);  // the block of the pair's smaller node
+                    }
+                    xw |= (slot | (gidx << 5)) << (12 * t);
+                }
+                lw0[Lidx] = xw;
+                lw1[Lidx] = yw;
+            };
+            if (Tn >= 5) {
+                const int L0 = base4 + 4 * (r4 + __popcll(m4 & below));
+                for (int g = 0; g < 4; ++g) lane_words(2 * g, L0 + g, 2u, g == 0);
+            } else if (Tn >= 3) {
+                const int L0 = base2 + 2 * (r2 + __popcll(m2 & below));
+                for (int g = 0; g < 2; ++g) lane_words(2 * g, L0 + g, 1u, g == 0);
+            } else {
+                lane_words(0, base1 + r1 + __popcll(m1 & below), 0u, true);
+            }
+        }
+        r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
+    // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
+    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, (n4 + n2 + n1 == h.nrow) ? 1 : 0, h.U);
+}
+
+hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
+                             const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
+                             int* slotv, int* status) {
+    if (npos <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
+                       p_elem, hdr, lanes, slotv, status);
+    return hipGetLastError();
+}
+
+hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+                              int ablate) {
+    void (*kern)(const KArgs, const AffineRowTables, int);
+    const bool ow = a.overwrite != 0;
+    if (op == FH_LAPLACE) {
+        kern = ablate ? k_affine_rows<FH_LAPLACE, true, true> : ow ? k_affine_rows<FH_LAPLACE, true, false> : k_affine_rows<FH_LAPLACE, false, false>;
+    } else {
+        kern = ablate ? k_affine_rows<FH_LINEAR_ELASTIC, true, true>
+                      : ow ? k_affine_rows<FH_LINEAR_ELASTIC, true, false> : k_affine_rows<FH_LINEAR_ELASTIC, false, false>;
+    }
+    if (lds_bytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(AFFINE_ROWS_THREADS), lds_bytes, stream, a, T, ablate);
+    return hipGetLastError();
+}
+
+}  // namespace fenris_hip

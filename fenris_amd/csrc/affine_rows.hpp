@@ -1,0 +1,37 @@
+// Affine-element owner-computes stiffness kernel, second form (k_affine_rows): interface of the translation unit
+// affine_rows.hip.  See that file for the design; engine.hip only builds the tables and launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_common.hpp"
+
+namespace fenris_hip {
+
+// per-position tables (position = node block all of whose elements are affine, in CSR order)
+struct AffineRowTables {
+    const int4* hdr;      // [npos]       {r0: first node-level CSR entry, nrow: node-level entries of the block's rows,
+                          //               flags (bit 0: every (node, column) block of the rows has an owner lane), number of slots}
+    const uint2* lanes;   // [npos][256]  lane records, see affine_rows.hip
+    const int* slotv;     // [npos][us][4] geometry nodes 0, 1, 3, 4 of the element in each slot (the edges xi, eta, zeta from node 0)
+    const int* elem;      // [npos][us]   element id per slot (-1: empty), read only to report a singular Jacobian
+    const double* ghat;   // [64][GW]     reference blocks Ghat_ab (all 64 (a, b); LinearElastic GW = 10, Laplace GW = 6)
+    int us, npos, acc_max;  // slots per position, positions, largest S * S * nrow
+};
+
+constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
+constexpr int AFFINE_ROWS_THREADS = 320;  // four row waves + one store wave
+
+size_t affine_rows_lds_bytes(int op, int us, int acc_max);
+
+// lane records, headers and slot vertices of every position from the pipelined kernel's position records (p_rec, layout of
+// k_build_pipe_tables) and its per-slot connectivity.  *status (device) is set to 1 when a block cannot be expressed
+// (more than 8 terms per block, more than 256 lanes, offsets out of range).
+hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
+                             const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
+                             int* slotv, int* status);
+
+// op: FH_LAPLACE or FH_LINEAR_ELASTIC; ablate != 0 selects the instrumented instantiation (profiling only)
+hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+                              int ablate);
+
+}  // namespace fenris_hip

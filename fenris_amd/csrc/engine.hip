@@ -17,6 +17,7 @@
 #include "hex27_mfma.hpp"
 #include "rows_kernel.hpp"
 #include "affine_kernel.hpp"
+#include "affine_rows.hpp"
 #include "device_common.hpp"
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
@@ -338,6 +339,9 @@ struct fh_ctx {
     bool has_ghat = false;
     DevBuf<int> a_rec, a_conn, a_elem;
     DevBuf<uint2> a_lanes;
+    DevBuf<int4> a_hdr;
+    DevBuf<int> a_slotv;            // k_affine_rows (affine_rows.hip): position headers, four vertices per slot
+    bool a_v1 = false;              // FENRIS_HIP_AFFINE_V1: the first form of the kernel (k_gather_affine), for A/B measurements
     int a_rw = 0, a_cs = 0, a_us = 0, a_npos = 0;
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
@@ -902,14 +906,23 @@ int build_partition(fh_ctx* c) {
                 c->a_rw = 8 + us / 4 + nb_target + 1;
                 c->a_cs = c->p_cs;
                 c->a_us = us;
+                c->a_v1 = std::getenv("FENRIS_HIP_AFFINE_V1") != nullptr;
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                HIP_TRY(c, c->a_rec.alloc((size_t)npos * c->a_rw));
-                HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
-                hipLaunchKernelGGL(k_build_row_lanes, dim3(npos), dim3(64), 0, c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos,
-                                   c->a_rw, c->a_rec.p, c->a_lanes.p, st.p, c->a_elem.p);
-                HIP_TRY(c, hipGetLastError());
+                if (c->a_v1) {
+                    HIP_TRY(c, c->a_rec.alloc((size_t)npos * c->a_rw));
+                    HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
+                    hipLaunchKernelGGL(k_build_row_lanes, dim3(npos), dim3(64), 0, c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos,
+                                       c->a_rw, c->a_rec.p, c->a_lanes.p, st.p, c->a_elem.p);
+                    HIP_TRY(c, hipGetLastError());
+                } else {
+                    HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
+                    HIP_TRY(c, c->a_slotv.alloc((size_t)npos * us * 4));
+                    HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
+                    HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
+                                                 c->p_cs, c->a_elem.p, c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, st.p));
+                }
                 int bad = 0;
                 HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -917,6 +930,7 @@ int build_partition(fh_ctx* c) {
                     c->aff_failed = true;
                     return build_partition(c);
                 }
+                if (!c->a_v1) c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
                 c->a_npos = npos;
             }
             c->npos_gen = (int)order[0].size();
@@ -1123,12 +1137,24 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
 
 // node blocks all of whose elements are affine: k_gather_affine over its own position tables
 int launch_affine(fh_ctx* c, KArgs& a) {
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (!c->a_v1) {
+        AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, c->a_elem.p,
+                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
+        const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
+        if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
+        const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+        const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+        if (std::getenv("FENRIS_HIP_VERBOSE"))
+            std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
+        HIP_TRY(c, affine_rows_launch(c->op, grid, lds, c->stream, a, T, a.ablate));
+        return FH_OK;
+    }
     AffineTables T{c->a_rec.p, c->a_lanes.p, c->a_conn.p, c->a_elem.p,
                    c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_rw, c->a_cs, c->a_us, c->p_nbs, c->a_npos, c->g_acc};
     const size_t lds = affine_lds_bytes(c->op, c->a_us, c->g_acc, c->a_rw);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
-    int dev_cus = 256;
-    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
     void (*kern)(const KArgs, const AffineTables) = (c->op == FH_LAPLACE) ? k_gather_affine<FH_LAPLACE> : k_gather_affine<FH_LINEAR_ELASTIC>;
@@ -1292,7 +1318,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             // node blocks whose elements are all affine (affine_kernel.hpp); the remaining positions follow below
             rc = launch_affine(c, a);
             if (rc) return rc;
-            c->last_kernel = "k_gather_affine";
+            c->last_kernel = c->a_v1 ? "k_gather_affine" : "k_affine_rows";
             if (c->npos_gen == 0) return FH_OK;
             c->last_kernel += " + ";
         }

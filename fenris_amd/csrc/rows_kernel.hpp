@@ -30,24 +30,6 @@ struct RowTables {
 //              y = pos0 | il0 << 7 | pos1 << 10 | il1 << 17 | two_outputs << 20 | store0 << 21 | store1 << 22
 __host__ __device__ inline unsigned row_term(unsigned slot, unsigned a, unsigned j) { return slot | (a << 8) | (j << 11); }
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-
-// value of lane ^ 4 (row_shl:4 into the lanes with bit 2 clear, row_shr:4 into the others)
-__device__ __forceinline__ double dpp_xor4(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x104, 0xF, 0x5, false);
-    lo = __builtin_amdgcn_update_dpp(lo, (int)b, 0x114, 0xF, 0xA, false);
-    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x104, 0xF, 0x5, false);
-    hi = __builtin_amdgcn_update_dpp(hi, (int)(b >> 32), 0x114, 0xF, 0xA, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-
 template <int OP>
 __global__ void __launch_bounds__(256, 2) k_gather_rows(const KArgs a, const RowTables T) {
     constexpr int EK = FH_HEX8, QC = 8;

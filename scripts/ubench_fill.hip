@@ -119,6 +119,26 @@ __global__ void __launch_bounds__(256) k_fill_mix(f64x2* out, size_t npair, cons
     }
 }
 
+
+// the store wave of k_affine_rows (affine_rows.hip) alone: workgroups of ONE wave, each walks a contiguous range of chunks and
+// writes whole 128-byte lines, 16 bytes per lane, four stores in flight per trip; `spin` dummy VALU iterations between chunks
+// stand for the time the row waves take (0 = stores back to back)
+__global__ void __launch_bounds__(64) k_fill_store_wave(double* out, size_t ndbl, int chunk_dbl, int spin, double v) {
+    const size_t nline = ndbl / 16;                         // whole lines only
+    const size_t lines_per_chunk = (size_t)chunk_dbl / 16;  // 13 lines + carry ~ 1664 doubles
+    const size_t nchunk = nline / lines_per_chunk;
+    const size_t c0 = (size_t)blockIdx.x * nchunk / gridDim.x, c1 = (size_t)(blockIdx.x + 1) * nchunk / gridDim.x;
+    f64x2 val = {v, v + 1.0};
+    const int npiece = (int)lines_per_chunk * 8;
+    for (size_t c = c0; c < c1; ++c) {
+        f64x2* o2 = reinterpret_cast<f64x2*>(out + c * lines_per_chunk * 16);
+        int k = threadIdx.x;
+        for (; k + 192 < npiece; k += 256) { o2[k] = val; o2[k + 64] = val; o2[k + 128] = val; o2[k + 192] = val; }
+        for (; k < npiece; k += 64) o2[k] = val;
+        for (int i = 0; i < spin; ++i) val.x = fma(val.x, 1.0000001, 1e-9);
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t ndbl = (argc > 1) ? std::strtoull(argv[1], nullptr, 10) : 2460235041ull;  // nnz of Hex8 elasticity 216^3
     const int reps = 5;
@@ -201,5 +221,11 @@ int main(int argc, char** argv) {
         timeit(nm, [&] { hipLaunchKernelGGL(k_fill_mix, dim3(4096), dim3(256), 0, 0, (f64x2*)buf, npair, rd, nin, every, 1.0); },
                B * (1.0 + 1.0 / every));
     }
+    for (int wg : {2, 3, 4, 6, 8})
+        for (int spin : {0, 200}) {
+            char nm[64];
+            std::snprintf(nm, sizeof nm, "store_wave_%dwg_spin%d", wg, spin);
+            timeit(nm, [&] { hipLaunchKernelGGL(k_fill_store_wave, dim3(256 * wg), dim3(64), 0, 0, buf, ndbl, 1701, spin, 1.0); }, B);
+        }
     return 0;
 }

@@ -1,5 +1,5 @@
 """Affine-element fast path of the owner-computes stiffness assembly (fenris_amd/csrc/affine_kernel.hpp): node blocks whose
-elements are all parallelepipeds run on k_gather_affine (K_ab = |det J| C(J^-T Ghat_ab J^-1), no quadrature loop), every other
+elements are all parallelepipeds run on k_affine_rows (K_ab = |det J| C(J^-T Ghat_ab J^-1), no quadrature loop), every other
 block keeps the general kernels.  Parity against the oracle (elliptic.rs:361-439 restated) on affine, mixed and non-affine
 meshes; exact symmetry like clone_upper_to_lower (util.rs:38-51); run-to-run reproducibility; the switch in the ABI."""
 import numpy as np
@@ -95,9 +95,9 @@ def test_affine_path_matches_oracle(engine, oracle, name, op):
     kern = engine.last_kernel_name()
     n_aff_el, n_aff_blk, n_gen_blk = engine.affine_stats()
     if EXPECT[name] == "affine":
-        assert kern == "k_gather_affine" and n_gen_blk == 0 and n_aff_el == mesh.num_elements()
+        assert kern == "k_affine_rows" and n_gen_blk == 0 and n_aff_el == mesh.num_elements()
     elif EXPECT[name] == "both":
-        assert kern.startswith("k_gather_affine + ") and n_aff_blk > 0 and n_gen_blk > 0
+        assert kern.startswith("k_affine_rows + ") and n_aff_blk > 0 and n_gen_blk > 0
         assert 0 < n_aff_el < mesh.num_elements()
     else:
         assert "affine" not in kern and n_aff_blk == 0 and n_aff_el == 0
@@ -135,7 +135,7 @@ def test_affine_mask_row_range_and_moving_mesh(engine, oracle, op):
     active = (np.arange(mesh.num_elements()) % 5 != 2)
     engine.set_active_elements(active)
     km = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert engine.last_kernel_name().startswith("k_gather_affine")
+    assert engine.last_kernel_name().startswith("k_affine_rows")
     ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
     assert np.abs(km.values - ka.values).max() <= TOL * np.abs(ka.values).max()
     engine.set_active_elements(None)
@@ -162,7 +162,7 @@ def test_affine_mask_row_range_and_moving_mesh(engine, oracle, op):
     ref3 = oracle.ElementAssembler(oracle.HEX8, ref.op_kind, box.vertices, box.connectivity, w, p, params=None if op == "LAPLACE" else LAME.as_pair())
     _, _, _, _, vals3 = oracle.assemble(ref3)
     k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert engine.last_kernel_name() == "k_gather_affine"
+    assert engine.last_kernel_name() == "k_affine_rows"
     assert np.abs(k3.values - vals3).max() <= TOL * np.abs(vals3).max()
 
 
@@ -174,7 +174,7 @@ def test_affine_other_rules_and_negative_weights(engine, oracle):
         asm, ref = _assemblers(engine, oracle, mesh, "LINEAR_ELASTIC", rule=rule)
         _, _, ro, ci, vals = oracle.assemble(ref)
         k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-        assert engine.last_kernel_name() == "k_gather_affine"
+        assert engine.last_kernel_name() == "k_affine_rows"
         assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
     # a (made-up) 9-point rule with one negative weight: 8 Gauss points scaled by 9/8 and the centre with weight -1
     w, p = quadrature.tensor.hexahedron_gauss(2)
@@ -207,4 +207,4 @@ def test_affine_singular_element_reported(engine):
     with pytest.raises(fa.SingularJacobianError) as ei:
         fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
     assert ei.value.element == 0
-    assert engine.last_kernel_name() == "k_gather_affine"
+    assert engine.last_kernel_name() == "k_affine_rows"

@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: elements/sec assembling the global stiffness matrix K, 3-D Hex8 linear elasticity.
+"""Benchmark of the hot path: numeric assembly of the global stiffness matrix K into a pre-built CSR pattern.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config ns|ns-perturbed|c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A step = one numeric assembly pass (CsrAssembler::assemble semantics: K written into a pre-built CSR
-pattern; benches/assembly.rs:126-145 times the same call) over a synthetic structured mesh that is
-already resident in HBM.  N = 1: BASELINE's north-star point, Hex8 elasticity on the 216^3 unit box
-(10 077 696 elements).  N > 1: weak scaling, the global mesh is 216 x 216 x (216 N) cells cut into N
-z-slabs, one per rank (see fenris_amd/distributed.py); value = all elements of all ranks / max-over-ranks time.
+A step = one numeric assembly pass (CsrAssembler::assemble semantics: K written into a pre-built CSR pattern;
+benches/assembly.rs:126-145 times the same call) over a synthetic mesh that is already resident in HBM.
+
+Configurations (BASELINE.json `configs`):
+  ns            north-star point, the default: Hex8 linear elasticity, structured 216^3 unit box (10 077 696 elements).
+                N > 1: weak scaling, 216 x 216 x (216 N) cells cut into N z-slabs, one per rank.
+  ns-perturbed  the same mesh with every vertex moved by up to +-0.1 h per coordinate: nothing is affine, the general
+                owner-computes kernel runs (reported next to the headline, VERDICT r01 task 1).
+  c2            Hex8 Poisson 128^3.
+  c3            Tet4 linear elasticity, BCC res 75, vertices and elements randomly permuted (seed 12345).
+  c4            Hex27 NeoHookean 50 x 50 x 80, hexahedron_gauss(3); roofline = fp64 matrix-core flops.
+  c5            Hex8 linear elasticity 256^3 cut into N z-slabs (strong scaling; 32 layers per rank at N = 8).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PEAK_FP64_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix-core peak
 
 
 def algorithmic_bytes(E, N, s, n, d, nnz, uses_u=False):
@@ -30,34 +39,144 @@ def algorithmic_bytes(E, N, s, n, d, nnz, uses_u=False):
     return E * n * 4 + N * d * 8 + (s * N * 8 if uses_u else 0) + nnz * 8 + nnz * 4 + (s * N + 1) * 8
 
 
-def cpu_baseline(cells, threads):
-    """The oracle (restatement of fenris's CPU path, NOT the Rust binary) timed on the host cores."""
+def host_threads():
+    """threads this process may actually use: CPU affinity, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, quota) if quota else n), n, quota
+
+
+def cpu_baseline(kind, budget_s=25.0):
+    """The oracle (restatement of fenris's CPU path, NOT the Rust binary) timed on the host cores: the serial assembler
+    (CsrAssembler, global.rs:133-182) and the coloured parallel one (CsrParAssembler, global.rs:314-376, OpenMP over the
+    elements of a colour) at several thread counts; the best parallel figure is the baseline."""
     import numpy as np
 
     from oracle import oracle
 
-    v, c = oracle.unit_box_hex_mesh(cells)
-    w, p = oracle.hexahedron_gauss(2)
-    asm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, v, c, w, p,
-                                  params=oracle.lame_from_young_poisson(1e6, 0.2))
+    lame = oracle.lame_from_young_poisson(1e6, 0.2)
+    if kind == "hex8_elasticity":
+        cells = 88
+        v, c = oracle.unit_box_hex_mesh(cells)
+        w, p = oracle.hexahedron_gauss(2)
+        asm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, v, c, w, p, params=lame)
+        what = f"Hex8 linear elasticity {cells}^3"
+    elif kind == "hex8_poisson":
+        cells = 100
+        v, c = oracle.unit_box_hex_mesh(cells)
+        w, p = oracle.hexahedron_gauss(2)
+        asm = oracle.ElementAssembler(oracle.HEX8, oracle.LAPLACE, v, c, w, p)
+        what = f"Hex8 Poisson {cells}^3"
+    elif kind == "tet4_elasticity":
+        cells = 40
+        v, c = oracle.unit_box_tet_mesh(cells)
+        w, p = oracle.tetrahedron_rule(1)
+        asm = oracle.ElementAssembler(oracle.TET4, oracle.LINEAR_ELASTIC, v, c, w, p, params=lame)
+        what = f"Tet4 linear elasticity BCC res {cells}"
+    else:  # hex27_neohookean
+        v8, c8 = oracle.hex_mesh(1.0, 1, 1, 1, 10)
+        v, c = oracle.hex8_to_hex27(v8, c8)
+        w, p = oracle.hexahedron_gauss(3)
+        A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
+        u = (0.05 * v @ A.T).reshape(-1)
+        asm = oracle.ElementAssembler(oracle.HEX27, oracle.NEO_HOOKEAN, v, c, w, p, params=lame, u=u)
+        what = "Hex27 NeoHookean 10^3"
+    E = len(c)
     ro, ci = oracle.pattern_for(asm)
     colors = oracle.color_nodes(asm)
     vals = np.zeros(len(ci))
-    t0 = time.perf_counter()
-    st, _ = oracle.par_assemble_into_csr(asm, colors, ro, ci, vals, num_threads=threads)
-    t_par = time.perf_counter() - t0
-    assert st == 0
-    vals[:] = 0
+    t_start = time.perf_counter()
     t0 = time.perf_counter()
     st, _ = oracle.assemble_into_csr(asm, ro, ci, vals)
     t_ser = time.perf_counter() - t0
     assert st == 0
-    E = len(c)
-    return {"value": E / t_par, "unit": "elements/s", "cores": threads, "kind": "port",
+    usable, affinity, quota = host_threads()
+    sweep = sorted({t for t in (1, 8, 32, usable) if t <= usable})
+    par = {}
+    for t in sweep:
+        if t == 1:
+            continue
+        if time.perf_counter() - t_start > budget_s:
+            break
+        vals[:] = 0
+        t0 = time.perf_counter()
+        st, _ = oracle.par_assemble_into_csr(asm, colors, ro, ci, vals, num_threads=t)
+        par[t] = time.perf_counter() - t0
+        assert st == 0
+    best_t, best = (min(par.items(), key=lambda kv: kv[1]) if par else (1, t_ser))
+    if t_ser < best:
+        best_t, best = 1, t_ser
+    return {"value": E / best, "unit": "elements/s", "cores": best_t, "kind": "port",
             "serial_value": E / t_ser,
-            "sample": f"Hex8 linear elasticity {cells}^3 = {E} elements, coloured parallel assembly "
-                      f"(CsrParAssembler restatement, {threads} OpenMP threads, {t_par:.1f} s) and serial "
-                      f"({t_ser:.1f} s); restatement of fenris CPU path, not the Rust binary"}
+            "threads_swept": {str(t): E / s for t, s in par.items()},
+            "host": {"os_cpu_count": os.cpu_count(), "affinity": affinity, "cgroup_quota": quota, "usable": usable},
+            "sample": f"{what} = {E} elements: serial CsrAssembler restatement {t_ser:.2f} s; coloured parallel "
+                      f"CsrParAssembler restatement (OpenMP over the elements of a colour) at "
+                      + ", ".join(f"{t} threads {s:.2f} s" for t, s in par.items())
+                      + f"; best = {best_t} thread(s).  Restatement of fenris's CPU path, not the Rust binary"}
+
+
+def measure_traffic(argv_child, kernel_substrs, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel from two rocprofv3 PMC passes of this very command (separate passes:
+    FETCH_SIZE and WRITE_SIZE do not fit one; MI355X_MICROARCH.md, HBM section).  Runs bench.py as a CHILD process under
+    rocprofv3 (never exec-replaces a process that touched the GPU).  FETCH_SIZE is doubled (gfx950 tallies 128-byte
+    requests at 64 bytes on wide coalesced reads: an upper bound for mixed-width reads), WRITE_SIZE taken as reported;
+    both are in KiB.  Returns (bytes or None, detail dict)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="fenris_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py")] + argv_child
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s, check=False)
+            except subprocess.TimeoutExpired:
+                return None, {"error": f"rocprofv3 pass {counter} timed out"}
+            rows = []  # (kernel name, value) of this counter, one per dispatch
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter:
+                            rows.append((row.get("Kernel_Name", ""), float(row["Counter_Value"])))
+            if not rows:  # ROCm 7 default output: a rocpd SQLite database
+                import sqlite3
+
+                for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                    try:
+                        db = sqlite3.connect(f)
+                        rows += [(k, float(v)) for k, v in db.execute(
+                            "select kernel_name, value from counters_collection where counter_name = ?", (counter,))]
+                    except sqlite3.Error:
+                        pass
+            total = 0.0
+            for kname in kernel_substrs:
+                vals = [v for k, v in rows if kname in k]
+                if not vals:
+                    return None, {"error": f"no {counter} rows for kernel {kname}"}
+                total += sum(vals) / len(vals)
+                out[f"{counter}_{kname}_KiB"] = sum(vals) / len(vals)
+                out[f"{counter}_{kname}_dispatches"] = len(vals)
+            out[counter] = total
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, out
 
 
 def main():
@@ -65,16 +184,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", type=int, default=216, help="cells per unit box edge (216 = north-star point)")
+    ap.add_argument("--config", default="ns", choices=["ns", "ns-perturbed", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--cells", type=int, default=0, help="override the cells per box edge of ns / ns-perturbed / c2 / c5")
     ap.add_argument("--scatter", default="gather", choices=["gather", "atomic", "colored"])
-    ap.add_argument("--operator", default="elasticity", choices=["elasticity", "poisson"])
+    ap.add_argument("--operator", default=None, choices=["elasticity", "poisson"], help="(compatibility) poisson = --config c2 sizes")
     ap.add_argument("--partition", default="exchange", choices=["exchange", "halo"],
                     help="N > 1: interface rows sent to their owner over RCCL (headline), or the halo element layer "
                          "recomputed locally with no communication")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange after the kernel instead of beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=88)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = args.config
+    if world > 1 and cfg not in ("ns", "c5"):
+        raise SystemExit(f"--config {cfg} is a single-GPU configuration")
+
+    # ---- HBM traffic of the dominant kernel: two PMC passes of this command as child processes, before this process
+    # touches the GPU (N = 1, rank 0 only)
+    traffic, traffic_detail = None, None
+    child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--scatter", args.scatter]
+    if args.cells:
+        child += ["--cells", str(args.cells)]
+    want_traffic = world == 1 and not args.no_traffic and os.environ.get("FENRIS_BENCH_CHILD") != "1"
 
     import numpy as np
     import torch
@@ -83,18 +218,73 @@ def main():
     import fenris_amd as fa
     from fenris_amd import quadrature
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # FENRIS_BENCH_SHARE_DEVICE=1 (validation only): all ranks on cuda:0 over gloo -- lets the N > 1 code path be
     # exercised on a single-GPU box; never used for reported numbers
     share = os.environ.get("FENRIS_BENCH_SHARE_DEVICE") == "1"
     if share:
         local_rank = 0
+
+    lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
+    n_el, d, s, uses_u = 8, 3, 3, False
+    u = None
+    cpu_kind = "hex8_elasticity"
+    metric = "elements/sec assembling global stiffness K, 3D Hex8 elasticity"
+    if cfg in ("ns", "ns-perturbed", "c5"):
+        cells = args.cells or (256 if cfg == "c5" else 216)
+        rule = quadrature.tensor.hexahedron_gauss(2)
+        op, params = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), lame
+        desc = f"Hex8 linear elasticity stiffness assembly, structured {cells}^3 unit-cell box"
+    elif cfg == "c2":
+        cells = args.cells or 128
+        rule = quadrature.tensor.hexahedron_gauss(2)
+        op, params, s = fa.LaplaceOperator(), None, 1
+        cpu_kind = "hex8_poisson"
+        metric = "elements/sec assembling global stiffness K, 3D Hex8 Poisson"
+        desc = f"Hex8 Poisson stiffness assembly, structured {cells}^3 unit-cell box"
+    elif cfg == "c3":
+        cells = args.cells or 75
+        rule = quadrature.total_order.tetrahedron(1)
+        op, params, n_el = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), lame, 4
+        cpu_kind = "tet4_elasticity"
+        metric = "elements/sec assembling global stiffness K, 3D Tet4 elasticity"
+        desc = f"Tet4 linear elasticity stiffness assembly, BCC unit box res {cells}, vertices and elements permuted (MT19937 seed 12345)"
+    else:  # c4
+        cells = 0
+        rule = quadrature.tensor.hexahedron_gauss(3)
+        op, params, n_el, uses_u = fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()), lame, 27, True
+        cpu_kind = "hex27_neohookean"
+        metric = "elements/sec assembling global stiffness K, 3D Hex27 NeoHookean"
+        desc = "Hex27 NeoHookean stiffness assembly, 50x50x80 box, hexahedron_gauss(3), u = 0.05 A X"
+    if args.operator == "poisson" and cfg == "ns":  # old spelling of the Poisson run at a chosen size
+        op, params, s = fa.LaplaceOperator(), None, 1
+        cpu_kind = "hex8_poisson"
+        metric = "elements/sec assembling global stiffness K, 3D Hex8 Poisson"
+        desc = f"Hex8 Poisson stiffness assembly, structured {cells}^3 unit-cell box"
+
+    weights, points = rule
+    qtable = fa.UniformQuadratureTable.from_points_and_weights(points, weights)
+    if params is not None:
+        qtable = qtable.with_uniform_data(params)
+
+    if want_traffic and rank == 0:
+        # kernels whose HBM traffic is summed (c4: both passes of the two-pass assembly)
+        knames = {"ns": ("k_affine_rows",), "c5": ("k_affine_rows",), "c2": ("k_affine_rows",), "ns-perturbed": ("k_gather_pipelined",),
+                  "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
+        t0 = time.perf_counter()
+        os.environ["FENRIS_BENCH_CHILD"] = "1"
+        try:
+            traffic, traffic_detail = measure_traffic(child, knames)
+        except Exception as exc:  # the profiler must never take the benchmark down
+            traffic, traffic_detail = None, {"error": repr(exc)}
+        del os.environ["FENRIS_BENCH_CHILD"]
+        if traffic_detail is not None:
+            traffic_detail["kernels"] = list(knames)
+            traffic_detail["seconds"] = time.perf_counter() - t0
+
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -102,27 +292,38 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    # ---- synthetic input: this rank's slab of the 216 x 216 x (216 world) box
-    cells = args.cells
     stream = torch.cuda.current_stream().cuda_stream
-    weights, points = quadrature.tensor.hexahedron_gauss(2)
-    qtable = fa.UniformQuadratureTable.from_points_and_weights(points, weights)
-    if args.operator == "elasticity":
-        lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
-        qtable = qtable.with_uniform_data(lame)
-        op, s = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), 3
-    else:
-        op, s = fa.LaplaceOperator(), 1
 
     def configure(engine, mesh_):
         return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh_).with_operator(op)
-                .with_quadrature_table(qtable).with_u(None).build())
+                .with_quadrature_table(qtable).with_u(u_for(mesh_)).build())
+
+    def u_for(mesh_):
+        if not uses_u:
+            return None
+        A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
+        return (0.05 * mesh_.vertices @ A.T).reshape(-1)
 
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
     slab_asm = None
+    scaling = "weak"
     if world == 1:
-        mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
+        if cfg == "c3":
+            m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(cells)
+            rng = np.random.Generator(np.random.MT19937(12345))
+            vp = rng.permutation(m.num_nodes())
+            inv = np.empty_like(vp)
+            inv[vp] = np.arange(len(vp))
+            mesh = fa.Mesh(m.vertices[vp], inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64),
+                           fa.TET4)
+        elif cfg == "c4":
+            mesh = fa.hex27_mesh_from_hex8(fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 5, 5, 8, 10))
+        else:
+            mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
+            if cfg == "ns-perturbed":
+                rng = np.random.Generator(np.random.MT19937(2024))
+                mesh = fa.Mesh(mesh.vertices + (0.1 / cells) * rng.uniform(-1.0, 1.0, mesh.vertices.shape), mesh.connectivity, fa.HEX8)
+                desc += ", every vertex moved by up to +-0.1 h per coordinate (MT19937 seed 2024): no affine element"
         eng = fa.Engine(local_rank, stream=stream)
         configure(eng, mesh)
         torch.cuda.synchronize()
@@ -130,10 +331,15 @@ def main():
         nnz = eng.build_pattern()  # assemble_pattern on the device (secondary metric)
         E = mesh.num_elements()
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        total_cells_desc = ""
     else:
         from fenris_amd import distributed as fd
 
-        slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world, args.partition)
+        if cfg == "c5":
+            slab = fd.make_slab(1.0, 1, 1, 1, cells, rank, world, args.partition)   # 256^3 cut into `world` z-slabs
+            scaling = "strong"
+        else:
+            slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world, args.partition)  # 216 x 216 x (216 world)
         mesh = slab.mesh
         t0 = time.perf_counter()  # N > 1: engines, masks and patterns of this rank
         # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
@@ -192,28 +398,43 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_elements * args.steps / elapsed
-        abytes = algorithmic_bytes(E, N, s, 8, 3, nnz)
+        abytes = algorithmic_bytes(E, N, s, n_el, d, nnz, uses_u)
         achieved = abytes / (kernel_avg_ms * 1e-3) / 1e9
+        if world > 1 and cfg == "ns":
+            desc = desc.replace(f"{cells}^3", f"{cells}x{cells}x{cells * world}")
         out = {
-            "metric": "elements/sec assembling global stiffness K, 3D Hex8 elasticity" if s == 3 else
-                      "elements/sec assembling global stiffness K, 3D Hex8 Poisson",
-            "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": metric, "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Hex8 {'linear elasticity' if s == 3 else 'Poisson'} stiffness assembly, "
-                                   f"structured {cells}x{cells}x{cells * world} unit-cell box "
-                                   f"({int(total_elements)} elements), hexahedron_gauss(2), "
-                                   f"YoungPoisson(1e6, 0.2), u = 0, CSR pattern pre-built, values overwritten",
-                       "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
+            "config": {"workload": f"{cfg}: {desc} ({int(total_elements)} elements), "
+                                   + ("YoungPoisson(1e6, 0.2), " if params is not None else "")
+                                   + ("u = 0, " if not uses_u else "") + "CSR pattern pre-built, values overwritten",
+                       "name": cfg, "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
                        "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
                        "pattern_build_s": t_pattern},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                         "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
-                         "kernel_min_ms": kernel_ms[0], "algorithmic_bytes_per_launch": abytes,
-                         "bytes_per_element": abytes / E},
         }
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+               "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
+               "kernel_min_ms": kernel_ms[0], "algorithmic_bytes_per_launch": abytes,
+               "bytes_per_element": abytes / E}
+        if traffic_detail is not None:
+            hbm["traffic_source"] = ("two rocprofv3 --pmc child passes of this command (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, "
+                                     "averaged over the dispatches of the dominant kernel)")
+            hbm["traffic_detail"] = traffic_detail
+        if cfg == "c4":
+            # compute-bound configuration: the two weighted Gram products of the dense element matrix,
+            # 2 (3n)^2 nq 2 flop, plus the trace term 6 n^2 nq flop, on the fp64 matrix cores; the HBM figures go along
+            flops = E * (2 * (3 * n_el) ** 2 * len(weights) * 2 + 6 * n_el * n_el * len(weights))
+            tf = flops / (kernel_avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
+                               "traffic": traffic, "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
+                               "kernel_min_ms": kernel_ms[0], "algorithmic_flops_per_launch": flops, "flops_per_element": flops / E,
+                               "note": "kernel_avg_ms covers both passes of the two-pass assembly (dense element matrices on the "
+                                       "matrix cores, then the row gather)", "hbm": hbm}
+        else:
+            out["roofline"] = hbm
         # what the device sustains on the dominant traffic of this kernel (writing the values once): a plain fill of
         # the same array, timed the same way -- the practical ceiling next to the nominal 8 TB/s
         try:
@@ -226,23 +447,12 @@ def main():
                 scratch.fill_(1.0)
             b0.record()
             torch.cuda.synchronize()
-            out["roofline"]["measured_write_GBps"] = 5 * nnz * 8 / (a0.elapsed_time(b0) * 1e-3) / 1e9
+            hbm["measured_write_GBps"] = 5 * nnz * 8 / (a0.elapsed_time(b0) * 1e-3) / 1e9
             del scratch
         except RuntimeError:
             pass
-        # HBM traffic of the dominant kernel from committed rocprofv3 PMC passes (bench.py cannot collect PMC
-        # itself): FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B on wide
-        # coalesced reads -- an upper bound for our mixed-width reads), WRITE_SIZE as reported; KB -> bytes.
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-            if t["cells"] == cells and t["scatter"] == args.scatter and t["operator"] == args.operator and world == 1:
-                out["roofline"]["traffic"] = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
-                out["roofline"]["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-        except (OSError, KeyError, ValueError):
-            pass
         if not args.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(args.cpu_cells, threads)
+            out["cpu_baseline"] = cpu_baseline(cpu_kind)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -45,7 +45,7 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4);
 }
 
-template <int OP, bool OVERWRITE, bool DBG>
+template <int OP, bool OVERWRITE, bool STAGED, bool DBG>
 __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     double* JS = GH + 65 * GW;                      // [2][us][GW]
     const int accp = (T.acc_max + 16 + 1) & ~1;
     double* OUT = JS + 2 * T.us * GW;               // [2][accp]
-    int4* HDR = reinterpret_cast<int4*>(OUT + 2 * accp);  // [4] ring of position headers, slot q & 3 holds hdr[q]: the row waves
-                                                    // fetch them from global memory, every wave reads them here
+    int4* HDR = reinterpret_cast<int4*>(OUT + 2 * accp);  // [4] ring of position headers, slot q & 3 holds hdr[q] (.w replaced by
+                                                    // the head of the position): the row waves fetch, every wave reads them here
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, npos = T.npos;
@@ -77,43 +77,73 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         // laid out from the line boundary below the block's first value (`head` doubles in), only complete lines are stored,
         // and when the next position continues these rows (positions are in CSR order) the incomplete last line is carried
         // into the head of the other buffer instead of being written.
-        auto write_out = [&](const int4 h, double* buf, double* other, bool carry_in, bool carry_out) {
-            const int head = h.w;
-            double* line0 = a.vals + (size_t)SS * (size_t)h.x - head;
-            const int lo = carry_in ? 0 : head, hi = head + SS * h.y;
+        // The wave's own instruction stream is on the critical path from barrier to barrier, so everything about a position
+        // is kept in scalar registers and the trips of the unrolled loops are skipped by scalar branches.
+        // STAGED: the rows are first fetched into registers (between the barriers that bracket the position) and stored to
+        // global memory behind the barrier; otherwise they are streamed LDS -> register -> memory before it.
+        constexpr int MAXP = STAGED ? 14 : 1;                    // 16-byte pieces per lane held in registers
+        f64x2 v[MAXP], vt = {0.0, 0.0};
+        f64x2* gout = reinterpret_cast<f64x2*>(a.vals);          // first whole piece of this lane in global memory
+        double* line0 = a.vals;
+        int nfull = 0, rem = 0, e_lo = -1, e_hi = -1;            // trips of 64 pieces, pieces of the last trip, end doubles
+        double ev_lo = 0.0, ev_hi = 0.0;
+        auto rfl = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+        auto put = [&](f64x2* dst, f64x2 val) {
+            if (DBG && (ablate & 1)) return;
+            if constexpr (OVERWRITE) *dst = val;
+            else { const f64x2 o = *dst; f64x2 r; r.x = o.x + val.x; r.y = o.y + val.y; *dst = r; }
+        };
+        auto put1 = [&](double* dst, double val) {
+            if (DBG && (ablate & 1)) return;
+            if constexpr (OVERWRITE) *dst = val; else *dst += val;
+        };
+        auto stage_read = [&](const int4 hv, double* buf, double* other, bool carry_in, bool carry_out) {
+            const int r0 = rfl(hv.x), nrow = rfl(hv.y), flags = rfl(hv.z), head = rfl(hv.w);
+            line0 = a.vals + (size_t)SS * (size_t)r0 - head;
+            const int lo = carry_in ? 0 : head, hi = head + SS * nrow;
             const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
-            const bool zero = !(h.z & 1);
-            f64x2* buf2 = reinterpret_cast<f64x2*>(buf);
-            f64x2* out2 = reinterpret_cast<f64x2*>(line0);
-            const f64x2 zero2 = {0.0, 0.0};
-            const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces
-            auto piece = [&](int k, f64x2 v) {
-                if (DBG && (ablate & 1)) return;
-                if constexpr (OVERWRITE) out2[k] = v;
-                else { const f64x2 o = out2[k]; f64x2 r; r.x = o.x + v.x; r.y = o.y + v.y; out2[k] = r; }
-            };
-            int k = k0 + lane;
-            for (; k + 192 < k1; k += 256) {
-                const f64x2 v0 = buf2[k], v1 = buf2[k + 64], v2 = buf2[k + 128], v3 = buf2[k + 192];
-                piece(k, v0); piece(k + 64, v1); piece(k + 128, v2); piece(k + 192, v3);
-                if (zero) { buf2[k] = zero2; buf2[k + 64] = zero2; buf2[k + 128] = zero2; buf2[k + 192] = zero2; }
+            const bool zero = !(flags & 1);
+            const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces [k0, k1)
+            const int np = max(k1 - k0, 0);
+            nfull = np >> 6;
+            rem = np & 63;
+            f64x2* b2 = reinterpret_cast<f64x2*>(buf) + k0 + lane;
+            gout = reinterpret_cast<f64x2*>(line0) + k0 + lane;
+            if constexpr (STAGED) {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i)
+                    if (i < nfull) v[i] = b2[64 * i];
+                for (int i = MAXP; i < nfull; ++i) put(gout + 64 * i, b2[64 * i]);   // rows longer than the registers hold
+                if (lane < rem) vt = b2[64 * nfull];
+            } else {
+                int i = 0;
+                for (; i + 4 <= nfull; i += 4) {
+                    const f64x2 v0 = b2[64 * i], v1 = b2[64 * i + 64], v2 = b2[64 * i + 128], v3 = b2[64 * i + 192];
+                    put(gout + 64 * i, v0); put(gout + 64 * i + 64, v1); put(gout + 64 * i + 128, v2); put(gout + 64 * i + 192, v3);
+                }
+                for (; i < nfull; ++i) put(gout + 64 * i, b2[64 * i]);
+                if (lane < rem) put(gout + 64 * nfull, b2[64 * nfull]);
             }
-            for (; k < k1; k += 64) {
-                const f64x2 v = buf2[k];
-                piece(k, v);
-                if (zero) buf2[k] = zero2;
+            e_lo = ((lo & 1) && lo < L) ? lo : -1;               // the ends of a run of positions: single doubles
+            e_hi = ((L & 1) && L - 1 >= lo) ? L - 1 : -1;
+            if (e_lo >= 0 && lane == 0) { if (STAGED) ev_lo = buf[e_lo]; else put1(line0 + e_lo, buf[e_lo]); }
+            if (e_hi >= 0 && lane == 0) { if (STAGED) ev_hi = buf[e_hi]; else put1(line0 + e_hi, buf[e_hi]); }
+            if (carry_out && lane < hi - L) other[lane] = buf[L + lane];
+            if (zero) {  // some (node, column) block of these rows has no owner lane (element masks): clear what was read
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int d = lo + lane; d < hi; d += 64) buf[d] = 0.0;
             }
-            if (lane == 0 && !(DBG && (ablate & 1))) {           // the ends of a run of positions: single doubles
-                if ((lo & 1) && lo < L) { if (OVERWRITE) line0[lo] = buf[lo]; else line0[lo] += buf[lo]; }
-                if ((L & 1) && L - 1 >= lo) { if (OVERWRITE) line0[L - 1] = buf[L - 1]; else line0[L - 1] += buf[L - 1]; }
-            }
-            if (zero && lane == 0) {
-                if ((lo & 1) && lo < L) buf[lo] = 0.0;
-                if ((L & 1) && L - 1 >= lo) buf[L - 1] = 0.0;
-            }
-            if (carry_out && lane < hi - L) {
-                other[lane] = buf[L + lane];
-                if (zero) buf[L + lane] = 0.0;
+        };
+        auto issue_stores = [&]() {
+            if constexpr (STAGED) {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i)
+                    if (i < nfull) put(gout + 64 * i, v[i]);
+                if (lane < rem) put(gout + 64 * nfull, vt);
+                if ((e_lo >= 0 || e_hi >= 0) && lane == 0) {
+                    if (e_lo >= 0) put1(line0 + e_lo, ev_lo);
+                    if (e_hi >= 0) put1(line0 + e_hi, ev_hi);
+                }
             }
         };
         lds_barrier();  // B0
@@ -121,15 +151,18 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         int par = 0;
         for (int p = p_begin; p < p_end; ++p, par ^= 1) {
             if (p > p_begin) {
-                const int4 h_prev = HDR[(p - 1) & 3], h_cur = HDR[p & 3];
-                const bool carry_out = h_cur.x == h_prev.x + h_prev.y;
-                write_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
+                const int4 h_prev = HDR[(p - 1) & 3];
+                const int r0_cur = rfl(HDR[p & 3].x);
+                const bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y);
+                stage_read(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
                 carry_in = carry_out;
             }
             lds_barrier();
+            if (p > p_begin) issue_stores();
         }
-        const int4 h_prev = HDR[(p_end - 1) & 3];
-        write_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
+        stage_read(HDR[(p_end - 1) & 3], OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_stores();
         return;
     }
 
@@ -145,6 +178,7 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     auto load_vidx = [&](int p) { return T.slotv[(size_t)((unsigned)min(p, npos - 1) * (unsigned)(4 * T.us) + (unsigned)jl_c)]; };
     double X[3];
     auto load_vert = [&](int v) {
+        if (DBG && (ablate & 128)) v = jk;  // profiling: every quad fetches the same four vertices (cache hits)
 #pragma unroll
         for (int c = 0; c < 3; ++c) X[c] = a.verts[(size_t)(unsigned)v * 3 + c];
     };
@@ -335,7 +369,13 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         }
 
         // records of the next position's slots (its vertices have landed by now)
-        if (jwave && have_next && !(DBG && (ablate & 4))) slot_record(p + 1, par ^ 1);
+        if (jwave && have_next && !(DBG && (ablate & 4))) {
+            if (DBG && (ablate & 32)) {  // profiling: wait for the vertices, skip the arithmetic
+                asm volatile("" :: "v"(X[0]), "v"(X[1]), "v"(X[2]));
+            } else {
+                slot_record(p + 1, par ^ 1);
+            }
+        }
         if (hwave && tid == 0) HDR[(p + 1) & 3] = with_head(h_nxt);
         h_nxt = h_nn;
         vi_nxt = vi_nn;
@@ -473,11 +513,13 @@ hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t st
                               int ablate) {
     void (*kern)(const KArgs, const AffineRowTables, int);
     const bool ow = a.overwrite != 0;
+    const bool staged = (ablate & 64) != 0;   // profiling: the register-staged store wave (stores behind the barrier)
     if (op == FH_LAPLACE) {
-        kern = ablate ? k_affine_rows<FH_LAPLACE, true, true> : ow ? k_affine_rows<FH_LAPLACE, true, false> : k_affine_rows<FH_LAPLACE, false, false>;
+        kern = ablate ? (staged ? k_affine_rows<FH_LAPLACE, true, true, true> : k_affine_rows<FH_LAPLACE, true, false, true>)
+                      : ow ? k_affine_rows<FH_LAPLACE, true, false, false> : k_affine_rows<FH_LAPLACE, false, false, false>;
     } else {
-        kern = ablate ? k_affine_rows<FH_LINEAR_ELASTIC, true, true>
-                      : ow ? k_affine_rows<FH_LINEAR_ELASTIC, true, false> : k_affine_rows<FH_LINEAR_ELASTIC, false, false>;
+        kern = ablate ? (staged ? k_affine_rows<FH_LINEAR_ELASTIC, true, true, true> : k_affine_rows<FH_LINEAR_ELASTIC, true, false, true>)
+                      : ow ? k_affine_rows<FH_LINEAR_ELASTIC, true, false, false> : k_affine_rows<FH_LINEAR_ELASTIC, false, false, false>;
     }
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -319,7 +319,6 @@ struct fh_ctx {
     // fixed-stride tables of the pipelined gather kernel
     DevBuf<int> p_conn, p_rec, p_elem;
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
-    DevBuf<uint2> r_lanes;      //                                     lanes per position (Hex8)
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
     int r_rw = 0, r_ls = 256;
     bool has_rows = false;
@@ -337,12 +336,11 @@ struct fh_ctx {
     uint64_t num_aff = 0;
     DevBuf<double> ghat;            // [64][10] LinearElastic blocks | [64][6] Laplace blocks
     bool has_ghat = false;
-    DevBuf<int> a_rec, a_conn, a_elem;
-    DevBuf<uint2> a_lanes;
-    DevBuf<int4> a_hdr;
-    DevBuf<int> a_slotv;            // k_affine_rows (affine_rows.hip): position headers, four vertices per slot
-    bool a_v1 = false;              // FENRIS_HIP_AFFINE_V1: the first form of the kernel (k_gather_affine), for A/B measurements
-    int a_rw = 0, a_cs = 0, a_us = 0, a_npos = 0;
+    DevBuf<int> a_conn, a_elem;     // k_affine_rows (affine_rows.hip): per-slot connectivity (table build only), element ids
+    DevBuf<uint2> a_lanes;          // lane records
+    DevBuf<int4> a_hdr;             // position headers
+    DevBuf<int> a_slotv;            // four vertices per slot
+    int a_us = 0, a_npos = 0;
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
@@ -817,7 +815,7 @@ int build_partition(fh_ctx* c) {
         if (us * c->ei.ng <= 512 && us <= 252 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb &&
             nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
             const int nblk = c->nblk;
-            // Block classes: 1 = every adjacent element is affine, the block runs on k_gather_affine; 0 = general kernels.
+            // Block classes: 1 = every adjacent element is affine, the block runs on k_affine_rows; 0 = general kernels.
             // Chains never mix classes, so each class gets its own sweep order and its own position-indexed tables.
             std::vector<unsigned char> cls((size_t)nblk, 0);
             DevBuf<unsigned char> cls_d;
@@ -903,26 +901,15 @@ int build_partition(fh_ctx* c) {
                 int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem);
                 if (rs) return rs;
                 const int npos = (int)order[1].size();
-                c->a_rw = 8 + us / 4 + nb_target + 1;
-                c->a_cs = c->p_cs;
                 c->a_us = us;
-                c->a_v1 = std::getenv("FENRIS_HIP_AFFINE_V1") != nullptr;
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                if (c->a_v1) {
-                    HIP_TRY(c, c->a_rec.alloc((size_t)npos * c->a_rw));
-                    HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
-                    hipLaunchKernelGGL(k_build_row_lanes, dim3(npos), dim3(64), 0, c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos,
-                                       c->a_rw, c->a_rec.p, c->a_lanes.p, st.p, c->a_elem.p);
-                    HIP_TRY(c, hipGetLastError());
-                } else {
-                    HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
-                    HIP_TRY(c, c->a_slotv.alloc((size_t)npos * us * 4));
-                    HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
-                    HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
-                                                 c->p_cs, c->a_elem.p, c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, st.p));
-                }
+                HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
+                HIP_TRY(c, c->a_slotv.alloc((size_t)npos * us * 4));
+                HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
+                HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
+                                             c->p_cs, c->a_elem.p, c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, st.p));
                 int bad = 0;
                 HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -930,7 +917,7 @@ int build_partition(fh_ctx* c) {
                     c->aff_failed = true;
                     return build_partition(c);
                 }
-                if (!c->a_v1) c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
+                c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
                 c->a_npos = npos;
             }
             c->npos_gen = (int)order[0].size();
@@ -942,26 +929,8 @@ int build_partition(fh_ctx* c) {
             if (std::getenv("FENRIS_HIP_VERBOSE"))
                 std::fprintf(stderr, "[fenris_hip] sweep order: %d general blocks in %d chains, %d affine blocks in %d chains (us=%d ms=%d)\n",
                              c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, (int)chain_off[1].size() - 1, us, ms);
-            // row-owner lanes (Hex8; opt-in while it is being measured)
             c->has_rows = false;
             const int npg = c->npos_gen;
-            if (c->elem_kind == FH_HEX8 && us * 8 <= 256 && nb_target <= 8 && npg > 0 && std::getenv("FENRIS_HIP_ROWS")) {
-                c->r_rw = 8 + us / 4 + nb_target + 1;
-                DevBuf<int> st;
-                HIP_TRY(c, st.alloc(1));
-                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                HIP_TRY(c, c->r_rec.alloc((size_t)npg * c->r_rw));
-                HIP_TRY(c, c->r_lanes.alloc((size_t)npg * 256));
-                hipLaunchKernelGGL(k_build_row_lanes, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target, npg,
-                                   c->r_rw, c->r_rec.p, c->r_lanes.p, st.p, (const int*)nullptr);
-                HIP_TRY(c, hipGetLastError());
-                int bad = 0;
-                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->has_rows = bad == 0;
-                if (std::getenv("FENRIS_HIP_VERBOSE"))
-                    std::fprintf(stderr, "[fenris_hip] row-owner lanes: %s\n", c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
-            }
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
             if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !std::getenv("FENRIS_HIP_NO_ROWS")) {
@@ -1002,24 +971,6 @@ int build_partition(fh_ctx* c) {
     c->g_acc = acc;
     c->g_nb = 64;
     c->has_partition = true;
-    return FH_OK;
-}
-
-template <int OP>
-int launch_rows(fh_ctx* c, KArgs& a, const RowTables& T) {
-    const size_t lds = make_layout<FH_HEX8, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 8, 0, 2).bytes();
-    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
-    int dev_cus = 256;
-    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int grid = std::min(c->npos_gen, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
-    auto kern = k_gather_rows<OP>;
-    if (lds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (std::getenv("FENRIS_HIP_VERBOSE"))
-        std::fprintf(stderr, "[fenris_hip] row-owner gather: lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
-    HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }
 
@@ -1135,35 +1086,19 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
     }
 }
 
-// node blocks all of whose elements are affine: k_gather_affine over its own position tables
+// node blocks all of whose elements are affine: k_affine_rows (affine_rows.hip) over its own position tables
 int launch_affine(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    if (!c->a_v1) {
-        AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, c->a_elem.p,
-                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
-        const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
-        if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
-        const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-        const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
-        if (std::getenv("FENRIS_HIP_VERBOSE"))
-            std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
-        HIP_TRY(c, affine_rows_launch(c->op, grid, lds, c->stream, a, T, a.ablate));
-        return FH_OK;
-    }
-    AffineTables T{c->a_rec.p, c->a_lanes.p, c->a_conn.p, c->a_elem.p,
-                   c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_rw, c->a_cs, c->a_us, c->p_nbs, c->a_npos, c->g_acc};
-    const size_t lds = affine_lds_bytes(c->op, c->a_us, c->g_acc, c->a_rw);
+    AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, c->a_elem.p,
+                      c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
+    const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
-    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
     const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
-    void (*kern)(const KArgs, const AffineTables) = (c->op == FH_LAPLACE) ? k_gather_affine<FH_LAPLACE> : k_gather_affine<FH_LINEAR_ELASTIC>;
-    if (lds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("FENRIS_HIP_VERBOSE"))
-        std::fprintf(stderr, "[fenris_hip] affine gather: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
-    HIP_TRY(c, hipGetLastError());
+        std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
+    HIP_TRY(c, affine_rows_launch(c->op, grid, lds, c->stream, a, T, a.ablate));
     return FH_OK;
 }
 
@@ -1318,7 +1253,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             // node blocks whose elements are all affine (affine_kernel.hpp); the remaining positions follow below
             rc = launch_affine(c, a);
             if (rc) return rc;
-            c->last_kernel = c->a_v1 ? "k_gather_affine" : "k_affine_rows";
+            c->last_kernel = "k_affine_rows";
             if (c->npos_gen == 0) return FH_OK;
             c->last_kernel += " + ";
         }
@@ -1358,14 +1293,6 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
             c->last_kernel += "k_gather_rows";
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
-        }
-        if (c->has_pipe && c->has_rows && c->elem_kind == FH_HEX8 && a.fast && !pipe_rules && c->nq == 8 &&
-            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
-            RowTables T{c->r_rec.p, c->r_lanes.p, c->p_conn.p, c->p_elem.p, c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->npos_gen};
-            a.ub = c->p_us;
-            a.nb_max = c->p_nbs;
-            c->last_kernel += "k_gather_rows";
-            return c->op == FH_LAPLACE ? launch_rows<FH_LAPLACE>(c, a, T) : launch_rows<FH_LINEAR_ELASTIC>(c, a, T);
         }
         if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
             a.fast = 1;

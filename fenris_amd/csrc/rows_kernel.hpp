@@ -1,14 +1,10 @@
-// Row-owner form of the owner-computes stiffness kernel (Hex8, 8-point rule, Laplace / uniform LinearElastic):
-// a lane owns an OUTPUT block (owned node I, column J) and walks a short list of terms (slot, local I, local J), so the
-// sums are complete in registers and go to global memory directly -- no ds_add_f64, no row accumulators in LDS, no
-// write-out pass.  Same sweep chains, slots, prefetch and phase B as k_gather_pipelined (assemble_kernels.hpp); replaces
-// its phase C / finalize / write-out.  Restates elliptic.rs:361-439 + global.rs:133-182 like the other kernels.
-//
-// A node's 27 blocks of a hexahedral mesh have 8 / 4 / 2 / 1 terms (self / face / edge / corner neighbour).  Two terms
-// per lane: blocks with more are split over an aligned group of 2 or 4 lanes whose partial sums meet by DPP quad
-// permutes; two one-term blocks share a lane.  k_build_row_lanes derives the lanes of every block from the
-// (entry, local node) -> column-slot table of the pipelined kernel; meshes it cannot express (more than 8 terms per
-// block, more than 256 lanes per node block) keep the pipelined kernel.
+// Row-owner form of the owner-computes stiffness kernel for Tet4 with a one-point rule (Laplace / LinearElastic, uniform or
+// per-element parameters): a lane owns an OUTPUT block (owned node I, column J) and walks a short list of terms
+// (slot, local I, local J), so the sums are complete in registers and go to global memory directly -- no ds_add_f64, no row
+// accumulators in LDS, no write-out pass.  Same sweep chains, slots, prefetch and phase B as k_gather_pipelined
+// (assemble_kernels.hpp); replaces its phase C / finalize / write-out.  Restates elliptic.rs:361-439 + global.rs:133-182 like
+// the other kernels.  (The Hex8 form of this idea is k_affine_rows, affine_rows.hip; on general hexahedra the pipelined kernel
+// is faster: 64 operand fetches per lane against 48, measured 1.7x.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,315 +13,9 @@
 
 namespace fenris_hip {
 
-struct RowTables {
-    const int* rec;      // [npos][rw]   GatherHdr (8 words) | occupied slots, 1 byte each, new ones first (us / 4 words) |
-                         //              node-level row offsets relative to the block start (nbs + 1 words)
-    const uint2* lanes;  // [npos][256]  see row_lane_* below
-    const int* conn;     // [npos][cs]   geometry-node indices per LDS slot
-    const int* elem;     // [npos][us]   element id per slot (error reporting)
-    int rw, cs, us, nbs, npos;
-};
-
-// lane record: x = slot0 | a0 << 8 | j0 << 11 | slot1 << 14 | a1 << 22 | j1 << 25 | nterms << 28 | log2(group) << 30
-//              y = pos0 | il0 << 7 | pos1 << 10 | il1 << 17 | two_outputs << 20 | store0 << 21 | store1 << 22
-__host__ __device__ inline unsigned row_term(unsigned slot, unsigned a, unsigned j) { return slot | (a << 8) | (j << 11); }
-
-template <int OP>
-__global__ void __launch_bounds__(256, 2) k_gather_rows(const KArgs a, const RowTables T) {
-    constexpr int EK = FH_HEX8, QC = 8;
-    using E = ElemT<EK>;
-    using O = OpT<OP, E::D>;
-    constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
-    static_assert(D == 3 && N == 8 && NG == 8, "row-owner kernel: Hex8");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, QC, 0, 2);
-    double* lds = reinterpret_cast<double*>(smem);
-    int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
-    const int tid = threadIdx.x;
-    const int G = gridDim.x;
-    stage_tables<EK>(a, L, lds);
-
-    struct Rec { int w; int conn; };
-    const int npos = T.npos;
-    const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
-    // branch-free, clamped prefetch (see k_gather_pipelined)
-    auto load_rec = [&](int p, Rec& r) {
-        p = min(p, npos - 1);
-        r.w = T.rec[(size_t)p * T.rw + min(tid, T.rw - 1)];
-        r.conn = T.conn[(size_t)p * T.cs + min(tid, T.cs - 1)];
-    };
-    auto load_lane = [&](int p) { return T.lanes[(size_t)min(p, npos - 1) * 256 + tid]; };
-    double V[D];
-    auto load_verts = [&](const Rec& r) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) V[c] = a.verts[(size_t)r.conn * D + c];
-    };
-    auto rec_base = [&](int parity) { return lds_i + parity * T.rw; };
-    auto park = [&](const Rec& r, int parity) {
-        if (tid < T.cs)
-#pragma unroll
-            for (int c = 0; c < D; ++c) lds[L.o_X + (tid / NG) * L.xs + (tid % NG) * D + c] = V[c];
-        if (tid < T.rw) rec_base(parity)[tid] = r.w;
-    };
-    const double sqw = sqrt(a.qw[tid % QC]);
-    int p = p_begin;
-    if (p >= p_end) return;
-    Rec nxt;
-    uint2 lane_cur;
-    {
-        Rec cur;
-        load_rec(p, cur);
-        load_verts(cur);
-        lane_cur = load_lane(p);
-        load_rec(p + 1, nxt);
-        park(cur, 0);
-        asm volatile("" : "+v"(nxt.w), "+v"(nxt.conn), "+v"(lane_cur.x), "+v"(lane_cur.y));
-    }
-    __syncthreads();
-
-    int parity = 0;
-    for (; p < p_end; ++p, parity ^= 1) {
-        const bool have_next = (p + 1) < p_end;
-        const int* rec = rec_base(parity);
-        const GatherHdr hc = *reinterpret_cast<const GatherHdr*>(rec);
-        const unsigned char* slot_b = reinterpret_cast<const unsigned char*>(rec + 8);
-        const int* noff_l = rec + 8 + T.us / 4;
-        load_verts(nxt);
-        Rec nn;
-        load_rec(p + 2, nn);
-        uint2 lane_nxt = load_lane(p + 1);
-        const int U = (p == p_begin) ? hc.U : hc.k0;
-        // phase B: one lane per (new slot, point)
-        if (tid < U * QC && !(a.ablate & 1)) {
-            const int u = (int)slot_b[tid / QC];
-            prologue<EK, OP, WHAT_MATRIX, true, true>(a, L, lds, lds_i, u, tid % QC, T.elem + (size_t)p * T.us + u, tid % QC, sqw);
-        }
-        lds_barrier();
-
-        // phase C: G = sum_q h_a h_j^T for the lane's two terms
-        const unsigned w0 = lane_cur.x, w1 = lane_cur.y;
-        const int nterms = (int)((w0 >> 28) & 3u), grp = (int)(w0 >> 30);
-        double Gt[2][D][D];
-        constexpr int QPD = 4 * N + 2;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) Gt[t][i][j] = 0.0;
-            if (a.ablate & 2) continue;
-            const unsigned term = (w0 >> (14 * t)) & 0x3fffu;
-            const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
-            const unsigned pa = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 7u));
-            const unsigned pj = (unsigned)(unsigned long long)(pq + 4 * ((term >> 11) & 7u));
-            // four ds_read_b128 per point, two points in flight while one is multiplied
-            constexpr int AHEAD = 2, NB = AHEAD + 1;
-            // [x y] as one ds_read_b128, z as ds_read_b64: a 16-byte fetch of [z 0] would leave half of its destination
-            // registers dead for the compiler, which then hands them to another value while the fetch is still in flight
-            f64x2 av[NB], bv[NB];
-            double az[NB], bz[NB];
-            auto fetchq = [&](auto qk) {
-                constexpr int qq = decltype(qk)::value, sl = qq % NB;
-                av[sl] = lds_read_f64x2<(qq * QPD) * 8>(pa);
-                az[sl] = lds_read_f64_at<(qq * QPD + 2) * 8>(pa);
-                bv[sl] = lds_read_f64x2<(qq * QPD) * 8>(pj);
-                bz[sl] = lds_read_f64_at<(qq * QPD + 2) * 8>(pj);
-            };
-            fetchq(std::integral_constant<int, 0>{});
-            fetchq(std::integral_constant<int, 1>{});
-            pipeline_consume<QC, D>([&](auto qk) {
-                constexpr int qq = decltype(qk)::value, sl = qq % NB;
-                constexpr int ahead = (QC - 1 - qq) < (AHEAD - 1) ? (QC - 1 - qq) : (AHEAD - 1);
-                lds_wait<ahead * 4>();
-                // the values exist only now: anything the compiler derives from them must come after the wait
-                asm volatile("" : "+v"(av[sl]), "+v"(az[sl]), "+v"(bv[sl]), "+v"(bz[sl]));
-                if constexpr (qq + AHEAD < QC) fetchq(std::integral_constant<int, qq + AHEAD>{});
-                __builtin_amdgcn_sched_barrier(0);
-                const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
-                const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) Gt[t][i][j] = fma(ai[i], bj[j], Gt[t][i][j]);
-            });
-        }
-        // unused terms read slot 0 (valid memory, arbitrary contents): discard by selection, never by multiplication
-        const bool two_out = (w1 >> 20) & 1u;
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                if (nterms < 1) Gt[0][i][j] = 0.0;
-                if (nterms < 2) Gt[1][i][j] = 0.0;
-                if (!two_out) Gt[0][i][j] += Gt[1][i][j];
-            }
-        // partial sums of a block split over an aligned group of 2 / 4 lanes
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double t1 = dpp_quad<0xB1>(Gt[0][i][j]);  // quad_perm [1,0,3,2]
-                if (grp >= 1) Gt[0][i][j] += t1;
-            }
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double t2 = dpp_quad<0x4E>(Gt[0][i][j]);  // quad_perm [2,3,0,1]
-                if (grp >= 2) Gt[0][i][j] += t2;
-            }
-        // s x s block from G (materials.rs:108-118 summed: mu (tr G I + G^T) + lambda G), straight to its CSR rows
-        auto store_block = [&](const double (&Gm)[D][D], int il, int pos) {
-            const int rb = noff_l[il], cnt = noff_l[il + 1] - rb;
-            double* base = a.vals + (size_t)S * S * ((size_t)hc.r0 + rb) + S * pos;
-            double tr = 0.0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) tr += Gm[i][i];
-            if (OP == FH_LAPLACE) {
-                if (a.overwrite) base[0] = tr; else base[0] += tr;
-            } else {
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double* row = base + (size_t)(i % S) * S * cnt;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const double v = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
-                        if (a.overwrite) row[j % S] = v; else row[j % S] += v;
-                    }
-                }
-            }
-        };
-        if (!(a.ablate & 4))
-        if ((w1 >> 21) & 1u) store_block(Gt[0], (int)((w1 >> 7) & 7u), (int)(w1 & 127u));
-        if (!(a.ablate & 4))
-        if ((w1 >> 22) & 1u) store_block(Gt[1], (int)((w1 >> 17) & 7u), (int)((w1 >> 10) & 127u));
-
-        if (have_next) park(nxt, parity ^ 1);
-        asm volatile("" : "+v"(nn.w), "+v"(nn.conn), "+v"(lane_nxt.x), "+v"(lane_nxt.y));
-        nxt = nn;
-        lane_cur = lane_nxt;
-        lds_barrier();
-    }
-}
-
-// Lanes of every position from the pipelined kernel's records (p_rec: GatherHdr | slots | entries | column slots | row
-// offsets).  One wavefront per position.  status |= 1 when a block cannot be expressed (see the header comment).
-// p_elem (optional, [npos][us] element id per slot): the terms of a block are ordered by element id instead of by slot, so
-// that the blocks (I, J) and (J, I) -- owned by different lanes, possibly at different positions -- add their elements'
-// contributions in the same order (k_gather_affine's bitwise symmetry).
-__global__ void __launch_bounds__(64) k_build_row_lanes(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
-                                                        int* rec_new, uint2* lanes, int* status, const int* p_elem) {
-    constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
-    __shared__ int cnt[NKEY];
-    __shared__ unsigned short bucket[NKEY * TMAX];
-    __shared__ unsigned lw0[256], lw1[256];
-    const int p = blockIdx.x, lane = threadIdx.x;
-    const int* rec = p_rec + (size_t)p * rw_old;
-    const GatherHdr h = *reinterpret_cast<const GatherHdr*>(rec);
-    const unsigned* ent = reinterpret_cast<const unsigned*>(rec + 8 + us / 4);
-    const unsigned char* posb = reinterpret_cast<const unsigned char*>(rec + 8 + us / 4 + ms);
-    const int* noff_old = rec + 8 + us / 4 + ms + ms * N / 4;
-    // the shared part of the record: header, slot list, row offsets
-    int* out = rec_new + (size_t)p * rw_new;
-    for (int i = lane; i < 8 + us / 4; i += 64) out[i] = rec[i];
-    for (int i = lane; i <= nbs; i += 64) out[8 + us / 4 + i] = noff_old[i];
-    for (int i = lane; i < NKEY; i += 64) cnt[i] = 0;
-    for (int i = lane; i < 256; i += 64) { lw0[i] = 0u; lw1[i] = 0u; }
-    __syncthreads();
-    bool bad = false;
-    for (int idx = lane; idx < h.m * N; idx += 64) {
-        const int t = idx / N, j = idx % N;
-        const unsigned e = ent[t];
-        const unsigned slot = e >> 16, a_loc = (e >> 8) & 0xffu, il = e & 0xffu, pos = posb[t * N + j];
-        if (il >= 8u || pos >= 128u || slot >= 256u || a_loc >= 8u) { bad = true; continue; }
-        const int key = (int)(il * 128u + pos);
-        const int s_ = atomicAdd(&cnt[key], 1);
-        if (s_ < TMAX) bucket[key * TMAX + s_] = (unsigned short)row_term(slot, a_loc, (unsigned)j);
-        else bad = true;
-    }
-    __syncthreads();
-    // fixed order of the terms of a block (the atomics above hand out positions in arbitrary order)
-    const int* el = p_elem ? p_elem + (size_t)p * us : nullptr;
-    auto term_key = [&](unsigned short v) -> long long {  // an element meets a block once: the element id alone orders the terms
-        return el ? (((long long)el[v & 255u] << 16) | v) : (long long)v;
-    };
-    for (int key = lane; key < NKEY; key += 64) {
-        const int Tn = min(cnt[key], TMAX);
-        unsigned short* b = bucket + key * TMAX;
-        for (int i = 1; i < Tn; ++i) {
-            const unsigned short v = b[i];
-            const long long kv = term_key(v);
-            int k = i - 1;
-            while (k >= 0 && term_key(b[k]) > kv) { b[k + 1] = b[k]; --k; }
-            b[k + 1] = v;
-        }
-    }
-    __syncthreads();
-    // classes: 5..8 terms -> 4 lanes, 3..4 -> 2 lanes, 2 -> one lane, 1 -> half a lane
-    int n4 = 0, n2 = 0, ns2 = 0, ns1 = 0;
-    for (int base = 0; base < NKEY; base += 64) {
-        const int Tn = min(cnt[base + lane], TMAX);
-        n4 += __popcll(__ballot(Tn >= 5));
-        n2 += __popcll(__ballot(Tn == 3 || Tn == 4));
-        ns2 += __popcll(__ballot(Tn == 2));
-        ns1 += __popcll(__ballot(Tn == 1));
-    }
-    const int base4 = 0, base2 = 4 * n4, bases2 = base2 + 2 * n2, bases1 = bases2 + ns2;
-    if (bases1 + (ns1 + 1) / 2 > 256) bad = true;
-    if (__ballot(bad)) {
-        if (lane == 0) atomicOr(status, 1);
-        for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(0u, 0u);
-        return;
-    }
-    int r4 = 0, r2 = 0, rs2 = 0, rs1 = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = 0; base < NKEY; base += 64) {
-        const int key = base + lane;
-        const int Tn = min(cnt[key], TMAX);
-        const unsigned il = (unsigned)key >> 7, pos = (unsigned)key & 127u;
-        const unsigned short* b = bucket + key * TMAX;
-        const unsigned long long m4 = __ballot(Tn >= 5), m2 = __ballot(Tn == 3 || Tn == 4), ms2 = __ballot(Tn == 2), ms1 = __ballot(Tn == 1);
-        auto lane_words = [&](int first, int Lidx, unsigned grp, bool leader) {
-            const int n = max(0, min(2, Tn - first));
-            unsigned x = ((unsigned)n << 28) | (grp << 30);
-            if (n >= 1) x |= (unsigned)b[first];
-            if (n >= 2) x |= (unsigned)b[first + 1] << 14;
-            lw0[Lidx] = x;
-            lw1[Lidx] = pos | (il << 7) | (leader ? (1u << 21) : 0u);
-        };
-        if (Tn >= 5) {
-            const int L0 = base4 + 4 * (r4 + __popcll(m4 & below));
-            for (int g = 0; g < 4; ++g) lane_words(2 * g, L0 + g, 2u, g == 0);
-        } else if (Tn >= 3) {
-            const int L0 = base2 + 2 * (r2 + __popcll(m2 & below));
-            for (int g = 0; g < 2; ++g) lane_words(2 * g, L0 + g, 1u, g == 0);
-        } else if (Tn == 2) {
-            lane_words(0, bases2 + rs2 + __popcll(ms2 & below), 0u, true);
-        } else if (Tn == 1) {
-            const int r = rs1 + __popcll(ms1 & below);
-            const int Lidx = bases1 + r / 2;
-            if ((r & 1) == 0) {
-                atomicAdd(&lw0[Lidx], (unsigned)b[0] | (1u << 28));
-                atomicAdd(&lw1[Lidx], pos | (il << 7) | (1u << 20) | (1u << 21));
-            } else {
-                atomicAdd(&lw0[Lidx], ((unsigned)b[0] << 14) | (1u << 28));
-                atomicAdd(&lw1[Lidx], (pos << 10) | (il << 17) | (1u << 22));
-            }
-        }
-        r4 += __popcll(m4); r2 += __popcll(m2); rs2 += __popcll(ms2); rs1 += __popcll(ms1);
-    }
-    __syncthreads();
-    for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
-}
-
-}  // namespace fenris_hip
-
-// ------------------------------------------------------------------------------------------------------------------
 // Tet4 (one-point rule): six terms per lane.  A node of a tetrahedral mesh has ~24 elements and ~15 columns: the diagonal
 // block takes 4 lanes (24 terms), everything else one lane.  Lane record (uint4):
 //   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 | nterms << 10 | log2(group) << 13 | store << 15
-namespace fenris_hip {
-
 struct RowTablesS {
     const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets (nbs + 1 words)
     const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256

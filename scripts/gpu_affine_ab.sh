@@ -20,3 +20,5 @@ run "v2 ablate 16 (dbg instantiation only)" FENRIS_HIP_ABLATE=16
 run "v2 ablate 3" FENRIS_HIP_ABLATE=3
 run "v2 ablate 14" FENRIS_HIP_ABLATE=14
 run "v2 ablate 15" FENRIS_HIP_ABLATE=15
+run "v2 staged store wave (64)" FENRIS_HIP_ABLATE=64
+run "v2 staged, no stores (65)" FENRIS_HIP_ABLATE=65

@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
     cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
     print("== counters:", f)
     q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-         "where (kernel_name like '%k_assemble%' or kernel_name like '%k_gather%') group by kernel_name, counter_name") if "kernel_name" in cols else None
+         "where kernel_name like '%fenris_hip::k_%' group by kernel_name, counter_name") if "kernel_name" in cols else None
     if q is None:
         print("   columns:", cols)
         continue

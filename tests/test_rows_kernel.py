@@ -1,7 +1,5 @@
-"""Row-owner (atomics-free) forms of the stiffness kernel (fenris_amd/csrc/rows_kernel.hpp): the Tet4 / one-point-rule
-kernel, which is the default there, and the Hex8 kernel, opt-in through FENRIS_HIP_ROWS (measured slower than the pipelined
-kernel).  Parity against the oracle on structured, distorted, mirrored / permuted, unstructured and masked meshes."""
-import os
+"""Row-owner (atomics-free) form of the stiffness kernel for Tet4 with a one-point rule (fenris_amd/csrc/rows_kernel.hpp),
+the default there.  Parity against the oracle on structured, distorted, unstructured / permuted and masked meshes."""
 
 import numpy as np
 import pytest
@@ -16,67 +14,9 @@ LAME = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
 
 @pytest.fixture()
 def rows_engine():
-    os.environ["FENRIS_HIP_ROWS"] = "1"
     eng = fa.Engine(0)
     yield eng
     eng.close()
-    del os.environ["FENRIS_HIP_ROWS"]
-
-
-def _meshes():
-    rng = np.random.default_rng(3)
-    out = {}
-    out["box12"] = fa.procedural.create_unit_box_uniform_hex_mesh_3d(12)
-    b = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 2, 1, 1, 5)
-    out["distorted"] = fa.Mesh(b.vertices + 0.03 * rng.standard_normal(b.vertices.shape), b.connectivity, fa.HEX8)
-    v = b.vertices + 0.02 * rng.standard_normal(b.vertices.shape)
-    conn = b.connectivity.copy()
-    flip = rng.random(len(conn)) < 0.5
-    conn[flip] = conn[flip][:, [4, 5, 6, 7, 0, 1, 2, 3]]
-    perm = rng.permutation(len(v))
-    inv = np.empty_like(perm)
-    inv[perm] = np.arange(len(v))
-    out["mirrored_permuted"] = fa.Mesh(v[perm], inv[conn][rng.permutation(len(conn))], fa.HEX8)
-    out["single_element"] = fa.procedural.create_unit_box_uniform_hex_mesh_3d(1)
-    out["thin_7x1x1"] = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 7, 1, 1, 1)
-    return out
-
-
-@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
-@pytest.mark.parametrize("name", ["box12", "distorted", "mirrored_permuted", "single_element", "thin_7x1x1"])
-def test_rows_kernel_matches_oracle(rows_engine, oracle, name, op):
-    mesh = _meshes()[name]
-    w, p = quadrature.tensor.hexahedron_gauss(2)
-    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
-    if op == "LAPLACE":
-        oper, oparams, oop = fa.LaplaceOperator(), None, oracle.LAPLACE
-    else:
-        qt = qt.with_uniform_data(LAME)
-        oper, oparams, oop = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), LAME.as_pair(), oracle.LINEAR_ELASTIC
-    asm = (fa.ElementEllipticAssemblerBuilder(rows_engine).with_finite_element_space(mesh).with_operator(oper)
-           .with_quadrature_table(qt).with_u(None).build())
-    ref = oracle.ElementAssembler(oracle.HEX8, oop, mesh.vertices, mesh.connectivity, w, p, params=oparams)
-    st, _, ro, ci, vals = oracle.assemble(ref)
-    assert st == 0
-    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    # a randomly numbered mesh has node blocks the lane table cannot express (too many elements per block): it keeps the
-    # pipelined kernel -- the fallback is part of the contract
-    expect = ("k_gather_rows", "k_gather_pipelined") if name == "mirrored_permuted" else ("k_gather_rows",)
-    assert rows_engine.last_kernel_name() in expect
-    assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
-    assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
-    # accumulate on top
-    fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
-    assert np.abs(k.values - 2.0 * vals).max() <= 2 * TOL * np.abs(vals).max()
-    # element mask: only the active elements contribute
-    active = (np.arange(mesh.num_elements()) % 3 != 1)
-    rows_engine.set_active_elements(active)
-    km = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert rows_engine.last_kernel_name() in expect
-    ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)   # same pattern (the mask keeps the mesh's pattern), element-centric kernel
-    assert np.abs(km.values - ka.values).max() <= TOL * max(np.abs(ka.values).max(), 1e-300)
-    assert np.abs(ka.values).max() < np.abs(vals).max() * 1.0000001 and not np.array_equal(ka.values, vals)
-    rows_engine.set_active_elements(None)
 
 
 @pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])

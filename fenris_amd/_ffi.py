@@ -57,6 +57,8 @@ _SIGS = {
     "fh_set_quadrature_compact": (C.c_int, [C.c_void_p, f64p, f64p, C.c_uint32, C.c_uint64, f64p, u64p]),
     "fh_set_row_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "fh_set_operator": (C.c_int, [C.c_void_p, C.c_int]),
+    "fh_set_quadrature_rules": (C.c_int, [C.c_void_p, C.c_uint64, u64p, f64p, f64p, f64p, u64p]),
+    "fh_quadrature_rule_groups": (C.c_int, [C.c_void_p, u64p]),
     "fh_set_affine_tolerance": (C.c_int, [C.c_void_p, C.c_double]),
     "fh_affine_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "fh_set_quadrature_uniform": (C.c_int, [C.c_void_p, f64p, f64p, C.c_uint32, f64p]),

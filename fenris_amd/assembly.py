@@ -91,9 +91,20 @@ class Engine:
 
     def set_quadrature_table(self, qtable):
         """UniformQuadratureTable or CompactQuadratureTable"""
-        if hasattr(qtable, "rules"):  # walked rule by rule by the global assemblers; stage the first rule for now
-            w, p, d = qtable.rules[0]
-            self.set_quadrature_uniform(w, p, d)
+        if hasattr(qtable, "rules"):  # rule-set table: grouped and walked inside the library (fh_set_quadrature_rules)
+            rules = qtable.rules
+            offs = np.zeros(len(rules) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([len(r[0]) for r in rules])
+            w = np.ascontiguousarray(np.concatenate([r[0] for r in rules]), dtype=np.float64)
+            p = np.ascontiguousarray(np.concatenate([np.asarray(r[1], dtype=np.float64).reshape(len(r[0]), -1) for r in rules]))
+            has_d = [r[2] is not None for r in rules]
+            if any(has_d) and not all(has_d):
+                raise ValueError("either every rule carries data or none does")
+            d = np.ascontiguousarray(np.concatenate([r[2] for r in rules]), dtype=np.float64) if all(has_d) else None
+            emap = _ffi.as_u64(qtable.element_to_rule_map)
+            self._keep_q = (offs, w, p, d, emap)
+            self._check(self._lib.fh_set_quadrature_rules(self._h, len(rules), _ffi.up(offs), _ffi.fp(w), _ffi.fp(p), _ffi.fp(d),
+                                                          _ffi.up(emap)))
         elif hasattr(qtable, "rule_params"):
             w, p = _ffi.as_f64(qtable.weights), _ffi.as_f64(qtable.points)
             self._keep_q = (w, p, qtable.rule_params, qtable.element_to_rule_map)
@@ -648,27 +659,6 @@ class MockElementAssembler:
 
 
 # ------------------------------------------------------------------------------------------ global
-def _for_each_rule(element_assembler, fn):
-    """Runs ``fn()`` once per distinct rule of a rule-set table (uniform tables: once), with the rule staged and the
-    element mask restricted to the elements that use it; every fn must ACCUMULATE into its output."""
-    qt = getattr(element_assembler, "qtable", None)
-    if qt is None or not hasattr(qt, "rules"):
-        return [fn()]
-    eng = element_assembler.engine
-    out = []
-    try:
-        for r, (w, p, d) in enumerate(qt.rules):
-            mask = (qt.element_to_rule_map == r).astype(np.uint8)
-            if not mask.any():
-                continue
-            eng.set_quadrature_uniform(w, p, d)
-            eng.set_active_elements(mask)
-            out.append(fn())
-    finally:
-        eng.set_active_elements(None)
-    return out
-
-
 class CsrAssembler:
     """src/assembly/global.rs:24-183.  ``scatter`` picks the device strategy (default: atomic adds)."""
 
@@ -702,12 +692,9 @@ class CsrAssembler:
             raise ValueError("CSR matrix does not have the pattern of this element assembler")
         flags = self.scatter
 
-        def run():
-            if flags == SCATTER_COLORED:
-                eng.color()
-            eng.assemble_matrix(csr.values, flags)
-
-        _for_each_rule(element_assembler, run)
+        if flags == SCATTER_COLORED:
+            eng.color()
+        eng.assemble_matrix(csr.values, flags)
 
 
 class CsrParAssembler:
@@ -727,11 +714,8 @@ class CsrParAssembler:
         eng = element_assembler.engine
         if len(csr.values) != eng.nnz():
             raise ValueError("CSR matrix does not have the pattern of this element assembler")
-        def run():
-            eng.set_colors(colors)
-            eng.assemble_matrix(csr.values, SCATTER_COLORED)
-
-        _for_each_rule(element_assembler, run)
+        eng.set_colors(colors)
+        eng.assemble_matrix(csr.values, SCATTER_COLORED)
 
 
 class VectorAssembler:
@@ -749,7 +733,7 @@ class VectorAssembler:
         if hasattr(element_assembler, "assemble_vector_into_engine"):  # ElementSourceAssembler
             element_assembler.assemble_vector_into_engine(output)
         else:
-            _for_each_rule(element_assembler, lambda: element_assembler.engine.assemble_vector(output))
+            element_assembler.engine.assemble_vector(output)
 
 
 class VectorParAssembler(VectorAssembler):
@@ -761,7 +745,7 @@ class VectorParAssembler(VectorAssembler):
 
 def assemble_scalar(element_assembler):
     """global.rs:697-711"""
-    return float(sum(_for_each_rule(element_assembler, element_assembler.engine.assemble_scalar)))
+    return float(element_assembler.engine.assemble_scalar())
 
 
 def color_nodes(mesh_or_assembler, engine: Optional[Engine] = None) -> DisjointSubsetsColors:

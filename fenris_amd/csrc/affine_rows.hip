@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     const int jl = tid - jbase;                       // >= 0 on Jacobian lanes
     const int jl_c = max(jl, 0);
     const int jk = jl_c & 3, jslot = jl_c >> 2;
-    auto load_lane = [&](int p) { return T.lanes[(size_t)((unsigned)min(p, npos - 1) * 256u + (unsigned)tid)]; };
+    // lane records: positions with identical records share one table (T.lanes[id]); the id rides in the header (flags >> 8)
+    auto load_lane_tab = [&](int id) { return T.lanes[(size_t)((unsigned)id * 256u + (unsigned)tid)]; };
     auto load_vidx = [&](int p) { return T.slotv[(size_t)((unsigned)min(p, npos - 1) * (unsigned)(4 * T.us) + (unsigned)jl_c)]; };
     double X[3];
     auto load_vert = [&](int v) {
@@ -229,13 +230,14 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         }
     };
 
-    uint2 lane_cur = load_lane(p_begin);
+    int id_cur = __builtin_amdgcn_readfirstlane(T.hdr[p_begin].z >> 8);
+    uint2 lane_cur = load_lane_tab(id_cur);
     int4 h_nxt = {0, 0, 0, 0};
     auto with_head = [&](int4 h) { h.w = head_of(h.x); return h; };
-    if (hwave) {
-        const int4 h0 = with_head(T.hdr[p_begin]);
-        h_nxt = T.hdr[min(p_begin + 1, npos - 1)];
-        if (tid == 0) HDR[p_begin & 3] = h0;
+    if (hwave) {  // the ring runs two positions ahead: the row waves read the lane-table id of p + 1 at the top of p
+        const int4 h0 = with_head(T.hdr[p_begin]), h1 = with_head(T.hdr[min(p_begin + 1, npos - 1)]);
+        h_nxt = T.hdr[min(p_begin + 2, npos - 1)];
+        if (tid == 0) { HDR[p_begin & 3] = h0; HDR[(p_begin + 1) & 3] = h1; }
     }
     int vi_nxt = 0;
     if (jwave) {
@@ -250,6 +252,7 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     lds_barrier();  // B0
 
     const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 12u;  // .w: head of the position
+    const unsigned hdr_addr_z = (unsigned)(unsigned long long)HDR + 8u;  // .z: flags | lane-table id << 8
     int par = 0;
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
         const bool have_next = (p + 1) < p_end;
@@ -259,14 +262,21 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         // prefetch: lane record of p + 1, vertices of p + 1 (their indices arrived during the previous position), indices and
         // header of p + 2
         uint2 lane_nxt = lane_cur;
-        if (!(DBG && (ablate & 8))) lane_nxt = load_lane(p + 1);
+        int id_nxt;
+        {
+            int z;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(z) : "v"(hdr_addr_z + 16u * (unsigned)((p + 1) & 3)) : "memory");
+            id_nxt = __builtin_amdgcn_readfirstlane(z) >> 8;
+        }
+        // the same table as this position's (the usual case inside a structured mesh): nothing to fetch
+        if (id_nxt != id_cur && !(DBG && (ablate & 8))) lane_nxt = load_lane_tab(id_nxt);
         int vi_nn = vi_nxt;
         if (jwave && !(DBG && (ablate & 4))) {
             load_vert(vi_nxt);
             vi_nn = load_vidx(p + 2);
         }
         int4 h_nn = h_nxt;
-        if (hwave) h_nn = T.hdr[min(p + 2, npos - 1)];
+        if (hwave) h_nn = T.hdr[min(p + 3, npos - 1)];
 
         const unsigned x = lane_cur.x, y = lane_cur.y;
         const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
@@ -376,8 +386,9 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
                 slot_record(p + 1, par ^ 1);
             }
         }
-        if (hwave && tid == 0) HDR[(p + 1) & 3] = with_head(h_nxt);
+        if (hwave && tid == 0) HDR[(p + 2) & 3] = with_head(h_nxt);
         h_nxt = h_nn;
+        id_cur = id_nxt;
         vi_nxt = vi_nn;
         lane_cur = lane_nxt;
         lds_barrier();
@@ -390,7 +401,8 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
 // offsets).  Terms are grouped by output block (node, column slot), ordered by element id, and dealt two per lane.
 __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                                                           const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
-                                                          int4* hdr_out, uint2* lanes, int* slotv, int* status) {
+                                                          int4* hdr_out, uint2* lanes, int* slotv, int* status,
+                                                          unsigned long long* hash_out) {
     constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
     __shared__ int cnt[NKEY];
     __shared__ unsigned short bucket[NKEY * TMAX];
@@ -453,6 +465,7 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
             hdr_out[p] = make_int4(h.r0, h.nrow, 0, h.U);
         }
         for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(idle, 0u);
+        if (lane == 0) hash_out[p] = 0ull;
         return;
     }
     int r4 = 0, r2 = 0, r1 = 0;
@@ -495,17 +508,48 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
     }
     __syncthreads();
-    for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
+    unsigned long long hsum = 0ull;  // order-independent hash of the 256 records (positions with equal tables are merged)
+    for (int i = lane; i < 256; i += 64) {
+        lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
+        unsigned long long z = ((unsigned long long)lw1[i] << 32 | lw0[i]) + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        hsum += z ^ (z >> 31);
+    }
+    for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
+    if (lane == 0) hash_out[p] = hsum;
     // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
     if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, (n4 + n2 + n1 == h.nrow) ? 1 : 0, h.U);
 }
 
+// table id of every position into its header (flags | id << 8), and the first position of every id gathered into the
+// compact table; *mismatch is set when a position's records differ from its table's (hash collision)
+__global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_full, const int* ids, const int* first_pos, int npos,
+                                                             int ntab, uint2* lanes_tab, int4* hdr, int* mismatch) {
+    const int p = blockIdx.x, t = threadIdx.x;
+    if (p < ntab) lanes_tab[(size_t)p * 256 + t] = lanes_full[(size_t)first_pos[p] * 256 + t];
+    if (p < npos) {
+        const int id = ids[p];
+        const uint2 mine = lanes_full[(size_t)p * 256 + t], ref = lanes_full[(size_t)first_pos[id] * 256 + t];
+        if (mine.x != ref.x || mine.y != ref.y) *mismatch = 1;
+        if (t == 0) hdr[p].z = (hdr[p].z & 1) | (id << 8);
+    }
+}
+
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* slotv, int* status) {
+                             int* slotv, int* status, unsigned long long* hash) {
     if (npos <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
-                       p_elem, hdr, lanes, slotv, status);
+                       p_elem, hdr, lanes, slotv, status, hash);
+    return hipGetLastError();
+}
+
+hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, const int* ids, const int* first_pos, int npos, int ntab,
+                               uint2* lanes_tab, int4* hdr, int* mismatch) {
+    if (npos <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_affine_rows_compact, dim3(npos > ntab ? npos : ntab), dim3(256), 0, stream, lanes_full, ids, first_pos, npos, ntab,
+                       lanes_tab, hdr, mismatch);
     return hipGetLastError();
 }
 

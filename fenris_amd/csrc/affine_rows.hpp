@@ -10,8 +10,9 @@ namespace fenris_hip {
 // per-position tables (position = node block all of whose elements are affine, in CSR order)
 struct AffineRowTables {
     const int4* hdr;      // [npos]       {r0: first node-level CSR entry, nrow: node-level entries of the block's rows,
-                          //               flags (bit 0: every (node, column) block of the rows has an owner lane), number of slots}
-    const uint2* lanes;   // [npos][256]  lane records, see affine_rows.hip
+                          //               flags (bit 0: every (node, column) block of the rows has an owner lane) | lane table << 8,
+                          //               number of slots}
+    const uint2* lanes;   // [ntab][256]  lane records, see affine_rows.hip; positions with identical records share a table
     const int* slotv;     // [npos][us][4] geometry nodes 0, 1, 3, 4 of the element in each slot (the edges xi, eta, zeta from node 0)
     const int* elem;      // [npos][us]   element id per slot (-1: empty), read only to report a singular Jacobian
     const double* ghat;   // [64][GW]     reference blocks Ghat_ab (all 64 (a, b); LinearElastic GW = 10, Laplace GW = 6)
@@ -28,7 +29,13 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 // (more than 8 terms per block, more than 256 lanes, offsets out of range).
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* slotv, int* status);
+                             int* slotv, int* status, unsigned long long* hash);
+
+// Positions with identical lane records share one table: `lanes_full` [npos][256] as written by affine_rows_build, `ids` the
+// table of every position, `first_pos` [ntab] a position that holds each table.  Writes the compact tables, puts the id into
+// every header, and sets *mismatch if the records of a position differ from its table (callers fall back to ids = identity).
+hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, const int* ids, const int* first_pos, int npos, int ntab,
+                               uint2* lanes_tab, int4* hdr, int* mismatch);
 
 // op: FH_LAPLACE or FH_LINEAR_ELASTIC; ablate != 0 selects the instrumented instantiation (profiling only)
 hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,

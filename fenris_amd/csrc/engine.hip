@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/fenris_hip.h"
@@ -340,10 +341,25 @@ struct fh_ctx {
     DevBuf<uint2> a_lanes;          // lane records
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<int> a_slotv;            // four vertices per slot
-    int a_us = 0, a_npos = 0;
+    int a_us = 0, a_npos = 0, a_ntab = 0;
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
+    // Rule-set quadrature tables (fh_set_quadrature_rules: GeneralQuadratureTable, CompactQuadratureTable with different
+    // point sets).  Rules with identical points and weights form a group; a group is staged as a uniform / compact table
+    // with the element mask restricted to its elements, and the global assemblers walk the groups, accumulating.
+    struct RuleSet {
+        bool active = false;
+        std::vector<uint64_t> offs;          // num_rules + 1: points of rule r are [offs[r], offs[r + 1])
+        std::vector<double> w, pts, par;     // concatenated weights, points (x d), parameters (x 2; empty: none)
+        std::vector<uint32_t> e2r;           // E
+        std::vector<int> rule_group, rule_local;
+        std::vector<std::vector<uint32_t>> groups;  // rules of each group
+        int staged = -1;
+    } rs;
+    bool rs_staging = false;                 // the setters are being called by the group walk, not by the user
+    std::vector<uint8_t> user_mask;          // fh_set_active_elements as the caller gave it
+    bool user_has_mask = false;
     // colours
     bool has_colors = false;
     std::vector<uint64_t> color_offsets;
@@ -659,7 +675,10 @@ int build_partition(fh_ctx* c) {
     unsigned max_row = 0;
     for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
     // nodes per block (tunable), entry capacity per batch, accumulator budget
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", S == 1 ? 8 : 7)));  // < 256: packed in 8 bits
+    // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
+    const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
+                          (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
+    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
     const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
     const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
@@ -727,6 +746,16 @@ int build_partition(fh_ctx* c) {
         }
     }
     c->nblk = (int)blk.size() - 1;
+    if (c->nblk <= 0) {  // empty row range: nothing to build, nothing to launch
+        c->nblk = 0;
+        c->has_pipe = false;
+        c->has_rows = false;
+        c->has_slotpar = false;
+        c->a_npos = 0;
+        c->npos_gen = 0;
+        c->has_partition = true;
+        return FH_OK;
+    }
     {   // tighten the accumulator budget to the largest block actually formed
         long long mx = 1;
         for (size_t b = 0; b + 1 < blk.size(); ++b) mx = std::max<long long>(mx, (long long)c->h_noff[blk[b + 1]] - c->h_noff[blk[b]]);
@@ -907,15 +936,63 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                 HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
                 HIP_TRY(c, c->a_slotv.alloc((size_t)npos * us * 4));
-                HIP_TRY(c, c->a_lanes.alloc((size_t)npos * 256));
+                DevBuf<uint2> lanes_full;
+                DevBuf<unsigned long long> hash_d;
+                HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
+                HIP_TRY(c, hash_d.alloc((size_t)npos));
                 HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
-                                             c->p_cs, c->a_elem.p, c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, st.p));
+                                             c->p_cs, c->a_elem.p, c->a_hdr.p, lanes_full.p, c->a_slotv.p, st.p, hash_d.p));
                 int bad = 0;
                 HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                std::vector<unsigned long long> hash_h((size_t)npos);
+                HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (bad) {  // a block the lane tables cannot express: everything on the general kernels
                     c->aff_failed = true;
                     return build_partition(c);
+                }
+                // positions with identical lane records (the interior of a structured mesh) share one table: the kernel
+                // skips the fetch when the table does not change, and what it fetches stays in the caches
+                {
+                    std::vector<int> ids((size_t)npos), first;
+                    auto dedupe = [&](bool identity) {
+                        first.clear();
+                        if (identity) {
+                            first.resize((size_t)npos);
+                            for (int p = 0; p < npos; ++p) { ids[p] = p; first[p] = p; }
+                            return;
+                        }
+                        std::unordered_map<unsigned long long, int> seen;
+                        seen.reserve(1024);
+                        for (int p = 0; p < npos; ++p) {
+                            auto it = seen.find(hash_h[p]);
+                            if (it == seen.end()) {
+                                it = seen.emplace(hash_h[p], (int)first.size()).first;
+                                first.push_back(p);
+                            }
+                            ids[p] = it->second;
+                        }
+                    };
+                    dedupe(std::getenv("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23));  // the id has 23 bits
+                    for (int attempt = 0; attempt < 2; ++attempt) {
+                        const int ntab = (int)first.size();
+                        DevBuf<int> ids_d, first_d;
+                        HIP_TRY(c, ids_d.alloc((size_t)npos));
+                        HIP_TRY(c, first_d.alloc((size_t)ntab));
+                        HIP_TRY(c, c->a_lanes.alloc((size_t)ntab * 256));
+                        HIP_TRY(c, hipMemcpyAsync(ids_d.p, ids.data(), sizeof(int) * (size_t)npos, hipMemcpyHostToDevice, c->stream));
+                        HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
+                        HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                        HIP_TRY(c, affine_rows_compact(c->stream, lanes_full.p, ids_d.p, first_d.p, npos, ntab, c->a_lanes.p, c->a_hdr.p, st.p));
+                        int mismatch = 0;
+                        HIP_TRY(c, hipMemcpyAsync(&mismatch, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        c->a_ntab = ntab;
+                        if (!mismatch) break;
+                        dedupe(true);  // a hash collision: every position keeps its own table
+                    }
+                    if (std::getenv("FENRIS_HIP_VERBOSE"))
+                        std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables\n", npos, c->a_ntab);
                 }
                 c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
                 c->a_npos = npos;
@@ -1220,13 +1297,13 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     return FH_OK;
 }
 
-int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags) {
+int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset = true) {
     int rc = check_ready(c, "fh_assemble_matrix", true);
     if (rc) return rc;
     if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
     const int mode = flags & FH_SCATTER_MASK;
     const int overwrite = (flags & FH_ASSEMBLE_OVERWRITE) ? 1 : 0;
-    rc = reset_status(c);
+    if (reset) rc = reset_status(c);
     if (rc) return rc;
     if (c->E == 0) return FH_OK;
     KArgs a;
@@ -1547,6 +1624,9 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->has_aff = false;
     c->aff_failed = false;
     c->has_ghat = false;
+    c->rs.active = false;  // rule-set tables and element masks are per-mesh state
+    c->user_has_mask = false;
+    c->user_mask.clear();
     c->row_lo = 0;   // the row range is per-mesh state
     c->row_hi = -1;
     c->nq = 0;  // reference gradient tables depend on the element kind
@@ -1655,9 +1735,15 @@ int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint6
     return FH_OK;
 }
 
+static int apply_mask(fh_ctx* c, const uint8_t* mask);
 int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
     if (!c) return FH_BAD_ARGUMENT;
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_active_elements: set the mesh first");
+    c->user_has_mask = mask != nullptr;
+    if (mask) c->user_mask.assign(mask, mask + c->E); else c->user_mask.clear();
+    return apply_mask(c, mask);
+}
+static int apply_mask(fh_ctx* c, const uint8_t* mask) {
     c->has_partition = false; c->has_tp_pos = false;
     if (!mask) {
         c->has_mask = false;
@@ -1726,6 +1812,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
 
 int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uint32_t nq, const double* params) {
     if (!c) return FH_BAD_ARGUMENT;
+    if (!c->rs_staging) c->rs.active = false;
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_uniform: set the mesh first");
     if (!w || !pts || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform: bad argument");
     const ElemInfo& ei = c->ei;
@@ -1830,6 +1917,118 @@ int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uin
     return FH_OK;
 }
 
+// ---- rule-set tables (quadrature_table.rs:57-210 GeneralQuadratureTable, :300-439 CompactQuadratureTable)
+static int rs_stage(fh_ctx* c, int g) {
+    auto& rs = c->rs;
+    const auto& G = rs.groups[(size_t)g];
+    const int d = c->ei.d;
+    const uint32_t r0 = G[0];
+    const uint32_t nq = (uint32_t)(rs.offs[r0 + 1] - rs.offs[r0]);
+    const double* w = rs.w.data() + rs.offs[r0];
+    const double* p = rs.pts.data() + rs.offs[r0] * (size_t)d;
+    int rc;
+    c->rs_staging = true;
+    if (rs.par.empty()) {
+        rc = fh_set_quadrature_uniform(c, w, p, nq, nullptr);
+    } else if (G.size() == 1) {
+        rc = fh_set_quadrature_uniform(c, w, p, nq, rs.par.data() + 2 * rs.offs[r0]);
+    } else {  // rules that share points and weights and differ in their data: the compact device table
+        std::vector<double> rp(G.size() * (size_t)nq * 2);
+        for (size_t k = 0; k < G.size(); ++k)
+            std::memcpy(rp.data() + k * nq * 2, rs.par.data() + 2 * rs.offs[G[k]], sizeof(double) * nq * 2);
+        std::vector<uint64_t> local((size_t)c->E, 0);
+        for (uint64_t el = 0; el < c->E; ++el)
+            if (rs.rule_group[rs.e2r[el]] == g) local[el] = (uint64_t)rs.rule_local[rs.e2r[el]];
+        rc = fh_set_quadrature_compact(c, w, p, nq, G.size(), rp.data(), local.data());
+    }
+    c->rs_staging = false;
+    if (rc) return rc;
+    std::vector<uint8_t> m((size_t)c->E);
+    for (uint64_t el = 0; el < c->E; ++el)
+        m[el] = (rs.rule_group[rs.e2r[el]] == g && (!c->user_has_mask || c->user_mask[el])) ? 1 : 0;
+    rc = apply_mask(c, m.data());
+    rs.staged = g;
+    return rc;
+}
+
+// fn(first) once per group that has active elements, with the group staged; restores the caller's element mask
+extern "C++" {
+template <class F>
+static int rs_for_each_group(fh_ctx* c, F&& fn) {
+    auto& rs = c->rs;
+    std::vector<uint64_t> count(rs.groups.size(), 0);
+    for (uint64_t el = 0; el < c->E; ++el)
+        if (!c->user_has_mask || c->user_mask[el]) ++count[(size_t)rs.rule_group[rs.e2r[el]]];
+    int rc = FH_OK;
+    bool first = true;
+    for (size_t g = 0; g < rs.groups.size() && rc == FH_OK; ++g) {
+        if (count[g] == 0) continue;
+        rc = rs_stage(c, (int)g);
+        if (rc == FH_OK) rc = fn(first);
+        first = false;
+    }
+    const int rc2 = apply_mask(c, c->user_has_mask ? c->user_mask.data() : nullptr);
+    return rc ? rc : rc2;
+}
+}  // extern "C++"
+
+int fh_set_quadrature_rules(fh_ctx* c, uint64_t num_rules, const uint64_t* rule_offsets, const double* weights, const double* points,
+                            const double* params, const uint64_t* elem_to_rule) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (!c->has_mesh || c->ragged || c->op < 0) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_rules: set mesh and operator first");
+    if (!rule_offsets || !weights || !points || num_rules == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_rules: bad argument");
+    if (!elem_to_rule && num_rules != c->E)
+        return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_rules: without a map there must be one rule per element");
+    const size_t d = (size_t)c->ei.d;
+    auto& rs = c->rs;
+    rs.active = false;
+    rs.offs.assign(rule_offsets, rule_offsets + num_rules + 1);
+    for (uint64_t r = 0; r < num_rules; ++r)
+        if (rs.offs[r + 1] <= rs.offs[r] || rs.offs[r + 1] - rs.offs[r] > 0xffffffffull)
+            return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_rules: every rule needs at least one point");
+    const size_t total = (size_t)rs.offs[num_rules];
+    rs.w.assign(weights, weights + total);
+    rs.pts.assign(points, points + total * d);
+    if (params) rs.par.assign(params, params + total * 2); else rs.par.clear();
+    rs.e2r.resize((size_t)c->E);
+    for (uint64_t el = 0; el < c->E; ++el) {
+        const uint64_t r = elem_to_rule ? elem_to_rule[el] : el;
+        // "Each rule index must correspond to a provided quadrature rule" (quadrature_table.rs:366-372 panics)
+        if (r >= num_rules) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_rules: rule index out of bounds");
+        rs.e2r[el] = (uint32_t)r;
+    }
+    // groups: rules with bitwise identical points and weights
+    rs.rule_group.assign((size_t)num_rules, -1);
+    rs.rule_local.assign((size_t)num_rules, 0);
+    rs.groups.clear();
+    std::unordered_map<std::string, int> seen;
+    for (uint64_t r = 0; r < num_rules; ++r) {
+        const size_t nq = (size_t)(rs.offs[r + 1] - rs.offs[r]);
+        std::string key(reinterpret_cast<const char*>(rs.w.data() + rs.offs[r]), sizeof(double) * nq);
+        key.append(reinterpret_cast<const char*>(rs.pts.data() + rs.offs[r] * d), sizeof(double) * nq * d);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            it = seen.emplace(std::move(key), (int)rs.groups.size()).first;
+            rs.groups.emplace_back();
+        }
+        rs.rule_group[r] = it->second;
+        rs.rule_local[r] = (int)rs.groups[(size_t)it->second].size();
+        rs.groups[(size_t)it->second].push_back((uint32_t)r);
+    }
+    rs.active = true;
+    // the first group stays staged (element-level queries see a valid table); the assemblers restage as they walk
+    int rc = rs_stage(c, 0);
+    const int rc2 = apply_mask(c, c->user_has_mask ? c->user_mask.data() : nullptr);
+    if (rc || rc2) { rs.active = false; return rc ? rc : rc2; }
+    return FH_OK;
+}
+
+int fh_quadrature_rule_groups(const fh_ctx* c, uint64_t* num_groups) {
+    if (!c || !num_groups) return FH_BAD_ARGUMENT;
+    *num_groups = c->rs.active ? c->rs.groups.size() : 0;
+    return FH_OK;
+}
+
 static int set_u_common(fh_ctx* c, const double* u, hipMemcpyKind kind) {
     if (!c->has_mesh || c->ragged || c->op < 0) return c->fail(FH_INVALID_STATE, "fh_set_u: set mesh and operator first");
     if (!u) { c->has_u = false; return FH_OK; }
@@ -1931,10 +2130,27 @@ int fh_set_colors(fh_ctx* c, uint64_t num_colors, const uint64_t* color_offsets,
 }
 
 // ---- numeric assembly
+static bool mode_is_colored(int flags) { return (flags & FH_SCATTER_MASK) == FH_SCATTER_COLORED; }
 int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
     if (!c) return FH_BAD_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
-    return assemble_matrix_enqueue(c, values_dev, flags);
+    if (!c->rs.active) return assemble_matrix_enqueue(c, values_dev, flags);
+    // rule-set table: one pass per group of rules, the first one with the caller's flags, the others accumulating
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    rc = reset_status(c);
+    if (rc) return rc;
+    bool any = false;
+    rc = rs_for_each_group(c, [&](bool first) {
+        any = true;
+        if (mode_is_colored(flags) && !c->has_colors) return c->fail(FH_INVALID_STATE, "fh_assemble_matrix: FH_SCATTER_COLORED needs fh_color / fh_set_colors");
+        return assemble_matrix_enqueue(c, values_dev, first ? flags : (flags & ~FH_ASSEMBLE_OVERWRITE), false);
+    });
+    if (rc) return rc;
+    if (!any && (flags & FH_ASSEMBLE_OVERWRITE) && fh_nnz(c))
+        HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * fh_nnz(c), c->stream));
+    return FH_OK;
 }
 
 int fh_poll_status(fh_ctx* c, uint64_t* failed) {
@@ -1956,7 +2172,9 @@ int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
     const uint64_t nnz = fh_nnz(c);
     DevBuf<double> d;
     HIP_TRY(c, d.alloc((size_t)nnz));
-    if (!(flags & FH_ASSEMBLE_OVERWRITE))
+    // the staging copy starts from the caller's values unless every entry is about to be overwritten: with a row range
+    // (fh_set_row_range) FH_ASSEMBLE_OVERWRITE writes the rows in range only, "the others are left untouched"
+    if (!(flags & FH_ASSEMBLE_OVERWRITE) || c->row_hi >= 0)
         HIP_TRY(c, hipMemcpyAsync(d.p, values, sizeof(double) * nnz, hipMemcpyHostToDevice, c->stream));
     rc = fh_assemble_matrix_dev(c, d.p, flags, failed);
     if (rc) return rc;
@@ -1973,6 +2191,20 @@ int fh_assemble_element_matrices_dev(fh_ctx* c, uint64_t first, uint64_t count, 
     if (count == 0) return FH_OK;
     rc = reset_status(c);
     if (rc) return rc;
+    if (c->rs.active) {  // rule-set table: runs of consecutive elements whose rules share points and weights
+        const size_t ld = (size_t)c->S() * c->ei.n;
+        for (uint64_t e0 = first; e0 < first + count && rc == FH_OK;) {
+            const int g = c->rs.rule_group[c->rs.e2r[e0]];
+            uint64_t e1 = e0 + 1;
+            while (e1 < first + count && c->rs.rule_group[c->rs.e2r[e1]] == g) ++e1;
+            if (c->rs.staged != g) rc = rs_stage(c, g);
+            if (rc == FH_OK) rc = element_matrices_enqueue(c, e0, e1 - e0, ke_dev + ld * ld * (e0 - first), false);
+            e0 = e1;
+        }
+        const int rc2 = apply_mask(c, c->user_has_mask ? c->user_mask.data() : nullptr);
+        if (rc || rc2) return rc ? rc : rc2;
+        return read_status(c, nullptr);
+    }
     rc = element_matrices_enqueue(c, first, count, ke_dev, false);
     if (rc) return rc;
     return read_status(c, nullptr);
@@ -1994,8 +2226,35 @@ int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, doub
     return FH_OK;
 }
 
+// the groups of a rule-set table one after the other; every pass accumulates.  The lowest failing element over all groups
+// is reported, like the serial loop of the reference would (global.rs:154: first error aborts).
+extern "C++" {
+template <class F>
+static int rs_walk_accumulating(fh_ctx* c, uint64_t* failed, F&& single) {
+    uint64_t fmin = ~0ull;
+    bool singular = false;
+    int rc = rs_for_each_group(c, [&](bool) {
+        uint64_t f = 0;
+        const int r = single(&f);
+        if (r == FH_SINGULAR_JACOBIAN) { singular = true; fmin = std::min(fmin, f); return (int)FH_OK; }
+        return r;
+    });
+    if (rc) return rc;
+    if (singular) {
+        if (failed) *failed = fmin;
+        return c->fail(FH_SINGULAR_JACOBIAN, "Singular element Jacobian encountered");
+    }
+    return FH_OK;
+}
+}  // extern "C++"
+
+static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed);
 int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    if (!c->rs.active) return assemble_vector_single(c, out_dev, failed);
+    return rs_walk_accumulating(c, failed, [&](uint64_t* f) { return assemble_vector_single(c, out_dev, f); });
+}
+static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) {
     int rc = check_ready(c, "fh_assemble_vector", false);
     if (rc) return rc;
     if (c->op > FH_STVK) return c->fail(FH_UNSUPPORTED, "fh_assemble_vector: the mass assembler has no vector form");
@@ -2076,6 +2335,7 @@ static int source_ready(fh_ctx* c, const char* who) {
 
 int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, const double* values_dev, double* out_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_assemble_source_vector: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, "fh_assemble_source_vector");
     if (rc) return rc;
     const int D = c->ei.d;
@@ -2155,6 +2415,7 @@ int fh_assemble_source_vector(fh_ctx* c, uint32_t sdim, const double* g, const d
 
 int fh_physical_quadrature_points_dev(fh_ctx* c, double* x_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_physical_quadrature_points: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, "fh_physical_quadrature_points");
     if (rc) return rc;
     if (!x_dev) return c->fail(FH_BAD_ARGUMENT, "fh_physical_quadrature_points: output is null");
@@ -2189,8 +2450,22 @@ int fh_physical_quadrature_points(fh_ctx* c, double* x) {
     return FH_OK;
 }
 
+static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed);
 int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    if (!c->rs.active) return assemble_scalar_single(c, out, failed);
+    if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_scalar: out is null");
+    double tot = 0.0;
+    const int rc = rs_walk_accumulating(c, failed, [&](uint64_t* f) {
+        double part = 0.0;
+        const int r = assemble_scalar_single(c, &part, f);
+        tot += part;
+        return r;
+    });
+    *out = tot;
+    return rc;
+}
+static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed) {
     int rc = check_ready(c, "fh_assemble_scalar", false);
     if (rc) return rc;
     if (c->op > FH_STVK) return c->fail(FH_UNSUPPORTED, "fh_assemble_scalar: the mass assembler has no scalar form");
@@ -2423,6 +2698,7 @@ int fh_cg_solve(fh_ctx* c, const double* values, const double* b, double* x, int
 }
 
 static int error_squared(fh_ctx* c, int which, uint32_t sdim, const double* uh_dev, const double* exact_dev, double* out) {
+    if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_estimate_*_error_squared: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, which ? "fh_estimate_H1_seminorm_error_squared" : "fh_estimate_L2_error_squared");
     if (rc) return rc;
     const int D = c->ei.d;

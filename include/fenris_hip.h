@@ -127,12 +127,27 @@ int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* poin
 /* CompactQuadratureTable::from_quadrature_rules_and_map (src/assembly/local/quadrature_table.rs:300-439) for rules
  * that share points and weights and differ in their per-point data -- piecewise material parameters: element e
  * uses rule_params[elem_to_rule[e]] (num_rules x nq x 2, same pair layout as the uniform table).  A rule index out
- * of bounds is FH_BAD_ARGUMENT (the reference panics).  Rules with different point sets are not expressible here:
- * assemble them rule by rule with fh_set_active_elements.  Rules whose data are the same at every point (one
+ * of bounds is FH_BAD_ARGUMENT (the reference panics).  Rules with different point sets: fh_set_quadrature_rules below.
+ * Rules whose data are the same at every point (one
  * LameParameters pair per element: the multi-material case) keep the fastest LinearElastic stiffness kernel, which then
  * reads the pair per element; rules that vary over their points take the per-point-coefficient kernels. */
 int fh_set_quadrature_compact(fh_ctx*, const double* weights, const double* points, uint32_t nq, uint64_t num_rules,
                               const double* rule_params, const uint64_t* elem_to_rule);
+/* Rule-set tables: GeneralQuadratureTable (one rule per element, src/assembly/local/quadrature_table.rs:57-210) and
+ * CompactQuadratureTable::from_quadrature_rules_and_map with rules of DIFFERENT point sets (:300-439).  Rule r holds the
+ * points [rule_offsets[r], rule_offsets[r + 1]) of `weights` (total), `points` (total x d) and `params` (total x 2, the pair
+ * layout of the uniform table, or NULL for operators without parameters); element e uses rule elem_to_rule[e]
+ * (NULL: rule e, then num_rules must equal the number of elements).  A rule index out of bounds or an empty rule is
+ * FH_BAD_ARGUMENT (the reference panics: check_rules_consistency, quadrature_table.rs:366-372).
+ * The engine groups the rules by (points, weights): a group runs as one uniform / compact device table over its elements,
+ * and fh_assemble_matrix*, fh_assemble_vector*, fh_assemble_scalar and fh_assemble_element_matrices* walk the groups
+ * inside the library, accumulating -- a table whose rules share their points costs one pass, E different point sets cost
+ * E passes.  The source-vector, physical-point and error-estimate entry points answer FH_UNSUPPORTED while such a table
+ * is set.  Replaced by the next fh_set_quadrature_* call; dropped by fh_set_mesh*. */
+int fh_set_quadrature_rules(fh_ctx*, uint64_t num_rules, const uint64_t* rule_offsets, const double* weights,
+                            const double* points, const double* params, const uint64_t* elem_to_rule);
+/* number of (points, weights) groups of the rule-set table in use (0: none set) = passes per assembly */
+int fh_quadrature_rule_groups(const fh_ctx*, uint64_t* num_groups);
 /* Affine-element fast path of FH_SCATTER_GATHER (Hex8; Laplace / LinearElastic with uniform parameters).  On an element
  * whose geometry map is affine the Jacobian of elliptic.rs:399 is the same at every quadrature point, so
  * K_ab = |det J| C(J^-T Ghat_ab J^-1) with Ghat_ab = sum_q w_q ghat_a ghat_b^T depending on the rule only -- the engine

@@ -251,3 +251,81 @@ def test_compact_table_helper_picks_the_single_launch_form():
     assert hasattr(qt2, "rules") and len(qt2.rules) == 2
     with pytest.raises(ValueError):
         fa.compact_quadrature_table([p], [w], [[fa.LameParameters(1, 1)] * len(w)], np.array([0, 1]))
+
+
+@pytest.mark.gpu
+def test_rule_set_table_through_the_c_abi(engine, oracle):
+    """fh_set_quadrature_rules called the way a Rust host would (raw arrays, include/fenris_hip.h): a GeneralQuadratureTable
+    with one rule PER ELEMENT (quadrature_table.rs:57-210) whose rules use two different point sets and per-element data.
+    The library groups the rules by (points, weights) -- two passes, not E -- and walks them for the matrix, the vector, the
+    energy and the element matrices; an element mask restricts all of them; entry points that do not walk say so."""
+    import ctypes as C
+
+    from fenris_amd import _ffi
+
+    m, _, _, _, _ = _setup("HEX8", seed=11)
+    E = m.num_elements()
+    w2, p2 = quadrature.tensor.hexahedron_gauss(2)
+    w3, p3 = quadrature.tensor.hexahedron_gauss(3)
+    rng = np.random.default_rng(12)
+    use3 = np.arange(E) % 4 == 1
+    lam = [(RULES[0][0] * (1.0 + 0.1 * rng.random()), RULES[0][1] * (1.0 + 0.1 * rng.random())) for _ in range(E)]
+    offs, W, P, D, rules = [0], [], [], [], []
+    for e in range(E):
+        w, p = (w3, p3) if use3[e] else (w2, p2)
+        d = np.tile(np.array(lam[e]), (len(w), 1))
+        offs.append(offs[-1] + len(w)); W.append(w); P.append(p); D.append(d)
+        rules.append((w, p, [fa.LameParameters(*lam[e])] * len(w)))
+    offs = np.array(offs, dtype=np.uint64)
+    W, P, D = (np.ascontiguousarray(np.concatenate(x), dtype=np.float64) for x in (W, P, D))
+    u = 0.01 * rng.standard_normal(3 * m.num_nodes())
+    engine.set_mesh(m)
+    engine.set_operator(_ffi.NEO_HOOKEAN)
+    lib, h = engine._lib, engine._h
+    engine._check(lib.fh_set_quadrature_rules(h, E, _ffi.up(offs), _ffi.fp(W), _ffi.fp(P), _ffi.fp(D), None))
+    ng = C.c_uint64()
+    assert lib.fh_quadrature_rule_groups(h, C.byref(ng)) == 0 and ng.value == 2
+    engine.set_u(u)
+    nnz = engine.build_pattern()
+    ro, ci, vals, fo, eo = _oracle_sum_over_rules(oracle, m, oracle.NEO_HOOKEAN, rules, np.arange(E), u)
+    for flags in (fa.SCATTER_GATHER, fa.SCATTER_ATOMIC):
+        buf = np.full(nnz, 7.0)
+        engine.assemble_matrix(buf, flags | fa.ASSEMBLE_OVERWRITE)
+        assert np.abs(buf - vals).max() <= 1e-12 * np.abs(vals).max()
+        engine.assemble_matrix(buf, flags)  # accumulate on top
+        assert np.abs(buf - 2.0 * vals).max() <= 2e-12 * np.abs(vals).max()
+    f = np.zeros(3 * m.num_nodes())
+    engine.assemble_vector(f)
+    assert np.abs(f - fo).max() <= 1e-12 * np.abs(fo).max()
+    assert abs(engine.assemble_scalar() - eo) <= 1e-12 * abs(eo)
+    # element matrices: every element with ITS rule
+    ke = engine.element_matrices(0, E)
+    for e in (0, 1, 2, 5, E - 1):
+        w, p, d = rules[e]
+        sub = oracle.ElementAssembler(oracle.HEX8, oracle.NEO_HOOKEAN, m.vertices, m.connectivity, w, p,
+                                      params=np.array([x.as_pair() for x in d]), u=u)
+        st, oke = sub.element_matrix(e)
+        assert st == 0
+        assert np.abs(ke[e] - oke).max() <= 1e-12 * np.abs(oke).max()
+    # element mask: both groups restricted
+    mask = (np.arange(E) % 3 != 0).astype(np.uint8)
+    engine.set_active_elements(mask)
+    sel = mask.astype(bool)
+    ro2, ci2, vals2, _, _ = _oracle_sum_over_rules(oracle, m, oracle.NEO_HOOKEAN, rules, np.where(sel, np.arange(E), -1), u)
+    buf = np.zeros(nnz)
+    engine.assemble_matrix(buf, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    assert np.abs(buf - vals2).max() <= 1e-12 * np.abs(vals).max()
+    engine.set_active_elements(None)
+    # entry points that do not walk the groups refuse instead of using one rule for every element
+    x = np.zeros((E * len(w2), 3))
+    assert lib.fh_physical_quadrature_points(h, _ffi.fp(x)) == _ffi.FH_UNSUPPORTED
+    # bad arguments: rule index out of bounds, empty rule
+    bad = np.arange(E, dtype=np.uint64)
+    bad[3] = E
+    assert lib.fh_set_quadrature_rules(h, E, _ffi.up(offs), _ffi.fp(W), _ffi.fp(P), _ffi.fp(D), _ffi.up(bad)) == _ffi.FH_BAD_ARGUMENT
+    offs_bad = offs.copy()
+    offs_bad[2] = offs_bad[1]
+    assert lib.fh_set_quadrature_rules(h, E, _ffi.up(offs_bad), _ffi.fp(W), _ffi.fp(P), _ffi.fp(D), None) == _ffi.FH_BAD_ARGUMENT
+    # a uniform table replaces the rule set
+    engine.set_quadrature_uniform(w2, p2, np.tile(np.array(RULES[0]), (len(w2), 1)))
+    assert lib.fh_quadrature_rule_groups(h, C.byref(ng)) == 0 and ng.value == 0

@@ -717,3 +717,24 @@ def test_mass_matrix_matches_oracle(engine, oracle, kind, sdim, scatter):
     assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
     with pytest.raises(fa.FenrisError):
         fa.VectorAssembler().assemble_vector(asm)
+
+
+def test_host_path_overwrite_with_row_range_keeps_other_rows(engine, oracle):
+    """fh_assemble_matrix (host arrays) with FH_ASSEMBLE_OVERWRITE and a row range: the rows in range are overwritten, every
+    other entry of the caller's array keeps its value (include/fenris_hip.h, fh_set_row_range) -- also for an empty range."""
+    mesh = fa.procedural.create_unit_box_uniform_hex_mesh_3d(5)
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", mesh=mesh)
+    st, _, ro, ci, vals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)       # builds the pattern
+    n = mesh.num_nodes()
+    for lo_n, hi_n in ((n // 3, 2 * n // 3), (7, 7)):
+        engine.set_row_range(lo_n, hi_n)
+        buf = np.full(len(vals), 123.25)
+        engine.assemble_matrix(buf, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        lo, hi = int(ro[3 * lo_n]), int(ro[3 * hi_n])
+        assert np.all(buf[:lo] == 123.25) and np.all(buf[hi:] == 123.25)
+        if hi > lo:
+            assert np.abs(buf[lo:hi] - vals[lo:hi]).max() <= TOL * np.abs(vals).max()
+    engine.set_row_range(0, n)
+    assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()

@@ -23,6 +23,8 @@
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
 
+extern char** environ;
+
 using namespace fenris_hip;
 
 namespace {
@@ -357,6 +359,17 @@ struct fh_ctx {
         std::vector<std::vector<uint32_t>> groups;  // rules of each group
         int staged = -1;
     } rs;
+    // Tuning / diagnostic switches: the FENRIS_HIP_* environment variables as they were when fh_create ran (read once; a
+    // host that wants different settings sets them before creating the context -- see include/fenris_hip.h)
+    std::unordered_map<std::string, std::string> env_vars;
+    const char* env(const char* name) const {
+        auto it = env_vars.find(name);
+        return it == env_vars.end() ? nullptr : it->second.c_str();
+    }
+    int env_int(const char* name, int dflt) const {
+        const char* v = env(name);
+        return (v && *v) ? std::atoi(v) : dflt;
+    }
     bool rs_staging = false;                 // the setters are being called by the group walk, not by the user
     std::vector<uint8_t> user_mask;          // fh_set_active_elements as the caller gave it
     bool user_has_mask = false;
@@ -394,11 +407,6 @@ struct fh_ctx {
     } while (0)
 
 namespace {
-
-int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : dflt;
-}
 
 int grid_for(long long n, int block, int cap = 256 * 32) {
     long long g = (n + block - 1) / block;
@@ -625,9 +633,9 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.n2e_off = c->n2e_off.p;
     a.n2e = c->n2e.p;
     a.status = c->status.p;
-    a.ablate = env_int("FENRIS_HIP_ABLATE", 0);
+    a.ablate = c->env_int("FENRIS_HIP_ABLATE", 0);
     a.trace = nullptr;
-    if (std::getenv("FENRIS_HIP_TRACE")) {
+    if (c->env("FENRIS_HIP_TRACE")) {
         if (!c->trace.p && c->trace.alloc(32) == hipSuccess) (void)hipMemset(c->trace.p, 0, 256);
         a.trace = c->trace.p;
     }
@@ -678,9 +686,9 @@ int build_partition(fh_ctx* c) {
     // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
                           (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
-    const int nb_target = std::max(1, std::min(64, env_int("FENRIS_HIP_GATHER_NB", (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
-    const int mb = std::max(16, std::min(1024, env_int("FENRIS_HIP_GATHER_MB", 128)));
-    const size_t lds_target = (size_t)env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
+    const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
+    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", 128)));
+    const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     long long sum_rows = 0;
     for (int i = 0; i < N; ++i) sum_rows += c->h_noff[i + 1] - c->h_noff[i];
@@ -696,7 +704,7 @@ int build_partition(fh_ctx* c) {
     // so that every line of a structured mesh is cut at the same places and consecutive blocks of a sweep chain
     // share exactly the elements between two lines.  Short runs (unstructured numberings) are merged greedily.
     std::vector<unsigned char> link((size_t)N + 1, 1);
-    if (N > 0 && !std::getenv("FENRIS_HIP_NO_ALIGN")) {
+    if (N > 0 && !c->env("FENRIS_HIP_NO_ALIGN")) {
         DevBuf<unsigned char> link_d;
         HIP_TRY(c, link_d.alloc((size_t)N + 1));
         hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
@@ -783,7 +791,7 @@ int build_partition(fh_ctx* c) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
         }
-        c->has_pos = max_row < 256 && !std::getenv("FENRIS_HIP_NO_POS");
+        c->has_pos = max_row < 256 && !c->env("FENRIS_HIP_NO_POS");
         if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
         hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
@@ -823,7 +831,7 @@ int build_partition(fh_ctx* c) {
         if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, 1, acc, 64, true, mb, c->fast_ok) > LDS_LIMIT)
             return c->fail(FH_UNSUPPORTED, "gather mode: a row block does not fit in LDS; use FH_SCATTER_ATOMIC");
     }
-    if (std::getenv("FENRIS_HIP_VERBOSE"))
+    if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] gather partition: nblk=%d nb=%d umax=%d mmax=%d acc=%d ub=%d lds=%zu B\n", c->nblk,
                      nb_target, umax, mmax, acc, ub,
                      layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, ub, acc, 64, true, mb, c->fast_ok));
@@ -832,12 +840,12 @@ int build_partition(fh_ctx* c) {
     c->has_rows = false;
     c->a_npos = 0;
     c->npos_gen = c->nblk;
-    if (c->has_pos && !std::getenv("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
+    if (c->has_pos && !c->env("FENRIS_HIP_NO_PIPE") && c->ei.n == c->ei.ng && c->ei.n <= 8 && c->nblk > 0) {
         const int n = c->ei.n;
         const int ms = (mmax + 3) / 4 * 4;
         const int us = (umax + 3) / 4 * 4;
         // local nodes per lane in the pipelined kernel's phase C
-        int jt = env_int("FENRIS_HIP_PIPE_JT", (n % 2 == 0) ? 2 : n);
+        int jt = c->env_int("FENRIS_HIP_PIPE_JT", (n % 2 == 0) ? 2 : n);
         if (jt != 1 && jt != 2 && jt != 4 && jt != n) jt = 1;
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
@@ -850,7 +858,7 @@ int build_partition(fh_ctx* c) {
             DevBuf<unsigned char> cls_d;
             const bool want_aff = c->elem_kind == FH_HEX8 && c->has_aff && c->has_ghat && c->num_aff > 0 && !c->has_rules &&
                                   !c->aff_failed && c->affine_tol > 0.0 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
-                                  us <= 32 && nb_target <= 8 && !std::getenv("FENRIS_HIP_NO_AFFINE");
+                                  us <= 32 && nb_target <= 8 && !c->env("FENRIS_HIP_NO_AFFINE");
             if (want_aff) {
                 HIP_TRY(c, cls_d.alloc((size_t)nblk));
                 hipLaunchKernelGGL(k_block_class, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, c->gt_elems.p,
@@ -863,7 +871,7 @@ int build_partition(fh_ctx* c) {
             std::vector<int> order[2], chain_off[2];
             chain_off[0].push_back(0);
             chain_off[1].push_back(0);
-            if (!std::getenv("FENRIS_HIP_NO_SWEEP")) {
+            if (!c->env("FENRIS_HIP_NO_SWEEP")) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
                 HIP_TRY(c, hipMemsetAsync(node2blk.p, 0xff, sizeof(int) * ((size_t)N + 1), c->stream));  // -1: not in a block
@@ -973,7 +981,7 @@ int build_partition(fh_ctx* c) {
                             ids[p] = it->second;
                         }
                     };
-                    dedupe(std::getenv("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23));  // the id has 23 bits
+                    dedupe(c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23));  // the id has 23 bits
                     for (int attempt = 0; attempt < 2; ++attempt) {
                         const int ntab = (int)first.size();
                         DevBuf<int> ids_d, first_d;
@@ -991,7 +999,7 @@ int build_partition(fh_ctx* c) {
                         if (!mismatch) break;
                         dedupe(true);  // a hash collision: every position keeps its own table
                     }
-                    if (std::getenv("FENRIS_HIP_VERBOSE"))
+                    if (c->env("FENRIS_HIP_VERBOSE"))
                         std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables\n", npos, c->a_ntab);
                 }
                 c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
@@ -1003,14 +1011,14 @@ int build_partition(fh_ctx* c) {
                 if (rs) return rs;
             }
             c->has_pipe = true;
-            if (std::getenv("FENRIS_HIP_VERBOSE"))
+            if (c->env("FENRIS_HIP_VERBOSE"))
                 std::fprintf(stderr, "[fenris_hip] sweep order: %d general blocks in %d chains, %d affine blocks in %d chains (us=%d ms=%d)\n",
                              c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, (int)chain_off[1].size() - 1, us, ms);
             c->has_rows = false;
             const int npg = c->npos_gen;
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
-            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !std::getenv("FENRIS_HIP_NO_ROWS")) {
+            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !c->env("FENRIS_HIP_NO_ROWS")) {
                 c->r_rw = 8 + us / 4 + nb_target + 1;
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
@@ -1029,7 +1037,7 @@ int build_partition(fh_ctx* c) {
                     if (bad != 2) break;  // 2: only the stride was too small
                 }
                 c->has_rows = bad == 0;
-                if (std::getenv("FENRIS_HIP_VERBOSE"))
+                if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, stride %d): %s\n", c->r_ls,
                                  c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
@@ -1058,11 +1066,11 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
-    const int grid = std::min(c->npos_gen, dev_cus * env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int grid = std::min(c->npos_gen, dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     auto kern = k_gather_rows_tet4<OP, ELEMPAR>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (std::getenv("FENRIS_HIP_VERBOSE"))
+    if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] row-owner gather (Tet4): lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
     HIP_TRY(c, hipGetLastError());
@@ -1078,17 +1086,17 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     bool fullq = false;
     if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
         const size_t lds_planar = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC, 0, 1).bytes();
-        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 && !std::getenv("FENRIS_HIP_NO_FULLQ") &&
+        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 && !c->env("FENRIS_HIP_NO_FULLQ") &&
                 (2 * lds_planar + 1024 <= LDS_LIMIT || 2 * lds + 1024 > LDS_LIMIT);
         if (fullq) lds = lds_planar;
     }
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int wgs = std::max(1, env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int wgs = std::max(1, c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     const int grid = std::min(c->npos_gen, dev_cus * wgs);
     // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
-    const bool dbg = (std::getenv("FENRIS_HIP_TRACE") || std::getenv("FENRIS_HIP_ABLATE") || std::getenv("FENRIS_HIP_DBG_KERNEL"));
+    const bool dbg = (c->env("FENRIS_HIP_TRACE") || c->env("FENRIS_HIP_ABLATE") || c->env("FENRIS_HIP_DBG_KERNEL"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
     constexpr int N_ = ElemT<EK>::N;
     constexpr bool DEFAULT_JT = JT == ((N_ % 2 == 0) ? 2 : N_);  // per-element data: the default tiling only
@@ -1111,7 +1119,7 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     }
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (std::getenv("FENRIS_HIP_VERBOSE"))
+    if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] pipelined gather: QC=%d JT=%d lds=%zu B wgs/cu=%d grid=%d\n", QC, JT, lds, wgs, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
     HIP_TRY(c, hipGetLastError());
@@ -1132,7 +1140,7 @@ template <int EK, int OP>
 int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
     // staged quadrature points per chunk: the largest chunk (not larger than the rule) that still lets >= 2
     // workgroups share a CU (measured on Hex8: profiles/r01_sweep_128_pipelined_nb_qc_jt.txt)
-    int qc = env_int("FENRIS_HIP_PIPE_QC", 0);
+    int qc = c->env_int("FENRIS_HIP_PIPE_QC", 0);
     if (qc <= 0) {
         qc = 1;
         for (int cand : {8, 4, 2}) {
@@ -1172,8 +1180,8 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
     const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
-    const int grid = std::min(c->a_npos, dev_cus * env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
-    if (std::getenv("FENRIS_HIP_VERBOSE"))
+    const int grid = std::min(c->a_npos, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+    if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
     HIP_TRY(c, affine_rows_launch(c->op, grid, lds, c->stream, a, T, a.ablate));
     return FH_OK;
@@ -1210,7 +1218,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     // first pass: Hex27 LinearElastic / NeoHookean with a uniform table run on the matrix cores (hex27_mfma.hpp) and
     // write the planar layout; everything else takes the generic element kernel (column-major K_e)
     const bool mfma = c->elem_kind == FH_HEX27 && (c->op == FH_LINEAR_ELASTIC || c->op == FH_NEO_HOOKEAN) && !c->has_rules &&
-                      c->nq == 27 && c->has_params && !std::getenv("FENRIS_HIP_NO_MFMA");
+                      c->nq == 27 && c->has_params && !c->env("FENRIS_HIP_NO_MFMA");
     int rc = FH_OK;
     if (mfma) {
         KArgs a;
@@ -1278,7 +1286,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     do {                                                                                                                       \
         void (*kern)(int, int, const unsigned*, const unsigned*, const unsigned*, const PT*, const double*, double*, int, int) = \
             k_rows_from_dense<SS, PT, PL>;                                                                                     \
-        if (!PL && !std::getenv("FENRIS_HIP_NO_ROWS_SMALL")) {                                                                 \
+        if (!PL && !c->env("FENRIS_HIP_NO_ROWS_SMALL")) {                                                                 \
             const int ld_ = SS * (int)c->ei.n;                                                                                 \
             if (ld_ <= 8) kern = k_rows_from_dense_small<SS, PT, 8>;                                                           \
             else if (ld_ <= 16) kern = k_rows_from_dense_small<SS, PT, 16>;                                                    \
@@ -1311,15 +1319,15 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     a.vals = values_dev;
     a.overwrite = overwrite;
     const uint64_t nnz = (uint64_t)c->S() * c->S() * c->nnz_nodes;
-    if (mode == FH_SCATTER_GATHER && c->row_hi < 0 && !std::getenv("FENRIS_HIP_NO_TWO_PASS")) {
+    if (mode == FH_SCATTER_GATHER && c->row_hi < 0 && !c->env("FENRIS_HIP_NO_TWO_PASS")) {
         // two-pass owner-computes (dense element matrices, then a row gather) where recomputing the element prologue per
         // owning node block is the expensive part: high-order elements, and the nonlinear materials on any element
         // (measured, Hex8 128^3: NeoHookean 11.1 -> 9.2 ms, StVK 19.2 -> 10.0 ms; LinearElastic with per-point
         // parameters is faster one-pass: 5.7 vs 8.2 ms).  The dense buffer costs E (s n)^2 doubles: capped.
         const size_t ld = (size_t)c->S() * c->ei.n;
         const double dense_gb = (double)c->E * ld * ld * 8.0 / 1e9;
-        const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || std::getenv("FENRIS_HIP_TWO_PASS");
-        if (want && dense_gb <= (double)env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) return assemble_two_pass(c, values_dev, overwrite);
+        const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || c->env("FENRIS_HIP_TWO_PASS");
+        if (want && dense_gb <= (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) return assemble_two_pass(c, values_dev, overwrite);
     }
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
@@ -1357,7 +1365,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
         // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
         if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pipe_rules) &&
-            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !std::getenv("FENRIS_HIP_TRACE")) {
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_TRACE")) {
             a.fast = 1;
             if (c->nq > 1) {
                 a.qw = c->qw.p + c->nq;
@@ -1392,7 +1400,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
     // high-order elements: column search of the scatter in LDS (neighbour lists staged per element)
-    if (c->ei.n > 8 && !std::getenv("FENRIS_HIP_NO_NC_LDS")) {
+    if (c->ei.n > 8 && !c->env("FENRIS_HIP_NO_NC_LDS")) {
         unsigned max_row = 0;
         for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
         const size_t with_nc = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, (int)max_row);
@@ -1451,7 +1459,7 @@ static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const long long nbatch = (a.work_end - a.work_begin + EPB - 1) / EPB;
-    const int per_cu = std::max(1, (int)std::min<size_t>(env_int("FENRIS_HIP_VEC_WGS_PER_CU", 3), (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int per_cu = std::max(1, (int)std::min<size_t>(c->env_int("FENRIS_HIP_VEC_WGS_PER_CU", 3), (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = (int)std::min<long long>(nbatch, (long long)dev_cus * per_cu);
     auto kern = k_assemble_vector_stream<EK, OP, NT>;
     if (lds > 48 * 1024)
@@ -1463,7 +1471,7 @@ static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
 template <int EK, int OP>
 static int launch_vector_stream(fh_ctx* c, KArgs& a) {
     if constexpr (ElemT<EK>::NG == ElemT<EK>::N && (ElemT<EK>::N == 4 || ElemT<EK>::N == 8)) {
-        int rs = env_int("FENRIS_HIP_VEC_NT", 256) == 256 ? launch_vector_stream_nt<EK, OP, 256>(c, a) : -1;
+        int rs = c->env_int("FENRIS_HIP_VEC_NT", 256) == 256 ? launch_vector_stream_nt<EK, OP, 256>(c, a) : -1;
         if (rs < 0) rs = launch_vector_stream_nt<EK, OP, 128>(c, a);
         return rs;
     } else {
@@ -1515,6 +1523,12 @@ fh_ctx* fh_create(int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) return nullptr;
     fh_ctx* c = new fh_ctx();
     c->device = device_id;
+    // the tuning / diagnostic switches, once (include/fenris_hip.h): nothing in the dispatch reads the environment later
+    for (char** ev = environ; ev && *ev; ++ev) {
+        if (std::strncmp(*ev, "FENRIS_HIP_", 11) != 0) continue;
+        const char* eq = std::strchr(*ev, '=');
+        if (eq) c->env_vars.emplace(std::string(*ev, (size_t)(eq - *ev)), std::string(eq + 1));
+    }
     if (c->status.alloc(1) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
@@ -1878,7 +1892,7 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
         c->uni_lambda = params[1];
         for (uint32_t q = 1; q < nq; ++q) c->fast_ok = c->fast_ok && params[2 * q] == params[0] && params[2 * q + 1] == params[1];
     }
-    if (std::getenv("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
+    if (c->env("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
     c->has_rules = false;
     c->elem_par = false;
     c->has_partition = false; c->has_tp_pos = false;
@@ -1910,7 +1924,7 @@ int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uin
         for (uint32_t q = 1; q < nq; ++q)
             rules_const = rules_const && rule_params[(r * nq + q) * 2] == rule_params[r * nq * 2] &&
                           rule_params[(r * nq + q) * 2 + 1] == rule_params[r * nq * 2 + 1];
-    c->elem_par = weights_ok && rules_const && !std::getenv("FENRIS_HIP_NO_FAST") && !std::getenv("FENRIS_HIP_NO_ELEM_PAR");
+    c->elem_par = weights_ok && rules_const && !c->env("FENRIS_HIP_NO_FAST") && !c->env("FENRIS_HIP_NO_ELEM_PAR");
     c->fast_ok = c->elem_par;
     c->has_slotpar = false;
     c->has_partition = false; c->has_tp_pos = false;
@@ -2272,8 +2286,8 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
     // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel).
     // Two passes by default: element vectors to a scratch buffer, then one thread per row sums its node's entries in
     // ascending element order -- no atomics, bitwise reproducible (FENRIS_HIP_VECTOR_ATOMICS keeps the one-pass scatter)
-    if (!a.labels && !std::getenv("FENRIS_HIP_NO_VECTOR_STREAM")) {
-        const bool two_pass = !std::getenv("FENRIS_HIP_VECTOR_ATOMICS") && !c->ragged &&
+    if (!a.labels && !c->env("FENRIS_HIP_NO_VECTOR_STREAM")) {
+        const bool two_pass = !c->env("FENRIS_HIP_VECTOR_ATOMICS") && !c->ragged &&
                               (c->elem_kind == FH_HEX8 || c->elem_kind == FH_TET4 || c->elem_kind == FH_QUAD4);
         if (two_pass) {
             rc = build_pattern(c);  // the node -> (element, local node) adjacency comes with the pattern
@@ -2365,7 +2379,7 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     if (a.work_end == 0) return FH_OK;
     // two passes without atomics where the node adjacency is available (it comes with the pattern, which needs an operator
     // for the solution dimension): element vectors to scratch, then a per-row sum in element order
-    bool two_pass = !a.labels && !c->ragged && c->op >= 0 && !std::getenv("FENRIS_HIP_VECTOR_ATOMICS");
+    bool two_pass = !a.labels && !c->ragged && c->op >= 0 && !c->env("FENRIS_HIP_VECTOR_ATOMICS");
     if (two_pass && build_pattern(c) != FH_OK) two_pass = false;
     if (two_pass) {
         const size_t need = (size_t)c->E * c->ei.n * sdim;

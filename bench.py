@@ -271,8 +271,9 @@ def main():
         qtable = qtable.with_uniform_data(params)
 
     if want_traffic and rank == 0:
-        # kernels whose HBM traffic is summed (c4: both passes of the two-pass assembly)
-        knames = {"ns": ("k_affine_rows",), "c5": ("k_affine_rows",), "c2": ("k_affine_rows",), "ns-perturbed": ("k_gather_pipelined",),
+        # kernels whose HBM traffic is summed (everything one assembly launches)
+        aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
+        knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_gather_pipelined",),
                   "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
         t0 = time.perf_counter()
         os.environ["FENRIS_BENCH_CHILD"] = "1"

@@ -29,6 +29,8 @@
 // reproducible for the same reason.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "affine_rows.hpp"
 #include "small_ops.hpp"
 
@@ -168,82 +170,41 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
 
     // ---------------------------------------------------------------------------------------------- row waves
     const bool hwave = wave == 0;                     // fetches the position headers
-    // Jacobian role: four lanes per element slot (one quad), lane k holds vertex k of (node 0, node 1, node 3, node 4)
-    const int jbase = 256 - 4 * T.us;
-    const bool jwave = wave >= (jbase >> 6);          // wave-uniform: the wave holds Jacobian lanes
-    const int jl = tid - jbase;                       // >= 0 on Jacobian lanes
+    // Record role: the last NPC us lanes of the row waves bring the element records of the NEXT position's slots (R or M,
+    // GW doubles each, written per element by k_affine_records right before this kernel) from global memory into LDS,
+    // 16 bytes per lane: lane i of the role fetches piece i % NPC of slot i / NPC.
+    constexpr int NPC = GW / 2;                       // 16-byte pieces per record
+    const int jbase = 256 - NPC * T.us;
+    const bool jwave = wave >= (max(jbase, 0) >> 6);  // wave-uniform: the wave holds lanes of the role
+    const int jl = tid - jbase;                       // >= 0 on lanes of the role
     const int jl_c = max(jl, 0);
-    const int jk = jl_c & 3, jslot = jl_c >> 2;
+    const int jslot = jl_c / NPC, jpiece = jl_c - jslot * NPC;
     // lane records: positions with identical records share one table (T.lanes[id]); the id rides in the header (flags >> 8)
     auto load_lane_tab = [&](int id) { return T.lanes[(size_t)((unsigned)id * 256u + (unsigned)tid)]; };
-    auto load_vidx = [&](int p) { return T.slotv[(size_t)((unsigned)min(p, npos - 1) * (unsigned)(4 * T.us) + (unsigned)jl_c)]; };
-    double X[3];
-    auto load_vert = [&](int v) {
-        if (DBG && (ablate & 128)) v = jk;  // profiling: every quad fetches the same four vertices (cache hits)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) X[c] = a.verts[(size_t)(unsigned)v * 3 + c];
+    auto load_elem = [&](int p) { return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)jslot)]; };
+    auto load_piece = [&](int e) {
+        return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)max(e, 0) * NPC + jpiece];
     };
-    // Records of the slots of position p from the vertices in registers.  The edges from node 0 to nodes 1, 3, 4 are twice
-    // the columns c0, c1, c2 of J (hexahedron.rs:49-58: nodes (---), (+--), (-+-), (--+); exact for a parallelepiped).  Lane
-    // k = 1, 2, 3 of a quad holds column k - 1, fetches the other two by quad permutes and forms row k - 1 of the adjugate,
-    // c_k x c_(k+1) (indices mod 3), and det J = c_(k-1) . row.  LinearElastic: R = sqrt(|det J|) J^-1 =
-    // sign(det J) rsqrt(|det J|) adj(J) (nine doubles); Laplace: M = R R^T (six).
-    auto slot_record = [&](int p, int parity) {
-        double E[3], A[3], B[3], row[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) E[c] = 0.5 * (X[c] - dpp_quad_full<0x00>(X[c]));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { A[c] = dpp_quad_full<0x78>(E[c]); B[c] = dpp_quad_full<0x9C>(E[c]); }
-        row[0] = A[1] * B[2] - A[2] * B[1];
-        row[1] = A[2] * B[0] - A[0] * B[2];
-        row[2] = A[0] * B[1] - A[1] * B[0];
-        const double detJ = fma(E[2], row[2], fma(E[1], row[1], E[0] * row[0]));
-        const bool mine = jl >= 0 && jk >= 1;
-        double sc = 0.0;
-        if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404); empty slots are degenerate too
-            if (mine) {
-                const int e = T.elem[(size_t)p * T.us + jslot];
-                if (e >= 0) report_singular(a.status, (long long)e);
-            }
-        } else {
-            sc = copysign(rsqrt_newton(fabs(detJ)), detJ);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) row[c] *= sc;
-        double* o = JS + ((size_t)parity * T.us + jslot) * GW;
-        if constexpr (LAP) {
-            double nb[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) nb[c] = dpp_quad_full<0x78>(row[c]);   // row of the next lane (cyclic over lanes 1, 2, 3)
-            const double dd = fma(row[2], row[2], fma(row[1], row[1], row[0] * row[0]));
-            const double od = fma(row[2], nb[2], fma(row[1], nb[1], row[0] * nb[0]));
-            // [M00, M01, M02, M11, M12, M22]: lane 1 holds M00, M01; lane 2 M11, M12; lane 3 M22, M20
-            if (mine) {
-                o[jk == 1 ? 0 : jk == 2 ? 3 : 5] = dd;
-                o[jk == 1 ? 1 : jk == 2 ? 4 : 2] = od;
-            }
-        } else {
-            if (mine) {
-                double* r = o + 3 * (jk - 1);
-                r[0] = row[0]; r[1] = row[1]; r[2] = row[2];
-            }
-        }
+    auto park_piece = [&](int parity, f64x2 v) {
+        if (jl >= 0) reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + jslot) * GW)[jpiece] = v;
     };
 
-    int id_cur = __builtin_amdgcn_readfirstlane(T.hdr[p_begin].z >> 8);
-    uint2 lane_cur = load_lane_tab(id_cur);
-    int4 h_nxt = {0, 0, 0, 0};
+    const int id_cur0 = __builtin_amdgcn_readfirstlane(T.hdr[p_begin].z >> 8);
+    const uint2 lane_cur0 = load_lane_tab(id_cur0);
+    int4 h_nxt0 = {0, 0, 0, 0};
     auto with_head = [&](int4 h) { h.w = head_of(h.x); return h; };
     if (hwave) {  // the ring runs two positions ahead: the row waves read the lane-table id of p + 1 at the top of p
         const int4 h0 = with_head(T.hdr[p_begin]), h1 = with_head(T.hdr[min(p_begin + 1, npos - 1)]);
-        h_nxt = T.hdr[min(p_begin + 2, npos - 1)];
+        h_nxt0 = T.hdr[min(p_begin + 2, npos - 1)];
         if (tid == 0) { HDR[p_begin & 3] = h0; HDR[(p_begin + 1) & 3] = h1; }
     }
-    int vi_nxt = 0;
-    if (jwave) {
-        load_vert(load_vidx(p_begin));
-        vi_nxt = load_vidx(p_begin + 1);
-        slot_record(p_begin, 0);
+    int e_nxt0 = 0;
+    f64x2 piece0 = {0.0, 0.0};
+    if (jwave) {  // records of p_begin into LDS now; the pieces of p_begin + 1 stay in registers, the elements of p_begin + 2 follow
+        park_piece(0, load_piece(load_elem(p_begin)));
+        const int e1 = load_elem(p_begin + 1);
+        e_nxt0 = load_elem(p_begin + 2);
+        piece0 = load_piece(e1);
     }
     // everything the prologue fetched has landed before the loop is entered: otherwise the waits the compiler derives for the
     // entry path (a prologue fetch older than the loop's own prefetches) are executed on every trip -- vmcnt(1) right behind the
@@ -253,14 +214,33 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
 
     const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 12u;  // .w: head of the position
     const unsigned hdr_addr_z = (unsigned)(unsigned long long)HDR + 8u;  // .z: flags | lane-table id << 8
+    // The loop exists twice, with and without the Jacobian role (wave-uniform choice outside the loop): inside, the role's
+    // arithmetic sits in the same basic block as the row role's products, so the compiler interleaves the two dependency
+    // chains instead of running the Jacobian chain alone at the end of the position.
+    auto run = [&](auto jw_tag) {
+    constexpr bool JW = decltype(jw_tag)::value;
+    // loop-carried state lives in the loop's own scope (values, not captures)
+    uint2 lane_cur = lane_cur0;
+    int id_cur = id_cur0, e_nxt = e_nxt0;
+    int4 h_nxt = h_nxt0;
+    f64x2 piece = piece0;
     int par = 0;
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
         const bool have_next = (p + 1) < p_end;
         // head of this position's rows (vector fetch: a scalar one would have to be waited for right here)
         int head;
         asm volatile("ds_read_b32 %0, %1" : "=v"(head) : "v"(hdr_addr + 16u * (unsigned)(p & 3)));
-        // prefetch: lane record of p + 1, vertices of p + 1 (their indices arrived during the previous position), indices and
-        // header of p + 2
+        // records of the next position's slots, fetched during the previous position, into LDS; then the fetch of the records
+        // of p + 2 (their elements arrived a position ago) and of the elements of p + 3 -- consumed in place, a whole position
+        // to land
+        if constexpr (JW) {
+            if (!(DBG && (ablate & 4))) {
+                if (have_next) park_piece(par ^ 1, piece);
+                piece = load_piece(e_nxt);
+                e_nxt = load_elem(p + 3);
+            }
+        }
+        // prefetch: lane record of p + 1, header of p + 3
         uint2 lane_nxt = lane_cur;
         int id_nxt;
         {
@@ -270,11 +250,6 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         }
         // the same table as this position's (the usual case inside a structured mesh): nothing to fetch
         if (id_nxt != id_cur && !(DBG && (ablate & 8))) lane_nxt = load_lane_tab(id_nxt);
-        int vi_nn = vi_nxt;
-        if (jwave && !(DBG && (ablate & 4))) {
-            load_vert(vi_nxt);
-            vi_nn = load_vidx(p + 2);
-        }
         int4 h_nn = h_nxt;
         if (hwave) h_nn = T.hdr[min(p + 3, npos - 1)];
 
@@ -378,21 +353,75 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
             }
         }
 
-        // records of the next position's slots (its vertices have landed by now)
-        if (jwave && have_next && !(DBG && (ablate & 4))) {
-            if (DBG && (ablate & 32)) {  // profiling: wait for the vertices, skip the arithmetic
-                asm volatile("" :: "v"(X[0]), "v"(X[1]), "v"(X[2]));
-            } else {
-                slot_record(p + 1, par ^ 1);
-            }
-        }
         if (hwave && tid == 0) HDR[(p + 2) & 3] = with_head(h_nxt);
         h_nxt = h_nn;
         id_cur = id_nxt;
-        vi_nxt = vi_nn;
         lane_cur = lane_nxt;
         lds_barrier();
     }
+    };
+    if (jwave) run(std::true_type{}); else run(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------------ element records
+// One thread per element, once per assembly, right before k_affine_rows: the record of an affine element from four of its
+// vertices.  The edges from node 0 to nodes 1, 3, 4 are twice the columns of J (hexahedron.rs:49-58: nodes (---), (+--),
+// (-+-), (--+); exact for a parallelepiped; elliptic.rs:398-404 evaluates the same Jacobian at every quadrature point).
+// LinearElastic: R = sqrt(|det J|) J^-1 = sign(det J) rsqrt(|det J|) adj(J), nine doubles + pad; Laplace: M = R R^T, six.
+// det J == 0 exactly is the reference's "Singular element Jacobian" (try_inverse fails only then): reported, record zero.
+template <int OP>
+__global__ void __launch_bounds__(256) k_affine_records(const double* verts, const int* conn, const unsigned char* elem_aff,
+                                                        const unsigned char* active, long long E, double* rec, DevStatus* status) {
+    constexpr bool LAP = (OP == FH_LAPLACE);
+    constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E || !elem_aff[e]) return;
+    const int4 c0 = reinterpret_cast<const int4*>(conn)[2 * e], c1 = reinterpret_cast<const int4*>(conn)[2 * e + 1];
+    const int vi[4] = {c0.x, c0.y, c0.w, c1.x};
+    double X[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[k][c] = verts[(size_t)vi[k] * 3 + c];
+    double J[3][3], R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) J[i][k] = 0.5 * (X[k + 1][i] - X[0][i]);
+    const double detJ = det_small<3>(J);
+    if (detJ == 0.0) {
+        if (!active || active[e]) report_singular(status, e);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R[i][j] = 0.0;
+    } else {
+        adj_scaled(J, copysign(rsqrt_newton(fabs(detJ)), detJ), R);
+    }
+    f64x2* o = reinterpret_cast<f64x2*>(rec + (size_t)e * GW);
+    if constexpr (LAP) {
+        double M[6];
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = c; d < 3; ++d, ++k) M[k] = R[c][0] * R[d][0] + R[c][1] * R[d][1] + R[c][2] * R[d][2];
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { f64x2 v; v.x = M[2 * h]; v.y = M[2 * h + 1]; o[h] = v; }
+    } else {
+        const double r9[10] = {R[0][0], R[0][1], R[0][2], R[1][0], R[1][1], R[1][2], R[2][0], R[2][1], R[2][2], 0.0};
+#pragma unroll
+        for (int h = 0; h < 5; ++h) { f64x2 v; v.x = r9[2 * h]; v.y = r9[2 * h + 1]; o[h] = v; }
+    }
+}
+
+hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts, const int* conn, const unsigned char* elem_aff,
+                                 const unsigned char* active, long long E, double* rec, DevStatus* status) {
+    if (E <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((E + 255) / 256));
+    if (op == FH_LAPLACE) hipLaunchKernelGGL(k_affine_records<FH_LAPLACE>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, E, rec, status);
+    else hipLaunchKernelGGL(k_affine_records<FH_LINEAR_ELASTIC>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, E, rec, status);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ table builder
@@ -401,7 +430,7 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
 // offsets).  Terms are grouped by output block (node, column slot), ordered by element id, and dealt two per lane.
 __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                                                           const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
-                                                          int4* hdr_out, uint2* lanes, int* slotv, int* status,
+                                                          int4* hdr_out, uint2* lanes, int* status,
                                                           unsigned long long* hash_out) {
     constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
     __shared__ int cnt[NKEY];
@@ -414,10 +443,6 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     const unsigned char* posb = reinterpret_cast<const unsigned char*>(rec + 8 + us / 4 + ms);
     const int* noff_old = rec + 8 + us / 4 + ms + ms * N / 4;
     const int* el = p_elem + (size_t)p * us;
-    for (int s = lane; s < us; s += 64) {
-        const int* c = p_conn + (size_t)p * cs + (size_t)s * N;
-        reinterpret_cast<int4*>(slotv)[(size_t)p * us + s] = make_int4(c[0], c[1], c[3], c[4]);
-    }
     for (int i = lane; i < NKEY; i += 64) cnt[i] = 0;
     const unsigned idle = (AR_ZERO_G << 5) | (AR_ZERO_G << 17);
     for (int i = lane; i < 256; i += 64) { lw0[i] = idle; lw1[i] = 0u; }
@@ -538,10 +563,10 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
 
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* slotv, int* status, unsigned long long* hash) {
+                             int* status, unsigned long long* hash) {
     if (npos <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
-                       p_elem, hdr, lanes, slotv, status, hash);
+                       p_elem, hdr, lanes, status, hash);
     return hipGetLastError();
 }
 

@@ -13,8 +13,8 @@ struct AffineRowTables {
                           //               flags (bit 0: every (node, column) block of the rows has an owner lane) | lane table << 8,
                           //               number of slots}
     const uint2* lanes;   // [ntab][256]  lane records, see affine_rows.hip; positions with identical records share a table
-    const int* slotv;     // [npos][us][4] geometry nodes 0, 1, 3, 4 of the element in each slot (the edges xi, eta, zeta from node 0)
-    const int* elem;      // [npos][us]   element id per slot (-1: empty), read only to report a singular Jacobian
+    const int* elem;      // [npos][us]   element id per slot (-1: empty)
+    const double* rec;    // [E][GW]      element records (R or M) written by affine_records_launch before every launch
     const double* ghat;   // [64][GW]     reference blocks Ghat_ab (all 64 (a, b); LinearElastic GW = 10, Laplace GW = 6)
     int us, npos, acc_max;  // slots per position, positions, largest S * S * nrow
 };
@@ -29,7 +29,13 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 // (more than 8 terms per block, more than 256 lanes, offsets out of range).
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* slotv, int* status, unsigned long long* hash);
+                             int* status, unsigned long long* hash);
+
+// element records of the affine elements (elem_aff[e] != 0) from the current vertex coordinates: once per assembly, on the same
+// stream right before affine_rows_launch.  A singular element (det J == 0 exactly) of the active set (active == NULL: all) is
+// reported through `status`.
+hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts, const int* conn, const unsigned char* elem_aff,
+                                 const unsigned char* active, long long E, double* rec, DevStatus* status);
 
 // Positions with identical lane records share one table: `lanes_full` [npos][256] as written by affine_rows_build, `ids` the
 // table of every position, `first_pos` [ntab] a position that holds each table.  Writes the compact tables, puts the id into

@@ -342,7 +342,7 @@ struct fh_ctx {
     DevBuf<int> a_conn, a_elem;     // k_affine_rows (affine_rows.hip): per-slot connectivity (table build only), element ids
     DevBuf<uint2> a_lanes;          // lane records
     DevBuf<int4> a_hdr;             // position headers
-    DevBuf<int> a_slotv;            // four vertices per slot
+    DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
     int a_us = 0, a_npos = 0, a_ntab = 0;
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
@@ -943,13 +943,12 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                 HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
-                HIP_TRY(c, c->a_slotv.alloc((size_t)npos * us * 4));
                 DevBuf<uint2> lanes_full;
                 DevBuf<unsigned long long> hash_d;
                 HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
                 HIP_TRY(c, hash_d.alloc((size_t)npos));
                 HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
-                                             c->p_cs, c->a_elem.p, c->a_hdr.p, lanes_full.p, c->a_slotv.p, st.p, hash_d.p));
+                                             c->p_cs, c->a_elem.p, c->a_hdr.p, lanes_full.p, st.p, hash_d.p));
                 int bad = 0;
                 HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 std::vector<unsigned long long> hash_h((size_t)npos);
@@ -1002,7 +1001,7 @@ int build_partition(fh_ctx* c) {
                     if (c->env("FENRIS_HIP_VERBOSE"))
                         std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables\n", npos, c->a_ntab);
                 }
-                c->a_conn.release();  // k_affine_rows reads four vertices per slot from a_slotv
+                c->a_conn.release();  // input of the lane builder only
                 c->a_npos = npos;
             }
             c->npos_gen = (int)order[0].size();
@@ -1175,7 +1174,12 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
 int launch_affine(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_slotv.p, c->a_elem.p,
+    // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly
+    const int gw = (c->op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
+    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, c->has_mask ? c->active.p : nullptr,
+                                     (long long)c->E, c->a_recs.p, c->status.p));
+    AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                       c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
     const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");

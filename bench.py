@@ -192,6 +192,9 @@ def main():
                     help="N > 1: interface rows sent to their owner over RCCL (headline), or the halo element layer "
                          "recomputed locally with no communication")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange after the kernel instead of beside it")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
+                    help="N > 1: interface rows moved by torch.distributed point-to-point (default) or by the library's own RCCL "
+                         "calls behind the C ABI (fh_group_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     args = ap.parse_args()
@@ -345,7 +348,7 @@ def main():
         t0 = time.perf_counter()  # N > 1: engines, masks and patterns of this rank
         # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
         slab_asm = fd.SlabAssembly(slab, configure, device=local_rank, overlap=(args.scatter == "gather" and not args.no_overlap),
-                                   stream=stream)
+                                   stream=stream, exchange=("torch" if share else args.exchange))
         eng, values, nnz = slab_asm.main, slab_asm.values, slab_asm.values.numel()
         E = slab.num_own_elements()  # numerics over own (+ halo in "halo" mode) elements, pattern over own + halo
     t_pattern = time.perf_counter() - t0

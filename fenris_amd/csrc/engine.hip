@@ -20,6 +20,7 @@
 #include "affine_kernel.hpp"
 #include "affine_rows.hpp"
 #include "device_common.hpp"
+#include "group_internal.hpp"
 #include "host_inputs.hpp"
 #include "pattern_kernels.hpp"
 
@@ -1560,6 +1561,12 @@ void fh_destroy(fh_ctx* c) {
 }
 
 const char* fh_last_error(const fh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+} // extern "C"
+// accessors for group.hip (group_internal.hpp)
+int fh_internal_fail(fh_ctx* c, int code, const std::string& msg) { return c ? c->fail(code, msg) : code; }
+int fh_internal_device(const fh_ctx* c) { return c->device; }
+hipStream_t fh_internal_stream(const fh_ctx* c) { return c->stream; }
+extern "C" {
 const char* fh_last_kernel_name(const fh_ctx* c) { return c ? c->last_kernel.c_str() : ""; }
 
 int fh_set_stream(fh_ctx* c, void* s) {

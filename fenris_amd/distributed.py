@@ -173,6 +173,70 @@ class InterfaceExchange:
         self.finish()
 
 
+class AbiInterfaceExchange:
+    """The same exchange through the C ABI (fh_group_*, fenris_amd/csrc/group.hip): RCCL ncclSend / ncclRecv on the
+    library's own side stream -- what a Rust host drives.  The 128-byte id is drawn by rank 0 and handed to the other ranks
+    over ``torch.distributed`` here (any transport does).  GPU only."""
+
+    def __init__(self, slab: SlabProblem, engine, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        self.slab, self.engine = slab, engine
+        lib = _ffi.lib()
+        idbuf = (C.c_uint8 * 128)()
+        world = slab.world
+        if world > 1:
+            t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{engine.device}")
+            if slab.rank == 0:
+                engine._check(lib.fh_group_unique_id(idbuf))
+                t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
+            dist.broadcast(t, 0, group=group)
+            for i, b in enumerate(t.cpu().tolist()):
+                idbuf[i] = b
+        else:
+            engine._check(lib.fh_group_unique_id(idbuf))
+        h = C.c_void_p()
+        engine._check(lib.fh_group_create(engine._h, idbuf, slab.rank, world, C.byref(h)))
+        self._g, self._lib = h, lib
+        self.values = None
+
+    def bind(self, engine, values):
+        ro, _ = engine.pattern(want_cols=False)
+        s = engine.solution_dim()
+
+        def seg(nodes):
+            return (int(ro[s * nodes[0]]), int(ro[s * nodes[1]])) if nodes else None
+
+        snd, rcv = seg(self.slab.send_nodes), seg(self.slab.recv_nodes)
+        self.values = values
+        self.engine._check(self._lib.fh_group_set_exchange(
+            self._g, self.slab.rank - 1 if snd else -1, snd[0] if snd else 0, snd[1] - snd[0] if snd else 0,
+            self.slab.rank + 1 if rcv else -1, rcv[0] if rcv else 0, rcv[1] - rcv[0] if rcv else 0))
+        return self
+
+    def start(self, comm_stream=None):
+        import ctypes as C
+
+        self.engine._check(self._lib.fh_group_exchange_start(self._g, C.c_void_p(self.values.data_ptr())))
+
+    def finish(self):
+        import ctypes as C
+
+        self.engine._check(self._lib.fh_group_exchange_finish(self._g, C.c_void_p(self.values.data_ptr())))
+
+    def run(self):
+        self.start()
+        self.finish()
+
+    def close(self):
+        if self._g:
+            self._lib.fh_group_destroy(self._g)
+            self._g = None
+
+
 class SlabAssembly:
     """One rank of the multi-GPU stiffness assembly.
 
@@ -182,7 +246,8 @@ class SlabAssembly:
     transfer to the owner rides a separate stream while the main launch computes all other rows; the received
     rows are added at the end.  In "halo" mode nothing is exchanged."""
 
-    def __init__(self, slab: SlabProblem, configure, device: int = 0, overlap: bool = True, group=None, stream=None):
+    def __init__(self, slab: SlabProblem, configure, device: int = 0, overlap: bool = True, group=None, stream=None,
+                 exchange: str = "torch"):
         import torch
 
         from .assembly import Engine
@@ -205,7 +270,10 @@ class SlabAssembly:
             self.main.set_row_range(split, slab.mesh.num_nodes())
         if overlap and (slab.send_nodes is not None or slab.recv_nodes is not None):
             self.comm = torch.cuda.Stream(device=device)
-        self.exchange = InterfaceExchange(slab, group).bind(self.main, self.values)
+        if exchange == "abi":   # RCCL inside the library (fh_group_*); the torch path stays the test harness
+            self.exchange = AbiInterfaceExchange(slab, self.main, group).bind(self.main, self.values)
+        else:
+            self.exchange = InterfaceExchange(slab, group).bind(self.main, self.values)
 
     def enqueue(self, flags):
         """one assembly of this rank's rows (values overwritten or accumulated according to ``flags``)"""

@@ -310,6 +310,31 @@ int fh_estimate_H1_seminorm_error_squared(fh_ctx*, uint32_t solution_dim, const 
 int fh_estimate_H1_seminorm_error_squared_dev(fh_ctx*, uint32_t solution_dim, const double* u_h_dev, const double* grad_exact_dev,
                                               double* out);
 
+/* ---- multi-GPU: one process or thread per GPU, each with its own fh_ctx holding one partition (its own
+ * elements plus the halo layers whose nodes it shares, so that interface rows have the global pattern and the same layout
+ * on both sides; numerics over the own elements: fh_set_active_elements).  The only data that crosses a partition boundary
+ * are the partial rows of interface nodes: the non-owner sends its contiguous segment of `values` to the owner, which adds
+ * it -- RCCL point-to-point (ncclSend / ncclRecv) on a side stream, each interface on its own xGMI link, beside the
+ * assembly launches; never a collective over the matrix.  Replaces, across partitions, what the shared address space does
+ * for CsrParAssembler::assemble_into_csr (src/assembly/global.rs:314-376).
+ * Bootstrap like NCCL: rank 0 draws an id, the host distributes its bytes to every rank by whatever means it has. */
+typedef struct fh_group fh_group;
+#define FH_GROUP_ID_BYTES 128
+int fh_group_unique_id(uint8_t id[FH_GROUP_ID_BYTES]);
+/* collective over all `world` ranks; `ctx` gives the device and the stream the exchange is ordered against */
+int fh_group_create(fh_ctx* ctx, const uint8_t id[FH_GROUP_ID_BYTES], int rank, int world, fh_group** out);
+void fh_group_destroy(fh_group*);
+/* What this rank moves in one exchange: values[send_first .. send_first + send_count) go to rank send_peer (-1: nothing);
+ * recv_count values arrive from rank recv_peer (-1: nothing) and are ADDED to values[recv_first ..).  For z-slabs:
+ * send = rows of the bottom ghost plane to rank - 1, receive = rows of the owned top plane from rank + 1. */
+int fh_group_set_exchange(fh_group*, int send_peer, uint64_t send_first, uint64_t send_count, int recv_peer,
+                          uint64_t recv_first, uint64_t recv_count);
+/* start: call after enqueueing the launch that produces the rows to send (fh_assemble_matrix_async_dev, possibly restricted
+ * with fh_set_row_range); the transfers run on the group's stream while the caller enqueues the rest of the assembly.
+ * finish: the context's stream waits for the transfers and adds the received rows.  Errors: fh_last_error(ctx). */
+int fh_group_exchange_start(fh_group*, double* values_dev);
+int fh_group_exchange_finish(fh_group*, double* values_dev);
+
 #ifdef __cplusplus
 }
 #endif

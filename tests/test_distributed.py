@@ -98,7 +98,7 @@ def _free_port():
     return port
 
 
-def _gloo_worker(rank, world, port, op_name, q):
+def _gloo_worker(rank, world, port, op_name, q, units_z=None, cells=2):
     import torch
     import torch.distributed as dist
 
@@ -109,12 +109,12 @@ def _gloo_worker(rank, world, port, op_name, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         op = getattr(oracle, op_name)
         s = 1 if op_name == "LAPLACE" else 3
-        cells = 2
-        slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world)
+        units_z = units_z or world          # units_z * cells element layers over `world` ranks (uneven when not divisible)
+        slab = fd.make_slab(1.0, 1, 1, units_z, cells, rank, world)
         ro, ci, vals = _oracle_partial(oracle, slab, op)
         values = torch.from_numpy(vals)
         fd.InterfaceExchange(slab).bind_offsets(ro, s, values).run()
-        gro, gci, gvals = _global_reference(oracle, world, cells, op)
+        gro, gci, gvals = _global_reference(oracle, units_z, cells, op)
         _check_owned_rows(slab, s, ro, ci, values.numpy(), gro, gci, gvals)
         dist.barrier()
         dist.destroy_process_group()
@@ -137,6 +137,26 @@ def test_two_rank_exchange_over_gloo(op_name):
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_four_rank_exchange_over_gloo_uneven_layers():
+    """world_size 4, seven element layers (1 x 1 x 7 units of one cell): slabs of 2, 2, 2 and 1 layers, three interfaces
+    exchanged concurrently; every rank's owned rows equal the single-mesh oracle matrix"""
+    import torch.multiprocessing as mp
+
+    assert [fd.slab_layers(7, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, "LINEAR_ELASTIC", q, 7, 1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in results:
@@ -247,4 +267,39 @@ def test_slabs_through_engine_match_global_oracle(oracle, scatter):
     for slab, ro, ci, values, _ in slabs:
         _check_owned_rows(slab, 3, ro, ci, values.cpu().numpy(), gro, gci, gvals)
     for eng in parts:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_group_abi_single_rank_plumbing():
+    """fh_group_* (include/fenris_hip.h, fenris_amd/csrc/group.hip) with one rank: RCCL loads, a communicator is created, an
+    exchange without peers starts and finishes, argument errors are reported.  (Transfers between ranks need one GPU per
+    rank: RCCL refuses two ranks on one device, so on the one-GPU test box only the plumbing can run.)"""
+    import ctypes as C
+
+    import torch
+
+    from fenris_amd import _ffi
+
+    lib = _ffi.lib()
+    eng = fa.Engine(0)
+    try:
+        idbuf = (C.c_uint8 * 128)()
+        assert lib.fh_group_unique_id(idbuf) == 0 and any(idbuf)
+        g = C.c_void_p()
+        assert lib.fh_group_create(eng._h, idbuf, 0, 1, C.byref(g)) == 0 and g.value
+        vals = torch.ones(1000, dtype=torch.float64, device="cuda")
+        assert lib.fh_group_set_exchange(g, -1, 0, 0, -1, 0, 0) == 0
+        assert lib.fh_group_exchange_start(g, C.c_void_p(vals.data_ptr())) == 0
+        assert lib.fh_group_exchange_start(g, C.c_void_p(vals.data_ptr())) == _ffi.FH_INVALID_STATE  # already started
+        assert lib.fh_group_exchange_finish(g, C.c_void_p(vals.data_ptr())) == 0
+        assert lib.fh_group_exchange_finish(g, C.c_void_p(vals.data_ptr())) == _ffi.FH_INVALID_STATE  # nothing started
+        assert lib.fh_group_set_exchange(g, 0, 0, 10, -1, 0, 0) == _ffi.FH_BAD_ARGUMENT  # a rank cannot send to itself
+        assert lib.fh_group_set_exchange(g, 3, 0, 10, -1, 0, 0) == _ffi.FH_BAD_ARGUMENT  # peer outside the group
+        torch.cuda.synchronize()
+        assert float(vals.sum()) == 1000.0
+        lib.fh_group_destroy(g)
+        bad = C.c_void_p()
+        assert lib.fh_group_create(eng._h, idbuf, 2, 1, C.byref(bad)) == _ffi.FH_BAD_ARGUMENT
+    finally:
         eng.close()

@@ -34,13 +34,19 @@ extern "C" {
 
 #define FH_ABI_VERSION 1
 
+/* Tuning and diagnostics: environment variables named FENRIS_HIP_* (scripts/README.md) are read ONCE, by fh_create, into the
+ * context; no later call reads the environment.  They change which kernel variant runs or print diagnostics, never results
+ * beyond rounding -- except FENRIS_HIP_ABLATE / FENRIS_HIP_TRACE, which select instrumented instantiations for profiling
+ * (FENRIS_HIP_ABLATE switches work off and produces wrong values by design). */
+
 /* status codes.  FH_SINGULAR_JACOBIAN is the reference's only runtime error on the path:
  * eyre!("Singular element Jacobian encountered"), src/assembly/local/elliptic.rs:401-404. */
 enum {
     FH_OK = 0,
     FH_SINGULAR_JACOBIAN = 1,
     FH_BAD_ARGUMENT = 2,
-    FH_HIP_ERROR = 3,
+    FH_HIP_ERROR = 3,         /* a HIP or RCCL call failed; fh_last_error has the text */
+    /* 4 is not used (reserved; ABI version 1 never returned it) */
     FH_INVALID_STATE = 5,     /* e.g. assemble before pattern, operator/element dimension mismatch */
     FH_UNSUPPORTED = 6,
     /* SolveErrorKind of the conjugate-gradient solver (fenris-sparse/src/cg.rs:277-286) */

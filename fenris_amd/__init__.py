@@ -14,6 +14,8 @@ from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsets
                        apply_homogeneous_dirichlet_bc_rhs, assemble_scalar, color_nodes, CgSolveError, ConjugateGradient,
                        IdentityOperator, JacobiPreconditioner, RelativeResidualCriterion, estimate_H1_seminorm_error,
                        estimate_H1_seminorm_error_squared, estimate_L2_error, estimate_L2_error_squared)
+from .compose import (AggregateElementAssembler, MapElementNodes, TransformElementMatrix, TransformElementScalar,
+                      TransformElementVector)
 from .mesh import Mesh, hex20_mesh_from_hex8, hex27_mesh_from_hex8, procedural, quad9_mesh_from_quad4, tet10_mesh_from_tet4, tet20_mesh_from_tet4, tri6_mesh_from_tri3
 from .operators import (Density, GravitySource, SourceFunction, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
                         NeoHookeanMaterial, StVKMaterial, YoungPoisson)

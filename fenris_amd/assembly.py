@@ -20,6 +20,8 @@ from typing import Optional
 import numpy as np
 
 from . import _ffi
+from .compose import _Composable, is_composed
+from . import compose as _compose
 from ._ffi import (ASSEMBLE_OVERWRITE, SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER, FenrisError,
                    SingularJacobianError)
 from .mesh import Mesh
@@ -495,7 +497,7 @@ class ElementEllipticAssemblerBuilder:
         return ElementEllipticAssembler(self._engine or Engine(), self._space, self._op, self._qtable, self._u)
 
 
-class ElementEllipticAssembler:
+class ElementEllipticAssembler(_Composable):
     """ElementEllipticAssembler<Mesh, Op, UniformQuadratureTable> (elliptic.rs:152-340), device resident."""
 
     def __init__(self, engine, space, op, qtable, u):
@@ -599,7 +601,7 @@ class ElementSourceAssemblerBuilder:
         return ElementSourceAssembler(self._engine or Engine(), self._space, self._source, self._qtable)
 
 
-class ElementSourceAssembler:
+class ElementSourceAssembler(_Composable):
     """src/assembly/local/source.rs:96-216: an ElementVectorAssembler for the (f, v) term.  ``source`` is a
     GravitySource (uniform Density table) or a SourceFunction (sampled on the host at the physical quadrature
     points, integrated on the device)."""
@@ -667,10 +669,19 @@ class CsrAssembler:
 
     def assemble_pattern(self, element_assembler):
         """global.rs:65-120 -> (row_offsets, col_indices) as uint64 arrays"""
+        if is_composed(element_assembler):
+            return _compose.aggregate_pattern(element_assembler)
         return element_assembler.engine.pattern()
 
     def assemble(self, element_assembler, device_values=False):
         """global.rs:124-131"""
+        if is_composed(element_assembler):  # AggregateElementAssembler / MapElementNodes / TransformElementMatrix
+            import torch
+
+            ro, ci = _compose.aggregate_pattern(element_assembler)
+            values = torch.zeros(len(ci), dtype=torch.float64, device="cuda")
+            _compose.assemble_matrix_into(ro, ci, values, element_assembler, self.scatter)
+            return CsrMatrix(ro, ci, values if device_values else values.cpu().numpy())
         eng = element_assembler.engine
         ro, ci = eng.pattern()
         if device_values:
@@ -685,6 +696,15 @@ class CsrAssembler:
 
     def assemble_into_csr(self, csr: CsrMatrix, element_assembler):
         """global.rs:133-182: accumulates into csr.values"""
+        if is_composed(element_assembler):
+            import torch
+
+            on_dev = _is_torch(csr.values)
+            values = csr.values if on_dev else torch.from_numpy(np.ascontiguousarray(csr.values)).cuda()
+            _compose.assemble_matrix_into(csr.row_offsets, csr.col_indices, values, element_assembler, self.scatter)
+            if not on_dev:
+                csr.values[:] = values.cpu().numpy()
+            return
         eng = element_assembler.engine
         if eng.nnz() == 0 and len(csr.values):
             eng.build_pattern()
@@ -730,7 +750,15 @@ class VectorAssembler:
         n = element_assembler.solution_dim() * element_assembler.num_nodes()
         if (output.numel() if _is_torch(output) else len(output)) != n:
             raise ValueError("Output dimensions mismatch")  # global.rs:592
-        if hasattr(element_assembler, "assemble_vector_into_engine"):  # ElementSourceAssembler
+        if is_composed(element_assembler):
+            import torch
+
+            on_dev = _is_torch(output)
+            out_t = output if on_dev else torch.from_numpy(np.ascontiguousarray(output)).cuda()
+            _compose.assemble_vector_into(out_t, element_assembler)
+            if not on_dev:
+                output[:] = out_t.cpu().numpy()
+        elif hasattr(element_assembler, "assemble_vector_into_engine"):  # ElementSourceAssembler
             element_assembler.assemble_vector_into_engine(output)
         else:
             element_assembler.engine.assemble_vector(output)
@@ -745,6 +773,8 @@ class VectorParAssembler(VectorAssembler):
 
 def assemble_scalar(element_assembler):
     """global.rs:697-711"""
+    if is_composed(element_assembler):
+        return _compose.assemble_scalar(element_assembler)
     return float(element_assembler.engine.assemble_scalar())
 
 

@@ -1566,6 +1566,16 @@ const char* fh_last_error(const fh_ctx* c) { return c ? c->err.c_str() : "null c
 int fh_internal_fail(fh_ctx* c, int code, const std::string& msg) { return c ? c->fail(code, msg) : code; }
 int fh_internal_device(const fh_ctx* c) { return c->device; }
 hipStream_t fh_internal_stream(const fh_ctx* c) { return c->stream; }
+bool fh_internal_pattern(const fh_ctx* c, const unsigned** noff, const unsigned** ncols, uint64_t* num_nodes, int* solution_dim) {
+    if (!c->has_pattern) return false;
+    *noff = c->noff.p; *ncols = c->ncols.p; *num_nodes = c->N; *solution_dim = c->S();
+    return true;
+}
+bool fh_internal_sizes(const fh_ctx* c, uint64_t* num_nodes, int* solution_dim) {
+    if (!c->has_mesh || (c->op < 0 && !c->ragged)) return false;
+    *num_nodes = c->N; *solution_dim = c->S();
+    return true;
+}
 extern "C" {
 const char* fh_last_kernel_name(const fh_ctx* c) { return c ? c->last_kernel.c_str() : ""; }
 

@@ -2,9 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <stdint.h>
+
 #include <string>
 
 struct fh_ctx;
 int fh_internal_fail(fh_ctx* c, int code, const std::string& msg);
 int fh_internal_device(const fh_ctx* c);
 hipStream_t fh_internal_stream(const fh_ctx* c);
+// node-level pattern of the context (device arrays); false when no pattern has been built
+bool fh_internal_pattern(const fh_ctx* c, const unsigned** noff, const unsigned** ncols, uint64_t* num_nodes, int* solution_dim);
+bool fh_internal_sizes(const fh_ctx* c, uint64_t* num_nodes, int* solution_dim);

@@ -10,9 +10,10 @@
 //     K_ij = (c_l A_i) A_j^T - (c_a A_j) A_i^T  [+ delta_ij sum_k (c_m G_k) G_k^T],     A_k, G_k: 27 nodes x 27 points
 // = "B^T D B" with K = 54 (+81): exactly the shape v_mfma_f64_16x16x4_f64 wants.  One workgroup (4 wavefronts) per
 // element: a cooperative prologue leaves G_k, A_k (rows padded to 32, points to 28, zeros) and the coefficients in
-// LDS; wavefront w owns the 16 x 16 tile (w >> 1, w & 1) of all nine K_ij and of the trace term (147 MFMAs); the
-// fragments are stored straight to the PLANAR dense layout ke[e][i][j][I][J] (J fastest: 16 lanes = 128 contiguous
-// bytes) that k_rows_from_dense reads in its second pass.  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
+// LDS; wavefront w owns the 16 x 16 tile (w >> 1, w & 1) of the six K_ij with i <= j and of the trace term (84 MFMAs; the
+// components below the diagonal are transposed copies, see the loop); the fragments are stored straight to the PLANAR
+// dense layout ke[e][i][j][I][J] (J fastest: 16 lanes = 128 contiguous bytes) that k_rows_from_dense reads in its second
+// pass.  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
 // the gain is not flops but operand traffic: 2 LDS doubles per lane feed 1024 FMAs (0.002 reads per FMA per lane
 // against 0.5 in the VALU pair loop).  Measured (C4, 200 k elements): VALU element kernel 9.85 ms, this kernel 6.0 ms, of
 // which the 588 MFMAs per element take 2.9 ms (the fp64 MFMA floor is 3.06 ms) and do not overlap with the prologue
@@ -171,7 +172,13 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             }
             __syncthreads();
         }
-        // ---- matrix cores: wavefront w owns tile (tI, tJ) of the nine K_ij and of the trace term
+        // ---- matrix cores: wavefront w owns tile (tI, tJ) of the six K_ij with i <= j and of the trace term.
+        // K_ji = K_ij^T (the element matrix is symmetric; util.rs:38-51 mirrors the upper triangle scalar by scalar), so the
+        // three components below the diagonal are never multiplied: they are written as transposed copies -- 84 MFMAs per
+        // wavefront instead of 147, and K_e symmetric bit for bit.  On the diagonal components the two terms share their
+        // operands, (c_l - c_a) a_I[i] a_J[i], and the coefficient is split as sign * sqrt|c| * sqrt|c| over the two
+        // operands: entry (I, J) and entry (J, I) are then sums of identical products in the same order, in whichever
+        // tile they lie.
         const int tI = wave >> 1, tJ = wave & 1;
         const int rI = 16 * tI + (lane & 15), rJ = 16 * tJ + (lane & 15), kq = lane >> 4;
         mfma_f64x4 acc[3][3], accM = {0, 0, 0, 0};
@@ -192,18 +199,20 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                 gc[k] = G[(k * RP + rJ) * QS + q];
             }
             const double cl = lds[L::o_coef + q], ca = lds[L::o_coef + 28 + q], cm = lds[L::o_coef + 56 + q];
-            double arl[3], ara[3];
+            const double cd = cl - ca;                               // diagonal components
+            const double rd = sqrt(fabs(cd)), rm = sqrt(fabs(cm));   // NaN coefficients (det F <= 0) stay NaN
+            const double rds = copysign(rd, cd), rms = copysign(rm, cm);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { arl[k] = cl * ar[k]; ara[k] = -(ca * ar[k]); }
+            for (int i = 0; i < 3; ++i) {
+                acc[i][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(rds * ar[i], rd * ac[i], acc[i][i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(arl[i], ac[j], acc[i][j], 0, 0, 0);  // c_l a_I[i] a_J[j]
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ara[j], ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                for (int j = i + 1; j < 3; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cl * ar[i], ac[j], acc[i][j], 0, 0, 0);     // c_l a_I[i] a_J[j]
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ca * ar[j]), ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
                 }
+            }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cm * gr[k], gc[k], accM, 0, 0, 0);
+            for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(rms * gr[k], rm * gc[k], accM, 0, 0, 0);
         }
         // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
         double* ke = a.ke_out + (size_t)e * (81 * 81);
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = i; j < 3; ++j) {
                 const mfma_f64x4 v = (i == j) ? acc[i][j] + accM : acc[i][j];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
@@ -220,6 +229,30 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                     if (I < N && J < N) ke[(size_t)(i * 3 + j) * (N * N) + I * N + J] = v[reg];
                 }
             }
+        __syncthreads();  // every wavefront is done with G / A: their space stages the transposed tiles
+        if (!(a.ablate & 4)) {
+            double* tr = G + (size_t)wave * (16 * 17);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 3; ++j) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) tr[((lane >> 4) + 4 * reg) * 17 + (lane & 15)] = acc[i][j][reg];
+                    // same wavefront writes and reads: LDS operations of a wave complete in order
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // K_ji tile (tJ, tI): row = node of the J range, column = node of the I range
+                    const int Ic = 16 * tI + (lane & 15);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int rr = (lane >> 4) + 4 * reg, Jr = 16 * tJ + rr;
+                        const double t = tr[(lane & 15) * 17 + rr];
+                        if (Jr < N && Ic < N) ke[(size_t)(j * 3 + i) * (N * N) + Jr * N + Ic] = t;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            // the staging area lies over rows / points of G whose padding must read zero for the next element
+            for (int k = lane; k < 16 * 17; k += 64) tr[k] = 0.0;
+        }
         __syncthreads();  // the next element's prologue overwrites G / A
     }
 }

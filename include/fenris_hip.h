@@ -316,6 +316,21 @@ int fh_estimate_H1_seminorm_error_squared(fh_ctx*, uint32_t solution_dim, const 
 int fh_estimate_H1_seminorm_error_squared_dev(fh_ctx*, uint32_t solution_dim, const double* u_h_dev, const double* grad_exact_dev,
                                               double* out);
 
+/* ---- composition of element assemblers: AggregateElementAssembler, MapElementNodes and TransformElementMatrix / Vector with
+ * a scale factor (src/assembly/local.rs:152-340; tests/unit_tests/assembly/local.rs:189-336).  Every body keeps its own
+ * context -- mesh, operator, table, element kind, fastest kernels -- and what it assembled in ITS node numbering is added,
+ * scaled, into a matrix / vector over the aggregate's node index space:
+ *     dst(map[i] s + r, map[j] s + c) += scale * src(i s + r, j s + c)        dst(map[i] s + r) += scale * src(i s + r)
+ * node_map_dev: num_nodes(ctx) u64 on the device, or NULL for the identity (an aggregate over one shared node space).
+ * The destination pattern (scalar CSR, u64, on the device; e.g. fh_pattern of a context that holds the aggregate's ragged
+ * connectivity, fh_set_connectivity_ragged) must hold every mapped entry: a node out of range or a missing column is
+ * FH_BAD_ARGUMENT (the reference panics, global.rs:531-533).  src/dst values on the device, same solution dimension. */
+int fh_add_mapped_matrix_dev(fh_ctx* ctx, const double* src_values_dev, const uint64_t* node_map_dev, double scale,
+                             uint64_t dst_num_nodes, const uint64_t* dst_row_offsets_dev, const uint64_t* dst_col_indices_dev,
+                             double* dst_values_dev);
+int fh_add_mapped_vector_dev(fh_ctx* ctx, const double* src_dev, const uint64_t* node_map_dev, double scale,
+                             uint64_t dst_num_nodes, double* dst_dev);
+
 /* ---- multi-GPU: one process or thread per GPU, each with its own fh_ctx holding one partition (its own
  * elements plus the halo layers whose nodes it shares, so that interface rows have the global pattern and the same layout
  * on both sides; numerics over the own elements: fh_set_active_elements).  The only data that crosses a partition boundary

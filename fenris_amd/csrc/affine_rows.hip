@@ -10,17 +10,20 @@
 // vertex coordinates (k_classify_affine_hex8 in affine_kernel.hpp); node blocks all of whose elements qualify run here, the
 // others keep the general kernels.
 //
-// Work distribution (one workgroup = 4 row waves + 1 store wave, persistent over a contiguous range of positions):
+// Work distribution (one workgroup = 4 row waves + 1 loader wave + 1 store wave, persistent over a contiguous range of
+// positions; position = block of up to seven consecutive nodes):
 //  * row lanes: a lane owns an output block (owned node I, column node J) and evaluates up to two of its terms
 //    (element slot, local a, local b); blocks with more terms are split over 2 / 4 adjacent lanes whose partial sums meet by
 //    DPP quad permutes (self block of a structured mesh: 8 terms, face 4, edge 2, corner 1: 36 lanes per node, 252 per 7-node
-//    block).  The finished 3 x 3 block goes to a staging buffer in LDS laid out like the CSR rows.  No LDS atomics.
-//  * one lane per element slot (in row wave 3) computes R of the NEXT position's elements from four vertices.
+//    block).  The finished 3 x 3 block goes to a staging buffer in LDS laid out like the CSR rows.  No LDS atomics, and no
+//    global memory traffic at all: everything the row waves read comes through LDS.
+//  * the loader wave issues every global load: the element records R (or M) of the next position's slots -- written per
+//    element by k_affine_records right before this kernel --, the lane table when it changes, the position headers.
 //  * the store wave streams the staged rows of the PREVIOUS position to global memory as 16-byte stores, whole 128-byte
-//    lines only (an incomplete last line is carried into the next position's buffer).  It never loads from global memory
-//    and the row waves never store to it, so no wave ever waits for its stores to drain (loads and stores share vmcnt):
-//    the stores of several positions stay in flight.
-// One barrier per position; staging buffers and slot records are double-buffered by position parity.
+//    lines only (an incomplete last line is carried into the next position's buffer).  It never loads from global memory,
+//    so it never waits for its stores to drain (loads and stores share vmcnt): the stores of several positions stay in
+//    flight.
+// One barrier per position; staging buffers, slot records and lane tables are double-buffered, the headers ride a ring.
 //
 // Exact symmetry (util.rs:38-51 mirrors the upper triangle): the owners of (I, J) and (J, I) both evaluate the block of
 // the pair with the smaller global node first (gidx below), the terms of a block are ordered by element id, the split over
@@ -44,11 +47,11 @@ constexpr unsigned AR_ZERO_G = 64u;
 size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     const int gw = (op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     const size_t accp = (size_t)((acc_max + 16 + 1) & ~1);
-    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4);
+    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
 }
 
 template <int OP, bool OVERWRITE, bool STAGED, bool DBG>
-__global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
+__global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
     constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
@@ -58,8 +61,11 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     double* JS = GH + 65 * GW;                      // [2][us][GW]
     const int accp = (T.acc_max + 16 + 1) & ~1;
     double* OUT = JS + 2 * T.us * GW;               // [2][accp]
-    int4* HDR = reinterpret_cast<int4*>(OUT + 2 * accp);  // [4] ring of position headers, slot q & 3 holds hdr[q] (.w replaced by
-                                                    // the head of the position): the row waves fetch, every wave reads them here
+    int4* HDR = reinterpret_cast<int4*>(OUT + 2 * accp);  // [4] ring of position headers, entry q & 3 = {first value, rows,
+                                                    // flags | table slot << 1 | table changed << 2 | table id << 8, head}:
+                                                    // written by the loader wave two positions ahead, read by every wave
+    uint2* LT = reinterpret_cast<uint2*>(HDR + 4);  // [2][256] lane tables: the one in use and the one that comes next
+
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, npos = T.npos;
@@ -70,9 +76,9 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
     const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
     auto head_of = [&](int r0) { return (int)((vals_w + (size_t)SS * (size_t)r0) & 15); };
 
-    if (wave == 4) {
+    if (wave == 5) {
         // ------------------------------------------------------------------------------------------ store wave
-        const int lane = tid - 256;
+        const int lane = tid - 320;
         // Rows of a finished position: LDS -> global memory.  The write path wants whole, aligned 128-byte lines (16-byte
         // stores that start a wave off a line boundary reach 4.3 TB/s instead of 6.2, and a line written in two parts costs
         // about ten full ones: scripts/ubench_fill.hip), but a block's rows start and end anywhere.  So the staging buffer is
@@ -168,90 +174,99 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
         return;
     }
 
-    // ---------------------------------------------------------------------------------------------- row waves
-    const bool hwave = wave == 0;                     // fetches the position headers
-    // Record role: the last NPC us lanes of the row waves bring the element records of the NEXT position's slots (R or M,
-    // GW doubles each, written per element by k_affine_records right before this kernel) from global memory into LDS,
-    // 16 bytes per lane: lane i of the role fetches piece i % NPC of slot i / NPC.
-    constexpr int NPC = GW / 2;                       // 16-byte pieces per record
-    const int jbase = 256 - NPC * T.us;
-    const bool jwave = wave >= (max(jbase, 0) >> 6);  // wave-uniform: the wave holds lanes of the role
-    const int jl = tid - jbase;                       // >= 0 on lanes of the role
-    const int jl_c = max(jl, 0);
-    const int jslot = jl_c / NPC, jpiece = jl_c - jslot * NPC;
-    // lane records: positions with identical records share one table (T.lanes[id]); the id rides in the header (flags >> 8)
-    auto load_lane_tab = [&](int id) { return T.lanes[(size_t)((unsigned)id * 256u + (unsigned)tid)]; };
-    auto load_elem = [&](int p) { return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)jslot)]; };
-    auto load_piece = [&](int e) {
-        return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)max(e, 0) * NPC + jpiece];
-    };
-    auto park_piece = [&](int parity, f64x2 v) {
-        if (jl >= 0) reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + jslot) * GW)[jpiece] = v;
-    };
-
-    const int id_cur0 = __builtin_amdgcn_readfirstlane(T.hdr[p_begin].z >> 8);
-    const uint2 lane_cur0 = load_lane_tab(id_cur0);
-    int4 h_nxt0 = {0, 0, 0, 0};
     auto with_head = [&](int4 h) { h.w = head_of(h.x); return h; };
-    if (hwave) {  // the ring runs two positions ahead: the row waves read the lane-table id of p + 1 at the top of p
-        const int4 h0 = with_head(T.hdr[p_begin]), h1 = with_head(T.hdr[min(p_begin + 1, npos - 1)]);
-        h_nxt0 = T.hdr[min(p_begin + 2, npos - 1)];
-        if (tid == 0) { HDR[p_begin & 3] = h0; HDR[(p_begin + 1) & 3] = h1; }
+    if (wave == 4) {
+        // ------------------------------------------------------------------------------------------ loader wave
+        // Every global load of the kernel: the element records of the next position's slots (R or M, GW doubles each, written
+        // per element by k_affine_records right before this kernel; 16 bytes per lane and round, parked in LDS), the lane
+        // table when it changes (positions with identical lane records share a table: the interior of a structured mesh
+        // never changes it), the position headers (into the ring, two positions ahead).  Everything is consumed in place a
+        // position after it was requested, so the wave waits for a fetch only when memory takes longer than a whole position;
+        // the row waves and the store wave never touch vmcnt.
+        const int lane = tid - 256;
+        constexpr int NPC = GW / 2;                    // 16-byte pieces per record
+        constexpr int ROUNDS = (NPC * 32 + 63) / 64;   // us <= 32 slots
+        const int npieces = NPC * T.us;
+        auto slot_of = [&](int r) { return min(lane + 64 * r, npieces - 1) / NPC; };
+        auto piece_of = [&](int r) { const int i = min(lane + 64 * r, npieces - 1); return i - (i / NPC) * NPC; };
+        auto load_elem = [&](int p, int r) { return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))]; };
+        auto load_piece = [&](int e, int r) { return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)max(e, 0) * NPC + piece_of(r)]; };
+        auto park_piece = [&](int parity, int r, f64x2 v) {
+            if (lane + 64 * r < npieces) reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + slot_of(r)) * GW)[piece_of(r)] = v;
+        };
+        auto load_tab = [&](int id, int half) { return reinterpret_cast<const uint4*>(T.lanes)[(size_t)(unsigned)id * 128u + 64u * half + lane]; };
+        auto park_tab = [&](int slot, int half, uint4 v) { reinterpret_cast<uint4*>(LT + 256 * slot)[64 * half + lane] = v; };
+        auto ring_entry = [&](int4 hq, int slot, bool changed) {
+            int4 o = with_head(hq);
+            o.z = (hq.z & 1) | (slot << 1) | (changed ? 4 : 0) | (hq.z & ~0xff);
+            return o;
+        };
+        // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
+        int4 hq0 = T.hdr[p_begin], hq1 = T.hdr[min(p_begin + 1, npos - 1)];
+        int4 h_nxt = T.hdr[min(p_begin + 2, npos - 1)];               // header of p + 2 while p is current
+        int slot_cur = 0;                                              // table slot of position p + 1 while p is current
+        int id_prev = hq0.z >> 8;
+        {
+            const uint4 t0 = load_tab(id_prev, 0), t1 = load_tab(id_prev, 1);
+            park_tab(0, 0, t0); park_tab(0, 1, t1);
+            const bool ch1 = (hq1.z >> 8) != id_prev;
+            if (ch1) { const uint4 u0 = load_tab(hq1.z >> 8, 0), u1 = load_tab(hq1.z >> 8, 1); park_tab(1, 0, u0); park_tab(1, 1, u1); slot_cur = 1; }
+            if (lane == 0) { HDR[p_begin & 3] = ring_entry(hq0, 0, true); HDR[(p_begin + 1) & 3] = ring_entry(hq1, slot_cur, ch1); }
+            id_prev = hq1.z >> 8;
+        }
+        f64x2 piece[ROUNDS];
+        int e_nxt[ROUNDS];
+        uint4 tab0 = {0, 0, 0, 0}, tab1 = {0, 0, 0, 0};
+        bool tab_pending = false;                                      // tab0 / tab1 hold the lane table of position p + 1
+        int slot_pending = 0;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) { const int e1 = load_elem(p_begin + 1, r); e_nxt[r] = load_elem(p_begin + 2, r); piece[r] = load_piece(e1, r); }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the row waves
+        lds_barrier();  // B0
+        int par = 0;
+        for (int p = p_begin; p < p_end; ++p, par ^= 1) {
+            // in place: what was requested a position ago goes to LDS, the next requests go out
+            if (!(DBG && (ablate & 4))) {
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    park_piece(par ^ 1, r, piece[r]);               // records of p + 1
+                    piece[r] = load_piece(e_nxt[r], r);              // records of p + 2
+                    e_nxt[r] = load_elem(p + 3, r);
+                }
+            }
+            // lane table of p + 1, requested a position ago, into its slot (nobody reads that slot during this position)
+            if (tab_pending) { park_tab(slot_pending, 0, tab0); park_tab(slot_pending, 1, tab1); tab_pending = false; }
+            // position p + 2: its header arrived a position ago -- ring entry, and the request for its lane table if it
+            // differs from that of p + 1 (parked during p + 1, read at the top of p + 2)
+            {
+                const int id2 = __builtin_amdgcn_readfirstlane(h_nxt.z) >> 8;
+                const bool ch2 = id2 != id_prev;
+                const int slot2 = ch2 ? (slot_cur ^ 1) : slot_cur;
+                if (lane == 0) HDR[(p + 2) & 3] = ring_entry(h_nxt, slot2, ch2);
+                if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }
+                slot_cur = slot2;
+                id_prev = id2;
+            }
+            h_nxt = T.hdr[min(p + 3, npos - 1)];
+            lds_barrier();
+        }
+        return;
     }
-    int e_nxt0 = 0;
-    f64x2 piece0 = {0.0, 0.0};
-    if (jwave) {  // records of p_begin into LDS now; the pieces of p_begin + 1 stay in registers, the elements of p_begin + 2 follow
-        park_piece(0, load_piece(load_elem(p_begin)));
-        const int e1 = load_elem(p_begin + 1);
-        e_nxt0 = load_elem(p_begin + 2);
-        piece0 = load_piece(e1);
-    }
-    // everything the prologue fetched has landed before the loop is entered: otherwise the waits the compiler derives for the
-    // entry path (a prologue fetch older than the loop's own prefetches) are executed on every trip -- vmcnt(1) right behind the
-    // issue of the prefetches
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    lds_barrier();  // B0
 
-    const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 12u;  // .w: head of the position
-    const unsigned hdr_addr_z = (unsigned)(unsigned long long)HDR + 8u;  // .z: flags | lane-table id << 8
-    // The loop exists twice, with and without the Jacobian role (wave-uniform choice outside the loop): inside, the role's
-    // arithmetic sits in the same basic block as the row role's products, so the compiler interleaves the two dependency
-    // chains instead of running the Jacobian chain alone at the end of the position.
-    auto run = [&](auto jw_tag) {
-    constexpr bool JW = decltype(jw_tag)::value;
-    // loop-carried state lives in the loop's own scope (values, not captures)
-    uint2 lane_cur = lane_cur0;
-    int id_cur = id_cur0, e_nxt = e_nxt0;
-    int4 h_nxt = h_nxt0;
-    f64x2 piece = piece0;
+    // ---------------------------------------------------------------------------------------------- row waves
+    // No global memory traffic at all: lane records, element records and headers come through LDS.
+    lds_barrier();  // B0
+    const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 8u;   // .z (flags | slot << 1 | changed << 2 | id << 8), .w (head)
+    uint2 lane_cur = {0u, 0u};
     int par = 0;
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
-        const bool have_next = (p + 1) < p_end;
-        // head of this position's rows (vector fetch: a scalar one would have to be waited for right here)
-        int head;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(head) : "v"(hdr_addr + 16u * (unsigned)(p & 3)));
-        // records of the next position's slots, fetched during the previous position, into LDS; then the fetch of the records
-        // of p + 2 (their elements arrived a position ago) and of the elements of p + 3 -- consumed in place, a whole position
-        // to land
-        if constexpr (JW) {
-            if (!(DBG && (ablate & 4))) {
-                if (have_next) park_piece(par ^ 1, piece);
-                piece = load_piece(e_nxt);
-                e_nxt = load_elem(p + 3);
-            }
-        }
-        // prefetch: lane record of p + 1, header of p + 3
-        uint2 lane_nxt = lane_cur;
-        int id_nxt;
-        {
-            int z;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(z) : "v"(hdr_addr_z + 16u * (unsigned)((p + 1) & 3)) : "memory");
-            id_nxt = __builtin_amdgcn_readfirstlane(z) >> 8;
-        }
-        // the same table as this position's (the usual case inside a structured mesh): nothing to fetch
-        if (id_nxt != id_cur && !(DBG && (ablate & 8))) lane_nxt = load_lane_tab(id_nxt);
-        int4 h_nn = h_nxt;
-        if (hwave) h_nn = T.hdr[min(p + 3, npos - 1)];
+        int zw[2];
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
+        const int z = __builtin_amdgcn_readfirstlane(zw[0]);
+        const int head = zw[1];
+        if (z & 4) lane_cur = LT[256 * ((z >> 1) & 1) + tid];   // the lane table changed with this position
 
         const unsigned x = lane_cur.x, y = lane_cur.y;
         const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
@@ -274,8 +289,6 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
             }
             if (grp >= 1) s += dpp_quad_full<0xB1>(s);
             if (grp >= 2) s += dpp_quad_full<0x4E>(s);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(head));
             if ((x >> 28) & 1u) *reinterpret_cast<double*>(out_par + 8 * head + (y & 0xffffu)) = s;
         } else {
             double H[3][3];
@@ -325,8 +338,6 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
 #pragma unroll
                     for (int s_ = 0; s_ < 3; ++s_) H[i][s_] += dpp_quad_full<0x4E>(H[i][s_]);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(head));
             if ((x >> 28) & 1u) {
                 const bool tr = (x >> 26) & 1u, dg = (x >> 27) & 1u;
                 const double mu_tr = a.mu * (H[0][0] + H[1][1] + H[2][2]);
@@ -352,15 +363,8 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 4) k_affine_rows(const KA
                 }
             }
         }
-
-        if (hwave && tid == 0) HDR[(p + 2) & 3] = with_head(h_nxt);
-        h_nxt = h_nn;
-        id_cur = id_nxt;
-        lane_cur = lane_nxt;
         lds_barrier();
     }
-    };
-    if (jwave) run(std::true_type{}); else run(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------ element records

@@ -20,7 +20,7 @@ struct AffineRowTables {
 };
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
-constexpr int AFFINE_ROWS_THREADS = 320;  // four row waves + one store wave
+constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave
 
 size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 

@@ -1,7 +1,7 @@
 # A/B and ablation timings of the affine-element kernel (k_affine_rows) on the headline configuration.
 # usage (GPU box, repo root): bash scripts/gpu_affine_ab.sh [cells]
 # FENRIS_HIP_ABLATE bits (instrumented instantiation, wrong results): 1 no global stores, 2 no sandwich products, 4 no record
-# fetches, 8 no lane-table fetches, 16 nothing switched off, 64 register-staged store wave (stores behind the barrier)
+# fetches, 16 nothing switched off, 64 register-staged store wave (stores behind the barrier)
 CELLS=${1:-216}
 OUT=gpurun_out/affine_ab.txt
 mkdir -p gpurun_out; : > $OUT
@@ -18,9 +18,8 @@ run "ablate 16 (dbg instantiation only)" FENRIS_HIP_ABLATE=16
 run "ablate 1 (no global stores)" FENRIS_HIP_ABLATE=1
 run "ablate 2 (no sandwich)" FENRIS_HIP_ABLATE=2
 run "ablate 4 (no record fetches)" FENRIS_HIP_ABLATE=4
-run "ablate 8 (no lane reload)" FENRIS_HIP_ABLATE=8
 run "ablate 5 (no stores, no records)" FENRIS_HIP_ABLATE=5
-run "ablate 14 (stores only)" FENRIS_HIP_ABLATE=14
-run "ablate 15 (skeleton)" FENRIS_HIP_ABLATE=15
+run "ablate 6 (stores, staging and barriers only)" FENRIS_HIP_ABLATE=6
+run "ablate 7 (skeleton)" FENRIS_HIP_ABLATE=7
 run "ablate 64 (staged store wave)" FENRIS_HIP_ABLATE=64
 run "no lane dedupe" FENRIS_HIP_NO_LANE_DEDUPE=1

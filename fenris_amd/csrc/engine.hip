@@ -345,6 +345,7 @@ struct fh_ctx {
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
     int a_us = 0, a_npos = 0, a_ntab = 0;
+    unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
@@ -513,6 +514,8 @@ int build_pattern(fh_ctx* c) {
     if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
     if (h_flags[1]) return c->fail(FH_UNSUPPORTED, "a node has more than 4096 candidate neighbours");
     c->nnz_nodes = c->h_noff[N];
+    c->max_row = 0;
+    for (int i = 0; i < N; ++i) c->max_row = std::max(c->max_row, c->h_noff[i + 1] - c->h_noff[i]);
     if (c->nnz_nodes >= (1ull << 32) - 1) return c->fail(FH_UNSUPPORTED, "node-level nnz exceeds 2^32");
     HIP_TRY(c, c->ncols.alloc((size_t)c->nnz_nodes + 1));
     if (N > 0) {
@@ -681,8 +684,7 @@ int build_partition(fh_ctx* c) {
     const unsigned* adj_d = c->has_mask ? c->n2e_c.p : c->n2e.p;
     const int S = c->S();
     const int N = (int)c->N;
-    unsigned max_row = 0;
-    for (int i = 0; i < N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+    const unsigned max_row = c->max_row;
     // nodes per block (tunable), entry capacity per batch, accumulator budget
     // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
@@ -1065,7 +1067,10 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
+    // workgroups per CU, measured: elasticity 3 (2: 5.4 ms, 4: 5.5 ms against 4.9 at 216^3 -- more store streams than the
+    // write path likes), Laplace 4 (rows of 216 bytes per node: latency, not stores: 0.39 -> 0.36 ms at 128^3)
+    const size_t cap = (c->op == FH_LAPLACE) ? 4 : 3;
+    const int per_cu = std::max(1, (int)std::min<size_t>(cap, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = std::min(c->npos_gen, dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     auto kern = k_gather_rows_tet4<OP, ELEMPAR>;
     if (lds > 48 * 1024)
@@ -1252,8 +1257,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         rc = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
         if (rc) return rc;
     }
-    unsigned max_row = 0;
-    for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+    const unsigned max_row = c->max_row;  // longest node row, cached with the pattern (no O(N) host scan per assembly)
     const size_t lds = (size_t)4 * sizeof(double) * S * S * max_row;
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "two-pass gather: a node row does not fit in LDS");
     if (max_row >= 65536) return c->fail(FH_UNSUPPORTED, "two-pass gather: node valence too large");
@@ -1406,8 +1410,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     a.ub = a.epb;
     // high-order elements: column search of the scatter in LDS (neighbour lists staged per element)
     if (c->ei.n > 8 && !c->env("FENRIS_HIP_NO_NC_LDS")) {
-        unsigned max_row = 0;
-        for (uint64_t i = 0; i < c->N; ++i) max_row = std::max(max_row, c->h_noff[i + 1] - c->h_noff[i]);
+        const unsigned max_row = c->max_row;
         const size_t with_nc = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, (int)max_row);
         if (with_nc <= LDS_TARGET + 16 * 1024) a.nc_row = (int)max_row;
     }

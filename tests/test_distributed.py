@@ -271,6 +271,32 @@ def test_slabs_through_engine_match_global_oracle(oracle, scatter):
 
 
 @pytest.mark.gpu
+def test_overlapped_slab_assembly_two_processes_one_device():
+    """SlabAssembly with overlap (rows of the ghost plane first, their transfer on a side stream beside the main launch,
+    fh_set_row_range) under a REAL process group: two fresh child processes -- started before anything here touches the
+    GPU state they use -- share cuda:0 over gloo, 5 element layers cut 3 + 2; every rank checks its owned rows against the
+    single-mesh oracle matrix (tests/slab_overlap_worker.py)."""
+    import subprocess
+    import sys
+
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_overlap_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), "4", "5"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        outs.append((pr.returncode, out))
+    for r, (rc, out) in enumerate(outs):
+        assert rc == 0 and f"rank {r} ok" in out, f"rank {r} rc={rc}\n{out[-3000:]}"
+
+
+@pytest.mark.gpu
 def test_group_abi_single_rank_plumbing():
     """fh_group_* (include/fenris_hip.h, fenris_amd/csrc/group.hip) with one rank: RCCL loads, a communicator is created, an
     exchange without peers starts and finishes, argument errors are reported.  (Transfers between ranks need one GPU per

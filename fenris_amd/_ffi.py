@@ -65,6 +65,7 @@ _SIGS = {
     "fh_group_set_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]),
     "fh_group_exchange_start": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fh_group_exchange_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fh_set_quadrature_uniform_data": (C.c_int, [C.c_void_p, f64p, f64p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]),
     "fh_set_quadrature_rules": (C.c_int, [C.c_void_p, C.c_uint64, u64p, f64p, f64p, f64p, u64p]),
     "fh_quadrature_rule_groups": (C.c_int, [C.c_void_p, u64p]),
     "fh_set_affine_tolerance": (C.c_int, [C.c_void_p, C.c_double]),

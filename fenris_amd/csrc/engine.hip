@@ -1923,6 +1923,23 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     return FH_OK;
 }
 
+// the per-point Parameters of the reference as the caller stores them: `stride` bytes from one point's record to the next,
+// `kind` says what the first doubles of a record are
+int fh_set_quadrature_uniform_data(fh_ctx* c, const double* w, const double* pts, uint32_t nq, const void* data, uint32_t stride,
+                                   int kind) {
+    if (!c) return FH_BAD_ARGUMENT;
+    if (kind == FH_DATA_NONE || !data) return fh_set_quadrature_uniform(c, w, pts, nq, nullptr);
+    const uint32_t need = (kind == FH_DATA_LAME) ? 16u : (kind == FH_DATA_DENSITY ? 8u : 0u);
+    if (!need || stride < need || stride % 8u) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform_data: bad kind or stride");
+    std::vector<double> pairs((size_t)nq * 2, 0.0);
+    for (uint32_t q = 0; q < nq; ++q) {
+        const double* rec = reinterpret_cast<const double*>(static_cast<const char*>(data) + (size_t)q * stride);
+        pairs[2 * q] = rec[0];
+        if (kind == FH_DATA_LAME) pairs[2 * q + 1] = rec[1];
+    }
+    return fh_set_quadrature_uniform(c, w, pts, nq, pairs.data());
+}
+
 int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uint32_t nq, uint64_t num_rules,
                               const double* rule_params, const uint64_t* elem_to_rule) {
     if (!c) return FH_BAD_ARGUMENT;

@@ -130,6 +130,13 @@ int fh_set_operator(fh_ctx*, int op_kind);
  * per point, fenris-solid/src/materials.rs:8-12) or NULL for operators without parameters. */
 int fh_set_quadrature_uniform(fh_ctx*, const double* weights, const double* points, uint32_t nq,
                               const double* params);
+/* The same table with the per-point data where and how the caller keeps it (`data: Vec<Parameters>` of
+ * UniformQuadratureTable, quadrature_table.rs:213-298): `stride` bytes from one point's record to the next (a multiple of
+ * 8), `kind` says what a record starts with -- FH_DATA_LAME: LameParameters {mu, lambda} (fenris-solid/src/materials.rs:8-12),
+ * FH_DATA_DENSITY: Density(rho) of the mass / gravity assemblers (fenris-solid/src/gravity_source.rs), FH_DATA_NONE: `()`. */
+enum { FH_DATA_NONE = 0, FH_DATA_LAME = 1, FH_DATA_DENSITY = 2 };
+int fh_set_quadrature_uniform_data(fh_ctx*, const double* weights, const double* points, uint32_t nq, const void* data,
+                                   uint32_t stride, int kind);
 /* CompactQuadratureTable::from_quadrature_rules_and_map (src/assembly/local/quadrature_table.rs:300-439) for rules
  * that share points and weights and differ in their per-point data -- piecewise material parameters: element e
  * uses rule_params[elem_to_rule[e]] (num_rules x nq x 2, same pair layout as the uniform table).  A rule index out

@@ -738,3 +738,29 @@ def test_host_path_overwrite_with_row_range_keeps_other_rows(engine, oracle):
             assert np.abs(buf[lo:hi] - vals[lo:hi]).max() <= TOL * np.abs(vals).max()
     engine.set_row_range(0, n)
     assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+
+
+def test_quadrature_data_with_record_stride(engine, oracle):
+    """fh_set_quadrature_uniform_data: the per-point Parameters where the host keeps them -- LameParameters inside a larger
+    record (stride 32), Density records (stride 8) -- give what the packed pair layout gives"""
+    import ctypes as C
+
+    from fenris_amd import _ffi
+
+    mesh = _mesh("HEX8")
+    w, p = _rule("HEX8")
+    nq = len(w)
+    lam = np.array([[LAME.mu * (1 + 0.03 * q), LAME.lambda_ * (1 - 0.02 * q)] for q in range(nq)])
+    asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", mesh=mesh)
+    ref = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, mesh.vertices, mesh.connectivity, w, p, params=lam)
+    _, _, ro, ci, vals = oracle.assemble(ref)
+    recs = np.zeros((nq, 4))           # {mu, lambda, something else, padding}
+    recs[:, :2] = lam
+    recs[:, 2] = 123.0
+    wv, pv = _ffi.as_f64(w), _ffi.as_f64(p)
+    lib = _ffi.lib()
+    engine._check(lib.fh_set_quadrature_uniform_data(engine._h, _ffi.fp(wv), _ffi.fp(pv), nq, recs.ctypes.data_as(C.c_void_p), 32, 1))
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+    assert lib.fh_set_quadrature_uniform_data(engine._h, _ffi.fp(wv), _ffi.fp(pv), nq, recs.ctypes.data_as(C.c_void_p), 12, 1) == _ffi.FH_BAD_ARGUMENT
+    assert lib.fh_set_quadrature_uniform_data(engine._h, _ffi.fp(wv), _ffi.fp(pv), nq, recs.ctypes.data_as(C.c_void_p), 8, 1) == _ffi.FH_BAD_ARGUMENT

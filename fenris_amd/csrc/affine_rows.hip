@@ -50,7 +50,7 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
 }
 
-template <int OP, bool OVERWRITE, bool STAGED, bool DBG>
+template <int OP, bool OVERWRITE, bool STAGED, bool DBG, int DEPTH>
 __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
@@ -75,6 +75,22 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
     for (int i = tid; i < 2 * accp; i += AFFINE_ROWS_THREADS) OUT[i] = 0.0;
     const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
     auto head_of = [&](int r0) { return (int)((vals_w + (size_t)SS * (size_t)r0) & 15); };
+    // FENRIS_HIP_TRACE (instrumented instantiation): cycles per role between barriers / at the barriers, summed over workgroups
+    unsigned long long tr_work = 0, tr_bar = 0, tr_t0 = 0, tr_seg = 0;
+    auto tr_start = [&]() { if (DBG && a.trace) tr_t0 = __builtin_readcyclecounter(); };
+    auto tr_barrier = [&]() {
+        if (DBG && a.trace) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            lds_barrier();
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            tr_work += t1 - tr_t0; tr_bar += t2 - t1; tr_t0 = t2;
+        } else lds_barrier();
+    };
+    auto tr_report = [&](int role) {
+        if (DBG && a.trace && (tid & 63) == 0) {
+            atomicAdd(a.trace + 7 * role + 0, tr_work); atomicAdd(a.trace + 7 * role + 1, tr_seg); atomicAdd(a.trace + 7 * role + 2, tr_bar); atomicAdd(a.trace + 7 * role + 6, 1ull);
+        }
+    };
 
     if (wave == 5) {
         // ------------------------------------------------------------------------------------------ store wave
@@ -106,7 +122,7 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
             if constexpr (OVERWRITE) *dst = val; else *dst += val;
         };
         auto stage_read = [&](const int4 hv, double* buf, double* other, bool carry_in, bool carry_out) {
-            const int r0 = rfl(hv.x), nrow = rfl(hv.y), flags = rfl(hv.z), head = rfl(hv.w);
+            const int r0 = rfl(hv.x), nrow = rfl(hv.y), flags = rfl(hv.z), head = rfl(hv.w) & 15;
             line0 = a.vals + (size_t)SS * (size_t)r0 - head;
             const int lo = carry_in ? 0 : head, hi = head + SS * nrow;
             const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
@@ -155,6 +171,7 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
             }
         };
         lds_barrier();  // B0
+        tr_start();
         bool carry_in = false;
         int par = 0;
         for (int p = p_begin; p < p_end; ++p, par ^= 1) {
@@ -165,16 +182,18 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
                 stage_read(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
                 carry_in = carry_out;
             }
-            lds_barrier();
+            tr_barrier();
             if (p > p_begin) issue_stores();
         }
         stage_read(HDR[(p_end - 1) & 3], OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue_stores();
+        tr_report(2);
         return;
     }
 
-    auto with_head = [&](int4 h) { h.w = head_of(h.x); return h; };
+    // ring entry .w: head | slots of the position << 8 (every field of the header is used: the fetch stays one 16-byte load)
+    auto with_head = [&](int4 h) { h.w = head_of(h.x) | (h.w << 8); return h; };
     if (wave == 4) {
         // ------------------------------------------------------------------------------------------ loader wave
         // Every global load of the kernel: the element records of the next position's slots (R or M, GW doubles each, written
@@ -203,7 +222,6 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
         int4 hq0 = T.hdr[p_begin], hq1 = T.hdr[min(p_begin + 1, npos - 1)];
-        int4 h_nxt = T.hdr[min(p_begin + 2, npos - 1)];               // header of p + 2 while p is current
         int slot_cur = 0;                                              // table slot of position p + 1 while p is current
         int id_prev = hq0.z >> 8;
         {
@@ -214,59 +232,99 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
             if (lane == 0) { HDR[p_begin & 3] = ring_entry(hq0, 0, true); HDR[(p_begin + 1) & 3] = ring_entry(hq1, slot_cur, ch1); }
             id_prev = hq1.z >> 8;
         }
-        f64x2 piece[ROUNDS];
-        int e_nxt[ROUNDS];
+        // Requests run DEPTH positions ahead of their use (memory answers in 1 - 2 us while the stores of every workgroup are
+        // in flight, a position takes well under one): stage k of the registers below belongs to the positions p with
+        // (p - p_begin) mod DEPTH = k.  While p is current, its stage holds the records of p + 1 (parked now), the element ids
+        // of p + 1 + DEPTH (their records are requested now) and the header of p + 2 (ring entry now); each is refilled in
+        // place with what the stage needs DEPTH positions later.
+        f64x2 piece[DEPTH][ROUNDS];
+        int e_nxt[DEPTH][ROUNDS];
+        int4 h_nxt[DEPTH];
         uint4 tab0 = {0, 0, 0, 0}, tab1 = {0, 0, 0, 0};
         bool tab_pending = false;                                      // tab0 / tab1 hold the lane table of position p + 1
         int slot_pending = 0;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) { const int e1 = load_elem(p_begin + 1, r); e_nxt[r] = load_elem(p_begin + 2, r); piece[r] = load_piece(e1, r); }
+        for (int k = 0; k < DEPTH; ++k) {
+            h_nxt[k] = T.hdr[min(p_begin + k + 2, npos - 1)];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int e1 = load_elem(p_begin + k + 1, r);
+                e_nxt[k][r] = load_elem(p_begin + k + 1 + DEPTH, r);
+                piece[k][r] = load_piece(e1, r);
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the row waves
         lds_barrier();  // B0
+        tr_start();
         int par = 0;
-        for (int p = p_begin; p < p_end; ++p, par ^= 1) {
-            // in place: what was requested a position ago goes to LDS, the next requests go out
-            if (!(DBG && (ablate & 4))) {
-#pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    park_piece(par ^ 1, r, piece[r]);               // records of p + 1
-                    piece[r] = load_piece(e_nxt[r], r);              // records of p + 2
-                    e_nxt[r] = load_elem(p + 3, r);
-                }
-            }
-            // lane table of p + 1, requested a position ago, into its slot (nobody reads that slot during this position)
-            if (tab_pending) { park_tab(slot_pending, 0, tab0); park_tab(slot_pending, 1, tab1); tab_pending = false; }
-            // position p + 2: its header arrived a position ago -- ring entry, and the request for its lane table if it
-            // differs from that of p + 1 (parked during p + 1, read at the top of p + 2)
-            {
-                const int id2 = __builtin_amdgcn_readfirstlane(h_nxt.z) >> 8;
-                const bool ch2 = id2 != id_prev;
-                const int slot2 = ch2 ? (slot_cur ^ 1) : slot_cur;
-                if (lane == 0) HDR[(p + 2) & 3] = ring_entry(h_nxt, slot2, ch2);
-                if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }
-                slot_cur = slot2;
-                id_prev = id2;
-            }
-            h_nxt = T.hdr[min(p + 3, npos - 1)];
-            lds_barrier();
+        // one position of the loader (a macro, not a lambda: the stages must stay in registers)
+#define AFFINE_LOADER_STEP(k, p)                                                                                              \
+        {                                                                                                                     \
+            /* in place: what was requested DEPTH positions ago goes to LDS, the next requests go out */                     \
+            unsigned long long tq0 = 0;                                                                                       \
+            if (DBG && a.trace) tq0 = __builtin_readcyclecounter();                                                           \
+            if (!(DBG && (ablate & 4))) {                                                                                     \
+                _Pragma("unroll") for (int r = 0; r < ROUNDS; ++r) {                                                          \
+                    park_piece(par ^ 1, r, piece[k][r]);              /* records of p + 1 */                                  \
+                    piece[k][r] = load_piece(e_nxt[k][r], r);         /* records of p + 1 + DEPTH */                          \
+                    e_nxt[k][r] = load_elem((p) + 1 + 2 * DEPTH, r);                                                          \
+                }                                                                                                             \
+            }                                                                                                                 \
+            if (DBG && a.trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_seg += __builtin_readcyclecounter() - tq0; } \
+            /* lane table of p + 1, requested a position ago, into its slot (nobody reads that slot during this position) */ \
+            if (tab_pending) { park_tab(slot_pending, 0, tab0); park_tab(slot_pending, 1, tab1); tab_pending = false; }       \
+            /* position p + 2: ring entry, and the request for its lane table if it differs from that of p + 1 (parked      \
+               during p + 1, read at the top of p + 2) */                                                                     \
+            const int id2 = __builtin_amdgcn_readfirstlane(h_nxt[k].z) >> 8;                                                  \
+            const bool ch2 = id2 != id_prev;                                                                                  \
+            const int slot2 = ch2 ? (slot_cur ^ 1) : slot_cur;                                                                \
+            if (lane == 0) HDR[((p) + 2) & 3] = ring_entry(h_nxt[k], slot2, ch2);                                             \
+            if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }          \
+            slot_cur = slot2;                                                                                                 \
+            id_prev = id2;                                                                                                    \
+            h_nxt[k] = T.hdr[min((p) + 2 + DEPTH, npos - 1)];                                                                 \
+            tr_barrier();                                                                                                     \
+            par ^= 1;                                                                                                         \
         }
+        // whole groups of DEPTH positions, then the rest: a loop that can be left between two stages makes the compiler wait
+        // for the youngest requests at its top (the exits share the latch)
+        int p0 = p_begin;
+        for (; p0 + DEPTH <= p_end; p0 += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) AFFINE_LOADER_STEP(k, p0 + k)
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH - 1; ++k)
+            if (p0 + k < p_end) AFFINE_LOADER_STEP(k, p0 + k)
+#undef AFFINE_LOADER_STEP
+        tr_report(1);
         return;
     }
 
     // ---------------------------------------------------------------------------------------------- row waves
     // No global memory traffic at all: lane records, element records and headers come through LDS.
     lds_barrier();  // B0
+    tr_start();
     const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 8u;   // .z (flags | slot << 1 | changed << 2 | id << 8), .w (head)
     uint2 lane_cur = {0u, 0u};
+    f64x2 gq0[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, gq1[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};   // Laplace: Ghat of the lane's terms
     int par = 0;
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
         int zw[2];
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
         const int z = __builtin_amdgcn_readfirstlane(zw[0]);
-        const int head = zw[1];
-        if (z & 4) lane_cur = LT[256 * ((z >> 1) & 1) + tid];   // the lane table changed with this position
+        const int head = zw[1] & 15;
+        if (z & 4) {   // the lane table changed with this position
+            lane_cur = LT[256 * ((z >> 1) & 1) + tid];
+            if constexpr (LAP) {  // ... and with it the reference blocks of this lane's two terms: kept in registers
+                const f64x2* q0 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((lane_cur.x >> 5) & 127u) * (GW * 8));
+                const f64x2* q1 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((lane_cur.x >> 17) & 127u) * (GW * 8));
+#pragma unroll
+                for (int h = 0; h < 3; ++h) { gq0[h] = q0[h]; gq1[h] = q1[h]; }
+            }
+        }
 
         const unsigned x = lane_cur.x, y = lane_cur.y;
         const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
@@ -277,15 +335,13 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
         char* out_par = reinterpret_cast<char*>(OUT + (size_t)par * accp);
         if constexpr (LAP) {
             const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
-            const f64x2* g0 = reinterpret_cast<const f64x2*>(gh + oG0);
             const f64x2* m1 = reinterpret_cast<const f64x2*>(js + oR1);
-            const f64x2* g1 = reinterpret_cast<const f64x2*>(gh + oG1);
             double s = 0.0;
             if (!(DBG && (ablate & 2))) {
 #pragma unroll
-                for (int h = 0; h < 3; ++h) { const f64x2 m = m0[h], g = g0[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
+                for (int h = 0; h < 3; ++h) { const f64x2 m = m0[h], g = gq0[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
 #pragma unroll
-                for (int h = 0; h < 3; ++h) { const f64x2 m = m1[h], g = g1[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
+                for (int h = 0; h < 3; ++h) { const f64x2 m = m1[h], g = gq1[h]; s = fma(g.x, m.x, s); s = fma(g.y, m.y, s); }
             }
             if (grp >= 1) s += dpp_quad_full<0xB1>(s);
             if (grp >= 2) s += dpp_quad_full<0x4E>(s);
@@ -363,8 +419,9 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
                 }
             }
         }
-        lds_barrier();
+        tr_barrier();
     }
+    if (wave == 0) tr_report(0);
 }
 
 // ------------------------------------------------------------------------------------------------ element records
@@ -582,18 +639,24 @@ hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, cons
     return hipGetLastError();
 }
 
-hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+template <int OP, int DEPTH>
+static auto affine_rows_pick(bool ow, bool dbg, bool staged) -> void (*)(const KArgs, const AffineRowTables, int) {
+    if (dbg) return staged ? k_affine_rows<OP, true, true, true, DEPTH> : k_affine_rows<OP, true, false, true, DEPTH>;
+    return ow ? k_affine_rows<OP, true, false, false, DEPTH> : k_affine_rows<OP, false, false, false, DEPTH>;
+}
+template <int OP>
+static auto affine_rows_pick_depth(int depth, bool ow, bool dbg, bool staged) -> void (*)(const KArgs, const AffineRowTables, int) {
+    // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
+    return depth <= 1 ? affine_rows_pick<OP, 1>(ow, dbg, staged) : affine_rows_pick<OP, 2>(ow, dbg, staged);
+}
+
+hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
                               int ablate) {
-    void (*kern)(const KArgs, const AffineRowTables, int);
     const bool ow = a.overwrite != 0;
     const bool staged = (ablate & 64) != 0;   // profiling: the register-staged store wave (stores behind the barrier)
-    if (op == FH_LAPLACE) {
-        kern = ablate ? (staged ? k_affine_rows<FH_LAPLACE, true, true, true> : k_affine_rows<FH_LAPLACE, true, false, true>)
-                      : ow ? k_affine_rows<FH_LAPLACE, true, false, false> : k_affine_rows<FH_LAPLACE, false, false, false>;
-    } else {
-        kern = ablate ? (staged ? k_affine_rows<FH_LINEAR_ELASTIC, true, true, true> : k_affine_rows<FH_LINEAR_ELASTIC, true, false, true>)
-                      : ow ? k_affine_rows<FH_LINEAR_ELASTIC, true, false, false> : k_affine_rows<FH_LINEAR_ELASTIC, false, false, false>;
-    }
+    void (*kern)(const KArgs, const AffineRowTables, int) =
+        op == FH_LAPLACE ? affine_rows_pick_depth<FH_LAPLACE>(depth, ow, ablate != 0, staged)
+                         : affine_rows_pick_depth<FH_LINEAR_ELASTIC>(depth, ow, ablate != 0, staged);
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;

@@ -43,8 +43,8 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
 hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, const int* ids, const int* first_pos, int npos, int ntab,
                                uint2* lanes_tab, int4* hdr, int* mismatch);
 
-// op: FH_LAPLACE or FH_LINEAR_ELASTIC; ablate != 0 selects the instrumented instantiation (profiling only)
-hipError_t affine_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+// op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; ablate != 0 selects the instrumented instantiation (profiling only)
+hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
                               int ablate);
 
 }  // namespace fenris_hip

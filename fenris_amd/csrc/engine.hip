@@ -1189,11 +1189,12 @@ int launch_affine(fh_ctx* c, KArgs& a) {
                       c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
     const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
-    const int per_cu = std::max(1, (int)std::min<size_t>(3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));  // 3: measured best
+    // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
+    const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = std::min(c->a_npos, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
     if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
-    HIP_TRY(c, affine_rows_launch(c->op, grid, lds, c->stream, a, T, a.ablate));
+    HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T, a.ablate));
     return FH_OK;
 }
 
@@ -1548,6 +1549,8 @@ void fh_destroy(fh_ctx* c) {
         unsigned long long h[32] = {0};
         (void)hipDeviceSynchronize();
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
+            // pipelined kernel: six phases of waves 0-3; affine kernel: "wave" = role (0 row wave, 1 loader, 2 store wave), phase 0 =
+            // work between barriers, phase 2 = at the barrier
             static const char* names[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};
             for (int w = 0; w < 4; ++w) {
                 const unsigned long long* r = h + 7 * w;

@@ -202,6 +202,16 @@ class Engine:
     def assemble_matrix_async(self, values_t, flags):
         self._check(self._lib.fh_assemble_matrix_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags))
 
+    def assemble_matrix_rows_async(self, values_t, flags, node_begin, node_end):
+        """rows of the nodes [node_begin, node_end) only, with the context's second set of tables (fh_assemble_matrix_rows_async_dev)"""
+        self._check(self._lib.fh_assemble_matrix_rows_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags,
+                                                                C.c_uint64(int(node_begin)), C.c_uint64(int(node_end))))
+
+    def assemble_matrix_rows(self, values_t, flags, node_begin, node_end):
+        failed = C.c_uint64(0)
+        self._check(self._lib.fh_assemble_matrix_rows_dev(self._h, C.c_void_p(values_t.data_ptr()), flags,
+                                                          C.c_uint64(int(node_begin)), C.c_uint64(int(node_end)), C.byref(failed)), failed)
+
     def poll_status(self):
         failed = C.c_uint64(0)
         self._check(self._lib.fh_poll_status(self._h, C.byref(failed)), failed)

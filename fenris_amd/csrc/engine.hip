@@ -349,6 +349,12 @@ struct fh_ctx {
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
+    // Second set of owner-computes tables (fh_assemble_matrix_rows_dev): the partition of another node range, swapped in for
+    // the duration of that call.  struct_gen counts everything that invalidates a partition; the stash remembers the count
+    // its tables were built at.
+    unsigned long long struct_gen = 0;
+    struct PartStash* rows_stash = nullptr;
+    int status_slot = 0;                // DevStatus slot the kernels of the current call report to (1: the rows call)
     // Rule-set quadrature tables (fh_set_quadrature_rules: GeneralQuadratureTable, CompactQuadratureTable with different
     // point sets).  Rules with identical points and weights form a group; a group is staged as a uniform / compact table
     // with the element mask restricted to its elements, and the global assemblers walk the groups, accumulating.
@@ -402,6 +408,27 @@ struct fh_ctx {
     }
 };
 
+// Everything build_partition produces (and the row range it was produced for), as a detachable unit.
+#define FH_PARTITION_MEMBERS(X)                                                                                              \
+    X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
+    X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
+    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(npos_gen)       \
+    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar)
+struct PartStash {
+#define X(name) decltype(fh_ctx::name) name{};
+    FH_PARTITION_MEMBERS(X)
+#undef X
+    unsigned long long built_gen = ~0ull;
+    PartStash() { row_lo = 0; row_hi = -1; r_ls = 256; p_jt = 1; }
+};
+template <class T> static void part_swap(DevBuf<T>& a, DevBuf<T>& b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+template <class T> static void part_swap(T& a, T& b) { std::swap(a, b); }
+static void swap_partition(fh_ctx* c, PartStash& st) {
+#define X(name) part_swap(c->name, st.name);
+    FH_PARTITION_MEMBERS(X)
+#undef X
+}
+
 #define HIP_TRY(ctx, expr)                                        \
     do {                                                          \
         hipError_t _e = (expr);                                   \
@@ -419,7 +446,7 @@ int grid_for(long long n, int block, int cap = 256 * 32) {
 
 void invalidate_pattern(fh_ctx* c) {
     c->has_pattern = false;
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     c->has_colors = false;
     c->nnz_nodes = 0;
 }
@@ -427,7 +454,7 @@ void invalidate_pattern(fh_ctx* c) {
 // node -> (active element, local index) adjacency used by the owner-computes kernels when an element
 // mask is set (multi-GPU partitions: the pattern comes from own + halo elements, numerics from own ones)
 int build_compute_adjacency(fh_ctx* c) {
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     if (!c->has_mask || !c->has_pattern) return FH_OK;
     const int N = (int)c->N;
     hipStream_t st = c->stream;
@@ -526,7 +553,7 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
     c->has_pattern = true;
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     return build_compute_adjacency(c);
 }
 
@@ -636,7 +663,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.ncols = c->ncols.p;
     a.n2e_off = c->n2e_off.p;
     a.n2e = c->n2e.p;
-    a.status = c->status.p;
+    a.status = c->status.p + c->status_slot;
     a.ablate = c->env_int("FENRIS_HIP_ABLATE", 0);
     a.trace = nullptr;
     if (c->env("FENRIS_HIP_TRACE")) {
@@ -646,21 +673,34 @@ void fill_common(fh_ctx* c, KArgs& a) {
 }
 
 int reset_status(fh_ctx* c) {
-    if (!c->status.p) HIP_TRY(c, c->status.alloc(1));
-    DevStatus s{0, 0, ~0ull};
-    HIP_TRY(c, hipMemcpyAsync(c->status.p, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    if (!c->status.p || c->status.n < 2) {
+        HIP_TRY(c, c->status.alloc(2));
+        const DevStatus z[2] = {{0, 0, ~0ull}, {0, 0, ~0ull}};
+        HIP_TRY(c, hipMemcpyAsync(c->status.p, z, sizeof z, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // z is on the stack
+    }
+    static const DevStatus s{0, 0, ~0ull};
+    HIP_TRY(c, hipMemcpyAsync(c->status.p + c->status_slot, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
     return FH_OK;
 }
 
 int read_status(fh_ctx* c, uint64_t* failed) {
-    DevStatus s{};
-    HIP_TRY(c, hipMemcpyAsync(&s, c->status.p, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    // slot 0: the context's own launches; slot 1: fh_assemble_matrix_rows_dev (reset by the next such call, or here once
+    // its error has been reported)
+    DevStatus s[2] = {};
+    const bool two = c->status.n >= 2;
+    HIP_TRY(c, hipMemcpyAsync(s, c->status.p, sizeof(DevStatus) * (two ? 2 : 1), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    if (s.singular) {
-        if (failed) *failed = s.failed_elem;
-        return c->fail(FH_SINGULAR_JACOBIAN, "Singular element Jacobian encountered");
-    }
+    for (int k = 0; k < (two ? 2 : 1); ++k)
+        if (s[k].singular) {
+            if (failed) *failed = s[k].failed_elem;
+            if (k == 1) {
+                static const DevStatus z{0, 0, ~0ull};
+                HIP_TRY(c, hipMemcpyAsync(c->status.p + 1, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+            }
+            return c->fail(FH_SINGULAR_JACOBIAN, "Singular element Jacobian encountered");
+        }
     return FH_OK;
 }
 
@@ -1184,7 +1224,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const int gw = (c->op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
     HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, c->has_mask ? c->active.p : nullptr,
-                                     (long long)c->E, c->a_recs.p, c->status.p));
+                                     (long long)c->E, c->a_recs.p, c->status.p + c->status_slot));
     AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                       c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
     const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
@@ -1538,7 +1578,11 @@ fh_ctx* fh_create(int device_id) {
         const char* eq = std::strchr(*ev, '=');
         if (eq) c->env_vars.emplace(std::string(*ev, (size_t)(eq - *ev)), std::string(eq + 1));
     }
-    if (c->status.alloc(1) != hipSuccess) { delete c; return nullptr; }
+    const DevStatus z[2] = {{0, 0, ~0ull}, {0, 0, ~0ull}};
+    if (c->status.alloc(2) != hipSuccess || hipMemcpy(c->status.p, z, sizeof z, hipMemcpyHostToDevice) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -1563,6 +1607,7 @@ void fh_destroy(fh_ctx* c) {
             }
         }
     }
+    delete c->rows_stash;
     delete c;
 }
 
@@ -1610,7 +1655,7 @@ static int classify_affine(fh_ctx* c) {
     c->has_aff = false;
     c->num_aff = 0;
     if (c->elem_kind != FH_HEX8 || c->E == 0 || !(c->affine_tol > 0.0)) {
-        if (had) c->has_partition = false;
+        if (had) c->has_partition = false; ++c->struct_gen;
         return FH_OK;
     }
     DevBuf<unsigned char> flags;
@@ -1642,7 +1687,7 @@ static int classify_affine(fh_ctx* c) {
     std::swap(c->elem_aff.n, flags.n);
     c->num_aff = h;
     c->has_aff = true;
-    if (!same) { c->has_partition = false; c->aff_failed = false; }
+    if (!same) { c->has_partition = false; ++c->struct_gen; c->aff_failed = false; }
     return FH_OK;
 }
 
@@ -1785,7 +1830,7 @@ int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
     return apply_mask(c, mask);
 }
 static int apply_mask(fh_ctx* c, const uint8_t* mask) {
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     if (!mask) {
         c->has_mask = false;
         if (c->has_colors) return upload_colors(c, c->host_colors_offs, c->host_colors_labels);
@@ -1818,7 +1863,7 @@ int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
     if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_set_row_range: bad node range");
     if (node_begin == 0 && node_end == c->N) { c->row_lo = 0; c->row_hi = -1; }
     else { c->row_lo = (long long)node_begin; c->row_hi = (long long)node_end; }
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -1847,7 +1892,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
     c->op = op_kind;
     if (c->S() != old_s) { c->has_u = false; c->has_tp_pos = false; }
     // the owner-computes partition (LDS budgets, kernel classes, slot parameters) is built for one operator
-    if (op_kind != old_op) { c->has_partition = false; c->has_slotpar = false; }
+    if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; }
     return FH_OK;
 }
 
@@ -1922,7 +1967,7 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     if (c->env("FENRIS_HIP_NO_FAST")) c->fast_ok = false;
     c->has_rules = false;
     c->elem_par = false;
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -1971,7 +2016,7 @@ int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uin
     c->elem_par = weights_ok && rules_const && !c->env("FENRIS_HIP_NO_FAST") && !c->env("FENRIS_HIP_NO_ELEM_PAR");
     c->fast_ok = c->elem_par;
     c->has_slotpar = false;
-    c->has_partition = false; c->has_tp_pos = false;
+    c->has_partition = false; ++c->struct_gen; c->has_tp_pos = false;
     return FH_OK;
 }
 
@@ -2209,6 +2254,39 @@ int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
     if (!any && (flags & FH_ASSEMBLE_OVERWRITE) && fh_nnz(c))
         HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * fh_nnz(c), c->stream));
     return FH_OK;
+}
+
+// The rows of the nodes [node_begin, node_end) with a second set of owner-computes tables; the context's own row range and
+// tables are untouched.  The second set is built on first use and rebuilt when the range or anything the tables depend on
+// (mesh, pattern, mask, operator, quadrature, affine classes) has changed since.
+int fh_assemble_matrix_rows_async_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end) {
+    if (!c) return FH_BAD_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_assemble_matrix_rows: set the mesh first");
+    if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix_rows: bad node range");
+    if ((flags & FH_SCATTER_MASK) != FH_SCATTER_GATHER) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix_rows: needs FH_SCATTER_GATHER");
+    if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix_rows: not with a rule-set quadrature table");
+    if (!c->rows_stash) c->rows_stash = new PartStash();
+    PartStash& st = *c->rows_stash;
+    swap_partition(c, st);   // the context's own tables wait in the stash
+    if (st.built_gen != c->struct_gen || c->row_lo != (long long)node_begin || c->row_hi != (long long)node_end) {
+        c->row_lo = (long long)node_begin;   // a range, even when it covers every node: the two-pass path does not apply
+        c->row_hi = (long long)node_end;
+        c->has_partition = false;
+        c->aff_failed = false;
+    }
+    c->status_slot = 1;
+    const int rc = assemble_matrix_enqueue(c, values_dev, flags);
+    c->status_slot = 0;
+    swap_partition(c, st);
+    st.built_gen = rc ? ~0ull : c->struct_gen;
+    return rc;
+}
+
+int fh_assemble_matrix_rows_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end, uint64_t* failed) {
+    const int rc = fh_assemble_matrix_rows_async_dev(c, values_dev, flags, node_begin, node_end);
+    if (rc) return rc;
+    return read_status(c, failed);
 }
 
 int fh_poll_status(fh_ctx* c, uint64_t* failed) {

@@ -242,7 +242,7 @@ class SlabAssembly:
 
     ``configure(engine, mesh)`` sets operator / quadrature / u on an engine for the given mesh (typically by building
     an ElementEllipticAssembler).  In "exchange" mode with ``overlap`` the rows of the bottom ghost plane are
-    produced by a first, small launch (a second context restricted to those rows, ``fh_set_row_range``); their
+    produced by a first, small launch (the same context's second set of tables, ``fh_assemble_matrix_rows_async_dev``); their
     transfer to the owner rides a separate stream while the main launch computes all other rows; the received
     rows are added at the end.  In "halo" mode nothing is exchanged."""
 
@@ -258,16 +258,13 @@ class SlabAssembly:
         self.main.set_active_elements(slab.active)
         nnz = self.main.build_pattern()
         self.values = torch.zeros(nnz, dtype=torch.float64, device=f"cuda:{device}")
-        self.first = None
+        self.split = None
         self.comm = None
         if overlap and slab.send_nodes is not None:
-            split = slab.send_nodes[1]  # the nodes below the ghost plane carry no active element
-            self.first = Engine(device, stream=stream)
-            configure(self.first, slab.mesh)
-            self.first.set_active_elements(slab.active)
-            self.first.build_pattern()
-            self.first.set_row_range(0, split)
-            self.main.set_row_range(split, slab.mesh.num_nodes())
+            # the rows of the bottom ghost plane come first, from the same context's second set of tables
+            # (fh_assemble_matrix_rows_async_dev); the nodes below the plane carry no active element
+            self.split = int(slab.send_nodes[1])
+            self.main.set_row_range(self.split, slab.mesh.num_nodes())
         if overlap and (slab.send_nodes is not None or slab.recv_nodes is not None):
             self.comm = torch.cuda.Stream(device=device)
         if exchange == "abi":   # RCCL inside the library (fh_group_*); the torch path stays the test harness
@@ -277,8 +274,8 @@ class SlabAssembly:
 
     def enqueue(self, flags):
         """one assembly of this rank's rows (values overwritten or accumulated according to ``flags``)"""
-        if self.first is not None:
-            self.first.assemble_matrix_async(self.values, flags)
+        if self.split is not None:
+            self.main.assemble_matrix_rows_async(self.values, flags, 0, self.split)
         if self.comm is not None:
             self.exchange.start(self.comm)
             self.main.assemble_matrix_async(self.values, flags)
@@ -289,13 +286,9 @@ class SlabAssembly:
 
     def poll_status(self):
         self.main.poll_status()
-        if self.first is not None:
-            self.first.poll_status()
 
     def close(self):
         self.main.close()
-        if self.first is not None:
-            self.first.close()
 
 
 def make_slab_problem(cells: int, rank: int, world: int, mode: str = "exchange"):

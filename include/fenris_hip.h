@@ -119,9 +119,9 @@ int fh_set_connectivity_ragged(fh_ctx*, uint64_t solution_dim, uint64_t num_node
  * see fenris_amd/distributed.py.  mask has num_elements bytes; NULL removes the mask. */
 int fh_set_active_elements(fh_ctx*, const uint8_t* mask);
 /* Restrict FH_SCATTER_GATHER assembly to the rows of the nodes [node_begin, node_end): only those CSR rows are
- * produced (the others are left untouched).  Two contexts on the same mesh with complementary ranges assemble the
- * matrix in two launches -- the multi-GPU path launches the rows of a partition interface first and sends them
- * while the rest is computed (fenris_amd/distributed.py).  (0, num_nodes) restores the default. */
+ * produced (the others are left untouched).  Together with fh_assemble_matrix_rows_dev (below) one context assembles
+ * the matrix in two launches over complementary ranges -- the multi-GPU path launches the rows of a partition interface
+ * first and sends them while the rest is computed (fenris_amd/distributed.py).  (0, num_nodes) restores the default. */
 int fh_set_row_range(fh_ctx*, uint64_t node_begin, uint64_t node_end);
 /* Operator: replaces .with_operator(&op) (elliptic.rs:99-108).  Solution dim s = 1 for Laplace, D else. */
 int fh_set_operator(fh_ctx*, int op_kind);
@@ -210,6 +210,14 @@ int fh_assemble_matrix_dev(fh_ctx*, double* values_dev, int flags, uint64_t* fai
 /* same, but only enqueues; check the status later with fh_poll_status (no host sync; for timing loops) */
 int fh_assemble_matrix_async_dev(fh_ctx*, double* values_dev, int flags);
 int fh_poll_status(fh_ctx*, uint64_t* failed_element);
+/* The CSR rows of the nodes [node_begin, node_end) only (FH_SCATTER_GATHER), whatever the context's own row range is: the
+ * context keeps a second set of owner-computes tables for this range next to its own (mesh, pattern, quadrature and operator
+ * are shared, nothing is duplicated), built on first use and rebuilt when the range or the context's configuration changes.
+ * A context with fh_set_row_range(split, N) plus this call on [0, split) produces the matrix in two launches.  Not with
+ * rule-set tables (fh_set_quadrature_rules).  The _async form only enqueues; fh_poll_status reports its errors too. */
+int fh_assemble_matrix_rows_dev(fh_ctx*, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end,
+                                uint64_t* failed_element);
+int fh_assemble_matrix_rows_async_dev(fh_ctx*, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end);
 /* VectorAssembler::assemble_vector_into / VectorParAssembler (global.rs:582-608, 643-685) with
  * assemble_element_elliptic_vector (elliptic.rs:457-531): out (s*N) is accumulated into. */
 int fh_assemble_vector(fh_ctx*, double* out, uint64_t* failed_element);
@@ -357,8 +365,8 @@ void fh_group_destroy(fh_group*);
  * send = rows of the bottom ghost plane to rank - 1, receive = rows of the owned top plane from rank + 1. */
 int fh_group_set_exchange(fh_group*, int send_peer, uint64_t send_first, uint64_t send_count, int recv_peer,
                           uint64_t recv_first, uint64_t recv_count);
-/* start: call after enqueueing the launch that produces the rows to send (fh_assemble_matrix_async_dev, possibly restricted
- * with fh_set_row_range); the transfers run on the group's stream while the caller enqueues the rest of the assembly.
+/* start: call after enqueueing the launch that produces the rows to send (fh_assemble_matrix_rows_async_dev for the
+ * interface rows); the transfers run on the group's stream while the caller enqueues the rest of the assembly.
  * finish: the context's stream waits for the transfers and adds the received rows.  Errors: fh_last_error(ctx). */
 int fh_group_exchange_start(fh_group*, double* values_dev);
 int fh_group_exchange_finish(fh_group*, double* values_dev);

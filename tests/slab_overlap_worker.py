@@ -36,7 +36,7 @@ def main():
                 .with_quadrature_table(qt).with_u(None).build())
 
     asm = fd.SlabAssembly(slab, configure, device=0, overlap=True, stream=torch.cuda.current_stream().cuda_stream)
-    assert (asm.first is not None) == (rank > 0)      # ranks with a ghost plane below launch its rows first
+    assert (asm.split is not None) == (rank > 0)      # ranks with a ghost plane below launch its rows first
     assert asm.comm is not None
     for _ in range(2):                                 # twice: overwrite semantics, buffers reused
         asm.enqueue(fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)

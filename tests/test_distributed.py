@@ -165,8 +165,9 @@ def test_four_rank_exchange_over_gloo_uneven_layers():
 
 @pytest.mark.gpu
 def test_row_range_split_equals_single_launch():
-    """SlabAssembly's two launches (rows of the ghost plane first, then the rest; fh_set_row_range) write exactly
-    the rows a single launch writes, with the same values up to the summation order inside the row accumulators"""
+    """SlabAssembly's two launches from ONE context (rows of the ghost plane first with the context's second set of
+    tables, fh_assemble_matrix_rows_async_dev; then the rest, fh_set_row_range) write exactly the rows a single launch
+    writes, with the same values up to the summation order inside the row accumulators"""
     import torch
 
     world, cells = 3, 4
@@ -179,10 +180,10 @@ def test_row_range_split_equals_single_launch():
 
     slab = fd.make_slab(1.0, 1, 1, world, cells, 1, world)
     sa = fd.SlabAssembly(slab, configure, device=0, overlap=True)
-    assert sa.first is not None and sa.comm is not None
+    assert sa.split is not None and sa.comm is not None
     flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
     sa.values.fill_(7.0)
-    sa.first.assemble_matrix_async(sa.values, flags)
+    sa.main.assemble_matrix_rows_async(sa.values, flags, 0, sa.split)
     torch.cuda.synchronize()
     a, b = sa.exchange.send_seg
     v1 = sa.values.cpu().numpy().copy()
@@ -201,9 +202,59 @@ def test_row_range_split_equals_single_launch():
     fv = full.cpu().numpy()
     assert np.abs(v2 - fv).max() <= 1e-12 * np.abs(fv).max()
     with pytest.raises(fa.FenrisError):  # a row range is an owner-computes notion
-        sa.first.assemble_matrix(sa.values, fa.SCATTER_ATOMIC)
+        sa.main.assemble_matrix_rows(sa.values, fa.SCATTER_ATOMIC, 0, sa.split)
+    with pytest.raises(fa.FenrisError):
+        sa.main.assemble_matrix(sa.values, fa.SCATTER_ATOMIC)
+    # the second set of tables follows the context: another range, then a changed mask, then the first range again
+    n = slab.mesh.num_nodes()
+    sa.values.fill_(7.0)
+    sa.main.assemble_matrix_rows(sa.values, flags, sa.split, n)       # same rows as the context's own range
+    v3 = sa.values.cpu().numpy().copy()
+    assert np.all(v3[:b] == 7.0) and np.array_equal(v3[b:], v2[b:])
+    mask = slab.active.copy()
+    mask[np.flatnonzero(mask)[::2]] = 0
+    sa.main.set_active_elements(mask)
+    ref.set_active_elements(mask)
+    ref.assemble_matrix(full, flags)
+    fv = full.cpu().numpy()
+    sa.values.fill_(7.0)
+    sa.main.assemble_matrix_rows(sa.values, flags, 0, sa.split)
+    sa.main.assemble_matrix(sa.values, flags)
+    v4 = sa.values.cpu().numpy()
+    assert np.abs(v4 - fv).max() <= 1e-12 * np.abs(fv).max()
     ref.close()
     sa.close()
+
+
+@pytest.mark.gpu
+def test_rows_call_reports_a_singular_element_of_its_range():
+    """fh_assemble_matrix_rows_*: a degenerate element touching the range is reported by the call / by the next poll, and a
+    later clean call clears it (the rows call has its own status slot)"""
+    import torch
+
+    mesh = fa.procedural.create_unit_box_uniform_hex_mesh_3d(3)
+    verts = mesh.vertices.copy()
+    e0 = mesh.connectivity[0]
+    verts[e0] = verts[e0[0]]                                          # element 0 collapsed to a point: det J == 0 exactly
+    bad = fa.Mesh(verts, mesh.connectivity.copy(), mesh.elem_kind)
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters(*LAME))
+    eng = fa.Engine(0)
+    (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(bad)
+     .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt).with_u(None).build())
+    nnz = eng.build_pattern()
+    vals = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+    flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+    n = bad.num_nodes()
+    with pytest.raises(fa.FenrisError, match="Singular"):
+        eng.assemble_matrix_rows(vals, flags, 0, 8)                   # node 0 belongs to element 0
+    eng.assemble_matrix_rows_async(vals, flags, 0, 8)
+    eng.set_row_range(8, n)
+    with pytest.raises(fa.FenrisError, match="Singular"):
+        eng.poll_status()                                             # reported although the context's own slot is clean
+    eng.assemble_matrix_rows(vals, flags, n - 4, n)                   # far corner: clean, and the slot is clear again
+    eng.poll_status()
+    eng.close()
 
 
 @pytest.mark.gpu

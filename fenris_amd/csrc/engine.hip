@@ -1284,7 +1284,11 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
         const int grid1 = (int)std::min<long long>(a.work_end, (long long)dev_cus * 2);
         if (grid1 > 0) {
-            if (c->op == FH_NEO_HOOKEAN) {
+            if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
+                auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, c->stream, a, c->uni_mu, c->uni_lambda);
+            } else if (c->op == FH_NEO_HOOKEAN) {
                 auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN>;
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
                 hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, c->stream, a, c->uni_mu, c->uni_lambda);
@@ -1606,6 +1610,18 @@ void fh_destroy(fh_ctx* c) {
                     std::fprintf(stderr, "[fenris_hip trace] wave %d %-24s %12.0f cycles/wave  %5.1f %%\n", w, names[k],
                                  (double)r[k] / (double)r[6], 100.0 * (double)r[k] / (double)tot);
             }
+        }
+    }
+    if (c->trace.p) {  // ... and of k_hex27_dense_mfma (hex27_mfma.hpp): cycles of wavefront 0 per phase and element
+        unsigned long long h[32] = {0};
+        if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[31]) {
+            static const char* names[9] = {"P0 inputs", "P1 J, inverse", "P2 gradients", "P3 grad u", "P4 F, coefficients", "P5 F^-T g", "MFMA",
+                                           "stores", "transposed stores"};
+            unsigned long long tot = 0;
+            for (int k = 0; k < 9; ++k) tot += h[16 + k];
+            for (int k = 0; k < 9; ++k)
+                std::fprintf(stderr, "[fenris_hip trace] hex27 %-20s %10.0f cycles/element  %5.1f %%\n", names[k],
+                             (double)h[16 + k] / (double)h[31], 100.0 * (double)h[16 + k] / (double)tot);
         }
     }
     delete c->rows_stash;

@@ -41,13 +41,14 @@ struct Hex27Lds {
     static constexpr int o_s = o_Jinv + NQ * 9 + 1;        // [q]     w |det J|
     static constexpr int o_gu = o_s + 28;                  // [q][k][c] grad u (d x s)
     static constexpr int o_Fi = o_gu + NQ * 9 + 1;         // [q][9]  F^-1
-    static constexpr int o_coef = o_Fi + NQ * 9 + 1;       // [3][28] c_l, c_a, c_m (entry 27 = 0)
-    static constexpr int o_G = o_coef + 3 * 28;            // [k][RP][QS]
+    static constexpr int o_coef = o_Fi + NQ * 9 + 1;       // [6][28] c_l, -c_a, sign sqrt|c_l - c_a|, sqrt|c_l - c_a|, sign sqrt|c_m|,
+                                                           //         sqrt|c_m| (entry 27 = 0)
+    static constexpr int o_G = o_coef + 6 * 28;            // [k][RP][QS]
     static constexpr int o_A = o_G + 3 * RP * QS;          // [k][RP][QS]
     static constexpr int total = o_A + 3 * RP * QS;
 };
 
-template <int OP>
+template <int OP, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
     using L = Hex27Lds;
     constexpr int N = L::N, NG = L::NG, NQ = L::NQ, RP = L::RP, QS = L::QS;
@@ -60,39 +61,63 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
     for (int i = tid; i < NQ * NG * 3; i += nt) lds[L::o_ggeom + i] = a.ggeom[i];
     for (int i = tid; i < 28; i += nt) lds[L::o_qw + i] = (i < NQ) ? a.qw[i] : 0.0;
     for (int i = tid; i < 2 * 3 * RP * QS; i += nt) lds[L::o_G + i] = 0.0;
-    for (int i = tid; i < 3 * 28; i += nt) lds[L::o_coef + i] = 0.0;
+    for (int i = tid; i < 6 * 28; i += nt) lds[L::o_coef + i] = 0.0;
     __syncthreads();
     double* G = lds + L::o_G;
     double* A = NH ? lds + L::o_A : G;  // LinearElastic: a_n = g_n
+    // FENRIS_HIP_TRACE: cycles of wavefront 0 per phase (P0, P1, P2, P3, P4, P5, MFMA, stores, transposed stores), summed over
+    // workgroups into trace[16 + phase]; trace[31] counts elements
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0, ph_n = 0;
+    const bool tracing = TRACE && a.trace != nullptr;   // instrumented instantiation only: the counters cost registers
+    auto mark = [&](int k) {
+        if (tracing) { const unsigned long long t = __builtin_readcyclecounter(); ph[k] += t - ph_t; ph_t = t; }
+    };
 
-    // The element's inputs -- 8 geometry vertices, 27 values of u: node index first, then the gather -- are prefetched in
-    // registers: the value of the NEXT element and the node index of the one after it are requested while this element is
-    // multiplied (the two dependent fetches used to stand in front of every element's prologue, about 2 us of 15).
+    // Coefficients of a point as the matrix-core loop wants them (one lane per point computes the roots once; every lane of
+    // every k-step used to).  On the diagonal components the two terms share their operands, (c_l - c_a) a_I[i] a_J[i], and
+    // the coefficient is split as sign * sqrt|c| * sqrt|c| over the two operands; NaN coefficients (det F <= 0) stay NaN.
+    auto put_coef = [&](int q, double c_l, double c_a, double c_m) {
+        const double cd = c_l - c_a, rd = sqrt(fabs(cd)), rm = sqrt(fabs(c_m));
+        lds[L::o_coef + q] = c_l;
+        lds[L::o_coef + 28 + q] = -c_a;
+        lds[L::o_coef + 56 + q] = copysign(rd, cd);
+        lds[L::o_coef + 84 + q] = rd;
+        lds[L::o_coef + 112 + q] = copysign(rm, c_m);
+        lds[L::o_coef + 140 + q] = rm;
+    };
+
+    // The element's inputs -- 8 geometry vertices, 27 values of u: element index, node index, then the gather -- are prefetched
+    // in registers as a chain of three requests, each consumed one element after it was issued: while element w is worked on,
+    // the values of w + G, the node indices of w + 2 G and the element index of w + 3 G are on their way.  EVERY thread takes
+    // part (threads without a role fetch a harmless duplicate) and nothing is fetched under a branch, so no wait stands
+    // behind a request in the element that issues it (a divergent form of this cost a full memory latency per element).
     const bool xrole = tid < NG * 3, urole = NH && tid >= 64 && tid < 64 + N * 3;
     const int ri = xrole ? tid : (urole ? tid - 64 : 0);         // component index of this thread's value
+    const double* src = (urole && a.u) ? a.u : a.verts;           // u = NULL: zeros
+    const bool val_used = xrole || (urole && a.u);
+    const long long Gs = gridDim.x;
     auto elem_of = [&](long long w) { const long long wc = min(w, a.work_end - 1); return a.labels ? (long long)a.labels[wc] : wc; };
-    auto node_of = [&](long long w) { return a.conn[(size_t)elem_of(w) * N + ri / 3]; };
-    auto value_of = [&](int node) {
-        if (xrole) return a.verts[(size_t)node * 3 + ri % 3];
-        return (urole && a.u) ? a.u[(size_t)node * 3 + ri % 3] : 0.0;
-    };
+    auto node_at = [&](long long e) { return a.conn[(size_t)e * N + ri / 3]; };
+    auto value_at = [&](int node) { return src[(size_t)node * 3 + ri % 3]; };
     const long long w0 = a.work_begin + blockIdx.x;
-    double val_cur = 0.0;
-    int node_nxt = 0;
-    if (w0 < a.work_end && (xrole || urole)) {
-        val_cur = value_of(node_of(w0));
-        node_nxt = node_of(w0 + gridDim.x);
-    }
-    for (long long w = w0; w < a.work_end; w += gridDim.x) {
-        const long long e = elem_of(w);
+    if (w0 >= a.work_end) return;
+    long long e_cur = elem_of(w0), e_n1 = elem_of(w0 + Gs), e_n2 = elem_of(w0 + 2 * Gs);
+    double val_cur = value_at(node_at(e_cur));
+    int node_n1 = node_at(e_n1);
+    // nothing pending at the loop's entry: otherwise the compiler takes the distance from these first requests to their use
+    // (a handful of operations) for every trip, and each element starts by waiting for the previous element's stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    for (long long w = w0; w < a.work_end; w += Gs) {
+        const long long e = e_cur;
+        if (tracing) { ph_t = __builtin_readcyclecounter(); ++ph_n; }
         // P0: geometry nodes (the first 8) and u of the element, from the registers; requests for the next elements
         if (xrole) lds[L::o_X + ri] = val_cur;
-        if (urole) lds[L::o_U + ri] = val_cur;
-        if (xrole || urole) {
-            val_cur = value_of(node_nxt);
-            node_nxt = node_of(w + 2 * (long long)gridDim.x);
-        }
-        __syncthreads();
+        if (urole) lds[L::o_U + ri] = val_used ? val_cur : 0.0;
+        double val_n1 = value_at(node_n1);
+        int node_n2 = node_at(e_n2);
+        long long e_n3 = elem_of(w + 3 * Gs);
+        lds_barrier();
+        mark(0);
         // P1: one lane per point: J = X G^T (hexahedron.rs:324-326 -> :101-107), inverse, s = w |det J|
         if (tid < NQ && !(a.ablate & 1)) {
             const int q = tid;
@@ -120,13 +145,10 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             const double s = lds[L::o_qw + q] * fabs(detJ);  // elliptic.rs:422
             lds[L::o_s + q] = s;
             const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
-            if (!NH) {
-                lds[L::o_coef + q] = s * lambda;
-                lds[L::o_coef + 28 + q] = -(s * mu);
-                lds[L::o_coef + 56 + q] = s * mu;
-            }
+            if (!NH) put_coef(q, s * lambda, -(s * mu), s * mu);
         }
-        __syncthreads();
+        lds_barrier();
+        mark(1);
         // P2: one lane per (point, node): g_n = J^-T grad_ref phi_n
         if (!(a.ablate & 1))
         for (int it = tid; it < NQ * N; it += nt) {
@@ -136,7 +158,8 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
             for (int i = 0; i < 3; ++i) G[(i * RP + n) * QS + q] = fma(Ji[0 * 3 + i], rv[0], fma(Ji[1 * 3 + i], rv[1], Ji[2 * 3 + i] * rv[2]));
         }
-        __syncthreads();
+        lds_barrier();
+        mark(2);
         if (NH && !(a.ablate & 1)) {
             // P3: grad u (d x s) = sum_n g_n u_n^T, one lane per (point, k, c)
             for (int it = tid; it < NQ * 9; it += nt) {
@@ -145,7 +168,8 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                 for (int n = 0; n < N; ++n) t = fma(G[(k * RP + n) * QS + q], lds[L::o_U + n * 3 + c], t);
                 lds[L::o_gu + it] = t;
             }
-            __syncthreads();
+            lds_barrier();
+            mark(3);
             // P4: one lane per point: F = I + (grad u)^T (fenris-solid/src/lib.rs:20-29), coefficients of
             // materials.rs:287-315 (J <= 0 => NaN block)
             if (tid < NQ) {
@@ -171,15 +195,14 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                     c_a = s * (-mu + lambda * log(Jd));
                     c_m = s * mu;
                 }
-                lds[L::o_coef + q] = c_l;
-                lds[L::o_coef + 28 + q] = c_a;
-                lds[L::o_coef + 56 + q] = c_m;
+                put_coef(q, c_l, c_a, c_m);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) lds[L::o_Fi + q * 9 + i * 3 + j] = Fi[i][j];
             }
-            __syncthreads();
+            lds_barrier();
+            mark(4);
             // P5: a_n = F^-T g_n
             for (int it = tid; it < NQ * N; it += nt) {
                 const int q = it / N, n = it % N;
@@ -188,7 +211,8 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
                 for (int i = 0; i < 3; ++i) A[(i * RP + n) * QS + q] = fma(Fi[0 * 3 + i], g0, fma(Fi[1 * 3 + i], g1, Fi[2 * 3 + i] * g2));
             }
-            __syncthreads();
+            lds_barrier();
+            mark(5);
         }
         // ---- matrix cores: wavefront w owns tile (tI, tJ) of the six K_ij with i <= j and of the trace term.
         // K_ji = K_ij^T (the element matrix is symmetric; util.rs:38-51 mirrors the upper triangle scalar by scalar), so the
@@ -204,34 +228,54 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
-        if (!(a.ablate & 2))
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
+        // k-steps of four points; the operands of the next step are fetched while this one is multiplied (the loop is not
+        // unrolled: all seven steps' operands in flight at once cost more registers than there are)
+        struct Ops { double ar[3], ac[3], gr[3], gc[3], cl, nca, rds, rd, rms, rm; };
+        auto fetch_ops = [&](int ks) {
             const int q = 4 * ks + kq;  // q = 27 is padding: operands and coefficients are zero there
-            double ar[3], ac[3], gr[3], gc[3];
+            Ops o;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                ar[k] = A[(k * RP + rI) * QS + q];
-                ac[k] = A[(k * RP + rJ) * QS + q];
-                gr[k] = G[(k * RP + rI) * QS + q];
-                gc[k] = G[(k * RP + rJ) * QS + q];
+                o.ar[k] = A[(k * RP + rI) * QS + q];
+                o.ac[k] = A[(k * RP + rJ) * QS + q];
+                o.gr[k] = G[(k * RP + rI) * QS + q];
+                o.gc[k] = G[(k * RP + rJ) * QS + q];
             }
-            const double cl = lds[L::o_coef + q], ca = lds[L::o_coef + 28 + q], cm = lds[L::o_coef + 56 + q];
-            const double cd = cl - ca;                               // diagonal components
-            const double rd = sqrt(fabs(cd)), rm = sqrt(fabs(cm));   // NaN coefficients (det F <= 0) stay NaN
-            const double rds = copysign(rd, cd), rms = copysign(rm, cm);
+            o.cl = lds[L::o_coef + q]; o.nca = lds[L::o_coef + 28 + q];
+            o.rds = lds[L::o_coef + 56 + q]; o.rd = lds[L::o_coef + 84 + q];
+            o.rms = lds[L::o_coef + 112 + q]; o.rm = lds[L::o_coef + 140 + q];
+            return o;
+        };
+        if (!(a.ablate & 2)) {
+            Ops cur = fetch_ops(0);
+            int nks = 7;
+            asm volatile("" : "+s"(nks));   // opaque trip count: the compiler unrolls a loop of seven whatever the pragma says
+#pragma unroll 1
+            for (int ks = 0; ks < nks; ++ks) {
+                const Ops nxt = fetch_ops(min(ks + 1, 6));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                acc[i][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(rds * ar[i], rd * ac[i], acc[i][i], 0, 0, 0);
+                for (int i = 0; i < 3; ++i) {
+                    acc[i][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rds * cur.ar[i], cur.rd * cur.ac[i], acc[i][i], 0, 0, 0);
 #pragma unroll
-                for (int j = i + 1; j < 3; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cl * ar[i], ac[j], acc[i][j], 0, 0, 0);     // c_l a_I[i] a_J[j]
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ca * ar[j]), ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                    for (int j = i + 1; j < 3; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.cl * cur.ar[i], cur.ac[j], acc[i][j], 0, 0, 0);   // c_l a_I[i] a_J[j]
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.nca * cur.ar[j], cur.ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(rms * gr[k], rm * gc[k], accM, 0, 0, 0);
+                for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rms * cur.gr[k], cur.rm * cur.gc[k], accM, 0, 0, 0);
+                cur = nxt;
+            }
         }
+        mark(6);
+        // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
+        // (loads and stores share one in-order counter: waiting for a load issued before a store waits for the store).
+        asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
+        val_cur = val_n1;
+        node_n1 = node_n2;
+        e_cur = e_n1;
+        e_n1 = e_n2;
+        e_n2 = e_n3;
         // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
         double* ke = a.ke_out + (size_t)e * (81 * 81);
         const int J = 16 * tJ + (lane & 15);
@@ -247,31 +291,28 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                     if (I < N && J < N) ke[(size_t)(i * 3 + j) * (N * N) + I * N + J] = v[reg];
                 }
             }
-        __syncthreads();  // every wavefront is done with G / A: their space stages the transposed tiles
+        mark(7);
+        // K_ji = K_ij^T straight from the fragments: entry (I, J) of the tile goes to (J, I) of the mirrored component.  Per store
+        // instruction a lane group writes four consecutive I of one J (32 bytes), and the four registers complete the 128 bytes
+        // of that J; the L2 merges them.  (Staging the tile through LDS to store it row-wise cost a barrier, three LDS round
+        // trips and the re-zeroing of the staging area: 2.4 k cycles per element against 1.x k.)
         if (!(a.ablate & 4)) {
-            double* tr = G + (size_t)wave * (16 * 17);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = i + 1; j < 3; ++j) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) tr[((lane >> 4) + 4 * reg) * 17 + (lane & 15)] = acc[i][j][reg];
-                    // same wavefront writes and reads: LDS operations of a wave complete in order
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // K_ji tile (tJ, tI): row = node of the J range, column = node of the I range
-                    const int Ic = 16 * tI + (lane & 15);
+                for (int j = i + 1; j < 3; ++j)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int rr = (lane >> 4) + 4 * reg, Jr = 16 * tJ + rr;
-                        const double t = tr[(lane & 15) * 17 + rr];
-                        if (Jr < N && Ic < N) ke[(size_t)(j * 3 + i) * (N * N) + Jr * N + Ic] = t;
+                        const int I = 16 * tI + (lane >> 4) + 4 * reg;
+                        if (I < N && J < N) ke[(size_t)(j * 3 + i) * (N * N) + J * N + I] = acc[i][j][reg];
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            // the staging area lies over rows / points of G whose padding must read zero for the next element
-            for (int k = lane; k < 16 * 17; k += 64) tr[k] = 0.0;
         }
-        __syncthreads();  // the next element's prologue overwrites G / A
+        lds_barrier();  // the next element's prologue overwrites G / A
+        mark(8);
+    }
+    if (tracing && tid == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(a.trace + 16 + k, ph[k]);
+        atomicAdd(a.trace + 31, ph_n);
     }
 }
 

@@ -1282,7 +1282,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         const size_t lds1 = sizeof(double) * (size_t)Hex27Lds::total;
         int dev_cus = 256;
         (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        const int grid1 = (int)std::min<long long>(a.work_end, (long long)dev_cus * 2);
+        const int grid1 = (int)std::min<long long>(a.work_end, (long long)dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", 2)));
         if (grid1 > 0) {
             if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
                 auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;

@@ -39,7 +39,8 @@ struct Hex27Lds {
     static constexpr int o_U = o_X + NG * 3;               // [n][3]
     static constexpr int o_Jinv = o_U + N * 3;             // [q][9]  J^-1, row-major
     static constexpr int o_s = o_Jinv + NQ * 9 + 1;        // [q]     w |det J|
-    static constexpr int o_gu = o_s + 28;                  // [q][k][c] grad u (d x s)
+    static constexpr int o_dF = o_s + 28;                  // [q]     det F
+    static constexpr int o_gu = o_dF + 28;                 // [q][k][c] grad u (d x s); before that: J of the point (P1)
     static constexpr int o_Fi = o_gu + NQ * 9 + 1;         // [q][9]  F^-1
     static constexpr int o_coef = o_Fi + NQ * 9 + 1;       // [6][28] c_l, -c_a, sign sqrt|c_l - c_a|, sqrt|c_l - c_a|, sign sqrt|c_m|,
                                                            //         sqrt|c_m| (entry 27 = 0)
@@ -77,7 +78,14 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
     // every k-step used to).  On the diagonal components the two terms share their operands, (c_l - c_a) a_I[i] a_J[i], and
     // the coefficient is split as sign * sqrt|c| * sqrt|c| over the two operands; NaN coefficients (det F <= 0) stay NaN.
     auto put_coef = [&](int q, double c_l, double c_a, double c_m) {
-        const double cd = c_l - c_a, rd = sqrt(fabs(cd)), rm = sqrt(fabs(c_m));
+        // roots by v_rsq_f64 + Newton (a few ulp are as good as exact here: the two factors only have to multiply back to c to
+        // rounding, and both mirror entries use the same pair); 0 and NaN map to themselves
+        auto root = [](double x) {
+            if (!(x > 0.0)) return x;
+            const double y = rsqrt_newton(x), r = x * y;
+            return fma(fma(-r, r, x), 0.5 * y, r);
+        };
+        const double cd = c_l - c_a, rd = root(fabs(cd)), rm = root(fabs(c_m));
         lds[L::o_coef + q] = c_l;
         lds[L::o_coef + 28 + q] = -c_a;
         lds[L::o_coef + 56 + q] = copysign(rd, cd);
@@ -118,34 +126,42 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         long long e_n3 = elem_of(w + 3 * Gs);
         lds_barrier();
         mark(0);
-        // P1: one lane per point: J = X G^T (hexahedron.rs:324-326 -> :101-107), inverse, s = w |det J|
-        if (tid < NQ && !(a.ablate & 1)) {
-            const int q = tid;
-            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) J[i][j] = fma(lds[L::o_X + g * 3 + i], lds[L::o_ggeom + (q * NG + g) * 3 + j], J[i][j]);
+        // The 3 x 3 work of a point (Jacobian, its inverse, F, its inverse) is spread over nine lanes, one per entry: a wavefront
+        // that runs it alone, one lane per point, issues ~250 dependent fp64 instructions while the other three wait at the
+        // barrier -- and while the other workgroup of the CU multiplies, each of them waits for a 64-cycle matrix instruction.
+        const int pq = min(tid / 9, NQ - 1), pi = (tid % 9) / 3, pj = tid % 3;     // (point, row, column) of this lane
+        // entry (pi, pj) of adj(m) r for the matrix at m9 (row-major in LDS): cofactor (pj, pi), the expressions of adj_scaled
+        auto inverse_entry = [&](const double* m9, double r) {
+            const int r1 = (pj + 1) % 3, r2 = (pj + 2) % 3, c1 = (pi + 1) % 3, c2 = (pi + 2) % 3;
+            return (m9[r1 * 3 + c1] * m9[r2 * 3 + c2] - m9[r2 * 3 + c1] * m9[r1 * 3 + c2]) * r;
+        };
+        // P1a: J = X G^T (hexahedron.rs:324-326 -> :101-107), one entry per lane, parked where grad u goes later
+        if (tid < NQ * 9 && !(a.ablate & 1)) {
+            double t = 0.0;
+            for (int g = 0; g < NG; ++g) t = fma(lds[L::o_X + g * 3 + pi], lds[L::o_ggeom + (pq * NG + g) * 3 + pj], t);
+            lds[L::o_gu + tid] = t;
+        }
+        lds_barrier();
+        // P1b: inverse entry; the lane of entry (0, 0) also leaves s = w |det J| and, for LinearElastic, the coefficients
+        if (tid < NQ * 9 && !(a.ablate & 1)) {
+            const double* m9 = lds + L::o_gu + pq * 9;
+            const double J[3][3] = {{m9[0], m9[1], m9[2]}, {m9[3], m9[4], m9[5]}, {m9[6], m9[7], m9[8]}};
             const double detJ = det_small<3>(J);
-            double Ji[3][3];
+            double v = 0.0;
             if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
-                report_singular(a.status, e);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) Ji[i][j] = 0.0;
+                if (pi == 0 && pj == 0) report_singular(a.status, e);
             } else {
-                inv_small(J, detJ, Ji);
+                v = inverse_entry(m9, 1.0 / detJ);
             }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) lds[L::o_Jinv + q * 9 + i * 3 + j] = Ji[i][j];
-            const double s = lds[L::o_qw + q] * fabs(detJ);  // elliptic.rs:422
-            lds[L::o_s + q] = s;
-            const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
-            if (!NH) put_coef(q, s * lambda, -(s * mu), s * mu);
+            lds[L::o_Jinv + tid] = v;
+            if (pi == 0 && pj == 0) {
+                const double s = lds[L::o_qw + pq] * fabs(detJ);  // elliptic.rs:422
+                lds[L::o_s + pq] = s;
+                if (!NH) {
+                    const double mu = a.qparams ? a.qparams[2 * pq] : mu_u, lambda = a.qparams ? a.qparams[2 * pq + 1] : lambda_u;
+                    put_coef(pq, s * lambda, -(s * mu), s * mu);
+                }
+            }
         }
         lds_barrier();
         mark(1);
@@ -170,46 +186,51 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             }
             lds_barrier();
             mark(3);
-            // P4: one lane per point: F = I + (grad u)^T (fenris-solid/src/lib.rs:20-29), coefficients of
-            // materials.rs:287-315 (J <= 0 => NaN block)
-            if (tid < NQ) {
-                const int q = tid;
-                double F[3][3], Fi[3][3];
+            // P4: F = I + (grad u)^T (fenris-solid/src/lib.rs:20-29), one entry of F^-1 per lane; det F goes to the lane that
+            // computes the point's coefficients in the next phase (J <= 0 => NaN block there, zeros here)
+            if (tid < NQ * 9) {
+                const double* gq = lds + L::o_gu + pq * 9;
+                double F9[9];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) F[i][j] = (i == j ? 1.0 : 0.0) + lds[L::o_gu + q * 9 + j * 3 + i];
+                    for (int j = 0; j < 3; ++j) F9[i * 3 + j] = (i == j ? 1.0 : 0.0) + gq[j * 3 + i];
+                const double F[3][3] = {{F9[0], F9[1], F9[2]}, {F9[3], F9[4], F9[5]}, {F9[6], F9[7], F9[8]}};
                 const double Jd = det_small<3>(F);
-                const double s = lds[L::o_s + q];
-                const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
-                double c_l, c_a, c_m;
-                if (Jd <= 0.0) {
-                    c_l = c_a = c_m = __builtin_nan("");
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) Fi[i][j] = 0.0;
-                } else {
-                    inv_small(F, Jd, Fi);
-                    c_l = s * lambda;
-                    c_a = s * (-mu + lambda * log(Jd));
-                    c_m = s * mu;
+                double v = 0.0;
+                if (Jd > 0.0) {
+                    // the cofactor of this lane from F: entry (r, c) of F is delta + gu[c][r]
+                    const int r1 = (pj + 1) % 3, r2 = (pj + 2) % 3, c1 = (pi + 1) % 3, c2 = (pi + 2) % 3;
+                    auto Fe = [&](int r, int c) { return (r == c ? 1.0 : 0.0) + gq[c * 3 + r]; };
+                    v = (Fe(r1, c1) * Fe(r2, c2) - Fe(r2, c1) * Fe(r1, c2)) * (1.0 / Jd);
                 }
-                put_coef(q, c_l, c_a, c_m);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) lds[L::o_Fi + q * 9 + i * 3 + j] = Fi[i][j];
+                lds[L::o_Fi + tid] = v;
+                if (pi == 0 && pj == 0) lds[L::o_dF + pq] = Jd;
             }
             lds_barrier();
             mark(4);
-            // P5: a_n = F^-T g_n
-            for (int it = tid; it < NQ * N; it += nt) {
-                const int q = it / N, n = it % N;
-                const double* Fi = lds + L::o_Fi + q * 9;
-                const double g0 = G[(0 * RP + n) * QS + q], g1 = G[(1 * RP + n) * QS + q], g2 = G[(2 * RP + n) * QS + q];
+            // P5: a_n = F^-T g_n on the first three wavefronts; meanwhile the fourth computes the coefficients of
+            // materials.rs:287-315, one lane per point (a logarithm and two roots: as long as the other three's share)
+            if (wave == 3) {
+                if (lane < NQ) {
+                    const int q = lane;
+                    const double Jd = lds[L::o_dF + q], s = lds[L::o_s + q];
+                    const double mu = a.qparams ? a.qparams[2 * q] : mu_u, lambda = a.qparams ? a.qparams[2 * q + 1] : lambda_u;
+                    if (Jd <= 0.0) {
+                        const double nan = __builtin_nan("");
+                        put_coef(q, nan, nan, nan);
+                    } else {
+                        put_coef(q, s * lambda, s * (-mu + lambda * log(Jd)), s * mu);
+                    }
+                }
+            } else {
+                for (int it = tid; it < NQ * N; it += 192) {
+                    const int q = it / N, n = it % N;
+                    const double* Fi = lds + L::o_Fi + q * 9;
+                    const double g0 = G[(0 * RP + n) * QS + q], g1 = G[(1 * RP + n) * QS + q], g2 = G[(2 * RP + n) * QS + q];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) A[(i * RP + n) * QS + q] = fma(Fi[0 * 3 + i], g0, fma(Fi[1 * 3 + i], g1, Fi[2 * 3 + i] * g2));
+                    for (int i = 0; i < 3; ++i) A[(i * RP + n) * QS + q] = fma(Fi[0 * 3 + i], g0, fma(Fi[1 * 3 + i], g1, Fi[2 * 3 + i] * g2));
+                }
             }
             lds_barrier();
             mark(5);

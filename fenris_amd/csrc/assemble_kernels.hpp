@@ -371,9 +371,16 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
             const double* par = a.rparams + ((size_t)a.rule_map[*elem_id] * a.nq + q) * 2;
             mu = par[0];
             lambda = par[1];
+            // landed inside this branch: left to the merge point, the wait for this fetch is placed on the common path as
+            // vmcnt(0), where it also waits for the register prefetch of the streaming kernels' next batch
+            asm volatile("" : "+v"(mu), "+v"(lambda));
         } else {
-            mu = lds[L.o_qpar + 2 * q];
-            lambda = lds[L.o_qpar + 2 * q + 1];
+            // through an LDS pointer proper: with a generic one the two branches become one flat load of a selected address,
+            // which counts as a vector-memory operation as well (same vmcnt(0))
+            typedef const __attribute__((address_space(3))) double* lds_cptr;
+            const lds_cptr qpar = (lds_cptr)(lds + L.o_qpar);
+            mu = qpar[2 * q];
+            lambda = qpar[2 * q + 1];
         }
     }
 
@@ -1891,6 +1898,10 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
 #pragma unroll
                     for (int m = 0; m < D; ++m) f[i] = fma(qp[i * D + m], r[m], f[i]);
             }
+            // The prefetched batch is parked BEFORE this batch's stores: loads and stores share one in-order counter, so a
+            // wait for the loads behind the stores would wait for the stores as well (a write latency per batch).  X / U
+            // are read by phase B only, which lies behind the barrier above.
+            park(b + G);
             if (b * EPB + u < total) {
                 if (a.ke_out) {  // two-pass form: the element vectors, (element, local node, component); k_vector_from_elements sums
                     double* dst = a.ke_out + ((size_t)elem_of(b) * N + I) * S;
@@ -1902,7 +1913,6 @@ __global__ void __launch_bounds__(NT) k_assemble_vector_stream(const KArgs a) {
                 }
             }
         }
-        park(b + G);  // X / U are read by phase B only, which lies behind the barrier above
         asm volatile("" : "+v"(node_n2));
         node_cur = node_n1;
         node_n1 = node_n2;

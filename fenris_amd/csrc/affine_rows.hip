@@ -115,8 +115,9 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
         auto rfl = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
         auto put = [&](f64x2* dst, f64x2 val) {
             if (DBG && (ablate & 1)) return;
-            // non-temporal (FENRIS_HIP_AFFINE_NT=0 switches it off): the rows are written once and never read by this kernel.
-            // Measured neutral on elasticity (4.93 / 4.99 against 4.98 / 4.99 ms), 3 % on Laplace.
+            // non-temporal stores (FENRIS_HIP_AFFINE_NT; default: Laplace only): the rows are written once and never read by this
+            // kernel.  3 % on Laplace; on elasticity equal on a cold device and 4 % slower once it is warm (5.19 - 5.24 against
+            // 4.98 ms in back-to-back runs on one box).
             if constexpr (OVERWRITE) { if (nt_stores) __builtin_nontemporal_store(val, dst); else *dst = val; }
             else { const f64x2 o = *dst; f64x2 r; r.x = o.x + val.x; r.y = o.y + val.y; *dst = r; }
         };

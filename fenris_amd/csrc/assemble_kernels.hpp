@@ -1418,8 +1418,10 @@ __global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size
 // block) touched by this block's elements -- i.e. the neighbouring block sharing the most elements.  One
 // wavefront per block.
 // cls (optional): class of every block; only blocks of the same class are candidates (chains never mix classes).
+// r2v (optional): position of every node in the order the blocks were formed in (null: the node numbering itself).
 __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
-                                                        const int* node2blk, int nblk, const unsigned char* cls, int* succ) {
+                                                        const int* node2blk, int nblk, const unsigned char* cls, int* succ,
+                                                        const int* r2v = nullptr) {
     __shared__ int cand[1024];
     __shared__ int best_blk, best_cnt;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1427,7 +1429,8 @@ __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, co
     const int last = h.i0 + h.nb - 1;
     const int total = min(h.U * N, 1024);
     for (int i = lane; i < total; i += 64) {
-        const int node = conn[(size_t)gt_elems[h.u_off + i / N] * N + i % N];
+        const int node_id = conn[(size_t)gt_elems[h.u_off + i / N] * N + i % N];
+        const int node = r2v ? r2v[node_id] : node_id;
         int cb = (node > last) ? node2blk[node] : -1;
         if (cls && cb >= 0 && cls[cb] != cls[b]) cb = -1;
         cand[i] = cb;
@@ -1639,6 +1642,52 @@ __global__ void k_linked_to_next(const unsigned* n2e_off, const unsigned* n2e, i
         }
     }
     link[i] = r;
+}
+
+// ---- locality order of the nodes (row-owner Tet4 kernel on meshes whose numbering has none: see build_partition)
+// Morton key of a vertex: 21 bits per coordinate of its position in the bounding box
+__global__ void k_morton_keys(const double* verts, int N, int D, double lo0, double lo1, double lo2, double s0, double s1, double s2,
+                              unsigned long long* keys, unsigned* ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double lo[3] = {lo0, lo1, lo2}, sc[3] = {s0, s1, s2};
+    unsigned long long key = 0;
+    for (int c = 0; c < D; ++c) {
+        double t = (verts[(size_t)i * D + c] - lo[c]) * sc[c];
+        t = fmin(fmax(t, 0.0), 2097151.0);
+        unsigned long long x = (unsigned long long)t;       // spread the 21 bits to every third position
+        x = (x | x << 32) & 0x1f00000000ffffull;
+        x = (x | x << 16) & 0x1f0000ff0000ffull;
+        x = (x | x << 8) & 0x100f00f00f00f00full;
+        x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+        x = (x | x << 2) & 0x1249249249249249ull;
+        key |= x << c;
+    }
+    keys[i] = key;
+    ids[i] = (unsigned)i;
+}
+__global__ void k_invert_perm(const unsigned* v2r, int N, int* r2v) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < N) r2v[v2r[v]] = v;
+}
+// len[v] = length of row v2r[v] of the offsets `off` (len[N] = 0: input of an exclusive scan)
+__global__ void k_perm_row_lengths(const unsigned* off, const unsigned* v2r, int N, unsigned* len) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < N) { const unsigned r = v2r[v]; len[v] = off[r + 1] - off[r]; }
+    if (v == N) len[v] = 0;
+}
+// dst row v = src row v2r[v] (contents unchanged)
+__global__ void k_perm_copy_rows(const unsigned* off_src, const unsigned* src, const unsigned* v2r, const unsigned* off_dst, unsigned* dst,
+                                 int N) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const unsigned r = v2r[v], a = off_src[r], n = off_src[r + 1] - a, b = off_dst[v];
+    for (unsigned k = 0; k < n; ++k) dst[b + k] = src[a + k];
+}
+// first node-level CSR entry of the real row of every node in partition order (v2r == null: the natural order)
+__global__ void k_row_starts(const unsigned* noff, const unsigned* v2r, int N, unsigned* row_real) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < N) row_real[v] = noff[v2r ? v2r[v] : (unsigned)v];
 }
 
 __global__ void k_hdr_counts(const GatherHdr* hdr, int nblk, unsigned* counts) {

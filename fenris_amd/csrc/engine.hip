@@ -323,6 +323,7 @@ struct fh_ctx {
     // fixed-stride tables of the pipelined gather kernel
     DevBuf<int> p_conn, p_rec, p_elem;
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
+    bool part_perm = false;     // the blocks were formed in a locality order of the nodes (row-owner Tet4 kernel only)
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
     int r_rw = 0, r_ls = 256;
     bool has_rows = false;
@@ -348,6 +349,7 @@ struct fh_ctx {
     unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
+    bool perm_failed = false;       // the locality order could not be used (no row-owner tables, or another kernel runs): natural order
     long long row_lo = 0, row_hi = -1;  // owner-computes node range (fh_set_row_range); row_hi < 0: all nodes
     // Second set of owner-computes tables (fh_assemble_matrix_rows_dev): the partition of another node range, swapped in for
     // the duration of that call.  struct_gen counts everything that invalidates a partition; the stash remembers the count
@@ -413,7 +415,7 @@ struct fh_ctx {
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(npos_gen)       \
-    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar)
+    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
     FH_PARTITION_MEMBERS(X)
@@ -725,6 +727,98 @@ int build_partition(fh_ctx* c) {
     const int S = c->S();
     const int N = (int)c->N;
     const unsigned max_row = c->max_row;
+    // The owner blocks are ranges of consecutive nodes.  On a mesh whose numbering has no locality (consecutive nodes share no
+    // element: every node of a block brings its own ~24 tetrahedra, C3: 128 slots and 11 kB of vertex gathers for 5 nodes) the
+    // row-owner Tet4 kernel -- whose lanes store every block of a row straight to its place, so that the rows of a block
+    // need not be neighbours in memory -- gets its blocks from a locality order instead: nodes sorted by the Morton key of
+    // their coordinates, the pattern rows and the node -> element adjacency permuted alike (contents unchanged: real node
+    // and element ids), the real first entry of every row handed to the kernel (r_rec).  Everything below then works on
+    // positions in that order; nothing else in the context sees it.
+    const unsigned* noff_d = c->noff.p;
+    const unsigned* ncols_d = c->ncols.p;
+    const std::vector<unsigned>* h_noff_p = &c->h_noff;
+    const std::vector<unsigned>* adj_off_hp = &adj_off_h;
+    DevBuf<unsigned> v2r_d, noff_v, ncols_v, adj_off_v, adj_v;
+    DevBuf<int> r2v_d;
+    std::vector<unsigned> h_noff_v, adj_off_hv;
+    c->part_perm = false;
+    const bool perm_cand = c->elem_kind == FH_TET4 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && c->row_hi < 0 &&
+                           !c->perm_failed && !c->has_rules && c->fast_ok && N > 64 && !c->env("FENRIS_HIP_NO_ROWS") &&
+                           !c->env("FENRIS_HIP_NO_NODE_ORDER") && !c->env("FENRIS_HIP_TRACE");
+    if (perm_cand) {
+        // how local is the numbering?  fraction of nodes that share an element with their successor
+        DevBuf<unsigned char> link_d;
+        HIP_TRY(c, link_d.alloc((size_t)N + 1));
+        hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
+        std::vector<unsigned char> lk((size_t)N);
+        HIP_TRY(c, hipMemcpyAsync(lk.data(), link_d.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        long long linked = 0;
+        for (int i = 0; i < N; ++i) linked += lk[i];
+        const bool force = c->env_int("FENRIS_HIP_NODE_ORDER", 0) != 0;
+        if (force || linked * 2 < (long long)N) {
+            const int D = c->ei.d;
+            std::vector<double> hv((size_t)N * D);
+            HIP_TRY(c, hipMemcpyAsync(hv.data(), c->verts.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+            for (int k = 0; k < D; ++k) { lo[k] = hv[k]; hi[k] = hv[k]; }
+            for (size_t i = 0; i < (size_t)N; ++i)
+                for (int k = 0; k < D; ++k) { lo[k] = std::min(lo[k], hv[i * D + k]); hi[k] = std::max(hi[k], hv[i * D + k]); }
+            for (int k = 0; k < D; ++k) sc[k] = (hi[k] > lo[k]) ? 2097151.0 / (hi[k] - lo[k]) : 0.0;
+            DevBuf<unsigned long long> keys, keys_s;
+            DevBuf<unsigned> ids;
+            HIP_TRY(c, keys.alloc((size_t)N));
+            HIP_TRY(c, keys_s.alloc((size_t)N));
+            HIP_TRY(c, ids.alloc((size_t)N));
+            HIP_TRY(c, v2r_d.alloc((size_t)N));
+            hipLaunchKernelGGL(k_morton_keys, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->verts.p, N, D, lo[0], lo[1], lo[2], sc[0],
+                               sc[1], sc[2], keys.p, ids.p);
+            size_t tb = 0;
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, keys_s.p, ids.p, v2r_d.p, N, 0, 64, c->stream));
+            DevBuf<char> tmp;
+            HIP_TRY(c, tmp.alloc(tb + 16));
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.p, keys_s.p, ids.p, v2r_d.p, N, 0, 64, c->stream));
+            HIP_TRY(c, r2v_d.alloc((size_t)N));
+            hipLaunchKernelGGL(k_invert_perm, dim3((N + 255) / 256), dim3(256), 0, c->stream, v2r_d.p, N, r2v_d.p);
+            // rows of the pattern and of the adjacency in that order
+            auto permute_rows = [&](const unsigned* off_src, const unsigned* src, size_t total, DevBuf<unsigned>& off_dst, DevBuf<unsigned>& dst,
+                                    std::vector<unsigned>& off_h) -> int {
+                DevBuf<unsigned> len;
+                HIP_TRY(c, len.alloc((size_t)N + 1));
+                HIP_TRY(c, off_dst.alloc((size_t)N + 1));
+                HIP_TRY(c, dst.alloc(total + 1));
+                hipLaunchKernelGGL(k_perm_row_lengths, dim3((N + 256) / 256), dim3(256), 0, c->stream, off_src, v2r_d.p, N, len.p);
+                size_t sb = 0;
+                HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, sb, len.p, off_dst.p, N + 1, c->stream));
+                DevBuf<char> t2;
+                HIP_TRY(c, t2.alloc(sb + 16));
+                HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(t2.p, sb, len.p, off_dst.p, N + 1, c->stream));
+                hipLaunchKernelGGL(k_perm_copy_rows, dim3((N + 255) / 256), dim3(256), 0, c->stream, off_src, src, v2r_d.p, off_dst.p, dst.p, N);
+                HIP_TRY(c, hipGetLastError());
+                off_h.resize((size_t)N + 1);
+                HIP_TRY(c, hipMemcpyAsync(off_h.data(), off_dst.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));  // len / t2 are released on return
+                return FH_OK;
+            };
+            int rp = permute_rows(c->noff.p, c->ncols.p, (size_t)c->h_noff[N], noff_v, ncols_v, h_noff_v);
+            if (rp) return rp;
+            rp = permute_rows(adj_off_d, adj_d, (size_t)adj_off_h[N], adj_off_v, adj_v, adj_off_hv);
+            if (rp) return rp;
+            noff_d = noff_v.p;
+            ncols_d = ncols_v.p;
+            adj_off_d = adj_off_v.p;
+            adj_d = adj_v.p;
+            h_noff_p = &h_noff_v;
+            adj_off_hp = &adj_off_hv;
+            c->part_perm = true;
+            if (c->env("FENRIS_HIP_VERBOSE"))
+                std::fprintf(stderr, "[fenris_hip] node numbering without locality (%.1f %% of the nodes share an element with their successor): "
+                                     "owner blocks formed in Morton order\n", 100.0 * (double)linked / (double)N);
+        }
+    }
+    const std::vector<unsigned>& h_noff = *h_noff_p;
+    const std::vector<unsigned>& adj_off_hh = *adj_off_hp;
     // nodes per block (tunable), entry capacity per batch, accumulator budget
     // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
@@ -734,7 +828,7 @@ int build_partition(fh_ctx* c) {
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     long long sum_rows = 0;
-    for (int i = 0; i < N; ++i) sum_rows += c->h_noff[i + 1] - c->h_noff[i];
+    for (int i = 0; i < N; ++i) sum_rows += h_noff[i + 1] - h_noff[i];
     const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
     int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
     std::vector<unsigned> blk;
@@ -756,7 +850,7 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     auto fits = [&](int a, int b) {  // nodes [a, b) within the accumulator and entry budgets
-        return S * S * ((long long)c->h_noff[b] - c->h_noff[a]) <= acc && (long long)adj_off_h[b] - adj_off_h[a] <= mb;
+        return S * S * ((long long)h_noff[b] - h_noff[a]) <= acc && (long long)adj_off_hh[b] - adj_off_hh[a] <= mb;
     };
     auto cut_greedy = [&](int a, int b) {  // blocks of up to nb_target nodes, shrunk where the budgets demand it
         while (a < b) {
@@ -809,7 +903,7 @@ int build_partition(fh_ctx* c) {
     }
     {   // tighten the accumulator budget to the largest block actually formed
         long long mx = 1;
-        for (size_t b = 0; b + 1 < blk.size(); ++b) mx = std::max<long long>(mx, (long long)c->h_noff[blk[b + 1]] - c->h_noff[blk[b]]);
+        for (size_t b = 0; b + 1 < blk.size(); ++b) mx = std::max<long long>(mx, (long long)h_noff[blk[b + 1]] - h_noff[blk[b]]);
         acc = (int)(S * S * mx);
     }
     HIP_TRY(c, c->blk_off.alloc(blk.size()));
@@ -818,7 +912,7 @@ int build_partition(fh_ctx* c) {
     {
         unsigned max_m = 0;
         for (size_t b = 0; b + 1 < blk.size(); ++b)
-            max_m = std::max(max_m, adj_off_h[blk[b + 1]] - adj_off_h[blk[b]]);
+            max_m = std::max(max_m, adj_off_hh[blk[b + 1]] - adj_off_hh[blk[b]]);
         if (max_m >= 65536) return c->fail(FH_UNSUPPORTED, "gather mode: a node block has more than 65535 adjacent entries");
         const size_t tb = sizeof(int) * 3 * (size_t)std::max(1u, max_m);
         if (tb > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "gather mode: node valence too large for the table builder");
@@ -836,7 +930,7 @@ int build_partition(fh_ctx* c) {
         }
         c->has_pos = max_row < 256 && !c->env("FENRIS_HIP_NO_POS");
         if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
-        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, adj_off_d, adj_d, c->ei.n,
+        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                            (const unsigned*)nullptr, (unsigned char*)nullptr);
         hipLaunchKernelGGL(k_hdr_counts, dim3((nblk + 256) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, nblk, counts.p);
@@ -849,8 +943,8 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(&total_u, uoff.p + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->gt_elems.alloc((size_t)total_u + 1));
-        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, c->noff.p, adj_off_d, adj_d, c->ei.n,
-                           c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p, c->conn.p, c->ncols.p,
+        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
+                           c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p, c->conn.p, ncols_d,
                            c->has_pos ? c->gt_pos.p : (unsigned char*)nullptr);
         HIP_TRY(c, hipGetLastError());
     }
@@ -921,7 +1015,8 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, succ_d.alloc((size_t)nblk));
                 hipLaunchKernelGGL(k_node_to_block, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->blk_off.p, nblk, node2blk.p);
                 hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
-                                   node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p);
+                                   node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p,
+                                   c->part_perm ? r2v_d.p : (const int*)nullptr);
                 std::vector<int> succ((size_t)nblk);
                 HIP_TRY(c, hipMemcpyAsync(succ.data(), succ_d.p, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -957,7 +1052,7 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, elem.alloc((size_t)npos * us));
 #define PT_LAUNCH(NGV)                                                                                                           \
     hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(nchains), dim3(64), 0, c->stream, order_d.p, chain_d.p, c->gt_hdr.p,        \
-                       c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, c->noff.p, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_rw,     \
+                       c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, noff_d, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_rw,     \
                        rec.p, conn.p, elem.p)
                 switch (c->ei.ng) {
                     case 3: PT_LAUNCH(3); break;
@@ -1061,7 +1156,11 @@ int build_partition(fh_ctx* c) {
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
             if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !c->env("FENRIS_HIP_NO_ROWS")) {
-                c->r_rw = 8 + us / 4 + nb_target + 1;
+                c->r_rw = 8 + us / 4 + nb_target + 1 + nb_target;
+                DevBuf<unsigned> row_real;   // first entry of every node's real row, in the order of the blocks
+                HIP_TRY(c, row_real.alloc((size_t)N + 1));
+                hipLaunchKernelGGL(k_row_starts, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->noff.p,
+                                   c->part_perm ? v2r_d.p : (const unsigned*)nullptr, N, row_real.p);
                 DevBuf<int> st;
                 HIP_TRY(c, st.alloc(1));
                 HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
@@ -1072,18 +1171,24 @@ int build_partition(fh_ctx* c) {
                     HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                     HIP_TRY(c, c->r_lanes4.alloc((size_t)npg * ls));
                     hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms,
-                                       nb_target, npg, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p);
+                                       nb_target, npg, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p, row_real.p);
                     HIP_TRY(c, hipGetLastError());
                     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     if (bad != 2) break;  // 2: only the stride was too small
                 }
                 c->has_rows = bad == 0;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));  // row_real is released at the end of this scope
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, stride %d): %s\n", c->r_ls,
                                  c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
         }
+    }
+    if (c->part_perm && !c->has_rows) {  // the locality order serves the row-owner kernel only: back to the node numbering
+        c->perm_failed = true;
+        c->part_perm = false;
+        return build_partition(c);
     }
     c->has_slotpar = false;
     if (c->has_rules && c->fast_ok && c->op != FH_LAPLACE && !c->has_pipe) {
@@ -1387,6 +1492,14 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
         if (rc) return rc;
+        if (c->part_perm && !(c->has_pipe && c->has_rows && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+                              !c->env("FENRIS_HIP_TRACE"))) {
+            // blocks in a locality order are for the row-owner kernel only (see build_partition); another kernel is about to run
+            c->perm_failed = true;
+            c->has_partition = false; ++c->struct_gen;
+            rc = build_partition(c);
+            if (rc) return rc;
+        }
         if (c->nblk == 0) return FH_OK;  // empty row range
         c->last_kernel.clear();
         if (c->a_npos > 0) {
@@ -1726,6 +1839,7 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->has_mask = false;
     c->has_aff = false;
     c->aff_failed = false;
+    c->perm_failed = false;
     c->has_ghat = false;
     c->rs.active = false;  // rule-set tables and element masks are per-mesh state
     c->user_has_mask = false;
@@ -1909,7 +2023,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
     c->op = op_kind;
     if (c->S() != old_s) { c->has_u = false; c->has_tp_pos = false; }
     // the owner-computes partition (LDS budgets, kernel classes, slot parameters) is built for one operator
-    if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; }
+    if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; c->perm_failed = false; }
     return FH_OK;
 }
 

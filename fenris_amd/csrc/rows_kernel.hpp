@@ -17,7 +17,9 @@ namespace fenris_hip {
 // block takes 4 lanes (24 terms), everything else one lane.  Lane record (uint4):
 //   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 | nterms << 10 | log2(group) << 13 | store << 15
 struct RowTablesS {
-    const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets (nbs + 1 words)
+    const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets relative to the block (nbs + 1 words)
+                         //              | first node-level CSR entry of every node's row (nbs words; the nodes of a block need not be
+                         //              consecutive in memory: build_partition may form the blocks in a locality order)
     const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256
     const int* conn;     // [npos][cs]
     const int* elem;     // [npos][us]
@@ -206,8 +208,8 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             }
         if ((wl >> 15) & 1u) {
             const int il = (int)((wl >> 7) & 7u), pos = (int)(wl & 127u);
-            const int rb = noff_l[il], cnt = noff_l[il + 1] - rb;
-            double* base = a.vals + (size_t)S * S * ((size_t)hc.r0 + rb) + S * pos;
+            const int cnt = noff_l[il + 1] - noff_l[il];
+            double* base = a.vals + (size_t)S * S * (size_t)(unsigned)noff_l[T.nbs + 1 + il] + S * pos;
             double tr = 0.0;
 #pragma unroll
             for (int i = 0; i < D; ++i) tr += Gm[i][i];
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 // at most ms N of them) behind per-column offsets; blocks with up to 48 terms (a node of an unstructured mesh easily has
 // 30-40 elements) take groups of up to 8 lanes.
 __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
-                                                             int* rec_new, uint4* lanes, int ls, int* status) {
+                                                             int* rec_new, uint4* lanes, int ls, int* status, const unsigned* row_real) {
     constexpr int N = 4, NKEY = 8 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
     __shared__ unsigned short terms[MAXTERMS];
@@ -254,6 +256,7 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
     int* out = rec_new + (size_t)p * rw_new;
     for (int i = lane; i < 8 + us / 4; i += 64) out[i] = rec[i];
     for (int i = lane; i <= nbs; i += 64) out[8 + us / 4 + i] = noff_old[i];
+    for (int i = lane; i < nbs; i += 64) out[8 + us / 4 + nbs + 1 + i] = (i < h.nb) ? (int)row_real[h.i0 + i] : 0;
     for (int i = lane; i < NKEY; i += 64) { cnt[i] = 0; fill[i] = 0; }
     for (int i = lane; i < 256 * 4; i += 64) lw[i / 4][i % 4] = 0u;
     __syncthreads();

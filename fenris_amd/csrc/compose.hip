@@ -81,7 +81,7 @@ int fh_add_mapped_matrix_dev(fh_ctx* c, const double* src_values_dev, const uint
     if (!src_values_dev || !dst_row_offsets_dev || !dst_col_indices_dev || !dst_values_dev)
         return fh_internal_fail(c, FH_BAD_ARGUMENT, "fh_add_mapped_matrix: null argument");
     if (N == 0) return FH_OK;
-    (void)hipSetDevice(fh_internal_device(c));
+    DevGuardExt dev_guard_(fh_internal_device(c));
     hipStream_t stream = fh_internal_stream(c);
     int* flag = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), stream) != hipSuccess)
@@ -106,7 +106,7 @@ int fh_add_mapped_vector_dev(fh_ctx* c, const double* src_dev, const uint64_t* n
     if (!fh_internal_sizes(c, &N, &S)) return fh_internal_fail(c, FH_INVALID_STATE, "fh_add_mapped_vector: set mesh and operator first");
     if (!src_dev || !dst_dev) return fh_internal_fail(c, FH_BAD_ARGUMENT, "fh_add_mapped_vector: null argument");
     if (N == 0) return FH_OK;
-    (void)hipSetDevice(fh_internal_device(c));
+    DevGuardExt dev_guard_(fh_internal_device(c));
     hipStream_t stream = fh_internal_stream(c);
     int* flag = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), stream) != hipSuccess)

@@ -431,6 +431,19 @@ static void swap_partition(fh_ctx* c, PartStash& st) {
 #undef X
 }
 
+// Every entry point that touches the device runs on the context's device and leaves the calling thread's current device as it
+// found it (several contexts on different GPUs in one process; torch's current device is the thread's too).
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev) { prev = cur; (void)hipSetDevice(dev); }
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
 #define HIP_TRY(ctx, expr)                                        \
     do {                                                          \
         hipError_t _e = (expr);                                   \
@@ -1687,7 +1700,7 @@ int fh_abi_version(void) { return FH_ABI_VERSION; }
 fh_ctx* fh_create(int device_id) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return nullptr;
-    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    DevGuard dev_guard_(device_id);   // the calling thread's current device is left as it was
     fh_ctx* c = new fh_ctx();
     c->device = device_id;
     // the tuning / diagnostic switches, once (include/fenris_hip.h): nothing in the dispatch reads the environment later
@@ -1706,7 +1719,7 @@ fh_ctx* fh_create(int device_id) {
 
 void fh_destroy(fh_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DevGuard dev_guard_(c->device);
     if (c->trace.p) {  // FENRIS_HIP_TRACE: average cycles per wave and phase of the pipelined kernel
         unsigned long long h[32] = {0};
         (void)hipDeviceSynchronize();
@@ -1762,11 +1775,13 @@ const char* fh_last_kernel_name(const fh_ctx* c) { return c ? c->last_kernel.c_s
 
 int fh_set_stream(fh_ctx* c, void* s) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     c->stream = reinterpret_cast<hipStream_t>(s);
     return FH_OK;
 }
 int fh_synchronize(fh_ctx* c) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FH_OK;
 }
@@ -1868,6 +1883,7 @@ static int narrow_conn(fh_ctx* c, const unsigned long long* conn_dev) {
 
 int fh_set_mesh(fh_ctx* c, int elem_kind, const double* vertices, uint64_t N, const uint64_t* connectivity, uint64_t E) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if ((N && !vertices) || (E && !connectivity)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh: null pointer");
     int rc = set_mesh_common(c, elem_kind, N, E);
     if (rc) return rc;
@@ -1887,6 +1903,7 @@ int fh_set_mesh(fh_ctx* c, int elem_kind, const double* vertices, uint64_t N, co
 
 int fh_set_mesh_dev(fh_ctx* c, int elem_kind, const double* vertices_dev, uint64_t N, const uint64_t* conn_dev, uint64_t E) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if ((N && !vertices_dev) || (E && !conn_dev)) return c->fail(FH_BAD_ARGUMENT, "fh_set_mesh_dev: null pointer");
     int rc = set_mesh_common(c, elem_kind, N, E);
     if (rc) return rc;
@@ -1901,6 +1918,7 @@ int fh_set_mesh_dev(fh_ctx* c, int elem_kind, const double* vertices_dev, uint64
 
 int fh_update_vertices(fh_ctx* c, const double* vertices) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_update_vertices: no mesh");
     if (!vertices) return c->fail(FH_BAD_ARGUMENT, "fh_update_vertices: null pointer");
     HIP_TRY(c, hipMemcpyAsync(c->verts.p, vertices, sizeof(double) * c->N * c->ei.d, hipMemcpyHostToDevice, c->stream));
@@ -1910,6 +1928,7 @@ int fh_update_vertices(fh_ctx* c, const double* vertices) {
 
 int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint64_t* eoff, const uint64_t* nodes, uint64_t E) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!eoff || sdim == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_connectivity_ragged: bad argument");
     const uint64_t total = eoff[E];
     if (total && !nodes) return c->fail(FH_BAD_ARGUMENT, "fh_set_connectivity_ragged: null node list");
@@ -1955,6 +1974,7 @@ int fh_set_connectivity_ragged(fh_ctx* c, uint64_t sdim, uint64_t N, const uint6
 static int apply_mask(fh_ctx* c, const uint8_t* mask);
 int fh_set_active_elements(fh_ctx* c, const uint8_t* mask) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_active_elements: set the mesh first");
     c->user_has_mask = mask != nullptr;
     if (mask) c->user_mask.assign(mask, mask + c->E); else c->user_mask.clear();
@@ -1990,6 +2010,7 @@ static int apply_mask(fh_ctx* c, const uint8_t* mask) {
 
 int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_row_range: set the mesh first");
     if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_set_row_range: bad node range");
     if (node_begin == 0 && node_end == c->N) { c->row_lo = 0; c->row_hi = -1; }
@@ -2000,6 +2021,7 @@ int fh_set_row_range(fh_ctx* c, uint64_t node_begin, uint64_t node_end) {
 
 int fh_set_affine_tolerance(fh_ctx* c, double rel_tol) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!(rel_tol >= 0.0) || rel_tol > 1e-6) return c->fail(FH_BAD_ARGUMENT, "fh_set_affine_tolerance: tolerance must be in [0, 1e-6]");
     if (rel_tol == c->affine_tol) return FH_OK;
     c->affine_tol = rel_tol;
@@ -2017,6 +2039,7 @@ int fh_affine_stats(const fh_ctx* c, uint64_t* affine_elements, uint64_t* affine
 
 int fh_set_operator(fh_ctx* c, int op_kind) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (op_kind < FH_LAPLACE || op_kind > FH_MASS_VECTOR) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
     if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
     const int old_s = c->S(), old_op = c->op;
@@ -2029,6 +2052,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
 
 int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uint32_t nq, const double* params) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->rs_staging) c->rs.active = false;
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_uniform: set the mesh first");
     if (!w || !pts || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform: bad argument");
@@ -2107,6 +2131,7 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
 int fh_set_quadrature_uniform_data(fh_ctx* c, const double* w, const double* pts, uint32_t nq, const void* data, uint32_t stride,
                                    int kind) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (kind == FH_DATA_NONE || !data) return fh_set_quadrature_uniform(c, w, pts, nq, nullptr);
     const uint32_t need = (kind == FH_DATA_LAME) ? 16u : (kind == FH_DATA_DENSITY ? 8u : 0u);
     if (!need || stride < need || stride % 8u) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_uniform_data: bad kind or stride");
@@ -2122,6 +2147,7 @@ int fh_set_quadrature_uniform_data(fh_ctx* c, const double* w, const double* pts
 int fh_set_quadrature_compact(fh_ctx* c, const double* w, const double* pts, uint32_t nq, uint64_t num_rules,
                               const double* rule_params, const uint64_t* elem_to_rule) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!rule_params || !elem_to_rule || num_rules == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_compact: bad argument");
     int rc = fh_set_quadrature_uniform(c, w, pts, nq, rule_params);  // tables; rule 0 stands in for the uniform data
     if (rc) return rc;
@@ -2209,6 +2235,7 @@ static int rs_for_each_group(fh_ctx* c, F&& fn) {
 int fh_set_quadrature_rules(fh_ctx* c, uint64_t num_rules, const uint64_t* rule_offsets, const double* weights, const double* points,
                             const double* params, const uint64_t* elem_to_rule) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh || c->ragged || c->op < 0) return c->fail(FH_INVALID_STATE, "fh_set_quadrature_rules: set mesh and operator first");
     if (!rule_offsets || !weights || !points || num_rules == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_quadrature_rules: bad argument");
     if (!elem_to_rule && num_rules != c->E)
@@ -2273,12 +2300,21 @@ static int set_u_common(fh_ctx* c, const double* u, hipMemcpyKind kind) {
     c->has_u = true;
     return FH_OK;
 }
-int fh_set_u(fh_ctx* c, const double* u) { return c ? set_u_common(c, u, hipMemcpyHostToDevice) : FH_BAD_ARGUMENT; }
-int fh_set_u_dev(fh_ctx* c, const double* u) { return c ? set_u_common(c, u, hipMemcpyDeviceToDevice) : FH_BAD_ARGUMENT; }
+int fh_set_u(fh_ctx* c, const double* u) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    return set_u_common(c, u, hipMemcpyHostToDevice);
+}
+int fh_set_u_dev(fh_ctx* c, const double* u) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    return set_u_common(c, u, hipMemcpyDeviceToDevice);
+}
 
 // ---- pattern
 int fh_pattern_dev(fh_ctx* c, uint64_t* row_offsets_dev, uint64_t* col_indices_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_pattern_dev: call fh_pattern first");
     const int S = c->S(), N = (int)c->N;
     if (row_offsets_dev)
@@ -2293,6 +2329,7 @@ int fh_pattern_dev(fh_ctx* c, uint64_t* row_offsets_dev, uint64_t* col_indices_d
 
 int fh_pattern(fh_ctx* c, uint64_t* row_offsets, uint64_t* nnz_out) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = build_pattern(c);
     if (rc) return rc;
@@ -2311,6 +2348,7 @@ int fh_pattern(fh_ctx* c, uint64_t* row_offsets, uint64_t* nnz_out) {
 
 int fh_pattern_cols(fh_ctx* c, uint64_t* col_indices) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_pattern_cols: call fh_pattern first");
     const uint64_t nnz = fh_nnz(c);
     if (nnz == 0) return FH_OK;
@@ -2327,6 +2365,7 @@ int fh_pattern_cols(fh_ctx* c, uint64_t* col_indices) {
 // ---- colouring
 int fh_color(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_color: no connectivity set");
     if (!c->has_host_conn) {  // mesh was given as device pointers: fetch the connectivity once
         std::vector<int> tmp(c->flat_len ? c->flat_len : 1);
@@ -2353,6 +2392,7 @@ int fh_color(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t*
 
 int fh_set_colors(fh_ctx* c, uint64_t num_colors, const uint64_t* color_offsets, const uint64_t* labels) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_set_colors: no connectivity set");
     if (!color_offsets || (!labels && c->E)) return c->fail(FH_BAD_ARGUMENT, "fh_set_colors: null pointer");
     if (color_offsets[0] != 0 || color_offsets[num_colors] != c->E)
@@ -2367,6 +2407,7 @@ int fh_set_colors(fh_ctx* c, uint64_t num_colors, const uint64_t* color_offsets,
 static bool mode_is_colored(int flags) { return (flags & FH_SCATTER_MASK) == FH_SCATTER_COLORED; }
 int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->rs.active) return assemble_matrix_enqueue(c, values_dev, flags);
     // rule-set table: one pass per group of rules, the first one with the caller's flags, the others accumulating
@@ -2392,6 +2433,7 @@ int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
 // (mesh, pattern, mask, operator, quadrature, affine classes) has changed since.
 int fh_assemble_matrix_rows_async_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_assemble_matrix_rows: set the mesh first");
     if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix_rows: bad node range");
@@ -2415,6 +2457,8 @@ int fh_assemble_matrix_rows_async_dev(fh_ctx* c, double* values_dev, int flags, 
 }
 
 int fh_assemble_matrix_rows_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     const int rc = fh_assemble_matrix_rows_async_dev(c, values_dev, flags, node_begin, node_end);
     if (rc) return rc;
     return read_status(c, failed);
@@ -2422,10 +2466,13 @@ int fh_assemble_matrix_rows_dev(fh_ctx* c, double* values_dev, int flags, uint64
 
 int fh_poll_status(fh_ctx* c, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     return read_status(c, failed);
 }
 
 int fh_assemble_matrix_dev(fh_ctx* c, double* values_dev, int flags, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);
     if (rc) return rc;
     return read_status(c, failed);
@@ -2433,6 +2480,7 @@ int fh_assemble_matrix_dev(fh_ctx* c, double* values_dev, int flags, uint64_t* f
 
 int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = check_ready(c, "fh_assemble_matrix", true);
     if (rc) return rc;
     if (!values) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
@@ -2452,6 +2500,7 @@ int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
 
 int fh_assemble_element_matrices_dev(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = check_ready(c, "fh_assemble_element_matrices", false);
     if (rc) return rc;
     if (first + count > c->E || (count && !ke_dev)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
@@ -2479,6 +2528,7 @@ int fh_assemble_element_matrices_dev(fh_ctx* c, uint64_t first, uint64_t count, 
 
 int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, double* ke_out) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = check_ready(c, "fh_assemble_element_matrices", false);
     if (rc) return rc;
     if (first + count > c->E || (count && !ke_out)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
@@ -2518,6 +2568,7 @@ static int rs_walk_accumulating(fh_ctx* c, uint64_t* failed, F&& single) {
 static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed);
 int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->rs.active) return assemble_vector_single(c, out_dev, failed);
     return rs_walk_accumulating(c, failed, [&](uint64_t* f) { return assemble_vector_single(c, out_dev, f); });
 }
@@ -2579,6 +2630,7 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
 
 int fh_assemble_vector(fh_ctx* c, double* out, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = check_ready(c, "fh_assemble_vector", false);
     if (rc) return rc;
     if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_vector: out is null");
@@ -2602,6 +2654,7 @@ static int source_ready(fh_ctx* c, const char* who) {
 
 int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, const double* values_dev, double* out_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_assemble_source_vector: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, "fh_assemble_source_vector");
     if (rc) return rc;
@@ -2662,6 +2715,7 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
 
 int fh_assemble_source_vector(fh_ctx* c, uint32_t sdim, const double* g, const double* values, double* out) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = source_ready(c, "fh_assemble_source_vector");
     if (rc) return rc;
     if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_source_vector: out is null");
@@ -2682,6 +2736,7 @@ int fh_assemble_source_vector(fh_ctx* c, uint32_t sdim, const double* g, const d
 
 int fh_physical_quadrature_points_dev(fh_ctx* c, double* x_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_physical_quadrature_points: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, "fh_physical_quadrature_points");
     if (rc) return rc;
@@ -2704,6 +2759,7 @@ int fh_physical_quadrature_points_dev(fh_ctx* c, double* x_dev) {
 
 int fh_physical_quadrature_points(fh_ctx* c, double* x) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = source_ready(c, "fh_physical_quadrature_points");
     if (rc) return rc;
     if (!x) return c->fail(FH_BAD_ARGUMENT, "fh_physical_quadrature_points: output is null");
@@ -2720,6 +2776,7 @@ int fh_physical_quadrature_points(fh_ctx* c, double* x) {
 static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed);
 int fh_assemble_scalar(fh_ctx* c, double* out, uint64_t* failed) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->rs.active) return assemble_scalar_single(c, out, failed);
     if (!out) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_scalar: out is null");
     double tot = 0.0;
@@ -2773,6 +2830,7 @@ static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed) {
 // ---- Dirichlet helpers
 int fh_apply_dirichlet_csr_dev(fh_ctx* c, double* values_dev, const uint64_t* nodes, uint64_t n) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!c->has_pattern) return c->fail(FH_INVALID_STATE, "fh_apply_dirichlet_csr_dev: call fh_pattern first");
     if (!values_dev || (n && !nodes)) return c->fail(FH_BAD_ARGUMENT, "fh_apply_dirichlet_csr_dev: null pointer");
     const int S = c->S(), N = (int)c->N;
@@ -2807,6 +2865,7 @@ int fh_apply_dirichlet_csr_dev(fh_ctx* c, double* values_dev, const uint64_t* no
 
 int fh_apply_dirichlet_rhs_dev(fh_ctx* c, double* rhs_dev, const uint64_t* nodes, uint64_t n) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (!rhs_dev || (n && !nodes)) return c->fail(FH_BAD_ARGUMENT, "fh_apply_dirichlet_rhs_dev: null pointer");
     if (n == 0) return FH_OK;
     for (uint64_t i = 0; i < n; ++i)
@@ -2855,6 +2914,7 @@ static int matrix_ready(fh_ctx* c, const char* who) {
 
 int fh_spmv_dev(fh_ctx* c, const double* values_dev, const double* x_dev, double* y_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = matrix_ready(c, "fh_spmv");
     if (rc) return rc;
     if (!values_dev || !x_dev || !y_dev) return c->fail(FH_BAD_ARGUMENT, "fh_spmv: null argument");
@@ -2866,6 +2926,7 @@ int fh_spmv_dev(fh_ctx* c, const double* values_dev, const double* x_dev, double
 int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, double* x_dev, int preconditioner, double rel_tol,
                     uint64_t max_iter, uint64_t* num_iterations) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     if (num_iterations) *num_iterations = 0;
     int rc = matrix_ready(c, "fh_cg_solve");
     if (rc) return rc;
@@ -2946,6 +3007,7 @@ int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, do
 int fh_cg_solve(fh_ctx* c, const double* values, const double* b, double* x, int preconditioner, double rel_tol, uint64_t max_iter,
                 uint64_t* num_iterations) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = matrix_ready(c, "fh_cg_solve");
     if (rc) return rc;
     if (!values || !b || !x) return c->fail(FH_BAD_ARGUMENT, "fh_cg_solve: null argument");
@@ -2965,6 +3027,7 @@ int fh_cg_solve(fh_ctx* c, const double* values, const double* b, double* x, int
 }
 
 static int error_squared(fh_ctx* c, int which, uint32_t sdim, const double* uh_dev, const double* exact_dev, double* out) {
+    DevGuard dev_guard_(c->device);
     if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_estimate_*_error_squared: rule-set quadrature tables (fh_set_quadrature_rules) are not walked here");
     int rc = source_ready(c, which ? "fh_estimate_H1_seminorm_error_squared" : "fh_estimate_L2_error_squared");
     if (rc) return rc;
@@ -2998,6 +3061,8 @@ static int error_squared(fh_ctx* c, int which, uint32_t sdim, const double* uh_d
 }
 
 static int error_squared_host(fh_ctx* c, int which, uint32_t sdim, const double* uh, const double* exact, double* out) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
     int rc = source_ready(c, "error estimate");
     if (rc) return rc;
     if (!uh || !exact || !out) return c->fail(FH_BAD_ARGUMENT, "error estimate: null argument");

@@ -1500,7 +1500,12 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         const size_t ld = (size_t)c->S() * c->ei.n;
         const double dense_gb = (double)c->E * ld * ld * 8.0 / 1e9;
         const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || c->env("FENRIS_HIP_TWO_PASS");
-        if (want && dense_gb <= (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) return assemble_two_pass(c, values_dev, overwrite);
+        if (want && dense_gb <= (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) {
+            // the dense buffer is allocated here: when the device cannot hold it the one-pass gather below takes over
+            if (c->ke_dense.n >= ld * ld * c->E || c->ke_dense.alloc(ld * ld * c->E) == hipSuccess)
+                return assemble_two_pass(c, values_dev, overwrite);
+            (void)hipGetLastError();
+        }
     }
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);

@@ -50,8 +50,8 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
 }
 
-template <int OP, bool OVERWRITE, bool STAGED, bool DBG, int DEPTH>
-__global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
+template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE>
+__global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
     constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
     const int G = gridDim.x, npos = T.npos;
     const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
     if (p_begin >= p_end) return;
-    for (int i = tid; i < 65 * GW; i += AFFINE_ROWS_THREADS) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
-    for (int i = tid; i < 2 * accp; i += AFFINE_ROWS_THREADS) OUT[i] = 0.0;
+    for (int i = tid; i < 65 * GW; i += (320 + 64 * NSTORE)) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
+    for (int i = tid; i < 2 * accp; i += (320 + 64 * NSTORE)) OUT[i] = 0.0;
     const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
     auto head_of = [&](int r0) { return (int)((vals_w + (size_t)SS * (size_t)r0) & 15); };
     // FENRIS_HIP_TRACE (instrumented instantiation): cycles per role between barriers / at the barriers, summed over workgroups
@@ -93,8 +93,10 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
         }
     };
 
-    if (wave == 5) {
-        // ------------------------------------------------------------------------------------------ store wave
+    if (wave >= 5) {
+        // ------------------------------------------------------------------------------------------ store wave(s)
+        // NSTORE wavefronts share the work as one unit of SL = 64 NSTORE lanes: a trip moves SL consecutive 16-byte pieces.
+        constexpr int SL = 64 * NSTORE;
         const int lane = tid - 320;
         // Rows of a finished position: LDS -> global memory.  The write path wants whole, aligned 128-byte lines (16-byte
         // stores that start a wave off a line boundary reach 4.3 TB/s instead of 6.2, and a line written in two parts costs
@@ -104,20 +106,11 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
         // into the head of the other buffer instead of being written.
         // The wave's own instruction stream is on the critical path from barrier to barrier, so everything about a position
         // is kept in scalar registers and the trips of the unrolled loops are skipped by scalar branches.
-        // STAGED: the rows are first fetched into registers (between the barriers that bracket the position) and stored to
-        // global memory behind the barrier; otherwise they are streamed LDS -> register -> memory before it.
-        constexpr int MAXP = STAGED ? 14 : 1;                    // 16-byte pieces per lane held in registers
-        f64x2 v[MAXP], vt = {0.0, 0.0};
-        f64x2* gout = reinterpret_cast<f64x2*>(a.vals);          // first whole piece of this lane in global memory
-        double* line0 = a.vals;
-        int nfull = 0, rem = 0, e_lo = -1, e_hi = -1;            // trips of 64 pieces, pieces of the last trip, end doubles
-        double ev_lo = 0.0, ev_hi = 0.0;
         auto rfl = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
         auto put = [&](f64x2* dst, f64x2 val) {
             if (DBG && (ablate & 1)) return;
             // non-temporal stores (FENRIS_HIP_AFFINE_NT; default: Laplace only): the rows are written once and never read by this
-            // kernel.  3 % on Laplace; on elasticity equal on a cold device and 4 % slower once it is warm (5.19 - 5.24 against
-            // 4.98 ms in back-to-back runs on one box).
+            // kernel.  3 % on Laplace; on elasticity equal within the run-to-run spread.
             if constexpr (OVERWRITE) { if (nt_stores) __builtin_nontemporal_store(val, dst); else *dst = val; }
             else { const f64x2 o = *dst; f64x2 r; r.x = o.x + val.x; r.y = o.y + val.y; *dst = r; }
         };
@@ -125,53 +118,39 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
             if (DBG && (ablate & 1)) return;
             if constexpr (OVERWRITE) { if (nt_stores) __builtin_nontemporal_store(val, dst); else *dst = val; } else *dst += val;
         };
-        auto stage_read = [&](const int4 hv, double* buf, double* other, bool carry_in, bool carry_out) {
+        auto stream_out = [&](const int4 hv, double* buf, double* other, bool carry_in, bool carry_out) {
             const int r0 = rfl(hv.x), nrow = rfl(hv.y), flags = rfl(hv.z), head = rfl(hv.w) & 15;
-            line0 = a.vals + (size_t)SS * (size_t)r0 - head;
+            double* line0 = a.vals + (size_t)SS * (size_t)r0 - head;
             const int lo = carry_in ? 0 : head, hi = head + SS * nrow;
             const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
             const bool zero = !(flags & 1);
             const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces [k0, k1)
             const int np = max(k1 - k0, 0);
-            nfull = np >> 6;
-            rem = np & 63;
+            const int nfull = np / SL, rem = np - nfull * SL;    // trips of SL pieces, pieces of the last trip
             f64x2* b2 = reinterpret_cast<f64x2*>(buf) + k0 + lane;
-            gout = reinterpret_cast<f64x2*>(line0) + k0 + lane;
-            if constexpr (STAGED) {
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i)
-                    if (i < nfull) v[i] = b2[64 * i];
-                for (int i = MAXP; i < nfull; ++i) put(gout + 64 * i, b2[64 * i]);   // rows longer than the registers hold
-                if (lane < rem) vt = b2[64 * nfull];
-            } else {
-                int i = 0;
-                for (; i + 4 <= nfull; i += 4) {
-                    const f64x2 v0 = b2[64 * i], v1 = b2[64 * i + 64], v2 = b2[64 * i + 128], v3 = b2[64 * i + 192];
-                    put(gout + 64 * i, v0); put(gout + 64 * i + 64, v1); put(gout + 64 * i + 128, v2); put(gout + 64 * i + 192, v3);
-                }
-                for (; i < nfull; ++i) put(gout + 64 * i, b2[64 * i]);
-                if (lane < rem) put(gout + 64 * nfull, b2[64 * nfull]);
+            f64x2* gout = reinterpret_cast<f64x2*>(line0) + k0 + lane;
+            int i = 0;
+            for (; i + 4 <= nfull; i += 4) {
+                const f64x2 v0 = b2[SL * i], v1 = b2[SL * (i + 1)], v2 = b2[SL * (i + 2)], v3 = b2[SL * (i + 3)];
+                put(gout + SL * i, v0); put(gout + SL * (i + 1), v1); put(gout + SL * (i + 2), v2); put(gout + SL * (i + 3), v3);
             }
-            e_lo = ((lo & 1) && lo < L) ? lo : -1;               // the ends of a run of positions: single doubles
-            e_hi = ((L & 1) && L - 1 >= lo) ? L - 1 : -1;
-            if (e_lo >= 0 && lane == 0) { if (STAGED) ev_lo = buf[e_lo]; else put1(line0 + e_lo, buf[e_lo]); }
-            if (e_hi >= 0 && lane == 0) { if (STAGED) ev_hi = buf[e_hi]; else put1(line0 + e_hi, buf[e_hi]); }
+            for (; i < nfull; ++i) put(gout + SL * i, b2[SL * i]);
+            if (lane < rem) put(gout + SL * nfull, b2[SL * nfull]);
+            const int e_lo = ((lo & 1) && lo < L) ? lo : -1;     // the ends of a run of positions: single doubles
+            const int e_hi = ((L & 1) && L - 1 >= lo) ? L - 1 : -1;
+            if (e_lo >= 0 && lane == 0) put1(line0 + e_lo, buf[e_lo]);
+            if (e_hi >= 0 && lane == 0) put1(line0 + e_hi, buf[e_hi]);
             if (carry_out && lane < hi - L) other[lane] = buf[L + lane];
-            if (zero) {  // some (node, column) block of these rows has no owner lane (element masks): clear what was read
+            if (zero) {  // some (node, column) block of these rows has no owner lane (element masks): clear what was read --
+                         // every lane the pieces it fetched itself, the first lanes the ends and the carried part
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int d = lo + lane; d < hi; d += 64) buf[d] = 0.0;
-            }
-        };
-        auto issue_stores = [&]() {
-            if constexpr (STAGED) {
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i)
-                    if (i < nfull) put(gout + 64 * i, v[i]);
-                if (lane < rem) put(gout + 64 * nfull, vt);
-                if ((e_lo >= 0 || e_hi >= 0) && lane == 0) {
-                    if (e_lo >= 0) put1(line0 + e_lo, ev_lo);
-                    if (e_hi >= 0) put1(line0 + e_hi, ev_hi);
-                }
+                const f64x2 z2 = {0.0, 0.0};
+                for (int t = 0; t < nfull; ++t) b2[SL * t] = z2;
+                if (lane < rem) b2[SL * nfull] = z2;
+                if (lane == 0 && e_lo >= 0) buf[e_lo] = 0.0;
+                if (lane == 0 && e_hi >= 0) buf[e_hi] = 0.0;
+                if (lane < hi - L) buf[L + lane] = 0.0;
+                if (lane < 2 * k0 - lo && lo + lane != e_lo) buf[lo + lane] = 0.0;   // nothing: [lo, 2 k0) is e_lo alone
             }
         };
         lds_barrier();  // B0
@@ -183,16 +162,13 @@ __global__ void __launch_bounds__(AFFINE_ROWS_THREADS, 5) k_affine_rows(const KA
                 const int4 h_prev = HDR[(p - 1) & 3];
                 const int r0_cur = rfl(HDR[p & 3].x);
                 const bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y);
-                stage_read(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
+                stream_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
                 carry_in = carry_out;
             }
             tr_barrier();
-            if (p > p_begin) issue_stores();
         }
-        stage_read(HDR[(p_end - 1) & 3], OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_stores();
-        tr_report(2);
+        stream_out(HDR[(p_end - 1) & 3], OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, false);
+        if (wave == 5) tr_report(2);
         return;
     }
 
@@ -643,29 +619,29 @@ hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, cons
     return hipGetLastError();
 }
 
-template <int OP, int DEPTH>
-static auto affine_rows_pick(bool ow, bool dbg, bool staged) -> void (*)(const KArgs, const AffineRowTables, int) {
-    if (dbg) return staged ? k_affine_rows<OP, true, true, true, DEPTH> : k_affine_rows<OP, true, false, true, DEPTH>;
-    return ow ? k_affine_rows<OP, true, false, false, DEPTH> : k_affine_rows<OP, false, false, false, DEPTH>;
+template <int OP, int DEPTH, int NSTORE>
+static auto affine_rows_pick(bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
+    if (dbg) return k_affine_rows<OP, true, true, DEPTH, NSTORE>;
+    return ow ? k_affine_rows<OP, true, false, DEPTH, NSTORE> : k_affine_rows<OP, false, false, DEPTH, NSTORE>;
 }
 template <int OP>
-static auto affine_rows_pick_depth(int depth, bool ow, bool dbg, bool staged) -> void (*)(const KArgs, const AffineRowTables, int) {
+static auto affine_rows_pick_variant(int depth, int nstore, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
     // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
-    return depth <= 1 ? affine_rows_pick<OP, 1>(ow, dbg, staged) : affine_rows_pick<OP, 2>(ow, dbg, staged);
+    if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2>(ow, dbg) : affine_rows_pick<OP, 2, 2>(ow, dbg);
+    return depth <= 1 ? affine_rows_pick<OP, 1, 1>(ow, dbg) : affine_rows_pick<OP, 2, 1>(ow, dbg);
 }
 
-hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
-                              int ablate) {
-    const bool ow = a.overwrite != 0;
-    const bool staged = (ablate & 64) != 0;   // profiling: the register-staged store wave (stores behind the barrier)
+hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a,
+                              const AffineRowTables& T, int ablate) {
+    const bool ow = a.overwrite != 0, dbg = (ablate & 0xffff) != 0;
     void (*kern)(const KArgs, const AffineRowTables, int) =
-        op == FH_LAPLACE ? affine_rows_pick_depth<FH_LAPLACE>(depth, ow, (ablate & 0xffff) != 0, staged)
-                         : affine_rows_pick_depth<FH_LINEAR_ELASTIC>(depth, ow, (ablate & 0xffff) != 0, staged);
+        op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE>(depth, nstore, ow, dbg)
+                         : affine_rows_pick_variant<FH_LINEAR_ELASTIC>(depth, nstore, ow, dbg);
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(AFFINE_ROWS_THREADS), lds_bytes, stream, a, T, ablate);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(320 + 64 * (nstore >= 2 ? 2 : 1)), lds_bytes, stream, a, T, ablate);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ struct AffineRowTables {
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
 constexpr int AFFINE_ROWS_NT_STORES = 0x10000;  // bit of the launcher's `ablate` argument: non-temporal stores of the rows
-constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave
+constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave (a second store wave: 448)
 
 size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 
@@ -44,8 +44,8 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
 hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, const int* ids, const int* first_pos, int npos, int ntab,
                                uint2* lanes_tab, int4* hdr, int* mismatch);
 
-// op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; ablate != 0 selects the instrumented instantiation (profiling only)
-hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+// op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; nstore (1 or 2): store waves; ablate != 0 selects the instrumented instantiation (profiling only)
+hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
                               int ablate);
 
 }  // namespace fenris_hip

@@ -1352,7 +1352,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const int grid = std::min(c->a_npos, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
     if (c->env("FENRIS_HIP_VERBOSE"))
         std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
-    HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
+    HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
                                   a.ablate | (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0)));
     return FH_OK;
 }

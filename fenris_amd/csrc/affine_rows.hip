@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         auto slot_of = [&](int r) { return min(lane + 64 * r, npieces - 1) / NPC; };
         auto piece_of = [&](int r) { const int i = min(lane + 64 * r, npieces - 1); return i - (i / NPC) * NPC; };
         auto load_elem = [&](int p, int r) { return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))]; };
-        auto load_piece = [&](int e, int r) { return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)max(e, 0) * NPC + piece_of(r)]; };
+        // ablate 128 (profiling): every record from the first 4096 (cache-resident): the same instruction stream without the HBM reads
+        auto load_piece = [&](int e, int r) { return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)((DBG && (ablate & 128)) ? (max(e, 0) & 4095) : max(e, 0)) * NPC + piece_of(r)]; };
         auto park_piece = [&](int parity, int r, f64x2 v) {
             if (lane + 64 * r < npieces) reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + slot_of(r)) * GW)[piece_of(r)] = v;
         };

@@ -1,7 +1,7 @@
 # A/B and ablation timings of the affine-element kernel (k_affine_rows) on the headline configuration.
 # usage (GPU box, repo root): bash scripts/gpu_affine_ab.sh [cells] [config]   (config: ns (default) or c2)
 # FENRIS_HIP_ABLATE bits (instrumented instantiation, wrong results): 1 no global stores, 2 no sandwich products, 4 no record
-# fetches, 16 nothing switched off
+# fetches, 16 nothing switched off, 128 every record from the first 4096 (no HBM reads, same instructions)
 CELLS=${1:-216}
 CFG=${2:-ns}
 OUT=gpurun_out/affine_ab_$CFG.txt

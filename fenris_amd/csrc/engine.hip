@@ -324,6 +324,7 @@ struct fh_ctx {
     DevBuf<int> p_conn, p_rec, p_elem;
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
     bool part_perm = false;     // the blocks were formed in a locality order of the nodes (row-owner Tet4 kernel only)
+    bool part_rows_only = false;  // tables that only the row-owner Tet4 kernel can use (locality order and / or larger blocks)
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
     int r_rw = 0, r_ls = 256;
     bool has_rows = false;
@@ -415,7 +416,7 @@ struct fh_ctx {
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(npos_gen)       \
-    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(perm_failed)
+    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
     FH_PARTITION_MEMBERS(X)
@@ -837,7 +838,12 @@ int build_partition(fh_ctx* c) {
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
                           (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
     const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
-    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", 128)));
+    // Tables for the row-owner Tet4 kernel alone may hold more entries per block than the pipelined kernel's lane mapping takes
+    // (224: seven nodes of ~24 tetrahedra instead of five -- a position then fills ~120 lanes and there are 25 % fewer of them;
+    // C3: 0.80 -> 0.67 ms; 192: 0.68, 256: 0.68)
+    const bool rows_special = perm_cand;
+    c->part_rows_only = rows_special;
+    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? 224 : 128)));
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     long long sum_rows = 0;
@@ -999,7 +1005,7 @@ int build_partition(fh_ctx* c) {
         if (jt != 1 && jt != 2 && jt != 4 && jt != n) jt = 1;
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
-        if (us * c->ei.ng <= 512 && us <= 252 && ms <= 256 && ms * (n / jt) <= 256 && ms * n / 4 <= 256 && ms <= mb &&
+        if (us * c->ei.ng <= (rows_special ? 1024 : 512) && us <= 252 && ms <= 256 && (rows_special || (ms * (n / jt) <= 256 && ms * n / 4 <= 256)) && ms <= mb &&
             nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
             const int nblk = c->nblk;
             // Block classes: 1 = every adjacent element is affine, the block runs on k_affine_rows; 0 = general kernels.
@@ -1198,9 +1204,10 @@ int build_partition(fh_ctx* c) {
             }
         }
     }
-    if (c->part_perm && !c->has_rows) {  // the locality order serves the row-owner kernel only: back to the node numbering
+    if (c->part_rows_only && !c->has_rows) {  // these tables serve the row-owner kernel only: back to the standard form
         c->perm_failed = true;
         c->part_perm = false;
+        c->part_rows_only = false;
         return build_partition(c);
     }
     c->has_slotpar = false;
@@ -1510,9 +1517,9 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     if (mode == FH_SCATTER_GATHER) {
         rc = build_partition(c);
         if (rc) return rc;
-        if (c->part_perm && !(c->has_pipe && c->has_rows && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+        if (c->part_rows_only && !(c->has_pipe && c->has_rows && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
                               !c->env("FENRIS_HIP_TRACE"))) {
-            // blocks in a locality order are for the row-owner kernel only (see build_partition); another kernel is about to run
+            // these tables are for the row-owner kernel only (see build_partition); another kernel is about to run
             c->perm_failed = true;
             c->has_partition = false; ++c->struct_gen;
             rc = build_partition(c);

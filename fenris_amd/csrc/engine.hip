@@ -325,6 +325,7 @@ struct fh_ctx {
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
     bool part_perm = false;     // the blocks were formed in a locality order of the nodes (row-owner Tet4 kernel only)
     bool part_rows_only = false;  // tables that only the row-owner Tet4 kernel can use (locality order and / or larger blocks)
+    int rows_try = 0;           // block sizes tried for them: 0 = nine nodes / 256 entries, 1 = seven / 224, then the standard form
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
     int r_rw = 0, r_ls = 256;
     bool has_rows = false;
@@ -416,7 +417,7 @@ struct fh_ctx {
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(npos_gen)       \
-    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(perm_failed)
+    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
     FH_PARTITION_MEMBERS(X)
@@ -837,13 +838,14 @@ int build_partition(fh_ctx* c) {
     // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
                           (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
-    const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
+    const bool rows_special = perm_cand;   // tables for the row-owner Tet4 kernel alone: larger blocks (below)
+    const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", rows_special ? (c->rows_try == 0 ? 9 : 7)
+                                                                                                     : (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
     // Tables for the row-owner Tet4 kernel alone may hold more entries per block than the pipelined kernel's lane mapping takes
-    // (224: seven nodes of ~24 tetrahedra instead of five -- a position then fills ~120 lanes and there are 25 % fewer of them;
-    // C3: 0.80 -> 0.67 ms; 192: 0.68, 256: 0.68)
-    const bool rows_special = perm_cand;
+    // and more nodes (the lane word has four bits for the node): nine nodes / 256 entries first (C3: 98 k positions of ~170 lanes
+    // instead of 171 k of ~90, 0.80 -> 0.64 ms), seven / 224 when that cannot be expressed (0.67 ms), then the standard form
     c->part_rows_only = rows_special;
-    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? 224 : 128)));
+    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? (c->rows_try == 0 ? 256 : 224) : 128)));
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     long long sum_rows = 0;
@@ -1174,7 +1176,7 @@ int build_partition(fh_ctx* c) {
             const int npg = c->npos_gen;
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
-            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 8 && npg > 0 && !c->env("FENRIS_HIP_NO_ROWS")) {
+            if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 16 && npg > 0 && !c->env("FENRIS_HIP_NO_ROWS")) {
                 c->r_rw = 8 + us / 4 + nb_target + 1 + nb_target;
                 DevBuf<unsigned> row_real;   // first entry of every node's real row, in the order of the blocks
                 HIP_TRY(c, row_real.alloc((size_t)N + 1));
@@ -1204,8 +1206,8 @@ int build_partition(fh_ctx* c) {
             }
         }
     }
-    if (c->part_rows_only && !c->has_rows) {  // these tables serve the row-owner kernel only: back to the standard form
-        c->perm_failed = true;
+    if (c->part_rows_only && !c->has_rows) {  // these tables serve the row-owner kernel only: smaller blocks, then the standard form
+        if (++c->rows_try >= 2) c->perm_failed = true;
         c->part_perm = false;
         c->part_rows_only = false;
         return build_partition(c);
@@ -1867,6 +1869,7 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->has_aff = false;
     c->aff_failed = false;
     c->perm_failed = false;
+    c->rows_try = 0;
     c->has_ghat = false;
     c->rs.active = false;  // rule-set tables and element masks are per-mesh state
     c->user_has_mask = false;
@@ -2058,7 +2061,7 @@ int fh_set_operator(fh_ctx* c, int op_kind) {
     c->op = op_kind;
     if (c->S() != old_s) { c->has_u = false; c->has_tp_pos = false; }
     // the owner-computes partition (LDS budgets, kernel classes, slot parameters) is built for one operator
-    if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; c->perm_failed = false; }
+    if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; c->perm_failed = false; c->rows_try = 0; }
     return FH_OK;
 }
 

@@ -15,7 +15,7 @@ namespace fenris_hip {
 
 // Tet4 (one-point rule): six terms per lane.  A node of a tetrahedral mesh has ~24 elements and ~15 columns: the diagonal
 // block takes 4 lanes (24 terms), everything else one lane.  Lane record (uint4):
-//   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 | nterms << 10 | log2(group) << 13 | store << 15
+//   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 (4 bits) | nterms << 11 | log2(group) << 14 | store << 16
 struct RowTablesS {
     const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets relative to the block (nbs + 1 words)
                          //              | first node-level CSR entry of every node's row (nbs words; the nodes of a block need not be
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 
         // phase C: G = sum over the lane's terms of h_a h_j^T
         const unsigned wl = lane_cur.w;
-        const int nterms = (int)((wl >> 10) & 7u), grp = (int)((wl >> 13) & 3u);
+        const int nterms = (int)((wl >> 11) & 7u), grp = (int)((wl >> 14) & 3u);
         const unsigned tw[3] = {lane_cur.x, lane_cur.y, lane_cur.z};
         double Gm[D][D], Gl[ELEMPAR ? D : 1][ELEMPAR ? D : 1];
 #pragma unroll
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                     if (grp >= 3) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t3l;
                 }
             }
-        if ((wl >> 15) & 1u) {
-            const int il = (int)((wl >> 7) & 7u), pos = (int)(wl & 127u);
+        if ((wl >> 16) & 1u) {
+            const int il = (int)((wl >> 7) & 15u), pos = (int)(wl & 127u);
             const int cnt = noff_l[il + 1] - noff_l[il];
             double* base = a.vals + (size_t)S * S * (size_t)(unsigned)noff_l[T.nbs + 1 + il] + S * pos;
             double tr = 0.0;
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 // 30-40 elements) take groups of up to 8 lanes.
 __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
                                                              int* rec_new, uint4* lanes, int ls, int* status, const unsigned* row_real) {
-    constexpr int N = 4, NKEY = 8 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;
+    constexpr int N = 4, NKEY = 16 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;   // up to 16 nodes per block
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
     __shared__ unsigned short terms[MAXTERMS];
     __shared__ unsigned lw[256][4];
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
         const int t = idx / N, j = idx % N;
         const unsigned e = ent[t];
         const unsigned il = e & 0xffu, pos = posb[t * N + j];
-        if (il >= 8u || pos >= 128u || (e >> 16) >= 256u || ((e >> 8) & 0xffu) >= 4u) { bad = true; break; }
+        if (il >= 16u || pos >= 128u || (e >> 16) >= 256u || ((e >> 8) & 0xffu) >= 4u) { bad = true; break; }
         atomicAdd(&cnt[(int)(il * 128u + pos)], 1);
     }
     __syncthreads();
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
             unsigned w3[3] = {0u, 0u, 0u};
             for (int t = 0; t < n; ++t) w3[t / 2] |= (unsigned)b[first + t] << (16 * (t % 2));
             lw[Lidx][0] = w3[0]; lw[Lidx][1] = w3[1]; lw[Lidx][2] = w3[2];
-            lw[Lidx][3] = pos | (il << 7) | ((unsigned)n << 10) | (grp << 13) | (leader ? (1u << 15) : 0u);
+            lw[Lidx][3] = pos | (il << 7) | ((unsigned)n << 11) | (grp << 14) | (leader ? (1u << 16) : 0u);
         };
         if (Tn > 4 * TL) {
             const int L0 = 8 * (r8 + __popcll(m8 & below));

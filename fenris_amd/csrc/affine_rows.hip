@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x, npos = T.npos;
-    const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
+    const int G = gridDim.x, npos = T.npos_all;
+    const int p_begin = T.pos0 + (int)((long long)blockIdx.x * T.npos / G), p_end = T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
     if (p_begin >= p_end) return;
     for (int i = tid; i < 65 * GW; i += (320 + 64 * NSTORE)) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
     for (int i = tid; i < 2 * accp; i += (320 + 64 * NSTORE)) OUT[i] = 0.0;
@@ -413,10 +413,10 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
 // det J == 0 exactly is the reference's "Singular element Jacobian" (try_inverse fails only then): reported, record zero.
 template <int OP>
 __global__ void __launch_bounds__(256) k_affine_records(const double* verts, const int* conn, const unsigned char* elem_aff,
-                                                        const unsigned char* active, long long E, double* rec, DevStatus* status) {
+                                                        const unsigned char* active, long long e_first, long long E, double* rec, DevStatus* status) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long e = e_first + (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= E || !elem_aff[e]) return;
     const int4 c0 = reinterpret_cast<const int4*>(conn)[2 * e], c1 = reinterpret_cast<const int4*>(conn)[2 * e + 1];
     const int vi[4] = {c0.x, c0.y, c0.w, c1.x};
@@ -458,11 +458,11 @@ __global__ void __launch_bounds__(256) k_affine_records(const double* verts, con
 }
 
 hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts, const int* conn, const unsigned char* elem_aff,
-                                 const unsigned char* active, long long E, double* rec, DevStatus* status) {
-    if (E <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((E + 255) / 256));
-    if (op == FH_LAPLACE) hipLaunchKernelGGL(k_affine_records<FH_LAPLACE>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, E, rec, status);
-    else hipLaunchKernelGGL(k_affine_records<FH_LINEAR_ELASTIC>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, E, rec, status);
+                                 const unsigned char* active, long long e_first, long long e_end, double* rec, DevStatus* status) {
+    if (e_end <= e_first) return hipSuccess;
+    const dim3 grid((unsigned)((e_end - e_first + 255) / 256));
+    if (op == FH_LAPLACE) hipLaunchKernelGGL(k_affine_records<FH_LAPLACE>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, e_first, e_end, rec, status);
+    else hipLaunchKernelGGL(k_affine_records<FH_LINEAR_ELASTIC>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, e_first, e_end, rec, status);
     return hipGetLastError();
 }
 
@@ -599,7 +599,10 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
         const int id = ids[p];
         const uint2 mine = lanes_full[(size_t)p * 256 + t], ref = lanes_full[(size_t)first_pos[id] * 256 + t];
         if (mine.x != ref.x || mine.y != ref.y) *mismatch = 1;
-        if (t == 0) hdr[p].z = (hdr[p].z & 1) | (id << 8);
+        if (t == 0) {
+            if (!(hdr[p].z & 1)) mismatch[1] = 1;   // a block without an owner lane somewhere
+            hdr[p].z = (hdr[p].z & 1) | (id << 8);
+        }
     }
 }
 

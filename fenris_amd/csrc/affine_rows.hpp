@@ -16,7 +16,9 @@ struct AffineRowTables {
     const int* elem;      // [npos][us]   element id per slot (-1: empty)
     const double* rec;    // [E][GW]      element records (R or M) written by affine_records_launch before every launch
     const double* ghat;   // [64][GW]     reference blocks Ghat_ab (all 64 (a, b); LinearElastic GW = 10, Laplace GW = 6)
-    int us, npos, acc_max;  // slots per position, positions, largest S * S * nrow
+    int us, npos, acc_max;  // slots per position, positions of this launch, largest S * S * nrow
+    int pos0, npos_all;     // first position of this launch (launches may cover a part of the sweep), positions in the tables
+    int incomplete;         // some position has a (node, column) block without an owner lane (element masks): staged rows are cleared behind the store
 };
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
@@ -32,11 +34,11 @@ hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, i
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
                              int* status, unsigned long long* hash);
 
-// element records of the affine elements (elem_aff[e] != 0) from the current vertex coordinates: once per assembly, on the same
+// element records of the affine elements (elem_aff[e] != 0) among [e_first, e_end) from the current vertex coordinates: once per assembly, on the same
 // stream right before affine_rows_launch.  A singular element (det J == 0 exactly) of the active set (active == NULL: all) is
 // reported through `status`.
 hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts, const int* conn, const unsigned char* elem_aff,
-                                 const unsigned char* active, long long E, double* rec, DevStatus* status);
+                                 const unsigned char* active, long long e_first, long long e_end, double* rec, DevStatus* status);
 
 // Positions with identical lane records share one table: `lanes_full` [npos][256] as written by affine_rows_build, `ids` the
 // table of every position, `first_pos` [ntab] a position that holds each table.  Writes the compact tables, puts the id into
@@ -46,6 +48,13 @@ hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, cons
 
 // op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; nstore (1 or 2): store waves; ablate != 0 selects the instrumented instantiation (profiling only)
 hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
+                              int ablate);
+
+// ---- third form, k_affine_ring (affine_ring.hip): no workgroup barrier in the sweep, rows staged in a ring that mirrors the value stream
+// ring size in doubles (a power of two holding at least two positions; want_kb > 0: at least that many KiB)
+int affine_ring_doubles(int acc_max, int want_kb);
+size_t affine_ring_lds_bytes(int op, int us, int ring);
+hipError_t affine_ring_launch(int op, int ring, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
                               int ablate);
 
 }  // namespace fenris_hip

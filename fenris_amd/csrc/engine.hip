@@ -347,7 +347,7 @@ struct fh_ctx {
     DevBuf<uint2> a_lanes;          // lane records
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
-    int a_us = 0, a_npos = 0, a_ntab = 0;
+    int a_us = 0, a_npos = 0, a_ntab = 0, a_incomplete = 0;
     unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
@@ -416,7 +416,7 @@ struct fh_ctx {
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
-    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(npos_gen)       \
+    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(npos_gen)       \
     X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
@@ -1099,8 +1099,8 @@ int build_partition(fh_ctx* c) {
                 const int npos = (int)order[1].size();
                 c->a_us = us;
                 DevBuf<int> st;
-                HIP_TRY(c, st.alloc(1));
-                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                HIP_TRY(c, st.alloc(2));
+                HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
                 HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
                 DevBuf<uint2> lanes_full;
                 DevBuf<unsigned long long> hash_d;
@@ -1148,13 +1148,14 @@ int build_partition(fh_ctx* c) {
                         HIP_TRY(c, c->a_lanes.alloc((size_t)ntab * 256));
                         HIP_TRY(c, hipMemcpyAsync(ids_d.p, ids.data(), sizeof(int) * (size_t)npos, hipMemcpyHostToDevice, c->stream));
                         HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
-                        HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                        HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
                         HIP_TRY(c, affine_rows_compact(c->stream, lanes_full.p, ids_d.p, first_d.p, npos, ntab, c->a_lanes.p, c->a_hdr.p, st.p));
-                        int mismatch = 0;
-                        HIP_TRY(c, hipMemcpyAsync(&mismatch, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                        int mismatch[2] = {0, 0};   // [1]: some position has a block without an owner lane
+                        HIP_TRY(c, hipMemcpyAsync(mismatch, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         c->a_ntab = ntab;
-                        if (!mismatch) break;
+                        c->a_incomplete = mismatch[1];
+                        if (!mismatch[0]) break;
                         dedupe(true);  // a hash collision: every position keeps its own table
                     }
                     if (c->env("FENRIS_HIP_VERBOSE"))
@@ -1343,27 +1344,52 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
     }
 }
 
-// node blocks all of whose elements are affine: k_affine_rows (affine_rows.hip) over its own position tables
+// node blocks all of whose elements are affine: k_affine_ring / k_affine_rows (affine_ring.hip, affine_rows.hip) over their position tables
 int launch_affine(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly
     const int gw = (c->op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
-    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, c->has_mask ? c->active.p : nullptr,
-                                     (long long)c->E, c->a_recs.p, c->status.p + c->status_slot));
-    AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
-                      c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, c->a_npos, c->g_acc};
-    const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
-    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
-    // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
-    const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int grid = std::min(c->a_npos, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
-    if (c->env("FENRIS_HIP_VERBOSE"))
-        std::fprintf(stderr, "[fenris_hip] affine rows: npos=%d lds=%zu B wgs/cu=%d grid=%d\n", c->a_npos, lds, per_cu, grid);
-    HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
-                                  a.ablate | (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0)));
-    return FH_OK;
+    const unsigned char* act = c->has_mask ? c->active.p : nullptr;
+    DevStatus* status = c->status.p + c->status_slot;
+    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0);
+    // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
+    const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
+    auto rows = [&](int pos0, int count) -> int {
+        AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
+                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete};
+        if (use_ring) {
+            const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
+            const size_t lds = affine_ring_lds_bytes(c->op, c->a_us, ring);
+            if (lds <= LDS_LIMIT) {
+                const int cap = c->op == FH_LAPLACE ? 4 : 3;
+                const int per_cu = std::max(1, (int)std::min<size_t>(cap, LDS_LIMIT / std::max<size_t>(lds, 1)));
+                const int grid = std::min(count, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+                if (c->env("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] affine ring: positions %d + %d ring=%d doubles lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, ring, lds, per_cu, grid);
+                HIP_TRY(c, affine_ring_launch(c->op, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
+                                              a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 0) & 3) << 28)));
+                return FH_OK;
+            }
+        }
+        const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
+        if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
+        // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
+        const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+        const int grid = std::min(count, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+        if (c->env("FENRIS_HIP_VERBOSE"))
+            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
+        HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
+                                      a.ablate | nt));
+        return FH_OK;
+    };
+    // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly.  (Round 3: making
+    // the records of all but the first eighth of the sweep on a second stream beside the first part's launch was measured 0.3 ms
+    // SLOWER than the 0.41 ms it hides -- the two kernels' workgroups compete for the CUs; two launches of the sweep in one stream cost
+    // nothing measurable, and records made chunk by chunk right before their part of the sweep (to be read back from the memory-side
+    // cache) change nothing up to 4 chunks and lose from 8 on.  profiles/r03_affine_experiments.txt)
+    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, act, 0, (long long)c->E, c->a_recs.p, status));
+    return rows(0, c->a_npos);
 }
 
 // dense element matrices of the elements [first, first + count) into device memory (no status read-back)
@@ -1740,8 +1766,14 @@ void fh_destroy(fh_ctx* c) {
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
             // pipelined kernel: six phases of waves 0-3; affine kernel: "wave" = role (0 row wave, 1 loader, 2 store wave), phase 0 =
             // work between barriers, phase 2 = at the barrier
-            static const char* names[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};
+            static const char* names_pipe[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};
+            // k_affine_ring: role 0 = row wave 0, 1 = loader wave, 2 = store wave
+            static const char* names_ring[3][6] = {{"work", "wait: loader", "wait: ring space", "drain + publish", "-", "-"},
+                                                   {"other", "wait: rows / store", "park + issue (vmcnt)", "headers, tables, publish", "-", "-"},
+                                                   {"stream", "wait: rows", "drain + publish", "-", "-", "-"}};
+            const bool ringl = h[30] == 0x52494E47ull;
             for (int w = 0; w < 4; ++w) {
+                const char* const* names = (ringl && w < 3) ? names_ring[w] : names_pipe;
                 const unsigned long long* r = h + 7 * w;
                 if (!r[6]) continue;
                 unsigned long long tot = 0;

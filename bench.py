@@ -3,6 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W [--config ns|ns-perturbed|c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    (``python bench.py --gpus N`` with N > 1 and no launcher around it starts that launcher itself -- one rank per GPU as a child
+    process group, before this process touches a GPU -- relays rank 0's line and fails loudly when it cannot.)
 
 A step = one numeric assembly pass (CsrAssembler::assemble semantics: K written into a pre-built CSR pattern;
 benches/assembly.rs:126-145 times the same call) over a synthetic mesh that is already resident in HBM.
@@ -17,7 +19,8 @@ Configurations (BASELINE.json `configs`):
   c4            Hex27 NeoHookean 50 x 50 x 80, hexahedron_gauss(3); roofline = fp64 matrix-core flops.
   c5            Hex8 linear elasticity 256^3 cut into N z-slabs (strong scaling; 32 layers per rank at N = 8).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The default run (--config ns on one GPU) appends `secondary`: every other configuration
+(c2, c3, c4, c5 at N = 1, ns-perturbed) timed in the same process after the headline -- {ms, frac of its roofline, kernel}.
 """
 import argparse
 import json
@@ -179,6 +182,147 @@ def measure_traffic(argv_child, kernel_substrs, timeout_s=240):
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, out
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher (WORLD_SIZE unset): start `torch.distributed.run` with N ranks as a CHILD process (this
+    process has not touched a GPU), relay rank 0's JSON line, exit with the child's code.  Refuses when the box has fewer GPUs."""
+    import socket
+
+    import torch  # device_count() does not initialise the GPU
+
+    share = os.environ.get("FENRIS_BENCH_SHARE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not share:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to report an N = {args.gpus} figure "
+                         f"from fewer devices\n")
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if pr.returncode != 0 or not lines:
+        sys.stderr.write(pr.stderr[-6000:])
+        sys.stderr.write(f"\nbench.py: the {args.gpus}-rank launch failed (exit code {pr.returncode})\n")
+        raise SystemExit(pr.returncode or 1)
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} GPUs, the ranks report {line.get('n_gpus')}\n")
+        raise SystemExit(1)
+    print(lines[-1])
+    raise SystemExit(0)
+
+
+def config_problem(cfg, cells, fa, quadrature, np):
+    """mesh builder, operator, quadrature table and bookkeeping of one configuration (one GPU)"""
+    lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
+    c = {"n_el": 8, "d": 3, "s": 3, "uses_u": False, "cpu_kind": "hex8_elasticity", "params": lame,
+         "metric": "elements/sec assembling global stiffness K, 3D Hex8 elasticity"}
+    if cfg in ("ns", "ns-perturbed", "c5"):
+        cells = cells or (256 if cfg == "c5" else 216)
+        rule = quadrature.tensor.hexahedron_gauss(2)
+        c["op"] = fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+        c["desc"] = f"Hex8 linear elasticity stiffness assembly, structured {cells}^3 unit-cell box"
+    elif cfg == "c2":
+        cells = cells or 128
+        rule = quadrature.tensor.hexahedron_gauss(2)
+        c.update(op=fa.LaplaceOperator(), params=None, s=1, cpu_kind="hex8_poisson",
+                 metric="elements/sec assembling global stiffness K, 3D Hex8 Poisson",
+                 desc=f"Hex8 Poisson stiffness assembly, structured {cells}^3 unit-cell box")
+    elif cfg == "c3":
+        cells = cells or 75
+        rule = quadrature.total_order.tetrahedron(1)
+        c.update(op=fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), n_el=4, cpu_kind="tet4_elasticity",
+                 metric="elements/sec assembling global stiffness K, 3D Tet4 elasticity",
+                 desc=f"Tet4 linear elasticity stiffness assembly, BCC unit box res {cells}, vertices and elements permuted (MT19937 seed 12345)")
+    else:  # c4
+        cells = 0
+        rule = quadrature.tensor.hexahedron_gauss(3)
+        c.update(op=fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()), n_el=27, uses_u=True, cpu_kind="hex27_neohookean",
+                 metric="elements/sec assembling global stiffness K, 3D Hex27 NeoHookean",
+                 desc="Hex27 NeoHookean stiffness assembly, 50x50x80 box, hexahedron_gauss(3), u = 0.05 A X")
+    c["cells"], c["weights"], c["points"] = cells, rule[0], rule[1]
+    qtable = fa.UniformQuadratureTable.from_points_and_weights(rule[1], rule[0])
+    c["qtable"] = qtable.with_uniform_data(c["params"]) if c["params"] is not None else qtable
+
+    def mesh():
+        if cfg == "c3":
+            m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(cells)
+            rng = np.random.Generator(np.random.MT19937(12345))
+            vp = rng.permutation(m.num_nodes())
+            inv = np.empty_like(vp)
+            inv[vp] = np.arange(len(vp))
+            return fa.Mesh(m.vertices[vp], inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64), fa.TET4)
+        if cfg == "c4":
+            return fa.hex27_mesh_from_hex8(fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 5, 5, 8, 10))
+        m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
+        if cfg == "ns-perturbed":
+            rng = np.random.Generator(np.random.MT19937(2024))
+            m = fa.Mesh(m.vertices + (0.1 / cells) * rng.uniform(-1.0, 1.0, m.vertices.shape), m.connectivity, fa.HEX8)
+        return m
+
+    def u_for(mesh_):
+        if not c["uses_u"]:
+            return None
+        A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
+        return (0.05 * mesh_.vertices @ A.T).reshape(-1)
+
+    def configure(engine, mesh_):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh_).with_operator(c["op"])
+                .with_quadrature_table(c["qtable"]).with_u(u_for(mesh_)).build())
+
+    c["mesh"], c["configure"] = mesh, configure
+    return c
+
+
+def roofline_of(cfg, c, E, N, nnz, kernel_ms):
+    """(bound, achieved, peak, unit, frac) of one assembly of kernel_ms milliseconds"""
+    if cfg == "c4":
+        nq, n_el = len(c["weights"]), c["n_el"]
+        flops = E * (2 * (3 * n_el) ** 2 * nq * 2 + 6 * n_el * n_el * nq)
+        tf = flops / (kernel_ms * 1e-3) / 1e12
+        return "mfma", tf, PEAK_FP64_TFLOPS, "TFLOP/s", tf / PEAK_FP64_TFLOPS
+    ab = algorithmic_bytes(E, N, c["s"], c["n_el"], c["d"], nnz, c["uses_u"])
+    gbs = ab / (kernel_ms * 1e-3) / 1e9
+    return "hbm", gbs, PEAK_HBM_GBS, "GB/s", gbs / PEAK_HBM_GBS
+
+
+def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
+    """one secondary configuration on this GPU: {ms, frac, kernel, ...}; everything it allocates is released before it returns"""
+    c = config_problem(cfg, 0, fa, quadrature, np)
+    mesh = c["mesh"]()
+    eng = fa.Engine(0, stream=stream)
+    try:
+        c["configure"](eng, mesh)
+        nnz = eng.build_pattern()
+        values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+        for _ in range(warmup):
+            eng.assemble_matrix_async(values, flags)
+        eng.poll_status()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record()
+            eng.assemble_matrix_async(values, flags)
+            b.record()
+        torch.cuda.synchronize()
+        eng.poll_status()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ms) / len(ms)
+        E, N = mesh.num_elements(), mesh.num_nodes()
+        bound, ach, peak, unit, frac = roofline_of(cfg, c, E, N, nnz, avg)
+        return {"workload": c["desc"], "elements": E, "nnz": nnz, "ms": avg, "ms_min": ms[0], "elements_per_s": E / (avg * 1e-3),
+                "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "kernel": eng.last_kernel_name(), "steps": steps}
+    finally:
+        eng.close()
+        values = None
+        torch.cuda.empty_cache()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,84 +341,31 @@ def main():
                          "calls behind the C ABI (fh_group_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configurations timed after the headline (N = 1, --config ns)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cfg = args.config
-    if world > 1 and cfg not in ("ns", "c5"):
+    if args.operator == "poisson" and cfg == "ns":  # old spelling of the Poisson run
+        cfg = "c2"
+        args.cells = args.cells or 216
+    if args.gpus > 1 and cfg not in ("ns", "c5"):
         raise SystemExit(f"--config {cfg} is a single-GPU configuration")
-
-    # ---- HBM traffic of the dominant kernel: two PMC passes of this command as child processes, before this process
-    # touches the GPU (N = 1, rank 0 only)
-    traffic, traffic_detail = None, None
-    child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--scatter", args.scatter]
-    if args.cells:
-        child += ["--cells", str(args.cells)]
-    want_traffic = world == 1 and not args.no_traffic and os.environ.get("FENRIS_BENCH_CHILD") != "1"
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    import fenris_amd as fa
-    from fenris_amd import quadrature
-
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and not launched:
+        self_launch(args)  # does not return
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if torch.cuda.device_count() == 0:
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # FENRIS_BENCH_SHARE_DEVICE=1 (validation only): all ranks on cuda:0 over gloo -- lets the N > 1 code path be
-    # exercised on a single-GPU box; never used for reported numbers
-    share = os.environ.get("FENRIS_BENCH_SHARE_DEVICE") == "1"
-    if share:
-        local_rank = 0
 
-    lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
-    n_el, d, s, uses_u = 8, 3, 3, False
-    u = None
-    cpu_kind = "hex8_elasticity"
-    metric = "elements/sec assembling global stiffness K, 3D Hex8 elasticity"
-    if cfg in ("ns", "ns-perturbed", "c5"):
-        cells = args.cells or (256 if cfg == "c5" else 216)
-        rule = quadrature.tensor.hexahedron_gauss(2)
-        op, params = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), lame
-        desc = f"Hex8 linear elasticity stiffness assembly, structured {cells}^3 unit-cell box"
-    elif cfg == "c2":
-        cells = args.cells or 128
-        rule = quadrature.tensor.hexahedron_gauss(2)
-        op, params, s = fa.LaplaceOperator(), None, 1
-        cpu_kind = "hex8_poisson"
-        metric = "elements/sec assembling global stiffness K, 3D Hex8 Poisson"
-        desc = f"Hex8 Poisson stiffness assembly, structured {cells}^3 unit-cell box"
-    elif cfg == "c3":
-        cells = args.cells or 75
-        rule = quadrature.total_order.tetrahedron(1)
-        op, params, n_el = fa.MaterialEllipticOperator(fa.LinearElasticMaterial()), lame, 4
-        cpu_kind = "tet4_elasticity"
-        metric = "elements/sec assembling global stiffness K, 3D Tet4 elasticity"
-        desc = f"Tet4 linear elasticity stiffness assembly, BCC unit box res {cells}, vertices and elements permuted (MT19937 seed 12345)"
-    else:  # c4
-        cells = 0
-        rule = quadrature.tensor.hexahedron_gauss(3)
-        op, params, n_el, uses_u = fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()), lame, 27, True
-        cpu_kind = "hex27_neohookean"
-        metric = "elements/sec assembling global stiffness K, 3D Hex27 NeoHookean"
-        desc = "Hex27 NeoHookean stiffness assembly, 50x50x80 box, hexahedron_gauss(3), u = 0.05 A X"
-    if args.operator == "poisson" and cfg == "ns":  # old spelling of the Poisson run at a chosen size
-        op, params, s = fa.LaplaceOperator(), None, 1
-        cpu_kind = "hex8_poisson"
-        metric = "elements/sec assembling global stiffness K, 3D Hex8 Poisson"
-        desc = f"Hex8 Poisson stiffness assembly, structured {cells}^3 unit-cell box"
-
-    weights, points = rule
-    qtable = fa.UniformQuadratureTable.from_points_and_weights(points, weights)
-    if params is not None:
-        qtable = qtable.with_uniform_data(params)
-
-    if want_traffic and rank == 0:
-        # kernels whose HBM traffic is summed (everything one assembly launches)
+    # ---- HBM traffic of the dominant kernel: two PMC passes of this command as child processes, BEFORE this process makes
+    # any torch.cuda call (N = 1, rank 0 only)
+    traffic, traffic_detail = None, None
+    if world == 1 and not args.no_traffic and os.environ.get("FENRIS_BENCH_CHILD") != "1":
+        child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--scatter", args.scatter]
+        if args.cells:
+            child += ["--cells", str(args.cells)]
         aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
         knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_gather_pipelined",),
                   "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
@@ -289,45 +380,61 @@ def main():
             traffic_detail["kernels"] = list(knames)
             traffic_detail["seconds"] = time.perf_counter() - t0
 
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fenris_amd as fa
+    from fenris_amd import quadrature
+
+    if torch.cuda.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # FENRIS_BENCH_SHARE_DEVICE=1 (validation only): all ranks on cuda:0 over gloo -- lets the N > 1 code path be
+    # exercised on a single-GPU box; never used for reported numbers
+    share = os.environ.get("FENRIS_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+
+    c = config_problem(cfg, args.cells, fa, quadrature, np)
+    cells, desc, metric, s, n_el, d, uses_u = c["cells"], c["desc"], c["metric"], c["s"], c["n_el"], c["d"], c["uses_u"]
+    configure = c["configure"]
+
     torch.cuda.set_device(local_rank)
+    rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.ones(1, device="cuda")
+            dist.all_reduce(t)  # the communicator exists from here on; every rank answered
+            rccl = {"backend": dist.get_backend(), "rccl_ranks": int(t.item()), "world_size": dist.get_world_size()}
     stream = torch.cuda.current_stream().cuda_stream
 
-    def configure(engine, mesh_):
-        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh_).with_operator(op)
-                .with_quadrature_table(qtable).with_u(u_for(mesh_)).build())
-
-    def u_for(mesh_):
-        if not uses_u:
-            return None
-        A = np.array([[1, .2, 0], [0, 1, .3], [.1, 0, 1]])
-        return (0.05 * mesh_.vertices @ A.T).reshape(-1)
+    # code objects of the library loaded and the device warm before anything is timed: one tiny assembly
+    t0 = time.perf_counter()
+    wc = config_problem("ns", 4, fa, quadrature, np)
+    weng = fa.Engine(local_rank, stream=stream)
+    wc["configure"](weng, wc["mesh"]())
+    wv = torch.zeros(weng.build_pattern(), dtype=torch.float64, device="cuda")
+    weng.assemble_matrix_async(wv, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    weng.poll_status()
+    torch.cuda.synchronize()
+    weng.close()
+    del wv, weng
+    t_warm = time.perf_counter() - t0
 
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]
     slab_asm = None
     scaling = "weak"
+    layers = None
     if world == 1:
-        if cfg == "c3":
-            m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(cells)
-            rng = np.random.Generator(np.random.MT19937(12345))
-            vp = rng.permutation(m.num_nodes())
-            inv = np.empty_like(vp)
-            inv[vp] = np.arange(len(vp))
-            mesh = fa.Mesh(m.vertices[vp], inv[m.connectivity.astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64),
-                           fa.TET4)
-        elif cfg == "c4":
-            mesh = fa.hex27_mesh_from_hex8(fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 5, 5, 8, 10))
-        else:
-            mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, cells)
-            if cfg == "ns-perturbed":
-                rng = np.random.Generator(np.random.MT19937(2024))
-                mesh = fa.Mesh(mesh.vertices + (0.1 / cells) * rng.uniform(-1.0, 1.0, mesh.vertices.shape), mesh.connectivity, fa.HEX8)
-                desc += ", every vertex moved by up to +-0.1 h per coordinate (MT19937 seed 2024): no affine element"
+        mesh = c["mesh"]()
+        if cfg == "ns-perturbed":
+            desc += ", every vertex moved by up to +-0.1 h per coordinate (MT19937 seed 2024): no affine element"
         eng = fa.Engine(local_rank, stream=stream)
         configure(eng, mesh)
         torch.cuda.synchronize()
@@ -335,15 +442,16 @@ def main():
         nnz = eng.build_pattern()  # assemble_pattern on the device (secondary metric)
         E = mesh.num_elements()
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
-        total_cells_desc = ""
     else:
         from fenris_amd import distributed as fd
 
         if cfg == "c5":
             slab = fd.make_slab(1.0, 1, 1, 1, cells, rank, world, args.partition)   # 256^3 cut into `world` z-slabs
             scaling = "strong"
+            layers = [fd.slab_layers(cells, r, world) for r in range(world)]
         else:
             slab = fd.make_slab(1.0, 1, 1, world, cells, rank, world, args.partition)  # 216 x 216 x (216 world)
+            layers = [fd.slab_layers(cells * world, r, world) for r in range(world)]
         mesh = slab.mesh
         t0 = time.perf_counter()  # N > 1: engines, masks and patterns of this rank
         # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
@@ -351,6 +459,8 @@ def main():
                                    stream=stream, exchange=("torch" if share else args.exchange))
         eng, values, nnz = slab_asm.main, slab_asm.values, slab_asm.values.numel()
         E = slab.num_own_elements()  # numerics over own (+ halo in "halo" mode) elements, pattern over own + halo
+        if rccl is not None and hasattr(slab_asm.exchange, "size"):
+            rccl["fh_group_ranks"] = slab_asm.exchange.size()   # ncclCommCount of the library's own communicator
     t_pattern = time.perf_counter() - t0
     N = mesh.num_nodes()
     if args.scatter == "colored":
@@ -411,13 +521,18 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{cfg}: {desc} ({int(total_elements)} elements), "
-                                   + ("YoungPoisson(1e6, 0.2), " if params is not None else "")
+                                   + ("YoungPoisson(1e6, 0.2), " if c["params"] is not None else "")
                                    + ("u = 0, " if not uses_u else "") + "CSR pattern pre-built, values overwritten",
                        "name": cfg, "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
                        "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
-                       "pattern_build_s": t_pattern},
+                       "pattern_build_s": t_pattern, "module_warmup_s": t_warm},
         }
+        if world > 1:
+            out["config"]["element_layers_per_rank"] = [l1 - l0 for l0, l1 in layers]
+            out["config"]["exchange"] = "torch.distributed point-to-point" if (share or args.exchange == "torch") else "fh_group_* (RCCL behind the C ABI)"
+            out["rccl"] = rccl if rccl is not None else {"backend": "gloo (FENRIS_BENCH_SHARE_DEVICE validation mode)", "rccl_ranks": 0}
+            out["rccl_ranks"] = out["rccl"]["rccl_ranks"]
         hbm = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
                "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
@@ -430,9 +545,9 @@ def main():
         if cfg == "c4":
             # compute-bound configuration: the two weighted Gram products of the dense element matrix,
             # 2 (3n)^2 nq 2 flop, plus the trace term 6 n^2 nq flop, on the fp64 matrix cores; the HBM figures go along
-            flops = E * (2 * (3 * n_el) ** 2 * len(weights) * 2 + 6 * n_el * n_el * len(weights))
-            tf = flops / (kernel_avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
+            _, tf, _, _, fr = roofline_of(cfg, c, E, N, nnz, kernel_avg_ms)
+            flops = tf * 1e12 * kernel_avg_ms * 1e-3
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": fr,
                                "traffic": traffic, "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
                                "kernel_min_ms": kernel_ms[0], "algorithmic_flops_per_launch": flops, "flops_per_element": flops / E,
                                "note": "kernel_avg_ms covers both passes of the two-pass assembly (dense element matrices on the "
@@ -455,12 +570,28 @@ def main():
             del scratch
         except RuntimeError:
             pass
+        # ---- the other configurations, same process, after the headline (driver-verifiable figures for the rows of DESIGN 3.4)
+        if world == 1 and cfg == "ns" and not args.cells and not args.no_secondary and os.environ.get("FENRIS_BENCH_CHILD") != "1":
+            eng.close()
+            del values
+            torch.cuda.empty_cache()
+            sec = {}
+            for name in ("c2", "c3", "c4", "c5", "ns-perturbed"):
+                t0 = time.perf_counter()
+                try:
+                    sec[name] = time_secondary(name, fa, quadrature, np, torch, stream)
+                    sec[name]["seconds_total"] = time.perf_counter() - t0
+                except Exception as exc:  # a secondary line must never take the headline down
+                    sec[name] = {"error": repr(exc)}
+            out["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cpu_kind)
+            out["cpu_baseline"] = cpu_baseline(c["cpu_kind"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
+        if slab_asm is not None:
+            slab_asm.close()
         dist.destroy_process_group()
 
 

@@ -51,6 +51,10 @@ class Engine:
         except Exception:
             pass
 
+    def last_error(self):
+        """fh_last_error: the message of the last failed call on this context"""
+        return (self._lib.fh_last_error(self._h) or b"").decode()
+
     def _check(self, rc, failed=None):
         if rc == _ffi.FH_OK:
             return

@@ -231,10 +231,15 @@ def assemble_vector_into(out_t, assembler):
     for base, m, _, sv, _ in _bodies(assembler):
         eng = base.engine
         part = torch.zeros(base.solution_dim() * base.num_nodes(), dtype=torch.float64, device=dev)
-        eng.assemble_vector(part)
+        # a body may be an ElementSourceAssembler (local/source.rs:159-278: the multi-body right-hand side): its context has no
+        # operator, the vector comes from the source and the solution dimension goes along explicitly
+        if hasattr(base, "assemble_vector_into_engine"):
+            base.assemble_vector_into_engine(part)
+        else:
+            eng.assemble_vector(part)
         m_t = None if m is None else torch.from_numpy(m.view(np.int64)).to(dev)
-        eng._check(lib.fh_add_mapped_vector_dev(eng._h, C.c_void_p(part.data_ptr()), C.c_void_p(m_t.data_ptr()) if m_t is not None else None,
-                                                float(sv), assembler.num_nodes(), C.c_void_p(out_t.data_ptr())))
+        eng._check(lib.fh_add_mapped_vector_sdim_dev(eng._h, C.c_void_p(part.data_ptr()), C.c_void_p(m_t.data_ptr()) if m_t is not None else None,
+                                                     float(sv), int(base.solution_dim()), assembler.num_nodes(), C.c_void_p(out_t.data_ptr())))
         torch.cuda.synchronize()
 
 

@@ -98,12 +98,18 @@ int fh_add_mapped_matrix_dev(fh_ctx* c, const double* src_values_dev, const uint
     return check_missing(c, flag, stream, "fh_add_mapped_matrix");
 }
 
-int fh_add_mapped_vector_dev(fh_ctx* c, const double* src_dev, const uint64_t* node_map_dev, double scale, uint64_t dst_num_nodes,
-                             double* dst_dev) {
+int fh_add_mapped_vector_sdim_dev(fh_ctx* c, const double* src_dev, const uint64_t* node_map_dev, double scale, int solution_dim,
+                                  uint64_t dst_num_nodes, double* dst_dev) {
     if (!c) return FH_BAD_ARGUMENT;
     uint64_t N = 0;
     int S = 0;
-    if (!fh_internal_sizes(c, &N, &S)) return fh_internal_fail(c, FH_INVALID_STATE, "fh_add_mapped_vector: set mesh and operator first");
+    if (solution_dim > 0) {   // a source vector: the context holds a mesh but no operator, the source gives the dimension
+        if (!fh_internal_num_nodes(c, &N)) return fh_internal_fail(c, FH_INVALID_STATE, "fh_add_mapped_vector: set the mesh first");
+        S = solution_dim;
+    } else if (!fh_internal_sizes(c, &N, &S)) {
+        return fh_internal_fail(c, FH_INVALID_STATE, "fh_add_mapped_vector: set mesh and operator first");
+    }
+    if (S < 1 || S > 3) return fh_internal_fail(c, FH_BAD_ARGUMENT, "fh_add_mapped_vector: solution dimension must be 1, 2 or 3");
     if (!src_dev || !dst_dev) return fh_internal_fail(c, FH_BAD_ARGUMENT, "fh_add_mapped_vector: null argument");
     if (N == 0) return FH_OK;
     DevGuardExt dev_guard_(fh_internal_device(c));
@@ -119,6 +125,11 @@ int fh_add_mapped_vector_dev(fh_ctx* c, const double* src_dev, const uint64_t* n
 #undef LAUNCH
     if (hipGetLastError() != hipSuccess) { (void)hipFree(flag); return fh_internal_fail(c, FH_HIP_ERROR, "fh_add_mapped_vector: launch failed"); }
     return check_missing(c, flag, stream, "fh_add_mapped_vector");
+}
+
+int fh_add_mapped_vector_dev(fh_ctx* c, const double* src_dev, const uint64_t* node_map_dev, double scale, uint64_t dst_num_nodes,
+                             double* dst_dev) {
+    return fh_add_mapped_vector_sdim_dev(c, src_dev, node_map_dev, scale, 0, dst_num_nodes, dst_dev);
 }
 
 }  // extern "C"

@@ -1811,6 +1811,11 @@ bool fh_internal_pattern(const fh_ctx* c, const unsigned** noff, const unsigned*
     *noff = c->noff.p; *ncols = c->ncols.p; *num_nodes = c->N; *solution_dim = c->S();
     return true;
 }
+bool fh_internal_num_nodes(const fh_ctx* c, uint64_t* num_nodes) {
+    if (!c->has_mesh) return false;
+    *num_nodes = c->N;
+    return true;
+}
 bool fh_internal_sizes(const fh_ctx* c, uint64_t* num_nodes, int* solution_dim) {
     if (!c->has_mesh || (c->op < 0 && !c->ragged)) return false;
     *num_nodes = c->N; *solution_dim = c->S();
@@ -1846,7 +1851,8 @@ static int classify_affine(fh_ctx* c) {
     c->has_aff = false;
     c->num_aff = 0;
     if (c->elem_kind != FH_HEX8 || c->E == 0 || !(c->affine_tol > 0.0)) {
-        if (had) c->has_partition = false; ++c->struct_gen;
+        if (had) c->has_partition = false;
+        ++c->struct_gen;   // always: the rows stash follows the classification through the generation counter
         return FH_OK;
     }
     DevBuf<unsigned char> flags;

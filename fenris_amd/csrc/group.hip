@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -21,6 +22,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -29,17 +31,27 @@ struct Rccl {
     std::string error;
     bool load() {
         if (handle) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // FENRIS_HIP_RCCL_LIB names the library (tests point it at a file that does not exist: the group calls must then report
+        // FH_UNSUPPORTED, not crash)
+        const char* forced = std::getenv("FENRIS_HIP_RCCL_LIB");
+        const char* dflt[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string why = "not found";
+        for (const char* name : dflt) {
+            if (forced && *forced) name = forced;
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
+            const char* m = dlerror();   // once: the call clears the message
+            if (m) why = m;
+            if (forced && *forced) break;
         }
-        if (!handle) { error = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return false; }
+        if (!handle) { error = "dlopen(librccl): " + why; return false; }
 #define SYM(field, sym)                                                    \
     field = reinterpret_cast<decltype(field)>(dlsym(handle, #sym));        \
-    if (!field) { error = "librccl: missing symbol " #sym; handle = nullptr; return false; }
+    if (!field) { error = "librccl: missing symbol " #sym; dlclose(handle); handle = nullptr; return false; }
         SYM(GetUniqueId, ncclGetUniqueId)
         SYM(CommInitRank, ncclCommInitRank)
         SYM(CommDestroy, ncclCommDestroy)
+        SYM(CommCount, ncclCommCount)
         SYM(Send, ncclSend)
         SYM(Recv, ncclRecv)
         SYM(GroupStart, ncclGroupStart)
@@ -102,6 +114,7 @@ int fh_group_create(fh_ctx* c, const uint8_t id[FH_GROUP_ID_BYTES], int rank, in
     g->rank = rank;
     g->world = world;
     g->device = fh_internal_device(c);
+    DevGuardExt dev_guard_(g->device);
     if (hipSetDevice(g->device) != hipSuccess || hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->done, hipEventDisableTiming) != hipSuccess) {
@@ -121,9 +134,15 @@ int fh_group_create(fh_ctx* c, const uint8_t id[FH_GROUP_ID_BYTES], int rank, in
     return FH_OK;
 }
 
+int fh_group_size(const fh_group* g, int* ranks) {
+    if (!g || !ranks) return FH_BAD_ARGUMENT;
+    if (!g->comm || !g_rccl.CommCount) return FH_INVALID_STATE;
+    return g_rccl.CommCount(g->comm, ranks) == ncclSuccess ? FH_OK : FH_HIP_ERROR;
+}
+
 void fh_group_destroy(fh_group* g) {
     if (!g) return;
-    (void)hipSetDevice(g->device);
+    DevGuardExt dev_guard_(g->device);
     if (g->side) (void)hipStreamSynchronize(g->side);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
     if (g->recv_buf) (void)hipFree(g->recv_buf);
@@ -144,7 +163,7 @@ int fh_group_set_exchange(fh_group* g, int send_peer, uint64_t send_first, uint6
     g->send_first = send_first; g->send_count = send_count;
     g->recv_first = recv_first; g->recv_count = recv_count;
     if (g->recv_peer >= 0 && g->recv_cap < recv_count) {
-        (void)hipSetDevice(g->device);
+        DevGuardExt dev_guard_(g->device);
         if (g->recv_buf) (void)hipFree(g->recv_buf);
         g->recv_buf = nullptr;
         g->recv_cap = 0;
@@ -157,19 +176,24 @@ int fh_group_set_exchange(fh_group* g, int send_peer, uint64_t send_first, uint6
 int fh_group_exchange_start(fh_group* g, double* values_dev) {
     if (!g || !values_dev) return FH_BAD_ARGUMENT;
     if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_start: already started");
-    g->in_flight = true;
-    if (g->send_peer < 0 && g->recv_peer < 0) return FH_OK;
-    G_HIP(g, hipSetDevice(g->device));
+    if (g->send_peer < 0 && g->recv_peer < 0) { g->in_flight = true; return FH_OK; }
+    DevGuardExt dev_guard_(g->device);
     hipStream_t main = fh_internal_stream(g->ctx);
     // the transfers are ordered after everything enqueued so far on the context's stream (the launch that produced the rows
     // to send) and run beside whatever is enqueued next
     G_HIP(g, hipEventRecord(g->ready, main));
     G_HIP(g, hipStreamWaitEvent(g->side, g->ready, 0));
+    // a failure inside the RCCL group must still close it, and must not leave the exchange marked as started
     G_NCCL(g, g_rccl.GroupStart());
-    if (g->send_peer >= 0) G_NCCL(g, g_rccl.Send(values_dev + g->send_first, g->send_count, ncclDouble, g->send_peer, g->comm, g->side));
-    if (g->recv_peer >= 0) G_NCCL(g, g_rccl.Recv(g->recv_buf, g->recv_count, ncclDouble, g->recv_peer, g->comm, g->side));
-    G_NCCL(g, g_rccl.GroupEnd());
+    ncclResult_t r = ncclSuccess;
+    const char* what = "";
+    if (g->send_peer >= 0) { r = g_rccl.Send(values_dev + g->send_first, g->send_count, ncclDouble, g->send_peer, g->comm, g->side); what = "ncclSend: "; }
+    if (r == ncclSuccess && g->recv_peer >= 0) { r = g_rccl.Recv(g->recv_buf, g->recv_count, ncclDouble, g->recv_peer, g->comm, g->side); what = "ncclRecv: "; }
+    const ncclResult_t r_end = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string(what) + g_rccl.GetErrorString(r));
+    if (r_end != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end));
     G_HIP(g, hipEventRecord(g->done, g->side));
+    g->in_flight = true;
     return FH_OK;
 }
 
@@ -178,7 +202,7 @@ int fh_group_exchange_finish(fh_group* g, double* values_dev) {
     if (!g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_finish: nothing started");
     g->in_flight = false;
     if (g->send_peer < 0 && g->recv_peer < 0) return FH_OK;
-    G_HIP(g, hipSetDevice(g->device));
+    DevGuardExt dev_guard_(g->device);
     hipStream_t main = fh_internal_stream(g->ctx);
     G_HIP(g, hipStreamWaitEvent(main, g->done, 0));   // also orders later writes to the sent rows behind the send
     if (g->recv_peer >= 0) {

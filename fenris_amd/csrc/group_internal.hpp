@@ -13,6 +13,7 @@ hipStream_t fh_internal_stream(const fh_ctx* c);
 // node-level pattern of the context (device arrays); false when no pattern has been built
 bool fh_internal_pattern(const fh_ctx* c, const unsigned** noff, const unsigned** ncols, uint64_t* num_nodes, int* solution_dim);
 bool fh_internal_sizes(const fh_ctx* c, uint64_t* num_nodes, int* solution_dim);
+bool fh_internal_num_nodes(const fh_ctx* c, uint64_t* num_nodes);   // false without a mesh
 
 // the context's device for the duration of a call; the calling thread's current device is restored on return
 struct DevGuardExt {

@@ -231,6 +231,14 @@ class AbiInterfaceExchange:
         self.start()
         self.finish()
 
+    def size(self):
+        """ranks of the communicator as RCCL reports it (ncclCommCount)"""
+        import ctypes as C
+
+        n = C.c_int(0)
+        self.engine._check(self._lib.fh_group_size(self._g, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if self._g:
             self._lib.fh_group_destroy(self._g)
@@ -288,6 +296,9 @@ class SlabAssembly:
         self.main.poll_status()
 
     def close(self):
+        # a group refers to its context (stream, error slot): it goes first
+        if hasattr(self.exchange, "close"):
+            self.exchange.close()
         self.main.close()
 
 

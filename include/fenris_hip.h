@@ -345,6 +345,10 @@ int fh_add_mapped_matrix_dev(fh_ctx* ctx, const double* src_values_dev, const ui
                              double* dst_values_dev);
 int fh_add_mapped_vector_dev(fh_ctx* ctx, const double* src_dev, const uint64_t* node_map_dev, double scale,
                              uint64_t dst_num_nodes, double* dst_dev);
+/* The same with the solution dimension given by the caller (> 0): for the vector of an ElementSourceAssembler body, whose
+ * context holds a mesh and a quadrature table but no operator (local/source.rs:159-278; the dimension is the source's). */
+int fh_add_mapped_vector_sdim_dev(fh_ctx* ctx, const double* src_dev, const uint64_t* node_map_dev, double scale, int solution_dim,
+                                  uint64_t dst_num_nodes, double* dst_dev);
 
 /* ---- multi-GPU: one process or thread per GPU, each with its own fh_ctx holding one partition (its own
  * elements plus the halo layers whose nodes it shares, so that interface rows have the global pattern and the same layout
@@ -359,7 +363,10 @@ typedef struct fh_group fh_group;
 int fh_group_unique_id(uint8_t id[FH_GROUP_ID_BYTES]);
 /* collective over all `world` ranks; `ctx` gives the device and the stream the exchange is ordered against */
 int fh_group_create(fh_ctx* ctx, const uint8_t id[FH_GROUP_ID_BYTES], int rank, int world, fh_group** out);
+/* A group refers to its context: destroy every group of a context BEFORE fh_destroy(ctx). */
 void fh_group_destroy(fh_group*);
+/* number of ranks of the communicator as RCCL reports it (ncclCommCount) */
+int fh_group_size(const fh_group*, int* ranks);
 /* What this rank moves in one exchange: values[send_first .. send_first + send_count) go to rank send_peer (-1: nothing);
  * recv_count values arrive from rank recv_peer (-1: nothing) and are ADDED to values[recv_first ..).  For z-slabs:
  * send = rows of the bottom ghost plane to rank - 1, receive = rows of the owned top plane from rank + 1. */

@@ -155,3 +155,31 @@ def test_mapped_add_reports_missing_entries():
     rc = _ffi.lib().fh_add_mapped_matrix_dev(eng._h, C.c_void_p(part.data_ptr()), None, 1.0, a2.num_nodes(), C.c_void_p(ro_t.data_ptr()),
                                              C.c_void_p(ci_t.data_ptr()), C.c_void_p(dst.data_ptr()))
     assert rc == _ffi.FH_BAD_ARGUMENT
+
+
+def test_aggregate_and_mapped_source_assemblers():
+    """The multi-body right-hand side (local.rs:152-340 over ElementSourceAssembler bodies, local/source.rs:159-278): two bodies
+    with their own meshes and gravity sources mapped into one node space, one of them scaled -- the bodies' contexts hold no
+    operator, the solution dimension goes along explicitly (fh_add_mapped_vector_sdim_dev)."""
+    def body(cells, g, rho0):
+        m = fa.procedural.create_unit_square_uniform_quad_mesh_2d(cells)
+        w, p = quadrature.tensor.quadrilateral_gauss(2)
+        rho = np.linspace(rho0, rho0 + 1.0, len(w))
+        qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_data([fa.Density(r) for r in rho])
+        asm = (fa.ElementSourceAssemblerBuilder.new(fa.Engine(0)).with_finite_element_space(m)
+               .with_source(fa.GravitySource.from_acceleration(np.asarray(g))).with_quadrature_table(qt).build())
+        return m, asm
+
+    m1, s1 = body(3, [0.0, -9.81], 1.0)
+    m2, s2 = body(4, [1.5, -2.0], 3.0)
+    f1, f2 = fa.VectorAssembler().assemble_vector(s1), fa.VectorAssembler().assemble_vector(s2)
+    n1, n = m1.num_nodes(), m1.num_nodes() + m2.num_nodes()
+    agg = fa.AggregateElementAssembler.from_assemblers([s1.map_element_nodes(n, lambda i: i),
+                                                        s2.map_element_nodes(n, lambda i: i + n1).transform_element_vector(-0.5)])
+    assert agg.solution_dim() == 2 and agg.num_nodes() == n
+    f = fa.VectorAssembler().assemble_vector(agg)
+    ref = np.concatenate([f1, -0.5 * f2])
+    assert np.abs(f - ref).max() <= 1e-14 * np.abs(ref).max()
+    # the same body twice: twice the vector
+    twice = fa.AggregateElementAssembler.from_assemblers([s1, s1])
+    assert np.abs(fa.VectorAssembler().assemble_vector(twice) - 2.0 * f1).max() <= 1e-14 * np.abs(f1).max()

@@ -16,6 +16,7 @@ from fenris_amd import distributed as fd
 from fenris_amd import quadrature
 
 LAME = (416666.6666666667, 277777.7777777778)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _global_reference(oracle, units_z, cells, op):
@@ -380,3 +381,58 @@ def test_group_abi_single_rank_plumbing():
         assert lib.fh_group_create(eng._h, idbuf, 2, 1, C.byref(bad)) == _ffi.FH_BAD_ARGUMENT
     finally:
         eng.close()
+
+
+def test_group_reports_unsupported_when_rccl_cannot_be_loaded():
+    """librccl missing: the group calls return FH_UNSUPPORTED -- they used to crash in the error path (dlerror() called twice).
+    A fresh process, because a loaded RCCL stays loaded; FENRIS_HIP_RCCL_LIB names a file that does not exist.  No GPU needed."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from fenris_amd import _ffi; lib = _ffi.lib(); "
+            "buf = (C.c_uint8 * 128)(); rc = lib.fh_group_unique_id(buf); print('rc', rc, _ffi.FH_UNSUPPORTED); "
+            "sys.exit(0 if rc == _ffi.FH_UNSUPPORTED else 1)") % ROOT
+    env = dict(os.environ, FENRIS_HIP_RCCL_LIB="/nonexistent/librccl.so.1")
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stdout + pr.stderr
+
+
+@pytest.mark.gpu
+def test_group_create_reports_unsupported_when_rccl_cannot_be_loaded():
+    import subprocess
+    import sys
+
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import fenris_amd as fa; from fenris_amd import _ffi; lib = _ffi.lib(); "
+            "eng = fa.Engine(0); buf = (C.c_uint8 * 128)(); g = C.c_void_p(); rc = lib.fh_group_create(eng._h, buf, 0, 1, C.byref(g)); "
+            "print('rc', rc, eng.last_error()); sys.exit(0 if rc == _ffi.FH_UNSUPPORTED and 'dlopen' in eng.last_error() else 1)") % ROOT
+    env = dict(os.environ, FENRIS_HIP_RCCL_LIB="/nonexistent/librccl.so.1")
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stdout + pr.stderr
+
+
+@pytest.mark.gpu
+def test_group_abi_two_ranks_rccl():
+    """fh_group_* between two ranks over RCCL, one GPU each (tests/group_rccl_worker.py): the communicator reports two ranks, the
+    sent segment arrives and is added.  Needs two devices: skipped on the one-GPU test box."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "group_rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        outs.append((pr.returncode, out))
+    for r, (rc, out) in enumerate(outs):
+        assert rc == 0 and f"rank {r} ok" in out, f"rank {r} rc={rc}\n{out[-3000:]}"

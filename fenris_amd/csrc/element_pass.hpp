@@ -1,0 +1,425 @@
+// Register-resident element pass for the residual vector, the energy and the source vector of the small iso-parametric
+// elements (Quad4, Tri3, Tet4, Hex8): ONE THREAD PER ELEMENT.  Replaces, for these elements, the LDS-staged kernels
+// k_assemble_vector_stream / k_assemble_scalar / k_assemble_source of assemble_kernels.hpp (round 2: residual 3.1 ms, energy
+// 3.4 ms, gravity source 5.5 ms on Hex8 216^3 -- all of them bound by instruction issue and LDS round trips, none by memory).
+//
+//  * a thread fetches its element's node indices, vertex coordinates and u once (8-byte gathers whose lanes walk consecutive
+//    nodes of consecutive elements), keeps them in registers and walks the quadrature points: J = X G^T, its inverse,
+//    grad u = J^-T (sum_n ghat_n u_n^T), the operator's stress / energy density, and f_n += (s P J^-T) ghat_n -- what
+//    assemble_element_elliptic_vector / compute_element_elliptic_energy do per point (src/assembly/local/elliptic.rs:457-605),
+//    with the physical gradients never formed.  The reference-gradient table is uniform over the wavefront: it comes through
+//    scalar loads and enters the multiplications as a scalar operand.
+//  * vectors, two passes without atomics, both coalesced: the element vectors go to a scratch array laid out BY LOCAL NODE,
+//    fe[a][e][c] -- consecutive threads (elements) write consecutive 8 S bytes -- and k_vector_from_elements_soa gives every
+//    node one thread that sums its (element, local node) entries in ascending element order (the reference's sequential
+//    order, bitwise reproducible): for neighbouring nodes of a structured mesh the k-th entries are neighbouring elements with
+//    the same local node, i.e. neighbouring places of fe[a].  (Round 2 stored fe[e][a][c]: 24-byte pieces 192 bytes apart on
+//    both sides.)
+//  * energy: element energies summed per wavefront and workgroup in a fixed tree, workgroup partials in index order by a second
+//    one-workgroup kernel: one double comes back to the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "device_common.hpp"
+#include "small_ops.hpp"
+
+namespace fenris_hip {
+
+enum { EP_VECTOR = 0, EP_SCALAR = 1 };
+
+// The quadrature tables (weights, reference gradients, basis values, uniform parameters) are read at wavefront-uniform addresses and
+// never written while a kernel runs: through the constant address space they come by scalar loads (s_load) and enter the
+// multiplications as scalar operands -- as plain global loads every table entry was a 64-lane vector load of one address.
+typedef const __attribute__((address_space(4))) double* ep_table;
+__device__ __forceinline__ ep_table ep_const(const double* p) { return (ep_table)p; }
+
+// stress P (s x d) and energy density psi of one quadrature point from grad u (d x s):
+// laplace.rs:26-73; fenris-solid/src/materials.rs:71-123 (LinearElastic), 236-353 (NeoHookean, J <= 0 => NaN block / inf),
+// 392-469 (StVK).  Same formulas as phase B of assemble_kernels.hpp.
+template <int OP, int D, int S, int WHAT>
+__device__ __forceinline__ void material_point(const double (&gu)[D][S], double mu, double lambda, double (&P)[S][D], double& psi) {
+    psi = 0.0;
+    if constexpr (OP == FH_LAPLACE) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) { P[0][k] = gu[k][0]; psi = fma(gu[k][0], gu[k][0], psi); }
+        psi *= 0.5;
+    } else {
+        double F[D][D];  // F = I + (grad u)^T  (fenris-solid/src/lib.rs:20-29)
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) F[i][j] = (i == j ? 1.0 : 0.0) + gu[j][i];
+        if constexpr (OP == FH_LINEAR_ELASTIC) {
+            double eps[D][D];
+            double tr = 0.0, ee = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    eps[i][j] = (F[j][i] + F[i][j]) * 0.5 - (i == j ? 1.0 : 0.0);
+                    ee = fma(eps[i][j], eps[i][j], ee);
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) tr += eps[i][i];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) P[i][j] = eps[i][j] * 2.0 * mu + (i == j ? lambda * tr : 0.0);
+            psi = mu * ee + 0.5 * lambda * (tr * tr);
+        } else if constexpr (OP == FH_NEO_HOOKEAN) {
+            const double Jd = det_small<D>(F);
+            if (Jd <= 0.0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) P[i][j] = __builtin_nan("");
+            } else {
+                double Fi[D][D];
+                inv_small(F, Jd, Fi);
+                const double c = -mu + lambda * log(Jd);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) P[i][j] = Fi[j][i] * c + F[i][j] * mu;
+            }
+            if constexpr (WHAT == EP_SCALAR) {
+                // materials.rs:249-262 with log_det_F of du_dX = (grad u)^T (logdet.rs:17-86)
+                double U[D][D];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) U[i][j] = gu[j][i];
+                double gamma;
+                if constexpr (D == 2) {
+                    gamma = U[0][0] * U[1][1] + U[0][0] + U[1][1] - U[0][1] * U[1][0];
+                } else {
+                    const double u11 = U[0][0], u22 = U[1][1], u33 = U[2][2];
+                    const double aa = 1.0 + u11, e2 = 1.0 + u22, i2 = 1.0 + u33;
+                    const double b = U[0][1], c = U[0][2], d2 = U[1][0], f = U[1][2], g = U[2][0], h = U[2][1];
+                    gamma = u11 * u22 * u33 + u11 * u22 + u11 * u33 + u22 * u33 + u11 + u22 + u33 + b * f * g + c * d2 * h -
+                            c * e2 * g - b * d2 * i2 - aa * f * h;
+                }
+                if (gamma > -1.0) {
+                    const double logJ = log1p(gamma);
+                    double trU = 0.0, nn = 0.0;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        trU += U[i][i];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) nn = fma(U[i][j], U[i][j], nn);
+                    }
+                    psi = mu * (trU + 0.5 * nn) - mu * logJ + (0.5 * lambda) * (logJ * logJ);
+                } else {
+                    psi = __builtin_inf();
+                }
+            }
+        } else {  // StVK: P = F E 2 mu + F lambda tr E ; psi = mu E:E + lambda/2 tr^2
+            double Eg[D][D];
+            double trE = 0.0, ee = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[k][i], F[k][j], t);
+                    Eg[i][j] = (t - (i == j ? 1.0 : 0.0)) * 0.5;
+                    ee = fma(Eg[i][j], Eg[i][j], ee);
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) trE += Eg[i][i];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(F[i][k], Eg[k][j], t);
+                    P[i][j] = t * 2.0 * mu + F[i][j] * lambda * trE;
+                }
+            psi = mu * ee + 0.5 * lambda * (trE * trE);
+        }
+    }
+}
+
+// sum of v over the workgroup (256 threads) in a fixed tree: lanes by xor-shuffles, wavefronts in index order
+__device__ __forceinline__ double block_sum_256(double v, double* lds4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// WHAT = EP_VECTOR: fe[a][e][c] (a.ke_out, E = a.num_elements);  EP_SCALAR: a.scalar_out[blockIdx.x] = energy of the workgroup's elements
+template <int EK, int OP, int WHAT>
+__global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S;
+    static_assert(E::NG == N && N <= 8, "element pass: small iso-parametric elements");
+    __shared__ double red[4];
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < a.num_elements;
+    const long long ec = live ? e : a.num_elements - 1;   // every lane computes (uniform control flow), the surplus ones store nothing
+    int nd[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) nd[n] = a.conn[(size_t)ec * N + n];
+    double X[N][D], U[N][S];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd[n] * D + i];
+#pragma unroll
+        for (int k = 0; k < S; ++k) U[n][k] = a.u ? a.u[(size_t)nd[n] * S + k] : 0.0;
+    }
+    double f[WHAT == EP_VECTOR ? N : 1][S];
+#pragma unroll
+    for (int n = 0; n < (WHAT == EP_VECTOR ? N : 1); ++n)
+#pragma unroll
+        for (int k = 0; k < S; ++k) f[n][k] = 0.0;
+    double energy = 0.0;
+    const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[ec] * a.nq * 2 : nullptr;
+    // The Jacobian of an affine element is the same at every point (simplices always; a Hex8 / Quad4 whose mixed coefficients
+    // vanish: every element of a structured, graded or sheared box mesh -- the test of k_classify_affine_hex8):
+    // when every element of the wavefront is affine, J, its inverse and the determinant are formed once instead of per point.
+    bool const_j = (EK == FH_TET4 || EK == FH_TRI3);
+    if constexpr (EK == FH_HEX8 || EK == FH_QUAD4) {
+        // reference node signs (hexahedron.rs:49-58, quadrilateral.rs:84-99): the coefficient of xi eta (, xi zeta, eta zeta, xi eta zeta)
+        constexpr int SG[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+        // against the length of the edges from node 0 (rounding leaves a few ulps of the coordinates in the mixed coefficients of an
+        // exact box): 2^-46 like fh_set_affine_tolerance's default -- the Jacobians of such an element differ by less than that
+        double len = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) len += fabs(X[1][i] - X[0][i]) + fabs(X[3][i] - X[0][i]) + (D == 3 ? fabs(X[4 % N][i] - X[0][i]) : 0.0);
+        const double tol = len * 0x1p-46;
+        bool aff = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double cxy = 0.0, cxz = 0.0, cyz = 0.0, cxyz = 0.0;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                cxy += (SG[n][0] * SG[n][1]) * X[n][i];
+                if (D == 3) {
+                    cxz += (SG[n][0] * SG[n][2]) * X[n][i];
+                    cyz += (SG[n][1] * SG[n][2]) * X[n][i];
+                    cxyz += (SG[n][0] * SG[n][1] * SG[n][2]) * X[n][i];
+                }
+            }
+            aff = aff && fabs(cxy) <= tol && fabs(cxz) <= tol && fabs(cyz) <= tol && fabs(cxyz) <= tol;
+        }
+        const_j = __all(aff ? 1 : 0) != 0;
+    }
+    double J[D][D], Ji[D][D], adet = 0.0;
+    // one quadrature point; NEED_J (compile time): form J, its inverse and |det J| here, or keep those of the first point
+    auto point = [&](int q, auto need_j_tag) {
+        constexpr bool need_j = decltype(need_j_tag)::value;
+        const ep_table G = ep_const(a.gref) + (size_t)q * N * D;   // uniform over the wavefront: scalar loads
+        double R[D][S];
+        if constexpr (need_j) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) J[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) R[i][k] = 0.0;
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double g = G[n * D + j];
+                if constexpr (need_j) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) J[i][j] = fma(X[n][i], g, J[i][j]);   // J = X G^T (hexahedron.rs:101-107)
+                }
+#pragma unroll
+                for (int k = 0; k < S; ++k) R[j][k] = fma(g, U[n][k], R[j][k]);       // sum_n ghat_n u_n^T
+            }
+        if constexpr (need_j) {
+            const double detJ = det_small<D>(J);
+            if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
+                if (live) report_singular(a.status, e);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Ji[i][j] = 0.0;
+            } else {
+                inv_small(J, detJ, Ji);
+            }
+            adet = fabs(detJ);
+        }
+        const double s = ep_const(a.qw)[q] * adet;   // w |det J| (elliptic.rs:422)
+        double gu[D][S];                          // grad u = J^-T R
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                double t = 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) t = fma(Ji[m][i], R[m][k], t);
+                gu[i][k] = t;
+            }
+        double mu = 0.0, lambda = 0.0;
+        if (OP != FH_LAPLACE) {
+            if (par_e) { mu = par_e[2 * q]; lambda = par_e[2 * q + 1]; }
+            else { mu = ep_const(a.qparams)[2 * q]; lambda = ep_const(a.qparams)[2 * q + 1]; }
+        }
+        double P[S][D], psi;
+        material_point<OP, D, S, WHAT>(gu, mu, lambda, P, psi);
+        if constexpr (WHAT == EP_SCALAR) {
+            energy = fma(s, psi, energy);
+        } else {
+            double M[S][D];   // s P J^-T
+#pragma unroll
+            for (int i = 0; i < S; ++i)
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(P[i][k], Ji[m][k], t);
+                    M[i][m] = s * t;
+                }
+#pragma unroll
+            for (int n = 0; n < N; ++n)
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const double g = G[n * D + m];
+#pragma unroll
+                    for (int i = 0; i < S; ++i) f[n][i] = fma(M[i][m], g, f[n][i]);
+                }
+        }
+    };
+    if (const_j) {   // uniform over the wavefront
+        point(0, std::true_type{});
+        for (int q = 1; q < a.nq; ++q) point(q, std::false_type{});
+    } else {
+        for (int q = 0; q < a.nq; ++q) point(q, std::true_type{});
+    }
+    if constexpr (WHAT == EP_SCALAR) {
+        const double tot = block_sum_256(live ? energy : 0.0, red);
+        if (threadIdx.x == 0) a.scalar_out[blockIdx.x] = tot;
+    } else {
+        if (live) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                double* dst = a.ke_out + ((size_t)n * (size_t)a.num_elements + (size_t)e) * S;
+#pragma unroll
+                for (int i = 0; i < S; ++i) dst[i] = f[n][i];
+            }
+        }
+    }
+}
+
+// source vector of the small iso-parametric elements (local/source.rs:159-278): f_n = sum_q w |det J| phi_n(xi_q) f(x_q), with
+// f = density_q g (GravitySource, fenris-solid/src/gravity_source.rs:57-65) or values sampled by the caller.  fe[a][e][c].
+template <int D, int S, int N>
+__global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const double* g, const double* values, double* fe) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.num_elements) return;
+    double X[N][D];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int nd = a.conn[(size_t)e * N + n];
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd * D + i];
+    }
+    double f[N][S];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int k = 0; k < S; ++k) f[n][k] = 0.0;
+    double gv[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) gv[k] = values ? 0.0 : ep_const(g)[k];
+    const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[e] * a.nq * 2 : nullptr;
+    for (int q = 0; q < a.nq; ++q) {
+        const ep_table G = ep_const(a.ggeom) + (size_t)q * N * D;
+        double J[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) J[i][j] = 0.0;
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double gg = G[n * D + j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) J[i][j] = fma(X[n][i], gg, J[i][j]);
+            }
+        const double wd = ep_const(a.qw)[q] * fabs(det_small<D>(J));
+        double fc[S];
+        if (values) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) fc[k] = values[((size_t)e * a.nq + q) * S + k];
+        } else {
+            const double rho = par_e ? par_e[2 * q] : (a.qparams ? ep_const(a.qparams)[2 * q] : 0.0);
+#pragma unroll
+            for (int k = 0; k < S; ++k) fc[k] = gv[k] * rho;
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const double t = wd * ep_const(a.phiref)[(size_t)q * N + n];
+#pragma unroll
+            for (int k = 0; k < S; ++k) f[n][k] = fma(t, fc[k], f[n][k]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        double* dst = fe + ((size_t)n * (size_t)a.num_elements + (size_t)e) * S;
+#pragma unroll
+        for (int k = 0; k < S; ++k) dst[k] = f[n][k];
+    }
+}
+
+// second pass: out[s node + c] += sum over the node's (element, local node) entries, ascending entry order (n2e is sorted
+// element-major like the reference's sequential loop: bitwise reproducible); entry v = e n + a lives at fe[a][e]
+template <int S>
+__global__ void __launch_bounds__(256) k_vector_from_elements_soa(int num_nodes, int n, long long E, const unsigned* n2e_off, const unsigned* n2e,
+                                                                  const double* fe, double* out) {
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= num_nodes) return;
+    double acc[S], prev[S];
+#pragma unroll
+    for (int c = 0; c < S; ++c) { acc[c] = 0.0; prev[c] = out[(size_t)node * S + c]; }
+    const unsigned k0 = n2e_off[node], k1 = n2e_off[node + 1];
+    // eight entries at a time: their indices, then all their values, are requested before the first sum (a node of a hexahedral
+    // mesh has eight entries: one round trip instead of eight dependent ones); the additions stay in entry order
+    for (unsigned kb = k0; kb < k1; kb += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = n2e[min(kb + j, k1 - 1)];
+        double t[8][S];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned e = v[j] / (unsigned)n, al = v[j] - e * (unsigned)n;
+            const double* p = fe + ((size_t)al * (size_t)E + e) * S;
+#pragma unroll
+            for (int c = 0; c < S; ++c) t[j][c] = p[c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (kb + j < k1) {
+#pragma unroll
+                for (int c = 0; c < S; ++c) acc[c] += t[j][c];
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < S; ++c) out[(size_t)node * S + c] = prev[c] + acc[c];
+}
+
+// partial sums in index order by one workgroup: thread t takes the partials t, t + 256, ... in order, then the fixed tree
+__global__ void __launch_bounds__(256) k_sum_partials(const double* partial, int n, double* out) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const double tot = block_sum_256(v, red);
+    if (threadIdx.x == 0) *out = tot;
+}
+
+}  // namespace fenris_hip

@@ -19,6 +19,7 @@
 #include "rows_kernel.hpp"
 #include "affine_kernel.hpp"
 #include "affine_rows.hpp"
+#include "element_pass.hpp"
 #include "device_common.hpp"
 #include "group_internal.hpp"
 #include "host_inputs.hpp"
@@ -395,6 +396,8 @@ struct fh_ctx {
     DevBuf<double> scratch;
     DevBuf<double> ke_dense;  // two-pass assembly of high-order elements: E dense element matrices
     DevBuf<double> fe_scratch;  // two-pass residual: E element vectors
+    DevBuf<unsigned> src_n2e_off, src_n2e;   // node -> (element, local node) adjacency of a context without an operator (source vectors)
+    unsigned long long src_adj_gen = ~0ull;
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
@@ -502,6 +505,45 @@ int build_compute_adjacency(fh_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->h_n2e_off_c.data(), c->n2e_off_c.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+// node -> (element, local node) adjacency alone (a context that holds a mesh but no operator: ElementSourceAssembler): what
+// build_pattern computes first, into buffers of its own
+int build_source_adjacency(fh_ctx* c) {
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "source adjacency: no finite element mesh set");
+    if (c->src_adj_gen == c->struct_gen && c->src_n2e_off.p) return FH_OK;
+    const int N = (int)c->N;
+    hipStream_t st = c->stream;
+    ConnView cv{c->conn.p, nullptr, nullptr, c->ei.n, (long long)c->flat_len, nullptr};
+    DevBuf<unsigned> deg, cursor;
+    DevBuf<int> flags;
+    HIP_TRY(c, deg.alloc((size_t)N + 1));
+    HIP_TRY(c, cursor.alloc((size_t)N + 1));
+    HIP_TRY(c, flags.alloc(2));
+    HIP_TRY(c, c->src_n2e_off.alloc((size_t)N + 1));
+    HIP_TRY(c, hipMemsetAsync(deg.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
+    HIP_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(int) * 2, st));
+    if (c->flat_len > 0)
+        hipLaunchKernelGGL(k_count_degree, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, deg.p, N, flags.p);
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg.p, c->src_n2e_off.p, N + 1, st));
+    DevBuf<char> tmp;
+    HIP_TRY(c, tmp.alloc(tmp_bytes + 16));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, deg.p, c->src_n2e_off.p, N + 1, st));
+    HIP_TRY(c, c->src_n2e.alloc((size_t)c->flat_len + 1));
+    if (c->flat_len > 0) {
+        hipLaunchKernelGGL(k_fill_n2e, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, c->src_n2e_off.p, cursor.p,
+                           c->src_n2e.p, N);
+        hipLaunchKernelGGL(k_sort_n2e, dim3(grid_for(N, 256, 1 << 30)), dim3(256), 0, st, c->src_n2e_off.p, c->src_n2e.p, N);
+    }
+    int h_flags[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
+    c->src_adj_gen = c->struct_gen;
     return FH_OK;
 }
 
@@ -1708,6 +1750,45 @@ static int launch_scalar(fh_ctx* c, KArgs& a, size_t lds, int grid) {
     return FH_OK;
 }
 
+// register-resident element pass (element_pass.hpp): one thread per element of the small iso-parametric kinds, operators with a
+// vector / scalar form.  Returns -1 when the combination is not covered (the callers keep the staged kernels).
+template <int WHAT>
+static int launch_element_pass(fh_ctx* c, KArgs& a) {
+    const int grid = (int)((a.num_elements + 255) / 256);
+    int rs = -1;
+#define EP_OP(EKC)                                                                                                          \
+    switch (c->op) {                                                                                                        \
+        case FH_LAPLACE: hipLaunchKernelGGL((k_element_pass<EKC, FH_LAPLACE, WHAT>), dim3(grid), dim3(256), 0, c->stream, a); rs = FH_OK; break; \
+        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_pass<EKC, FH_LINEAR_ELASTIC, WHAT>), dim3(grid), dim3(256), 0, c->stream, a); rs = FH_OK; break; \
+        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_pass<EKC, FH_NEO_HOOKEAN, WHAT>), dim3(grid), dim3(256), 0, c->stream, a); rs = FH_OK; break; \
+        case FH_STVK: hipLaunchKernelGGL((k_element_pass<EKC, FH_STVK, WHAT>), dim3(grid), dim3(256), 0, c->stream, a); rs = FH_OK; break; \
+        default: break;                                                                                                     \
+    }
+    switch (c->elem_kind) {
+        case FH_QUAD4: EP_OP(FH_QUAD4) break;
+        case FH_TRI3: EP_OP(FH_TRI3) break;
+        case FH_TET4: EP_OP(FH_TET4) break;
+        case FH_HEX8: EP_OP(FH_HEX8) break;
+        default: break;
+    }
+#undef EP_OP
+    if (rs == FH_OK) HIP_TRY(c, hipGetLastError());
+    return rs;
+}
+static int launch_vector_from_elements_soa(fh_ctx* c, int sdim, const double* fe, double* out_dev, const unsigned* adj_off = nullptr,
+                                           const unsigned* adj = nullptr) {
+    const int grid = (int)(((long long)c->N + 255) / 256);
+    if (!adj_off) { adj_off = c->n2e_off.p; adj = c->n2e.p; }
+    if (sdim == 1) hipLaunchKernelGGL(k_vector_from_elements_soa<1>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    else if (sdim == 2) hipLaunchKernelGGL(k_vector_from_elements_soa<2>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    else hipLaunchKernelGGL(k_vector_from_elements_soa<3>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+static bool element_pass_covers(const fh_ctx* c) {
+    return !c->ragged && !c->env("FENRIS_HIP_NO_ELEMENT_PASS") &&
+           (c->elem_kind == FH_HEX8 || c->elem_kind == FH_TET4 || c->elem_kind == FH_QUAD4 || c->elem_kind == FH_TRI3);
+}
 
 static int upload_colors(fh_ctx* c, const std::vector<uint64_t>& offs, const std::vector<uint64_t>& labels) {
     // with an element mask only the active elements of each colour are launched
@@ -2640,6 +2721,24 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return read_status(c, failed);
+    // small iso-parametric elements without an element list: one thread per element, element vectors laid out by local node, then
+    // one thread per node (element_pass.hpp); no atomics, bitwise reproducible
+    if (!a.labels && element_pass_covers(c) && !c->env("FENRIS_HIP_VECTOR_ATOMICS")) {
+        rc = build_pattern(c);  // the node -> (element, local node) adjacency comes with the pattern
+        if (rc) return rc;
+        const size_t need = (size_t)c->E * c->ei.n * c->S();
+        if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
+        a.ke_out = c->fe_scratch.p;
+        const int rs = launch_element_pass<EP_VECTOR>(c, a);
+        if (rs == FH_OK) {
+            c->last_kernel = "k_element_pass + k_vector_from_elements_soa";
+            rc = launch_vector_from_elements_soa(c, c->S(), c->fe_scratch.p, out_dev);
+            if (rc) return rc;
+            return read_status(c, failed);
+        }
+        if (rs > 0) return rs;
+        a.ke_out = nullptr;
+    }
     // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel).
     // Two passes by default: element vectors to a scratch buffer, then one thread per row sums its node's entries in
     // ascending element order -- no atomics, bitwise reproducible (FENRIS_HIP_VECTOR_ATOMICS keeps the one-pass scatter)
@@ -2740,11 +2839,36 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     // for the solution dimension): element vectors to scratch, then a per-row sum in element order
     bool two_pass = !a.labels && !c->ragged && c->op >= 0 && !c->env("FENRIS_HIP_VECTOR_ATOMICS");
     if (two_pass && build_pattern(c) != FH_OK) two_pass = false;
+    // a context without an operator (the usual case of a source assembler): the adjacency alone, for the element pass
+    const unsigned *adj_off = nullptr, *adj = nullptr;
+    if (!two_pass && !a.labels && c->op < 0 && element_pass_covers(c) && !c->env("FENRIS_HIP_VECTOR_ATOMICS") && build_source_adjacency(c) == FH_OK) {
+        two_pass = true;
+        adj_off = c->src_n2e_off.p;
+        adj = c->src_n2e.p;
+    }
     if (two_pass) {
         const size_t need = (size_t)c->E * c->ei.n * sdim;
         if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
         a.ke_out = c->fe_scratch.p;
     }
+    if (two_pass && element_pass_covers(c)) {   // one thread per element, element vectors by local node, one thread per node (element_pass.hpp)
+        const int ge = (int)((c->E + 255) / 256);
+        double* fe = c->fe_scratch.p;
+#define SRC(DV, SV, NV) hipLaunchKernelGGL((k_source_elements<DV, SV, NV>), dim3(ge), dim3(256), 0, c->stream, a, sa.g, sa.values, fe)
+        const int n = c->ei.n;
+        if (D == 2 && n == 4) { if (sdim == 1) SRC(2, 1, 4); else SRC(2, 2, 4); }
+        else if (D == 2) { if (sdim == 1) SRC(2, 1, 3); else SRC(2, 2, 3); }
+        else if (n == 8) { if (sdim == 1) SRC(3, 1, 8); else SRC(3, 3, 8); }
+        else { if (sdim == 1) SRC(3, 1, 4); else SRC(3, 3, 4); }
+#undef SRC
+        HIP_TRY(c, hipGetLastError());
+        c->last_kernel = "k_source_elements + k_vector_from_elements_soa";
+        rc = launch_vector_from_elements_soa(c, (int)sdim, fe, out_dev, adj_off, adj);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // gd is released on return
+        return FH_OK;
+    }
+    if (adj_off) { two_pass = false; a.ke_out = nullptr; }   // (not covered after all: the one-pass scatter)
     a.epb = std::max(1, 256 / std::max(c->nq, c->ei.n));
     const size_t lds = sizeof(double) * (size_t)a.epb * c->nq;
     const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
@@ -2857,6 +2981,23 @@ static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed) {
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return FH_OK;
+    if (!a.labels && element_pass_covers(c)) {
+        // one thread per element (element_pass.hpp), workgroup partials in a fixed tree, the partials summed in index order by one
+        // workgroup: one double comes back (global.rs:703-709 sums element by element; same terms, fixed association)
+        const int grid = (int)((c->E + 255) / 256);
+        DevBuf<double> partial;
+        HIP_TRY(c, partial.alloc((size_t)grid + 1));
+        a.scalar_out = partial.p;
+        const int rs = launch_element_pass<EP_SCALAR>(c, a);
+        if (rs == FH_OK) {
+            c->last_kernel = "k_element_pass<scalar>";
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, partial.p, grid, partial.p + grid);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(out, partial.p + grid, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            return read_status(c, failed);
+        }
+        if (rs > 0) return rs;
+    }
     // a batch of elements per workgroup: element energies summed in element order inside the batch, the batch partials in
     // order on the host (global.rs:703-709 sums element by element; same terms, fixed association)
     a.epb = std::max(1, std::min(choose_epb(c, WHAT_SCALAR), std::max(1, 256 / std::max(c->nq, 1))));

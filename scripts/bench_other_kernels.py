@@ -63,9 +63,23 @@ def north_star(cells):
     eng.assemble_matrix(values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
     f = torch.zeros(n, dtype=torch.float64, device="cuda")
     # residual f(u): connectivity + vertices + u read once, the vector written once
-    line("residual vector (k_assemble_vector_stream + k_vector_from_elements)", ev_time(lambda: eng.assemble_vector(f)),
-         E * 8 * 4 + N * 3 * 8 + 2 * n * 8, config=tag, elements_per_s=None)
-    line("energy (assemble_scalar)", ev_time(lambda: eng.assemble_scalar(), steps=5), E * 8 * 4 + N * 3 * 8 + n * 8, config=tag)
+    ms = ev_time(lambda: eng.assemble_vector(f))
+    line("residual vector (" + eng.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + 2 * n * 8, config=tag, elements_per_s=E / ms * 1e3)
+    ms = ev_time(lambda: eng.assemble_scalar(), steps=5)
+    line("energy, assemble_scalar (" + eng.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + n * 8, config=tag, elements_per_s=E / ms * 1e3)
+    if os.environ.get("FENRIS_BENCH_OTHER_OPERATORS", "1") == "1":   # the nonlinear operators through the same passes
+        for opname, mat in (("NeoHookean", fa.NeoHookeanMaterial()), ("StVK", fa.StVKMaterial())):
+            e2 = fa.Engine(0, stream=stream)
+            (fa.ElementEllipticAssemblerBuilder(e2).with_finite_element_space(mesh).with_operator(fa.MaterialEllipticOperator(mat))
+             .with_quadrature_table(qt).with_u(u).build())
+            e2.build_pattern()
+            ms = ev_time(lambda: e2.assemble_vector(f), steps=5)
+            line(f"residual vector, {opname} (" + e2.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + 2 * n * 8, config=f"Hex8 {opname} {cells}^3",
+                 elements_per_s=E / ms * 1e3)
+            ms = ev_time(lambda: e2.assemble_scalar(), steps=5)
+            line(f"energy, {opname} (" + e2.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + n * 8, config=f"Hex8 {opname} {cells}^3",
+                 elements_per_s=E / ms * 1e3)
+            e2.close()
     x = torch.randn(n, dtype=torch.float64, device="cuda")
     y = torch.zeros_like(x)
     # SpMV on the blocked CSR: values, one column index per 3 x 3 block, x gathered (counted once), y written
@@ -89,8 +103,9 @@ def north_star(cells):
     src_eng = fa.Engine(0, stream=stream)
     (fa.ElementSourceAssemblerBuilder.new(src_eng).with_finite_element_space(mesh).with_source(fa.GravitySource([0.0, 0.0, -9.81]))
      .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.Density(1000.0))).build())
-    line("source vector, GravitySource (k_assemble_source)", ev_time(lambda: src_eng.assemble_source_vector(f, 3, g=[0.0, 0.0, -9.81]), steps=5),
-         E * 8 * 4 + N * 3 * 8 + n * 8, config=tag)
+    src_eng.set_operator_for_pattern(3) if hasattr(src_eng, "set_operator_for_pattern") else None
+    ms = ev_time(lambda: src_eng.assemble_source_vector(f, 3, g=[0.0, 0.0, -9.81]), steps=5)
+    line("source vector, GravitySource (" + src_eng.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + n * 8, config=tag, elements_per_s=E / ms * 1e3)
     src_eng.close()
 
 

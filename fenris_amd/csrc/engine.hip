@@ -1397,6 +1397,9 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
     const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
+    if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)
+        std::fprintf(stderr, "[fenris_hip ptrs] recs=%p hdr=%p elem=%p lanes=%p vals=%p verts=%p conn=%p\n", (void*)c->a_recs.p, (void*)c->a_hdr.p,
+                     (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                           c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete};

@@ -206,6 +206,12 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                     if (grp >= 3) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t3l;
                 }
             }
+        // The requests of this position (vertices of the next block, records and lane words of the one after) are consumed HERE,
+        // in front of the stores: loads and stores share one in-order counter, and behind the (branch-guarded) stores the wait
+        // for these loads becomes vmcnt(0) -- every position then waited for its own nine stores per lane to drain, a write
+        // latency per position (round 3: C3 0.63 -> see DESIGN 3.4).  X is read by phase B only, which lies behind the barrier above.
+        if (have_next) park(nxt, parity ^ 1);
+        asm volatile("" : "+v"(nn.w), "+v"(nn.conn[0]), "+v"(nn.conn[SLOTS - 1]), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
         if ((wl >> 16) & 1u) {
             const int il = (int)((wl >> 7) & 15u), pos = (int)(wl & 127u);
             const int cnt = noff_l[il + 1] - noff_l[il];
@@ -229,8 +235,6 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                 }
             }
         }
-        if (have_next) park(nxt, parity ^ 1);
-        asm volatile("" : "+v"(nn.w), "+v"(nn.conn[0]), "+v"(nn.conn[SLOTS - 1]), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
         nxt = nn;
         lane_cur = lane_nxt;
         lds_barrier();

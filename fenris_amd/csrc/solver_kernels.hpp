@@ -66,6 +66,57 @@ __global__ void __launch_bounds__(256) k_spmv_blocked(int num_nodes, const unsig
     if (dot_partial) block_sum_store<1>(dot, dot_partial + blockIdx.x);
 }
 
+// The same product for patterns whose node rows hold at most 32 column blocks (Quad4 9, Tet4 ~15, Hex8 27): HALF a wavefront per
+// node, one lane per column block -- the lane fetches its column index, the S entries of x and its S x S block (S runs of S
+// contiguous doubles; neighbouring lanes read neighbouring runs) -- and two node pairs per wavefront in flight.  The
+// one-wavefront-per-node form above walks a row of 81 entries in two trips of 64 lanes behind three dependent fetches (row offset
+// -> column index -> x): with 32 wavefronts per CU that chain, not the memory system, set its rate (3.2 TB/s on Hex8 216^3).
+template <int S, int UN = 2>
+__global__ void __launch_bounds__(256) k_spmv_blocked_half(int num_nodes, const unsigned* noff, const unsigned* ncols, const double* vals,
+                                                           const double* x, double* y, double* dot_partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    // UN: node pairs in flight per wavefront
+    double dot[1] = {0.0};
+    const int stride = gridDim.x * 4 * 2 * UN;
+    for (int base = (blockIdx.x * 4 + wave) * 2 * UN; base < num_nodes; base += stride) {
+        double acc[UN][S];
+        int node[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            node[u] = base + 2 * u + half;
+            const int nc = min(node[u], num_nodes - 1);
+            const unsigned r0 = noff[nc], cnt = noff[nc + 1] - r0;
+            const bool act = node[u] < num_nodes && (unsigned)hl < cnt;
+#pragma unroll
+            for (int a = 0; a < S; ++a) acc[u][a] = 0.0;
+            if (act) {
+                const unsigned col = ncols[r0 + hl];
+                double xv[S];
+#pragma unroll
+                for (int c = 0; c < S; ++c) xv[c] = x[(size_t)S * col + c];
+                const double* blk = vals + (size_t)S * S * r0 + (size_t)S * hl;
+#pragma unroll
+                for (int a = 0; a < S; ++a)
+#pragma unroll
+                    for (int c = 0; c < S; ++c) acc[u][a] = fma(blk[(size_t)a * S * cnt + c], xv[c], acc[u][a]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                double s = acc[u][a];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);   // over the half wavefront
+                if (hl == 0 && node[u] < num_nodes) {
+                    y[(size_t)S * node[u] + a] = s;
+                    dot[0] = fma(x[(size_t)S * node[u] + a], s, dot[0]);
+                }
+            }
+    }
+    if (dot_partial) block_sum_store<1>(dot, dot_partial + blockIdx.x);
+}
+
 // 1 / diagonal of the blocked CSR (matrix.diagonal_as_csr() + recip, poisson_mms_common.rs:148-151)
 template <int S>
 __global__ void __launch_bounds__(256) k_inverse_diagonal(int num_nodes, const unsigned* noff, const unsigned* ncols, const double* vals,

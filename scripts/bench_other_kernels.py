@@ -83,7 +83,8 @@ def north_star(cells):
     x = torch.randn(n, dtype=torch.float64, device="cuda")
     y = torch.zeros_like(x)
     # SpMV on the blocked CSR: values, one column index per 3 x 3 block, x gathered (counted once), y written
-    line("SpMV y = K x (k_spmv_blocked<3>)", ev_time(lambda: eng.spmv(values, x, y)), nnz * 8 + nnz // 9 * 4 + 2 * n * 8, config=tag)
+    ms = ev_time(lambda: eng.spmv(values, x, y))
+    line("SpMV y = K x (" + eng.last_kernel_name() + "<3>)", ms, nnz * 8 + nnz // 9 * 4 + 2 * n * 8, config=tag)
     bc = np.where(mesh.vertices[:, 0] < 1e-9)[0]
     eng.apply_dirichlet_csr_dev(values, bc)
     b = torch.zeros(n, dtype=torch.float64, device="cuda")

@@ -3131,6 +3131,7 @@ int fh_spmv_dev(fh_ctx* c, const double* values_dev, const double* x_dev, double
     if (!values_dev || !x_dev || !y_dev) return c->fail(FH_BAD_ARGUMENT, "fh_spmv: null argument");
     if (c->N == 0) return FH_OK;
     const int grid = (int)std::min<uint64_t>(4096, (c->N + 3) / 4);
+    c->last_kernel = (c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE")) ? "k_spmv_blocked_half" : "k_spmv_blocked";
     return spmv_launch(c, values_dev, x_dev, y_dev, nullptr, grid);
 }
 

@@ -342,6 +342,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configurations timed after the headline (N = 1, --config ns)")
+    ap.add_argument("--no-module-warmup", action="store_true",
+                    help="skip the tiny assembly that loads the code objects before anything is timed (profiling runs: its dispatches would "
+                         "enter the per-kernel averages)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -363,7 +366,8 @@ def main():
     # any torch.cuda call (N = 1, rank 0 only)
     traffic, traffic_detail = None, None
     if world == 1 and not args.no_traffic and os.environ.get("FENRIS_BENCH_CHILD") != "1":
-        child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--scatter", args.scatter]
+        child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--no-module-warmup",
+                 "--scatter", args.scatter]
         if args.cells:
             child += ["--cells", str(args.cells)]
         aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
@@ -416,15 +420,16 @@ def main():
 
     # code objects of the library loaded and the device warm before anything is timed: one tiny assembly
     t0 = time.perf_counter()
-    wc = config_problem("ns", 4, fa, quadrature, np)
-    weng = fa.Engine(local_rank, stream=stream)
-    wc["configure"](weng, wc["mesh"]())
-    wv = torch.zeros(weng.build_pattern(), dtype=torch.float64, device="cuda")
-    weng.assemble_matrix_async(wv, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
-    weng.poll_status()
-    torch.cuda.synchronize()
-    weng.close()
-    del wv, weng
+    if not args.no_module_warmup:
+        wc = config_problem("ns", 4, fa, quadrature, np)
+        weng = fa.Engine(local_rank, stream=stream)
+        wc["configure"](weng, wc["mesh"]())
+        wv = torch.zeros(weng.build_pattern(), dtype=torch.float64, device="cuda")
+        weng.assemble_matrix_async(wv, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        weng.poll_status()
+        torch.cuda.synchronize()
+        weng.close()
+        del wv, weng
     t_warm = time.perf_counter() - t0
 
     flags = {"gather": fa.SCATTER_GATHER, "atomic": fa.SCATTER_ATOMIC, "colored": fa.SCATTER_COLORED}[args.scatter]

@@ -1421,7 +1421,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
         const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-        const int grid = std::min(count, dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu));
+        const int grid = std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu)));
         if (c->env("FENRIS_HIP_VERBOSE"))
             std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
         HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,

@@ -415,45 +415,60 @@ template <int OP>
 __global__ void __launch_bounds__(256) k_affine_records(const double* verts, const int* conn, const unsigned char* elem_aff,
                                                         const unsigned char* active, long long e_first, long long E, double* rec, DevStatus* status) {
     constexpr bool LAP = (OP == FH_LAPLACE);
-    constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
-    const long long e = e_first + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= E || !elem_aff[e]) return;
-    const int4 c0 = reinterpret_cast<const int4*>(conn)[2 * e], c1 = reinterpret_cast<const int4*>(conn)[2 * e + 1];
-    const int vi[4] = {c0.x, c0.y, c0.w, c1.x};
-    double X[4][3];
+    constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE, NPC = GW / 2;
+    // the records of the workgroup's 256 consecutive elements are staged in LDS and leave as consecutive 16-byte pieces: a thread's
+    // own record is 80 (48) bytes, so stores straight from the registers put every lane on a line of its own
+    __shared__ f64x2 stage[256 * NPC];
+    __shared__ unsigned char ok[256];
+    const long long e0 = e_first + (long long)blockIdx.x * 256;
+    const long long e = e0 + threadIdx.x;
+    const bool mine = e < E && elem_aff[e];
+    ok[threadIdx.x] = mine ? 1 : 0;
+    if (mine) {
+        const int4 c0 = reinterpret_cast<const int4*>(conn)[2 * e], c1 = reinterpret_cast<const int4*>(conn)[2 * e + 1];
+        const int vi[4] = {c0.x, c0.y, c0.w, c1.x};
+        double X[4][3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) X[k][c] = verts[(size_t)vi[k] * 3 + c];
-    double J[3][3], R[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) J[i][k] = 0.5 * (X[k + 1][i] - X[0][i]);
-    const double detJ = det_small<3>(J);
-    if (detJ == 0.0) {
-        if (!active || active[e]) report_singular(status, e);
+            for (int c = 0; c < 3; ++c) X[k][c] = verts[(size_t)vi[k] * 3 + c];
+        double J[3][3], R[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) R[i][j] = 0.0;
-    } else {
-        adj_scaled(J, copysign(rsqrt_newton(fabs(detJ)), detJ), R);
+            for (int k = 0; k < 3; ++k) J[i][k] = 0.5 * (X[k + 1][i] - X[0][i]);
+        const double detJ = det_small<3>(J);
+        if (detJ == 0.0) {
+            if (!active || active[e]) report_singular(status, e);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) R[i][j] = 0.0;
+        } else {
+            adj_scaled(J, copysign(rsqrt_newton(fabs(detJ)), detJ), R);
+        }
+        f64x2* o = stage + threadIdx.x * NPC;
+        if constexpr (LAP) {
+            double M[6];
+            int k = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int d = c; d < 3; ++d, ++k) M[k] = R[c][0] * R[d][0] + R[c][1] * R[d][1] + R[c][2] * R[d][2];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) { f64x2 v; v.x = M[2 * h]; v.y = M[2 * h + 1]; o[h] = v; }
+        } else {
+            const double r9[10] = {R[0][0], R[0][1], R[0][2], R[1][0], R[1][1], R[1][2], R[2][0], R[2][1], R[2][2], 0.0};
+#pragma unroll
+            for (int h = 0; h < 5; ++h) { f64x2 v; v.x = r9[2 * h]; v.y = r9[2 * h + 1]; o[h] = v; }
+        }
     }
-    f64x2* o = reinterpret_cast<f64x2*>(rec + (size_t)e * GW);
-    if constexpr (LAP) {
-        double M[6];
-        int k = 0;
+    __syncthreads();
+    f64x2* out = reinterpret_cast<f64x2*>(rec + (size_t)e0 * GW);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int d = c; d < 3; ++d, ++k) M[k] = R[c][0] * R[d][0] + R[c][1] * R[d][1] + R[c][2] * R[d][2];
-#pragma unroll
-        for (int h = 0; h < 3; ++h) { f64x2 v; v.x = M[2 * h]; v.y = M[2 * h + 1]; o[h] = v; }
-    } else {
-        const double r9[10] = {R[0][0], R[0][1], R[0][2], R[1][0], R[1][1], R[1][2], R[2][0], R[2][1], R[2][2], 0.0};
-#pragma unroll
-        for (int h = 0; h < 5; ++h) { f64x2 v; v.x = r9[2 * h]; v.y = r9[2 * h + 1]; o[h] = v; }
+    for (int k = 0; k < NPC; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        if (ok[idx / NPC]) out[idx] = stage[idx];   // records of elements that are not affine stay untouched
     }
 }
 

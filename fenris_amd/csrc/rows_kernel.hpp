@@ -173,39 +173,37 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                 }
             }
         });
+        // Partial sums of a block meet by DPP exchanges in groups of 2 / 4 / 8 lanes.  Whether a lane takes part is a factor (1.0 or
+        // 0.0) of a multiply-add, not a branch: nine guarded additions per stage cost an exec-mask pair each.  The third stage (groups
+        // of eight: a node with more than 24 elements) is skipped by the whole wavefront when none of its lanes needs it.
+        const double m1 = grp >= 1 ? 1.0 : 0.0, m2 = grp >= 2 ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double t1 = dpp_quad<0xB1>(Gm[i][j]);
-                if (grp >= 1) Gm[i][j] += t1;
-                if constexpr (ELEMPAR) {
-                    const double t1l = dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
-                    if (grp >= 1) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t1l;
-                }
+                Gm[i][j] = fma(dpp_quad<0xB1>(Gm[i][j]), m1, Gm[i][j]);
+                if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                    fma(dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m1, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
             }
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double t2 = dpp_quad<0x4E>(Gm[i][j]);
-                if (grp >= 2) Gm[i][j] += t2;
-                if constexpr (ELEMPAR) {
-                    const double t2l = dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
-                    if (grp >= 2) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t2l;
-                }
+                Gm[i][j] = fma(dpp_quad<0x4E>(Gm[i][j]), m2, Gm[i][j]);
+                if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                    fma(dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m2, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
             }
+        if (__builtin_amdgcn_ballot_w64(grp >= 3) != 0ull) {   // uniform over the wavefront
+            const double m3 = grp >= 3 ? 1.0 : 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+            for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double t3 = dpp_xor4(Gm[i][j]);
-                if (grp >= 3) Gm[i][j] += t3;
-                if constexpr (ELEMPAR) {
-                    const double t3l = dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
-                    if (grp >= 3) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] += t3l;
+                for (int j = 0; j < D; ++j) {
+                    Gm[i][j] = fma(dpp_xor4(Gm[i][j]), m3, Gm[i][j]);
+                    if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                        fma(dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m3, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
                 }
-            }
+        }
         // The requests of this position (vertices of the next block, records and lane words of the one after) are consumed HERE,
         // in front of the stores: loads and stores share one in-order counter, and behind the (branch-guarded) stores the wait
         // for these loads becomes vmcnt(0) -- every position then waited for its own nine stores per lane to drain, a write

@@ -206,6 +206,18 @@ class Engine:
     def assemble_matrix_async(self, values_t, flags):
         self._check(self._lib.fh_assemble_matrix_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags))
 
+    def time_assembly(self, values_t, flags, reps=3):
+        """fh_time_assembly_dev: milliseconds per assembly (events on the context's stream), after one untimed assembly"""
+        ms = C.c_double(0.0)
+        self._check(self._lib.fh_time_assembly_dev(self._h, C.c_void_p(values_t.data_ptr()), flags, int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def tune_placement(self, values_t, flags, tries=3):
+        """fh_tune_placement_dev: the better of several allocations of the library's own streamed buffer; (ms before, ms after)"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.fh_tune_placement_dev(self._h, C.c_void_p(values_t.data_ptr()), flags, int(tries), C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def assemble_matrix_rows_async(self, values_t, flags, node_begin, node_end):
         """rows of the nodes [node_begin, node_end) only, with the context's second set of tables (fh_assemble_matrix_rows_async_dev)"""
         self._check(self._lib.fh_assemble_matrix_rows_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags,

@@ -210,6 +210,15 @@ int fh_assemble_matrix_dev(fh_ctx*, double* values_dev, int flags, uint64_t* fai
 /* same, but only enqueues; check the status later with fh_poll_status (no host sync; for timing loops) */
 int fh_assemble_matrix_async_dev(fh_ctx*, double* values_dev, int flags);
 int fh_poll_status(fh_ctx*, uint64_t* failed_element);
+/* Placement of the streamed buffers.  On MI355X the time of the owner-computes kernels follows how the large buffers they stream
+ * through happen to be backed by device memory: the same context and arguments run at one of several levels up to 10 % apart, for
+ * the life of an allocation, and no HIP call chooses the backing.  fh_time_assembly_dev times `reps` assemblies (after one untimed)
+ * with events on the context's stream; a caller uses it to keep the better of several allocations of its `values`.
+ * fh_tune_placement_dev does the same for the library's own large buffer (the element records of the affine-element kernel): up to
+ * `tries` re-allocations, each timed with three assemblies, the fastest kept.  Needs FH_ASSEMBLE_OVERWRITE (the trial assemblies
+ * write `values`).  No reference counterpart. */
+int fh_time_assembly_dev(fh_ctx*, double* values_dev, int flags, int reps, double* ms_per_assembly);
+int fh_tune_placement_dev(fh_ctx*, double* values_dev, int flags, int tries, double* ms_before, double* ms_after);
 /* The CSR rows of the nodes [node_begin, node_end) only (FH_SCATTER_GATHER), whatever the context's own row range is: the
  * context keeps a second set of owner-computes tables for this range next to its own (mesh, pattern, quadrature and operator
  * are shared, nothing is duplicated), built on first use and rebuilt when the range or the context's configuration changes.

@@ -208,3 +208,35 @@ def test_affine_singular_element_reported(engine):
         fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
     assert ei.value.element == 0
     assert engine.last_kernel_name() == "k_affine_rows"
+
+
+@pytest.mark.gpu
+def test_placement_tuning_keeps_the_matrix():
+    """fh_time_assembly_dev / fh_tune_placement_dev (round 3): re-allocating the element records and timing real assemblies must leave
+    K exactly as it was (the kernel is reproducible bit for bit), and the tuning refuses to run without FH_ASSEMBLE_OVERWRITE."""
+    import torch
+
+    mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, 10)
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    lame = fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2))
+    eng = fa.Engine(0)
+    try:
+        (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial()))
+         .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(lame)).with_u(None).build())
+        nnz = eng.build_pattern()
+        flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+        ref = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(ref, flags)
+        assert eng.last_kernel_name() == "k_affine_rows"
+        vals = torch.zeros_like(ref)
+        ms = eng.time_assembly(vals, flags, reps=2)
+        assert ms > 0.0 and torch.equal(vals, ref)
+        before, after = eng.tune_placement(vals, flags, tries=3)
+        assert 0.0 < after <= before
+        vals.zero_()
+        eng.assemble_matrix(vals, flags)
+        assert torch.equal(vals, ref)
+        with pytest.raises(fa.FenrisError):
+            eng.tune_placement(vals, fa.SCATTER_GATHER, tries=1)
+    finally:
+        eng.close()

@@ -297,7 +297,7 @@ def probe_placement(eng, values, flags, torch, tries):
     seen = [eng.time_assembly(values, flags)]
     best, rejected = values, []
     for _ in range(tries):
-        cand = torch.empty_like(values)          # the previous candidates stay allocated: a new one gets other memory
+        cand = torch.zeros_like(values)          # the previous candidates stay allocated: a new one gets other memory
         t = eng.time_assembly(cand, flags)
         if t < 0.98 * min(seen):
             rejected.append(best)
@@ -489,7 +489,8 @@ def main():
         t0 = time.perf_counter()  # N > 1: engines, masks and patterns of this rank
         # interface rows first, their RCCL transfer overlapped with the rest (owner-computes only)
         slab_asm = fd.SlabAssembly(slab, configure, device=local_rank, overlap=(args.scatter == "gather" and not args.no_overlap),
-                                   stream=stream, exchange=("torch" if share else args.exchange))
+                                   stream=stream, exchange=("torch" if share else args.exchange),
+                                   placement_tries=(args.placement_tries if args.scatter == "gather" else 0))
         eng, values, nnz = slab_asm.main, slab_asm.values, slab_asm.values.numel()
         E = slab.num_own_elements()  # numerics over own (+ halo in "halo" mode) elements, pattern over own + halo
         if rccl is not None and hasattr(slab_asm.exchange, "size"):
@@ -499,7 +500,7 @@ def main():
     if args.scatter == "colored":
         eng.color()
     flags |= fa.ASSEMBLE_OVERWRITE
-    placement = None
+    placement = slab_asm.placement if slab_asm is not None else None   # N > 1: rank 0's (every rank probes its own buffers)
     if world == 1 and args.placement_tries > 0 and args.scatter == "gather":
         values, placement = probe_placement(eng, values, flags, torch, args.placement_tries)
 

@@ -255,7 +255,7 @@ class SlabAssembly:
     rows are added at the end.  In "halo" mode nothing is exchanged."""
 
     def __init__(self, slab: SlabProblem, configure, device: int = 0, overlap: bool = True, group=None, stream=None,
-                 exchange: str = "torch"):
+                 exchange: str = "torch", placement_tries: int = 0):
         import torch
 
         from .assembly import Engine
@@ -273,6 +273,28 @@ class SlabAssembly:
             # (fh_assemble_matrix_rows_async_dev); the nodes below the plane carry no active element
             self.split = int(slab.send_nodes[1])
             self.main.set_row_range(self.split, slab.mesh.num_nodes())
+        self.placement = None
+        if placement_tries > 0:
+            # the better of several allocations of this rank's values and of the library's record buffer (fh_time_assembly_dev /
+            # fh_tune_placement_dev: the time of the owner-computes kernels follows the physical memory behind them); rank-local,
+            # no collective, before anything is bound to the array
+            from .assembly import ASSEMBLE_OVERWRITE, SCATTER_GATHER
+
+            fl = SCATTER_GATHER | ASSEMBLE_OVERWRITE
+            seen, rejected = [self.main.time_assembly(self.values, fl)], []
+            for _ in range(placement_tries):
+                cand = torch.zeros_like(self.values)
+                t = self.main.time_assembly(cand, fl)
+                if t < 0.98 * min(seen):
+                    rejected.append(self.values)
+                    self.values = cand
+                else:
+                    rejected.append(cand)
+                seen.append(t)
+            before, after = self.main.tune_placement(self.values, fl, placement_tries)
+            del rejected
+            torch.cuda.empty_cache()
+            self.placement = {"values_ms_seen": [round(x, 4) for x in seen], "records_ms_before": round(before, 4), "records_ms_after": round(after, 4)}
         if overlap and (slab.send_nodes is not None or slab.recv_nodes is not None):
             self.comm = torch.cuda.Stream(device=device)
         if exchange == "abi":   # RCCL inside the library (fh_group_*); the torch path stays the test harness

@@ -61,6 +61,7 @@ _SIGS = {
     "fh_add_mapped_vector_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p]),
     "fh_add_mapped_vector_sdim_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_uint64, C.c_void_p]),
     "fh_group_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "fh_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "fh_time_assembly_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "fh_tune_placement_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fh_group_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

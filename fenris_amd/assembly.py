@@ -206,6 +206,10 @@ class Engine:
     def assemble_matrix_async(self, values_t, flags):
         self._check(self._lib.fh_assemble_matrix_async_dev(self._h, C.c_void_p(values_t.data_ptr()), flags))
 
+    def set_option(self, name, value):
+        """fh_set_option: a FENRIS_HIP_* switch of this context (value None removes it)"""
+        self._check(self._lib.fh_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
     def time_assembly(self, values_t, flags, reps=3):
         """fh_time_assembly_dev: milliseconds per assembly (events on the context's stream), after one untimed assembly"""
         ms = C.c_double(0.0)

@@ -1917,6 +1917,16 @@ bool fh_internal_sizes(const fh_ctx* c, uint64_t* num_nodes, int* solution_dim) 
 extern "C" {
 const char* fh_last_kernel_name(const fh_ctx* c) { return c ? c->last_kernel.c_str() : ""; }
 
+// A tuning switch of THIS context (the FENRIS_HIP_* names, read by fh_create from the environment): set or, with value == NULL,
+// removed.  Switches that select a launch variant take effect at the next call; those that shape tables need the tables rebuilt
+// (fh_set_operator / fh_set_mesh).  For experiments that compare variants inside one context, on the same buffers -- the only
+// comparison that resolves less than ~4 %.
+int fh_set_option(fh_ctx* c, const char* name, const char* value) {
+    if (!c || !name) return FH_BAD_ARGUMENT;
+    if (value) c->env_vars[name] = value; else c->env_vars.erase(name);
+    return FH_OK;
+}
+
 int fh_set_stream(fh_ctx* c, void* s) {
     if (!c) return FH_BAD_ARGUMENT;
     DevGuard dev_guard_(c->device);

@@ -217,6 +217,9 @@ int fh_poll_status(fh_ctx*, uint64_t* failed_element);
  * fh_tune_placement_dev does the same for the library's own large buffer (the element records of the affine-element kernel): up to
  * `tries` re-allocations, each timed with three assemblies, the fastest kept.  Needs FH_ASSEMBLE_OVERWRITE (the trial assemblies
  * write `values`).  No reference counterpart. */
+/* A tuning switch of this context (a FENRIS_HIP_* name as fh_create reads them from the environment): set, or removed with value ==
+ * NULL.  Launch-variant switches act at the next call.  For comparing variants inside ONE context on the same buffers. */
+int fh_set_option(fh_ctx*, const char* name, const char* value);
 int fh_time_assembly_dev(fh_ctx*, double* values_dev, int flags, int reps, double* ms_per_assembly);
 int fh_tune_placement_dev(fh_ctx*, double* values_dev, int flags, int tries, double* ms_before, double* ms_after);
 /* The CSR rows of the nodes [node_begin, node_end) only (FH_SCATTER_GATHER), whatever the context's own row range is: the

@@ -238,5 +238,11 @@ def test_placement_tuning_keeps_the_matrix():
         assert torch.equal(vals, ref)
         with pytest.raises(fa.FenrisError):
             eng.tune_placement(vals, fa.SCATTER_GATHER, tries=1)
+        # a launch variant switched inside the context (fh_set_option): the barrier-free ring form gives the same bits
+        eng.set_option("FENRIS_HIP_AFFINE_RING", 1)
+        vals.zero_()
+        eng.assemble_matrix(vals, flags)
+        assert torch.equal(vals, ref)
+        eng.set_option("FENRIS_HIP_AFFINE_RING", None)
     finally:
         eng.close()

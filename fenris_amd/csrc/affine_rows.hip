@@ -188,9 +188,17 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         const int npieces = NPC * T.us;
         auto slot_of = [&](int r) { return min(lane + 64 * r, npieces - 1) / NPC; };
         auto piece_of = [&](int r) { const int i = min(lane + 64 * r, npieces - 1); return i - (i / NPC) * NPC; };
-        auto load_elem = [&](int p, int r) { return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))]; };
+        // (profiling, instrumented instantiation: 256 no element-id fetches -- the record of slot s of position p is taken from element
+        // 32 p + s --, 512 only the first of the three record rounds)
+        auto load_elem = [&](int p, int r) {
+            if (DBG && (ablate & 256)) return (int)(((unsigned)p * 32u + (unsigned)slot_of(r)) & 0x7fffffu);
+            return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))];
+        };
         // ablate 128 (profiling): every record from the first 4096 (cache-resident): the same instruction stream without the HBM reads
-        auto load_piece = [&](int e, int r) { return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)((DBG && (ablate & 128)) ? (max(e, 0) & 4095) : max(e, 0)) * NPC + piece_of(r)]; };
+        auto load_piece = [&](int e, int r) {
+            if (DBG && (ablate & 512) && r > 0) return f64x2{0.0, 0.0};
+            return reinterpret_cast<const f64x2*>(T.rec)[(size_t)(unsigned)((DBG && (ablate & 128)) ? (max(e, 0) & 4095) : max(e, 0)) * NPC + piece_of(r)];
+        };
         auto park_piece = [&](int parity, int r, f64x2 v) {
             if (lane + 64 * r < npieces) reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + slot_of(r)) * GW)[piece_of(r)] = v;
         };
@@ -647,6 +655,8 @@ template <int OP>
 static auto affine_rows_pick_variant(int depth, int nstore, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
     // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
     if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2>(ow, dbg) : affine_rows_pick<OP, 2, 2>(ow, dbg);
+    if (depth >= 4) return affine_rows_pick<OP, 4, 1>(ow, dbg);
+    if (depth == 3) return affine_rows_pick<OP, 3, 1>(ow, dbg);
     return depth <= 1 ? affine_rows_pick<OP, 1, 1>(ow, dbg) : affine_rows_pick<OP, 2, 1>(ow, dbg);
 }
 

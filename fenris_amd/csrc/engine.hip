@@ -1286,9 +1286,9 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    // workgroups per CU, measured: elasticity 3 (2: 5.4 ms, 4: 5.5 ms against 4.9 at 216^3 -- more store streams than the
-    // write path likes), Laplace 4 (rows of 216 bytes per node: latency, not stores: 0.39 -> 0.36 ms at 128^3)
-    const size_t cap = (c->op == FH_LAPLACE) ? 4 : 3;
+    // workgroups per CU, measured inside one context on the same buffers (scripts/ab_in_context.py, C3): elasticity 2 (0.562 ms; 3: 0.594,
+    // 4: 0.603, 5: 0.585), Laplace 4
+    const size_t cap = (c->op == FH_LAPLACE) ? 4 : 2;
     const int per_cu = std::max(1, (int)std::min<size_t>(cap, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = std::min(c->npos_gen, dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     auto kern = k_gather_rows_tet4<OP, ELEMPAR>;

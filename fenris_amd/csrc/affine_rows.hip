@@ -655,8 +655,6 @@ template <int OP>
 static auto affine_rows_pick_variant(int depth, int nstore, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
     // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
     if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2>(ow, dbg) : affine_rows_pick<OP, 2, 2>(ow, dbg);
-    if (depth >= 4) return affine_rows_pick<OP, 4, 1>(ow, dbg);
-    if (depth == 3) return affine_rows_pick<OP, 3, 1>(ow, dbg);
     return depth <= 1 ? affine_rows_pick<OP, 1, 1>(ow, dbg) : affine_rows_pick<OP, 2, 1>(ow, dbg);
 }
 

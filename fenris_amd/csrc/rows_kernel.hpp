@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         uint4 lane_nxt = load_lane(p + 1);
         const int U = (p == p_begin) ? hc.U : hc.k0;
         // phase B: one lane per new slot (one quadrature point)
-        if (tid < U) {
+        if (tid < U && !(a.ablate & 1)) {   // (FENRIS_HIP_ABLATE bit 0, profiling: no phase B)
             const int u = (int)slot_b[tid];
             prologue<EK, OP, WHAT_MATRIX, true, true>(a, L, lds, lds_i, u, 0, T.elem + (size_t)p * T.us + u, 0, sqw);
         }
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             asm volatile("" : "+v"(av[sl]), "+v"(az[sl]), "+v"(bv[sl]), "+v"(bz[sl]));
             if constexpr (tt + AHEAD < TL) fetcht(std::integral_constant<int, tt + AHEAD>{});
             __builtin_amdgcn_sched_barrier(0);
-            if (tt < nterms) {  // unused terms read slot 0: never let their values in
+            if (tt < nterms && !(a.ablate & 2)) {  // unused terms read slot 0: never let their values in  (ablate bit 1: no products)
                 const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
                 const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         // latency per position (round 3: C3 0.63 -> see DESIGN 3.4).  X is read by phase B only, which lies behind the barrier above.
         if (have_next) park(nxt, parity ^ 1);
         asm volatile("" : "+v"(nn.w), "+v"(nn.conn[0]), "+v"(nn.conn[SLOTS - 1]), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
-        if ((wl >> 16) & 1u) {
+        if (((wl >> 16) & 1u) && !(a.ablate & 4)) {   // (ablate bit 2: no global stores)
             const int il = (int)((wl >> 7) & 15u), pos = (int)(wl & 127u);
             const int cnt = noff_l[il + 1] - noff_l[il];
             double* base = a.vals + (size_t)S * S * (size_t)(unsigned)noff_l[T.nbs + 1 + il] + S * pos;

@@ -182,6 +182,53 @@ def measure_traffic(argv_child, kernel_substrs, timeout_s=240):
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, out
 
 
+def start_traffic_helper(argv_child, kernel_substrs):
+    """A child process started BEFORE this one touches a GPU; it waits on its stdin and, when told to, runs the two PMC passes
+    (measure_traffic) and prints their result.  This way the passes come AFTER the timed region -- with them in front the device
+    entered the timed region in a slower state (five runs on one box type: 4.80 - 4.88 ms after the passes, 4.62 - 4.68 without them;
+    profiles/r03_affine_experiments.txt 11) -- and still no process that has initialised the GPU ever spawns another."""
+    env = dict(os.environ, FENRIS_BENCH_CHILD="1")
+    return subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-helper",
+                             json.dumps({"child": argv_child, "kernels": list(kernel_substrs)})],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+
+
+def traffic_helper_main(spec):
+    """body of the helper process: never imports torch, never touches the GPU itself"""
+    spec = json.loads(spec)
+    line = sys.stdin.readline().strip()
+    if line != "go":
+        return
+    t0 = time.perf_counter()
+    try:
+        traffic, detail = measure_traffic(spec["child"], spec["kernels"])
+    except Exception as exc:  # the profiler must never take the benchmark down
+        traffic, detail = None, {"error": repr(exc)}
+    if detail is not None:
+        detail["kernels"] = spec["kernels"]
+        detail["seconds"] = time.perf_counter() - t0
+    print(json.dumps({"traffic": traffic, "detail": detail}), flush=True)
+
+
+def finish_traffic_helper(helper, go, timeout_s=600):
+    """tell the helper to run (or to leave), collect (traffic, detail)"""
+    if helper is None:
+        return None, None
+    try:
+        out, _ = helper.communicate("go\n" if go else "skip\n", timeout=timeout_s)
+        for line in out.splitlines():
+            if line.startswith("{"):
+                d = json.loads(line)
+                return d["traffic"], d["detail"]
+        return None, ({"error": "traffic helper printed nothing"} if go else None)
+    except Exception as exc:
+        try:
+            helper.kill()
+        except OSError:
+            pass
+        return None, {"error": repr(exc)}
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher (WORLD_SIZE unset): start `torch.distributed.run` with N ranks as a CHILD process (this
     process has not touched a GPU), relay rank 0's JSON line, exit with the child's code.  Refuses when the box has fewer GPUs."""
@@ -349,6 +396,8 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--traffic-helper":
+        return traffic_helper_main(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -390,9 +439,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    # ---- HBM traffic of the dominant kernel: two PMC passes of this command as child processes, BEFORE this process makes
-    # any torch.cuda call (N = 1, rank 0 only)
-    traffic, traffic_detail = None, None
+    # ---- HBM traffic of the dominant kernel: two PMC passes of this command as child processes of a helper that is started HERE,
+    # before this process makes any torch.cuda call, and told to run after the timed region (N = 1, rank 0 only)
+    traffic, traffic_detail, helper = None, None, None
     if world == 1 and not args.no_traffic and os.environ.get("FENRIS_BENCH_CHILD") != "1":
         child = ["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--no-module-warmup",
                  "--scatter", args.scatter]
@@ -401,16 +450,10 @@ def main():
         aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
         knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_gather_pipelined",),
                   "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
-        t0 = time.perf_counter()
-        os.environ["FENRIS_BENCH_CHILD"] = "1"
         try:
-            traffic, traffic_detail = measure_traffic(child, knames)
-        except Exception as exc:  # the profiler must never take the benchmark down
-            traffic, traffic_detail = None, {"error": repr(exc)}
-        del os.environ["FENRIS_BENCH_CHILD"]
-        if traffic_detail is not None:
-            traffic_detail["kernels"] = list(knames)
-            traffic_detail["seconds"] = time.perf_counter() - t0
+            helper = start_traffic_helper(child, knames)
+        except OSError as exc:
+            traffic_detail = {"error": repr(exc)}
 
     import numpy as np
     import torch
@@ -575,10 +618,6 @@ def main():
                "kernel": eng.last_kernel_name(), "kernel_avg_ms": kernel_avg_ms,
                "kernel_min_ms": kernel_ms[0], "algorithmic_bytes_per_launch": abytes,
                "bytes_per_element": abytes / E}
-        if traffic_detail is not None:
-            hbm["traffic_source"] = ("two rocprofv3 --pmc child passes of this command (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, "
-                                     "averaged over the dispatches of the dominant kernel)")
-            hbm["traffic_detail"] = traffic_detail
         if cfg == "c4":
             # compute-bound configuration: the two weighted Gram products of the dense element matrix,
             # 2 (3n)^2 nq 2 flop, plus the trace term 6 n^2 nq flop, on the fp64 matrix cores; the HBM figures go along
@@ -622,6 +661,22 @@ def main():
                 except Exception as exc:  # a secondary line must never take the headline down
                     sec[name] = {"error": repr(exc)}
             out["secondary"] = sec
+        # ---- now the PMC passes (the helper started at the top runs them; this process only waits, its GPU work is done)
+        if helper is not None:
+            try:
+                eng.close()
+            except Exception:
+                pass
+            values = None
+            torch.cuda.empty_cache()
+            traffic, traffic_detail = finish_traffic_helper(helper, True)
+        hbm["traffic"] = traffic
+        if "hbm" in out["roofline"]:
+            out["roofline"]["traffic"] = traffic
+        if traffic_detail is not None:
+            hbm["traffic_source"] = ("two rocprofv3 --pmc child passes of this command, run after the timed region (FETCH_SIZE x 2 + "
+                                     "WRITE_SIZE, KiB -> bytes, averaged over the dispatches of the dominant kernel)")
+            hbm["traffic_detail"] = traffic_detail
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c["cpu_kind"])
         else:

@@ -127,9 +127,11 @@ __device__ __forceinline__ void pipeline_consume(F&& f) {
 // VCOMPACT (WHAT_VECTOR only): the point record is the 3 x 3 matrix  M = s P J^-T  instead of the N physical gradients and
 // s P -- the element vector is  f_n = sum_q M_q grad_ref_n(xi_q)  with the reference gradients from the (constant) table;
 // grad u comes from  J^-T (sum_n grad_ref_n u_n^T), so the physical gradients are never formed
-template <int EK, int OP, int WHAT, bool PLANAR = false, bool NODEMAJOR = false, bool VCOMPACT = false>
+// XIND (planar Tet4, rows_kernel.hpp): the vertices of the element are not a row of X but four entries of a table of the position's
+//   UNIQUE vertices (32 bytes each: [x y | z -]) at L.o_X, selected by the four bytes of `xind`
+template <int EK, int OP, int WHAT, bool PLANAR = false, bool NODEMAJOR = false, bool VCOMPACT = false, bool XIND = false>
 __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double* lds, const int* lds_i, int u, int q,
-                                         const int* elem_id, int qslot = -1, double sqw = 0.0) {
+                                         const int* elem_id, int qslot = -1, double sqw = 0.0, unsigned xind = 0u) {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
@@ -157,25 +159,38 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         // per step, two steps in flight: 24 wide fetches instead of 48 narrow ones
         static_assert(!PLANAR || (NG == N && N % 2 == 0 && D == 3), "planar phase B: iso-parametric, even node count, 3D");
         const unsigned xa = (unsigned)(unsigned long long)X, ga = (unsigned)(unsigned long long)gg;
+        const unsigned xtab = (unsigned)(unsigned long long)(lds + L.o_X);
         constexpr int NS = N / 2;  // steps
         f64x2 xf[NS][3], gf[NS][3];
+        double xz[XIND ? NS : 1][2];
         auto fetch2 = [&](auto sk) {
             constexpr int st = decltype(sk)::value;
-            xf[st][0] = lds_read_f64x2<(6 * st) * 8>(xa);
-            xf[st][1] = lds_read_f64x2<(6 * st + 2) * 8>(xa);
-            xf[st][2] = lds_read_f64x2<(6 * st + 4) * 8>(xa);
+            if constexpr (XIND) {
+                const unsigned a0 = xtab + 32u * ((xind >> (16 * st)) & 255u), a1 = xtab + 32u * ((xind >> (16 * st + 8)) & 255u);
+                xf[st][0] = lds_read_f64x2<0>(a0);
+                xz[st][0] = lds_read_f64_at<16>(a0);
+                xf[st][1] = lds_read_f64x2<0>(a1);
+                xz[st][1] = lds_read_f64_at<16>(a1);
+            } else {
+                xf[st][0] = lds_read_f64x2<(6 * st) * 8>(xa);
+                xf[st][1] = lds_read_f64x2<(6 * st + 2) * 8>(xa);
+                xf[st][2] = lds_read_f64x2<(6 * st + 4) * 8>(xa);
+            }
             gf[st][0] = lds_read_f64x2<(6 * st) * 8>(ga);
             gf[st][1] = lds_read_f64x2<(6 * st + 2) * 8>(ga);
             gf[st][2] = lds_read_f64x2<(6 * st + 4) * 8>(ga);
         };
+        constexpr int PER = XIND ? 7 : 6;   // LDS fetches of a step
         fetch2(std::integral_constant<int, 0>{});
         fetch2(std::integral_constant<int, 1>{});
         pipeline_consume<NS, D>([&](auto sk) {
             constexpr int st = decltype(sk)::value;
-            lds_wait<(st + 1 < NS) ? 6 : 0>();
+            lds_wait<(st + 1 < NS) ? PER : 0>();
             if constexpr (st + 2 < NS) fetch2(std::integral_constant<int, st + 2>{});
             __builtin_amdgcn_sched_barrier(0);
-            const double xe[2][3] = {{xf[st][0].x, xf[st][0].y, xf[st][1].x}, {xf[st][1].y, xf[st][2].x, xf[st][2].y}};
+            if constexpr (XIND) asm volatile("" : "+v"(xz[XIND ? st : 0][0]), "+v"(xz[XIND ? st : 0][1]));
+            const double xe[2][3] = {{xf[st][0].x, xf[st][0].y, XIND ? xz[XIND ? st : 0][0] : xf[st][1].x},
+                                     {XIND ? xf[st][1].x : xf[st][1].y, XIND ? xf[st][1].y : xf[st][2].x, XIND ? xz[XIND ? st : 0][1] : xf[st][2].y}};
             const double ge[2][3] = {{gf[st][0].x, gf[st][0].y, gf[st][1].x}, {gf[st][1].y, gf[st][2].x, gf[st][2].y}};
 #pragma unroll
             for (int h = 0; h < 2; ++h)

@@ -337,6 +337,7 @@ struct fh_ctx {
     bool part_rows_only = false;  // tables that only the row-owner Tet4 kernel can use (locality order and / or larger blocks)
     int rows_try = 0;           // block sizes tried for them: 0 = nine nodes / 256 entries, 1 = seven / 224, then the standard form
     DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
+    DevBuf<int> r_vconn;        //                                     unique vertices + slot words per position (Tet4)
     int r_rw = 0, r_ls = 256;
     bool has_rows = false;
     int p_rw = 0;
@@ -426,7 +427,7 @@ struct fh_ctx {
 
 // Everything build_partition produces (and the row range it was produced for), as a detachable unit.
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
-    X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_rw) X(r_ls)  \
+    X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(npos_gen)       \
     X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
@@ -1250,6 +1251,14 @@ int build_partition(fh_ctx* c) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     if (bad != 2) break;  // 2: only the stride was too small
                 }
+                if (bad == 0) {   // the position's unique vertices and the slot words that index them
+                    HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                    HIP_TRY(c, c->r_vconn.alloc((size_t)npg * (ROWS_TET4_VMAX + us)));
+                    hipLaunchKernelGGL(k_build_row_verts_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_conn.p, us, npg, c->r_vconn.p, st.p);
+                    HIP_TRY(c, hipGetLastError());
+                    HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                }
                 c->has_rows = bad == 0;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));  // row_real is released at the end of this scope
                 if (c->env("FENRIS_HIP_VERBOSE"))
@@ -1282,7 +1291,9 @@ int build_partition(fh_ctx* c) {
 
 template <int OP, bool ELEMPAR = false>
 int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
-    const size_t lds = make_layout<FH_TET4, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 1, 0, 2).bytes();
+    // the layout's integers + two parities of the record + the slot words
+    const size_t lds = make_layout<FH_TET4, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 1, 0, 2).bytes() +
+                       sizeof(int) * (size_t)(2 * T.rw + T.us + 4);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
@@ -1291,7 +1302,7 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     const size_t cap = (c->op == FH_LAPLACE) ? 4 : 2;
     const int per_cu = std::max(1, (int)std::min<size_t>(cap, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int grid = std::min(c->npos_gen, dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
-    auto kern = k_gather_rows_tet4<OP, ELEMPAR>;
+    auto kern = a.trace ? k_gather_rows_tet4<OP, ELEMPAR, true> : k_gather_rows_tet4<OP, ELEMPAR>;   // FENRIS_HIP_TRACE: instrumented twin
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (c->env("FENRIS_HIP_VERBOSE"))
@@ -1640,15 +1651,15 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
         // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
         if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pipe_rules) &&
-            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_TRACE")) {
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
             a.fast = 1;
             if (c->nq > 1) {
                 a.qw = c->qw.p + c->nq;
                 a.nq = 1;
             }
-            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
-                         c->r_rw, c->p_cs, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
-            a.ub = c->p_us;
+            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->r_vconn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
+                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
+            a.ub = std::max(c->p_us, 76);   // the X region of the layout (14 doubles per slot) holds the vertex table: 256 x 4 doubles
             a.nb_max = c->p_nbs;
             c->last_kernel += "k_gather_rows";
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);

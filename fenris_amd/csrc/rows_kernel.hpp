@@ -21,17 +21,21 @@ struct RowTablesS {
                          //              | first node-level CSR entry of every node's row (nbs words; the nodes of a block need not be
                          //              consecutive in memory: build_partition may form the blocks in a locality order)
     const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256
-    const int* conn;     // [npos][cs]
+    const int* vconn;    // [npos][256 + us]   the position's UNIQUE vertices (node ids; padded with its first one), then one word per slot:
+                         //              the four bytes index that list (k_build_row_verts_tet4).  A block of nine nodes sees ~180 elements
+                         //              but only ~70 distinct vertices: gathering every (slot, local node) coordinate again at every
+                         //              position was 720 scattered 24-byte fetches and twelve LDS writes per lane
     const int* elem;     // [npos][us]
     const double* slotpar;  // [npos][us][2] (mu, lambda) of the element in each slot (piecewise-constant material), or null
-    int rw, cs, us, nbs, npos, ls;
+    int rw, us, nbs, npos, ls;
 };
+constexpr int ROWS_TET4_VMAX = 256;   // unique vertices per position the tables can express (one per lane)
 
 // ELEMPAR: (mu, lambda) per element: every term carries its element's pair, the block is
 //   sum_e mu_e (tr G_e I + G_e^T) + lambda_e G_e  =  tr(Gmu) I + Gmu^T + Gla   with Gmu = sum mu_e G_e, Gla = sum lambda_e G_e
-template <int OP, bool ELEMPAR = false>
+template <int OP, bool ELEMPAR = false, bool DBG = false>
 __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, const RowTablesS T) {
-    constexpr int EK = FH_TET4, QC = 1, TL = 6, SLOTS = 4;
+    constexpr int EK = FH_TET4, QC = 1, TL = 6;
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, NG = E::NG, S = O::S;
@@ -40,18 +44,18 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
     const Layout L = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, QC, 0, 2);
     double* lds = reinterpret_cast<double*>(smem);
     int* lds_i = reinterpret_cast<int*>(smem + sizeof(double) * (size_t)L.n_doubles);
-    const int tid = threadIdx.x, nt = 256;
+    const int tid = threadIdx.x;
     const int G = gridDim.x;
     stage_tables<EK>(a, L, lds);
 
-    struct Rec { int w; int conn[SLOTS]; };
-    const int npos = T.npos;
+    struct Rec { int w, vid, sw; };   // record word, vertex id and slot word of this lane
+    const int npos = T.npos, vs = ROWS_TET4_VMAX + T.us;
     const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
     auto load_rec = [&](int p, Rec& r) {
         p = min(p, npos - 1);
         r.w = T.rec[(size_t)p * T.rw + min(tid, T.rw - 1)];
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) r.conn[k] = T.conn[(size_t)p * T.cs + min(tid + k * nt, T.cs - 1)];
+        r.vid = T.vconn[(size_t)p * vs + tid];
+        r.sw = T.vconn[(size_t)p * vs + ROWS_TET4_VMAX + min(tid, T.us - 1)];
     };
     // lanes beyond the table's stride re-read its last record and switch themselves off
     auto load_lane = [&](int p) {
@@ -59,22 +63,20 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         if (tid >= T.ls) r.w = 0u;
         return r;
     };
-    double V[SLOTS][D];
+    double V[D];
     auto load_verts = [&](const Rec& r) {
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k)
-#pragma unroll
-            for (int c = 0; c < D; ++c) V[k][c] = a.verts[(size_t)r.conn[k] * D + c];
+        for (int c = 0; c < D; ++c) V[c] = a.verts[(size_t)((a.ablate & 8) ? tid : r.vid) * D + c];   // (ablate bit 3: coalesced stand-in)
     };
     auto rec_base = [&](int parity) { return lds_i + parity * T.rw; };
+    int* const slot_words = lds_i + 2 * T.rw;            // [us]: read by phase B only, like the vertex table
     auto park = [&](const Rec& r, int parity) {
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const int sidx = tid + k * nt;
-            if (sidx < T.cs)
-#pragma unroll
-                for (int c = 0; c < D; ++c) lds[L.o_X + (sidx / NG) * L.xs + (sidx % NG) * D + c] = V[k][c];
-        }
+        f64x2 xy;
+        xy.x = V[0]; xy.y = V[1];
+        double* row = lds + L.o_X + 4 * tid;             // vertex table: 32 bytes per entry, [x y | z -]
+        *reinterpret_cast<f64x2*>(row) = xy;
+        row[2] = V[2];
+        if (tid < T.us) slot_words[tid] = r.sw;
         if (tid < T.rw) rec_base(parity)[tid] = r.w;
     };
     const double sqw = sqrt(a.qw[0]);
@@ -89,10 +91,20 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         lane_cur = load_lane(p);
         load_rec(p + 1, nxt);
         park(cur, 0);
-        asm volatile("" : "+v"(nxt.w), "+v"(nxt.conn[0]), "+v"(nxt.conn[SLOTS - 1]), "+v"(lane_cur.x), "+v"(lane_cur.w));
+        asm volatile("" : "+v"(nxt.w), "+v"(nxt.vid), "+v"(nxt.sw), "+v"(lane_cur.x), "+v"(lane_cur.w));
     }
     __syncthreads();
 
+    // FENRIS_HIP_TRACE (instrumented instantiation): cycles per phase and wavefront, reported by fh_destroy under the pipelined kernel's names
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tr_t = 0;
+    auto stamp = [&](int k) {
+        if constexpr (DBG) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            tr[k] += t - tr_t;
+            tr_t = t;
+        }
+    };
+    if constexpr (DBG) tr_t = __builtin_readcyclecounter();
     int parity = 0;
     for (; p < p_end; ++p, parity ^= 1) {
         const bool have_next = (p + 1) < p_end;
@@ -105,12 +117,16 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         load_rec(p + 2, nn);
         uint4 lane_nxt = load_lane(p + 1);
         const int U = (p == p_begin) ? hc.U : hc.k0;
+        stamp(0);
         // phase B: one lane per new slot (one quadrature point)
         if (tid < U && !(a.ablate & 1)) {   // (FENRIS_HIP_ABLATE bit 0, profiling: no phase B)
             const int u = (int)slot_b[tid];
-            prologue<EK, OP, WHAT_MATRIX, true, true>(a, L, lds, lds_i, u, 0, T.elem + (size_t)p * T.us + u, 0, sqw);
+            prologue<EK, OP, WHAT_MATRIX, true, true, false, true>(a, L, lds, lds_i, u, 0, T.elem + (size_t)p * T.us + u, 0, sqw,
+                                                                   (unsigned)slot_words[u]);
         }
+        stamp(1);
         lds_barrier();
+        stamp(2);
 
         // phase C: G = sum over the lane's terms of h_a h_j^T
         const unsigned wl = lane_cur.w;
@@ -204,12 +220,13 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                         fma(dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m3, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
                 }
         }
+        stamp(3);
         // The requests of this position (vertices of the next block, records and lane words of the one after) are consumed HERE,
         // in front of the stores: loads and stores share one in-order counter, and behind the (branch-guarded) stores the wait
         // for these loads becomes vmcnt(0) -- every position then waited for its own nine stores per lane to drain, a write
         // latency per position (round 3: C3 0.63 -> see DESIGN 3.4).  X is read by phase B only, which lies behind the barrier above.
         if (have_next) park(nxt, parity ^ 1);
-        asm volatile("" : "+v"(nn.w), "+v"(nn.conn[0]), "+v"(nn.conn[SLOTS - 1]), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
+        asm volatile("" : "+v"(nn.w), "+v"(nn.vid), "+v"(nn.sw), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
         if (((wl >> 16) & 1u) && !(a.ablate & 4)) {   // (ablate bit 2: no global stores)
             const int il = (int)((wl >> 7) & 15u), pos = (int)(wl & 127u);
             const int cnt = noff_l[il + 1] - noff_l[il];
@@ -220,22 +237,42 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             if (OP == FH_LAPLACE) {
                 if (a.overwrite) base[0] = tr; else base[0] += tr;
             } else {
+                // a row of the block is 24 bytes at an 8-byte boundary: one 16-byte and one 8-byte store (the 16-byte one needs no
+                // more than the 8-byte alignment), six store instructions per lane instead of nine
+                typedef double f64x2_u8 __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
                     double* row = base + (size_t)(i % S) * S * cnt;
+                    double v[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        double v;
-                        if constexpr (ELEMPAR) v = ((i == j) ? tr : 0.0) + Gm[j][i] + Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)];
-                        else v = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
-                        if (a.overwrite) row[j % S] = v; else row[j % S] += v;
+                        if constexpr (ELEMPAR) v[j] = ((i == j) ? tr : 0.0) + Gm[j][i] + Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)];
+                        else v[j] = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
+                    }
+                    if (a.overwrite) {
+                        f64x2_u8 lo;
+                        lo.x = v[0]; lo.y = v[1];
+                        *reinterpret_cast<f64x2_u8*>(row) = lo;
+                        row[2 % S] = v[2];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) row[j % S] += v[j];
                     }
                 }
             }
         }
         nxt = nn;
         lane_cur = lane_nxt;
+        stamp(4);
         lds_barrier();
+        stamp(5);
+    }
+    if constexpr (DBG) {
+        if (a.trace && (tid & 63) == 0) {
+            unsigned long long* r = a.trace + 7 * (tid >> 6);
+            for (int k = 0; k < 6; ++k) atomicAdd(r + k, tr[k]);
+            atomicAdd(r + 6, 1ull);
+        }
     }
 }
 
@@ -355,6 +392,55 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
     }
     __syncthreads();
     for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
+}
+
+// Unique vertices of every position for the Tet4 kernel (RowTablesS::vconn) from the per-slot connectivity of the pipelined tables
+// (p_conn: [npos][us * 4], node 0 in empty slots).  One wavefront per position: the node ids go through a hash table in LDS, the occupied
+// cells are numbered in table order, every slot gets the four numbers of its nodes.  Which cell a node lands in may depend on the order
+// the lanes arrive (linear probing): only the numbering inside the position's vertex table does, never a value of the matrix.
+// More than ROWS_TET4_VMAX distinct vertices: status bit 2 (the caller keeps the pipelined kernel).
+__global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p_conn, int us, int npos, int* vconn, int* status) {
+    constexpr int H = 2048, CSMAX = 1024;
+    __shared__ int key[H];
+    __shared__ unsigned short cell_of[CSMAX], num[H];
+    const int p = blockIdx.x, lane = threadIdx.x, cs = 4 * us, vs = ROWS_TET4_VMAX + us;
+    const int* conn = p_conn + (size_t)p * cs;
+    int* out = vconn + (size_t)p * vs;
+    for (int i = lane; i < H; i += 64) key[i] = -1;
+    __syncthreads();
+    for (int i = lane; i < cs; i += 64) {
+        const int v = conn[i];
+        unsigned h = ((unsigned)v * 2654435761u) >> 21;   // 11 bits
+        for (;;) {
+            const int old = atomicCAS(&key[h], -1, v);
+            if (old == -1 || old == v) break;
+            h = (h + 1) & (H - 1);
+        }
+        cell_of[i] = (unsigned short)h;
+    }
+    __syncthreads();
+    int total = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < H; base += 64) {
+        const bool occ = key[base + lane] != -1;
+        const unsigned long long m = __ballot(occ);
+        const int idx = total + __popcll(m & below);
+        num[base + lane] = (unsigned short)idx;
+        if (occ && idx < ROWS_TET4_VMAX) out[idx] = key[base + lane];
+        total += __popcll(m);
+    }
+    if (total > ROWS_TET4_VMAX) {
+        if (lane == 0) atomicOr(status, 4);
+        return;
+    }
+    __syncthreads();
+    const int first = (cs > 0) ? conn[0] : 0;
+    for (int i = total + lane; i < ROWS_TET4_VMAX; i += 64) out[i] = first;   // padding: a vertex this position fetches anyway
+    for (int s_ = lane; s_ < us; s_ += 64) {
+        unsigned w = 0;
+        for (int g = 0; g < 4; ++g) w |= (unsigned)num[cell_of[4 * s_ + g]] << (8 * g);
+        out[ROWS_TET4_VMAX + s_] = (int)w;
+    }
 }
 
 }  // namespace fenris_hip

@@ -91,6 +91,7 @@ _SIGS = {
     "fh_assemble_matrix": (C.c_int, [C.c_void_p, f64p, C.c_int, u64p]),
     "fh_assemble_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, u64p]),
     "fh_assemble_matrix_async_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fh_assemble_vector_async_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fh_poll_status": (C.c_int, [C.c_void_p, u64p]),
     "fh_assemble_matrix_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, u64p]),
     "fh_assemble_matrix_rows_async_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]),

@@ -244,6 +244,10 @@ class Engine:
             rc = self._lib.fh_assemble_vector(self._h, _ffi.fp(out), C.byref(failed))
         self._check(rc, failed)
 
+    def assemble_vector_async(self, out):
+        """fh_assemble_vector_async_dev: enqueue only (device tensor); poll_status() reports a singular element"""
+        self._check(self._lib.fh_assemble_vector_async_dev(self._h, C.c_void_p(out.data_ptr())))
+
     def assemble_source_vector(self, out, solution_dim, g=None, values=None):
         """fh_assemble_source_vector(_dev): out += sum_q w |det J| f phi (source.rs:219-278)"""
         gp = _ffi.fp(np.ascontiguousarray(g, dtype=np.float64)) if g is not None else None

@@ -317,8 +317,12 @@ __global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
 
 // source vector of the small iso-parametric elements (local/source.rs:159-278): f_n = sum_q w |det J| phi_n(xi_q) f(x_q), with
 // f = density_q g (GravitySource, fenris-solid/src/gravity_source.rs:57-65) or values sampled by the caller.  fe[a][e][c].
-template <int D, int S, int N>
-__global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const double* g, const double* values, double* fe) {
+// FACT (GravitySource: f = density_q g with one g for the whole mesh): the element pass leaves the SCALAR  m_n = sum_q w |det J| phi_n rho_q
+// per local node (fe[a][e], a third of the scratch traffic of a three-component vector) and the node sum multiplies by g:
+// f_n = g sum m_n -- the same numbers as sum_q (w |det J| phi_n)(rho_q g) up to the rounding of the products.
+struct SourceG { double v[3]; };   // by value: no device buffer, no copy, no synchronisation per call
+template <int D, int S, int N, bool FACT>
+__global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const SourceG g, const double* values, double* fe) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.num_elements) return;
     double X[N][D];
@@ -328,14 +332,15 @@ __global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const do
 #pragma unroll
         for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd * D + i];
     }
-    double f[N][S];
+    constexpr int SF = FACT ? 1 : S;
+    double f[N][SF];
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
-        for (int k = 0; k < S; ++k) f[n][k] = 0.0;
-    double gv[S];
+        for (int k = 0; k < SF; ++k) f[n][k] = 0.0;
+    double gv[SF];
 #pragma unroll
-    for (int k = 0; k < S; ++k) gv[k] = values ? 0.0 : ep_const(g)[k];
+    for (int k = 0; k < SF; ++k) gv[k] = FACT ? 1.0 : (values ? 0.0 : g.v[k]);
     const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[e] * a.nq * 2 : nullptr;
     for (int q = 0; q < a.nq; ++q) {
         const ep_table G = ep_const(a.ggeom) + (size_t)q * N * D;
@@ -353,40 +358,45 @@ __global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const do
                 for (int i = 0; i < D; ++i) J[i][j] = fma(X[n][i], gg, J[i][j]);
             }
         const double wd = ep_const(a.qw)[q] * fabs(det_small<D>(J));
-        double fc[S];
-        if (values) {
+        double fc[SF];
+        if (!FACT && values) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) fc[k] = values[((size_t)e * a.nq + q) * S + k];
+            for (int k = 0; k < SF; ++k) fc[k] = values[((size_t)e * a.nq + q) * S + k];
         } else {
             const double rho = par_e ? par_e[2 * q] : (a.qparams ? ep_const(a.qparams)[2 * q] : 0.0);
 #pragma unroll
-            for (int k = 0; k < S; ++k) fc[k] = gv[k] * rho;
+            for (int k = 0; k < SF; ++k) fc[k] = gv[k] * rho;
         }
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             const double t = wd * ep_const(a.phiref)[(size_t)q * N + n];
 #pragma unroll
-            for (int k = 0; k < S; ++k) f[n][k] = fma(t, fc[k], f[n][k]);
+            for (int k = 0; k < SF; ++k) f[n][k] = fma(t, fc[k], f[n][k]);
         }
     }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-        double* dst = fe + ((size_t)n * (size_t)a.num_elements + (size_t)e) * S;
+        double* dst = fe + ((size_t)n * (size_t)a.num_elements + (size_t)e) * SF;
 #pragma unroll
-        for (int k = 0; k < S; ++k) dst[k] = f[n][k];
+        for (int k = 0; k < SF; ++k) dst[k] = f[n][k];
     }
 }
 
 // second pass: out[s node + c] += sum over the node's (element, local node) entries, ascending entry order (n2e is sorted
 // element-major like the reference's sequential loop: bitwise reproducible); entry v = e n + a lives at fe[a][e]
-template <int S>
+// SO > 0: the entries are scalars (S = 1) and the node's SO components are  g[c] sum  (k_source_elements<FACT>)
+template <int S, int SO = 0>
 __global__ void __launch_bounds__(256) k_vector_from_elements_soa(int num_nodes, int n, long long E, const unsigned* n2e_off, const unsigned* n2e,
-                                                                  const double* fe, double* out) {
+                                                                  const double* fe, double* out, const SourceG g = SourceG{{0.0, 0.0, 0.0}}) {
+    static_assert(SO == 0 || S == 1, "scaled node sum: scalar entries");
     const int node = blockIdx.x * 256 + threadIdx.x;
     if (node >= num_nodes) return;
-    double acc[S], prev[S];
+    constexpr int SP = SO > 0 ? SO : S;
+    double acc[S], prev[SP];
 #pragma unroll
-    for (int c = 0; c < S; ++c) { acc[c] = 0.0; prev[c] = out[(size_t)node * S + c]; }
+    for (int c = 0; c < S; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < SP; ++c) prev[c] = out[(size_t)node * SP + c];
     const unsigned k0 = n2e_off[node], k1 = n2e_off[node + 1];
     // eight entries at a time: their indices, then all their values, are requested before the first sum (a node of a hexahedral
     // mesh has eight entries: one round trip instead of eight dependent ones); the additions stay in entry order
@@ -409,8 +419,13 @@ __global__ void __launch_bounds__(256) k_vector_from_elements_soa(int num_nodes,
                 for (int c = 0; c < S; ++c) acc[c] += t[j][c];
             }
     }
+    if constexpr (SO > 0) {
 #pragma unroll
-    for (int c = 0; c < S; ++c) out[(size_t)node * S + c] = prev[c] + acc[c];
+        for (int c = 0; c < SO; ++c) out[(size_t)node * SO + c] = fma(g.v[c], acc[0], prev[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < S; ++c) out[(size_t)node * S + c] = prev[c] + acc[c];
+    }
 }
 
 // partial sums in index order by one workgroup: thread t takes the partials t, t + 256, ... in order, then the fixed tree

@@ -412,6 +412,7 @@ struct fh_ctx {
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
     DevBuf<unsigned long long> trace;
+    bool defer_status = false;   // fh_assemble_vector_async_dev: the launches are only enqueued, fh_poll_status reports their errors
 
     int S() const {
         if (ragged) return (int)sdim_ragged;
@@ -754,6 +755,7 @@ int reset_status(fh_ctx* c) {
 }
 
 int read_status(fh_ctx* c, uint64_t* failed) {
+    if (c->defer_status) return FH_OK;   // an _async entry point: nothing is waited for here
     // slot 0: the context's own launches; slot 1: fh_assemble_matrix_rows_dev (reset by the next such call, or here once
     // its error has been reported)
     DevStatus s[2] = {};
@@ -1799,12 +1801,19 @@ static int launch_element_pass(fh_ctx* c, KArgs& a) {
     return rs;
 }
 static int launch_vector_from_elements_soa(fh_ctx* c, int sdim, const double* fe, double* out_dev, const unsigned* adj_off = nullptr,
-                                           const unsigned* adj = nullptr) {
+                                           const unsigned* adj = nullptr, const SourceG* scaled = nullptr) {
     const int grid = (int)(((long long)c->N + 255) / 256);
     if (!adj_off) { adj_off = c->n2e_off.p; adj = c->n2e.p; }
-    if (sdim == 1) hipLaunchKernelGGL(k_vector_from_elements_soa<1>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
-    else if (sdim == 2) hipLaunchKernelGGL(k_vector_from_elements_soa<2>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
-    else hipLaunchKernelGGL(k_vector_from_elements_soa<3>, dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    if (scaled) {   // scalar entries, sdim components g[c] sum
+        if (sdim == 1) hipLaunchKernelGGL((k_vector_from_elements_soa<1, 1>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev, *scaled);
+        else if (sdim == 2) hipLaunchKernelGGL((k_vector_from_elements_soa<1, 2>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev, *scaled);
+        else hipLaunchKernelGGL((k_vector_from_elements_soa<1, 3>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev, *scaled);
+        HIP_TRY(c, hipGetLastError());
+        return FH_OK;
+    }
+    if (sdim == 1) hipLaunchKernelGGL((k_vector_from_elements_soa<1, 0>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    else if (sdim == 2) hipLaunchKernelGGL((k_vector_from_elements_soa<2, 0>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
+    else hipLaunchKernelGGL((k_vector_from_elements_soa<3, 0>), dim3(grid), dim3(256), 0, c->stream, (int)c->N, c->ei.n, (long long)c->E, adj_off, adj, fe, out_dev);
     HIP_TRY(c, hipGetLastError());
     return FH_OK;
 }
@@ -2810,6 +2819,13 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
     if (!c->rs.active) return assemble_vector_single(c, out_dev, failed);
     return rs_walk_accumulating(c, failed, [&](uint64_t* f) { return assemble_vector_single(c, out_dev, f); });
 }
+int fh_assemble_vector_async_dev(fh_ctx* c, double* out_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    c->defer_status = true;
+    const int rc = fh_assemble_vector_dev(c, out_dev, nullptr);
+    c->defer_status = false;
+    return rc;
+}
 static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) {
     int rc = check_ready(c, "fh_assemble_vector", false);
     if (rc) return rc;
@@ -2928,12 +2944,10 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     sa.NG = c->ei.ng;
     sa.phigeom = c->phigeom.p;
     sa.values = values_dev;
-    DevBuf<double> gd;
-    if (!values_dev) {
-        HIP_TRY(c, gd.alloc(sdim));
-        HIP_TRY(c, hipMemcpyAsync(gd.p, g, sizeof(double) * sdim, hipMemcpyHostToDevice, c->stream));
-        sa.g = gd.p;
-    }
+    DevBuf<double> gd;      // device copy of g: only the one-pass scatter below reads it through a pointer
+    SourceG gval{{0.0, 0.0, 0.0}};
+    if (!values_dev)
+        for (uint32_t k = 0; k < sdim; ++k) gval.v[k] = g[k];
     a.vec_out = out_dev;
     a.work_begin = 0;
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
@@ -2958,7 +2972,12 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     if (two_pass && element_pass_covers(c)) {   // one thread per element, element vectors by local node, one thread per node (element_pass.hpp)
         const int ge = (int)((c->E + 255) / 256);
         double* fe = c->fe_scratch.p;
-#define SRC(DV, SV, NV) hipLaunchKernelGGL((k_source_elements<DV, SV, NV>), dim3(ge), dim3(256), 0, c->stream, a, sa.g, sa.values, fe)
+        const bool fact = !values_dev;   // GravitySource: scalar element entries, the node sum multiplies by g (element_pass.hpp)
+#define SRC(DV, SV, NV)                                                                                                                     \
+        do {                                                                                                                                \
+            if (fact) hipLaunchKernelGGL((k_source_elements<DV, SV, NV, true>), dim3(ge), dim3(256), 0, c->stream, a, gval, sa.values, fe); \
+            else hipLaunchKernelGGL((k_source_elements<DV, SV, NV, false>), dim3(ge), dim3(256), 0, c->stream, a, gval, sa.values, fe);     \
+        } while (0)
         const int n = c->ei.n;
         if (D == 2 && n == 4) { if (sdim == 1) SRC(2, 1, 4); else SRC(2, 2, 4); }
         else if (D == 2) { if (sdim == 1) SRC(2, 1, 3); else SRC(2, 2, 3); }
@@ -2967,12 +2986,14 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
 #undef SRC
         HIP_TRY(c, hipGetLastError());
         c->last_kernel = "k_source_elements + k_vector_from_elements_soa";
-        rc = launch_vector_from_elements_soa(c, (int)sdim, fe, out_dev, adj_off, adj);
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // gd is released on return
-        return FH_OK;
+        return launch_vector_from_elements_soa(c, (int)sdim, fe, out_dev, adj_off, adj, fact ? &gval : nullptr);
     }
     if (adj_off) { two_pass = false; a.ke_out = nullptr; }   // (not covered after all: the one-pass scatter)
+    if (!values_dev) {
+        HIP_TRY(c, gd.alloc(sdim));
+        HIP_TRY(c, hipMemcpyAsync(gd.p, g, sizeof(double) * sdim, hipMemcpyHostToDevice, c->stream));
+        sa.g = gd.p;
+    }
     a.epb = std::max(1, 256 / std::max(c->nq, c->ei.n));
     const size_t lds = sizeof(double) * (size_t)a.epb * c->nq;
     const int grid = (int)((a.work_end + a.epb - 1) / a.epb);

@@ -119,8 +119,11 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         const int U = (p == p_begin) ? hc.U : hc.k0;
         stamp(0);
         // phase B: one lane per new slot (one quadrature point)
-        if (tid < U && !(a.ablate & 1)) {   // (FENRIS_HIP_ABLATE bit 0, profiling: no phase B)
-            const int u = (int)slot_b[tid];
+        // ... on the LAST lanes of the workgroup: the row lanes fill the first wavefronts (162 of 256 lanes on a BCC mesh, the four-lane
+        // groups of the diagonal blocks in wavefront 0), so the two phases load different SIMDs and the two workgroups of a CU overlap better
+        const int bi = 255 - tid;
+        if (bi < U && !(a.ablate & 1)) {   // (FENRIS_HIP_ABLATE bit 0, profiling: no phase B)
+            const int u = (int)slot_b[bi];
             prologue<EK, OP, WHAT_MATRIX, true, true, false, true>(a, L, lds, lds_i, u, 0, T.elem + (size_t)p * T.us + u, 0, sqw,
                                                                    (unsigned)slot_words[u]);
         }
@@ -140,85 +143,92 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                 Gm[i][j] = 0.0;
                 if (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] = 0.0;
             }
-        unsigned pa[TL], pj[TL];
-        double mu_t[ELEMPAR ? TL : 1], la_t[ELEMPAR ? TL : 1];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) {
-            const unsigned term = (tw[t / 2] >> (16 * (t % 2))) & 0xffffu;
-            const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
-            pa[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 3u));
-            pj[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 10) & 3u));
-            if constexpr (ELEMPAR) {  // fetched now (global memory), used after phase B
-                const double* sp = T.slotpar + 2 * ((size_t)p * T.us + (term & 255u));
-                mu_t[t] = sp[0];
-                la_t[t] = sp[1];
+        // a wavefront without a single term (the lanes behind the last block of the position) skips the phase altogether
+        if (__builtin_amdgcn_ballot_w64(nterms > 0) != 0ull) {
+            unsigned pa[TL], pj[TL];
+            double mu_t[ELEMPAR ? TL : 1], la_t[ELEMPAR ? TL : 1];
+    #pragma unroll
+            for (int t = 0; t < TL; ++t) {
+                const unsigned term = (tw[t / 2] >> (16 * (t % 2))) & 0xffffu;
+                const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
+                pa[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 3u));
+                pj[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 10) & 3u));
+                if constexpr (ELEMPAR) {  // fetched now (global memory), used after phase B
+                    const double* sp = T.slotpar + 2 * ((size_t)p * T.us + (term & 255u));
+                    mu_t[t] = sp[0];
+                    la_t[t] = sp[1];
+                }
             }
-        }
-        // [x y] by ds_read_b128, z by ds_read_b64 (see k_gather_rows); two terms in flight while one is multiplied
-        constexpr int AHEAD = 2, NB = AHEAD + 1;
-        f64x2 av[NB], bv[NB];
-        double az[NB], bz[NB];
-        auto fetcht = [&](auto tk) {
-            constexpr int tt = decltype(tk)::value, sl = tt % NB;
-            av[sl] = lds_read_f64x2<0>(pa[tt]);
-            az[sl] = lds_read_f64_at<16>(pa[tt]);
-            bv[sl] = lds_read_f64x2<0>(pj[tt]);
-            bz[sl] = lds_read_f64_at<16>(pj[tt]);
-        };
-        fetcht(std::integral_constant<int, 0>{});
-        fetcht(std::integral_constant<int, 1>{});
-        pipeline_consume<TL, D>([&](auto tk) {
-            constexpr int tt = decltype(tk)::value, sl = tt % NB;
-            constexpr int ahead = (TL - 1 - tt) < (AHEAD - 1) ? (TL - 1 - tt) : (AHEAD - 1);
-            lds_wait<ahead * 4>();
-            asm volatile("" : "+v"(av[sl]), "+v"(az[sl]), "+v"(bv[sl]), "+v"(bz[sl]));
-            if constexpr (tt + AHEAD < TL) fetcht(std::integral_constant<int, tt + AHEAD>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (tt < nterms && !(a.ablate & 2)) {  // unused terms read slot 0: never let their values in  (ablate bit 1: no products)
-                const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
-                const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    const double am = ELEMPAR ? mu_t[ELEMPAR ? tt : 0] * ai[i] : ai[i];
-                    const double al = ELEMPAR ? la_t[ELEMPAR ? tt : 0] * ai[i] : 0.0;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        Gm[i][j] = fma(am, bj[j], Gm[i][j]);
-                        if (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] = fma(al, bj[j], Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+            // [x y] by ds_read_b128, z by ds_read_b64 (see k_gather_rows); two terms in flight while one is multiplied
+            constexpr int AHEAD = 2, NB = AHEAD + 1;
+            f64x2 av[NB], bv[NB];
+            double az[NB], bz[NB];
+            auto fetcht = [&](auto tk) {
+                constexpr int tt = decltype(tk)::value, sl = tt % NB;
+                av[sl] = lds_read_f64x2<0>(pa[tt]);
+                az[sl] = lds_read_f64_at<16>(pa[tt]);
+                bv[sl] = lds_read_f64x2<0>(pj[tt]);
+                bz[sl] = lds_read_f64_at<16>(pj[tt]);
+            };
+            fetcht(std::integral_constant<int, 0>{});
+            fetcht(std::integral_constant<int, 1>{});
+            pipeline_consume<TL, D>([&](auto tk) {
+                constexpr int tt = decltype(tk)::value, sl = tt % NB;
+                constexpr int ahead = (TL - 1 - tt) < (AHEAD - 1) ? (TL - 1 - tt) : (AHEAD - 1);
+                lds_wait<ahead * 4>();
+                asm volatile("" : "+v"(av[sl]), "+v"(az[sl]), "+v"(bv[sl]), "+v"(bz[sl]));
+                if constexpr (tt + AHEAD < TL) fetcht(std::integral_constant<int, tt + AHEAD>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (tt < nterms && !(a.ablate & 2)) {  // unused terms read slot 0: never let their values in  (ablate bit 1: no products)
+                    const double ai[D] = {av[sl].x, av[sl].y, az[sl]};
+                    const double bj[D] = {bv[sl].x, bv[sl].y, bz[sl]};
+    #pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        const double am = ELEMPAR ? mu_t[ELEMPAR ? tt : 0] * ai[i] : ai[i];
+                        const double al = ELEMPAR ? la_t[ELEMPAR ? tt : 0] * ai[i] : 0.0;
+    #pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            Gm[i][j] = fma(am, bj[j], Gm[i][j]);
+                            if (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] = fma(al, bj[j], Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                        }
                     }
                 }
+            });
+            // Partial sums of a block meet by DPP exchanges in groups of 2 / 4 / 8 lanes.  Whether a lane takes part is a factor (1.0 or
+            // 0.0) of a multiply-add, not a branch: nine guarded additions per stage cost an exec-mask pair each.  The third stage (groups
+            // of eight: a node with more than 24 elements) is skipped by the whole wavefront when none of its lanes needs it.
+            const double m1 = grp >= 1 ? 1.0 : 0.0, m2 = grp >= 2 ? 1.0 : 0.0;
+            if (__builtin_amdgcn_ballot_w64(grp >= 1) != 0ull) {   // every stage is skipped by a wavefront none of whose lanes needs it
+    #pragma unroll
+                for (int i = 0; i < D; ++i)
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Gm[i][j] = fma(dpp_quad<0xB1>(Gm[i][j]), m1, Gm[i][j]);
+                        if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                            fma(dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m1, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    }
             }
-        });
-        // Partial sums of a block meet by DPP exchanges in groups of 2 / 4 / 8 lanes.  Whether a lane takes part is a factor (1.0 or
-        // 0.0) of a multiply-add, not a branch: nine guarded additions per stage cost an exec-mask pair each.  The third stage (groups
-        // of eight: a node with more than 24 elements) is skipped by the whole wavefront when none of its lanes needs it.
-        const double m1 = grp >= 1 ? 1.0 : 0.0, m2 = grp >= 2 ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                Gm[i][j] = fma(dpp_quad<0xB1>(Gm[i][j]), m1, Gm[i][j]);
-                if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                    fma(dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m1, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+            if (__builtin_amdgcn_ballot_w64(grp >= 2) != 0ull) {
+    #pragma unroll
+                for (int i = 0; i < D; ++i)
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Gm[i][j] = fma(dpp_quad<0x4E>(Gm[i][j]), m2, Gm[i][j]);
+                        if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                            fma(dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m2, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    }
             }
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                Gm[i][j] = fma(dpp_quad<0x4E>(Gm[i][j]), m2, Gm[i][j]);
-                if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                    fma(dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m2, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+            if (__builtin_amdgcn_ballot_w64(grp >= 3) != 0ull) {   // uniform over the wavefront
+                const double m3 = grp >= 3 ? 1.0 : 0.0;
+    #pragma unroll
+                for (int i = 0; i < D; ++i)
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Gm[i][j] = fma(dpp_xor4(Gm[i][j]), m3, Gm[i][j]);
+                        if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
+                            fma(dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m3, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                    }
             }
-        if (__builtin_amdgcn_ballot_w64(grp >= 3) != 0ull) {   // uniform over the wavefront
-            const double m3 = grp >= 3 ? 1.0 : 0.0;
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    Gm[i][j] = fma(dpp_xor4(Gm[i][j]), m3, Gm[i][j]);
-                    if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                        fma(dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m3, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
-                }
         }
         stamp(3);
         // The requests of this position (vertices of the next block, records and lane words of the one after) are consumed HERE,

@@ -234,6 +234,9 @@ int fh_assemble_matrix_rows_async_dev(fh_ctx*, double* values_dev, int flags, ui
  * assemble_element_elliptic_vector (elliptic.rs:457-531): out (s*N) is accumulated into. */
 int fh_assemble_vector(fh_ctx*, double* out, uint64_t* failed_element);
 int fh_assemble_vector_dev(fh_ctx*, double* out_dev, uint64_t* failed_element);
+/* the same, only enqueued on the context's stream: a singular element is reported by the next fh_poll_status (like
+ * fh_assemble_matrix_async_dev) */
+int fh_assemble_vector_async_dev(fh_ctx*, double* out_dev);
 /* assemble_scalar (global.rs:697-711) with compute_element_elliptic_energy (elliptic.rs:551-605) */
 int fh_assemble_scalar(fh_ctx*, double* out, uint64_t* failed_element);
 /* ElementSourceAssembler through VectorAssembler (src/assembly/local/source.rs:159-278, global.rs:582-608):

@@ -63,7 +63,8 @@ def north_star(cells):
     eng.assemble_matrix(values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
     f = torch.zeros(n, dtype=torch.float64, device="cuda")
     # residual f(u): connectivity + vertices + u read once, the vector written once
-    ms = ev_time(lambda: eng.assemble_vector(f))
+    ms = ev_time(lambda: eng.assemble_vector_async(f))   # enqueue only, like the stiffness benchmark; errors at the poll below
+    eng.poll_status()
     line("residual vector (" + eng.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + 2 * n * 8, config=tag, elements_per_s=E / ms * 1e3)
     ms = ev_time(lambda: eng.assemble_scalar(), steps=5)
     line("energy, assemble_scalar (" + eng.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + n * 8, config=tag, elements_per_s=E / ms * 1e3)
@@ -73,7 +74,8 @@ def north_star(cells):
             (fa.ElementEllipticAssemblerBuilder(e2).with_finite_element_space(mesh).with_operator(fa.MaterialEllipticOperator(mat))
              .with_quadrature_table(qt).with_u(u).build())
             e2.build_pattern()
-            ms = ev_time(lambda: e2.assemble_vector(f), steps=5)
+            ms = ev_time(lambda: e2.assemble_vector_async(f), steps=5)
+            e2.poll_status()
             line(f"residual vector, {opname} (" + e2.last_kernel_name() + ")", ms, E * 8 * 4 + N * 3 * 8 + 2 * n * 8, config=f"Hex8 {opname} {cells}^3",
                  elements_per_s=E / ms * 1e3)
             ms = ev_time(lambda: e2.assemble_scalar(), steps=5)

@@ -342,6 +342,36 @@ def test_vector_and_scalar_match_oracle(engine, oracle, kind, op):
         assert np.array_equal(fa.VectorAssembler().assemble_vector(asm), f)
 
 
+def test_vector_async_matches_the_blocking_call_and_reports_through_poll(engine, oracle):
+    """fh_assemble_vector_async_dev only enqueues: same bits as fh_assemble_vector_dev, a singular element comes out of fh_poll_status"""
+    import torch
+
+    asm, ref = _pair(engine, oracle, "HEX8", "NEO_HOOKEAN")
+    n = asm.solution_dim() * asm.num_nodes()
+    a = torch.zeros(n, dtype=torch.float64, device="cuda")
+    b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    engine.assemble_vector(a)
+    engine.assemble_vector_async(b)
+    engine.poll_status()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    st, _, of = oracle.assemble_vector(ref)
+    assert np.abs(a.cpu().numpy() - of).max() <= TOL * np.abs(of).max()
+    # a collapsed element: the enqueue succeeds, the poll raises
+    mesh = _mesh("HEX8", distort=False)
+    v = mesh.vertices.copy()
+    v[mesh.connectivity[7].astype(int)] = v[int(mesh.connectivity[7][0])]
+    w, p = _rule("HEX8")
+    bad = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(fa.Mesh(v, mesh.connectivity, fa.HEX8))
+           .with_operator(fa.LaplaceOperator()).with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w))
+           .with_u(np.zeros(len(v))).build())
+    assert bad.engine is engine
+    c = torch.zeros(len(v), dtype=torch.float64, device="cuda")
+    engine.assemble_vector_async(c)
+    with pytest.raises(fa.SingularJacobianError):
+        engine.poll_status()
+
+
 def test_residual_is_K_times_u_for_linear_operators(engine, oracle):
     asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", u_scale=1e-3)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm).to_scipy()

@@ -87,6 +87,7 @@ _SIGS = {
     "fh_pattern_cols": (C.c_int, [C.c_void_p, u64p]),
     "fh_pattern_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "fh_color": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "fh_color_parallel": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "fh_set_colors": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p]),
     "fh_assemble_matrix": (C.c_int, [C.c_void_p, f64p, C.c_int, u64p]),
     "fh_assemble_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, u64p]),

@@ -188,6 +188,15 @@ class Engine:
         self._check(self._lib.fh_color(self._h, C.byref(nc), _ffi.up(co), _ffi.up(lab)))
         return DisjointSubsetsColors(co[: nc.value + 1].copy(), lab[:E].copy())
 
+    def color_parallel(self):
+        """fh_color_parallel: a valid element colouring computed on the device (not the reference's sequential greedy one)"""
+        E = self.num_elements()
+        nc = C.c_uint64()
+        co = np.zeros(E + 2, dtype=np.uint64)
+        lab = np.zeros(max(E, 1), dtype=np.uint64)
+        self._check(self._lib.fh_color_parallel(self._h, C.byref(nc), _ffi.up(co), _ffi.up(lab)))
+        return DisjointSubsetsColors(co[: nc.value + 1].copy(), lab[:E].copy())
+
     def set_colors(self, colors: "DisjointSubsetsColors"):
         co, lab = _ffi.as_u64(colors.color_offsets), _ffi.as_u64(colors.labels)
         lab_p = lab if len(lab) else np.zeros(1, dtype=np.uint64)

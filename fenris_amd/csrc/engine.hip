@@ -20,6 +20,7 @@
 #include "affine_kernel.hpp"
 #include "affine_rows.hpp"
 #include "element_pass.hpp"
+#include "coloring_kernels.hpp"
 #include "device_common.hpp"
 #include "group_internal.hpp"
 #include "host_inputs.hpp"
@@ -2566,6 +2567,69 @@ int fh_color(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t*
     std::vector<uint64_t> offs, lab;
     static const uint64_t zero = 0;
     greedy_coloring(c->E, eoff, c->h_nodes.empty() ? &zero : c->h_nodes.data(), offs, lab);
+    if (num_colors) *num_colors = offs.size() - 1;
+    if (color_offsets) std::copy(offs.begin(), offs.end(), color_offsets);
+    if (labels) std::copy(lab.begin(), lab.end(), labels);
+    return upload_colors(c, offs, lab);
+}
+
+int fh_color_parallel(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_color_parallel: no connectivity set");
+    if (c->ragged) return c->fail(FH_UNSUPPORTED, "fh_color_parallel: ragged connectivity is coloured by fh_color (host)");
+    if (c->E >= (1ull << 31)) return c->fail(FH_UNSUPPORTED, "fh_color_parallel: more than 2^31 elements");
+    int rc = build_source_adjacency(c);
+    if (rc) return rc;
+    const int E = (int)c->E, n = c->ei.n;
+    std::vector<uint64_t> offs(1, 0), lab((size_t)E);
+    if (E > 0) {
+        hipStream_t st = c->stream;
+        DevBuf<int> color, tent, keys_s, flag;
+        DevBuf<unsigned> ids, ids_s, remaining;
+        HIP_TRY(c, color.alloc(E));
+        HIP_TRY(c, tent.alloc(E));
+        HIP_TRY(c, keys_s.alloc(E));
+        HIP_TRY(c, ids.alloc(E));
+        HIP_TRY(c, ids_s.alloc(E));
+        HIP_TRY(c, flag.alloc(1));
+        HIP_TRY(c, remaining.alloc(1));
+        HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), st));
+        const int grid = (E + 255) / 256;
+        hipLaunchKernelGGL(k_color_iota, dim3(grid), dim3(256), 0, st, E, ids.p, color.p, -1);
+        unsigned left = (unsigned)E;
+        int rounds = 0, over = 0;
+        while (left > 0) {
+            if (++rounds > 4096) return c->fail(FH_HIP_ERROR, "fh_color_parallel: no progress");
+            HIP_TRY(c, hipMemsetAsync(remaining.p, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_color_propose, dim3(grid), dim3(256), 0, st, E, n, c->conn.p, c->src_n2e_off.p, c->src_n2e.p, color.p, tent.p, flag.p);
+            hipLaunchKernelGGL(k_color_resolve, dim3(grid), dim3(256), 0, st, E, n, c->conn.p, c->src_n2e_off.p, c->src_n2e.p, tent.p, color.p,
+                               remaining.p);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&left, remaining.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(&over, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (over) return c->fail(FH_UNSUPPORTED, "fh_color_parallel: more than 128 colours needed (use fh_color)");
+        }
+        // colours in order, the elements of a colour ascending: a stable sort of (colour, element)
+        size_t tb = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, 8, st));
+        DevBuf<char> tmp;
+        HIP_TRY(c, tmp.alloc(tb + 16));
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, 8, st));
+        std::vector<int> hk((size_t)E);
+        std::vector<unsigned> hi((size_t)E);
+        HIP_TRY(c, hipMemcpyAsync(hk.data(), keys_s.p, sizeof(int) * (size_t)E, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(hi.data(), ids_s.p, sizeof(unsigned) * (size_t)E, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int i = 0; i < E; ++i) {
+            lab[i] = hi[i];
+            if (i > 0 && hk[i] != hk[i - 1]) offs.push_back((uint64_t)i);
+        }
+        offs.push_back((uint64_t)E);
+        if (c->env("FENRIS_HIP_VERBOSE"))
+            std::fprintf(stderr, "[fenris_hip] parallel colouring: %zu colours in %d rounds\n", offs.size() - 1, rounds);
+    }
     if (num_colors) *num_colors = offs.size() - 1;
     if (color_offsets) std::copy(offs.begin(), offs.end(), color_offsets);
     if (labels) std::copy(lab.begin(), lab.end(), labels);

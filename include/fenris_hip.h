@@ -197,6 +197,11 @@ int fh_pattern_dev(fh_ctx*, uint64_t* row_offsets_dev, uint64_t* col_indices_dev
 /* color_offsets: capacity num_elements+2 (or NULL); labels: num_elements entries (or NULL):
  * elements of colour c are labels[color_offsets[c] .. color_offsets[c+1]) in ascending order */
 int fh_color(fh_ctx*, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels);
+/* the same outputs, computed ON the device: Luby-style rounds (propose the smallest colour no finished neighbour holds, keep it unless
+ * a neighbour of smaller hashed priority proposed the same), deterministic.  A valid colouring -- no two elements of a colour share a
+ * node, which is all CsrParAssembler / DisjointSubsets require -- but generally not the sequential greedy one of fh_color (more colours
+ * are possible; at most 128).  Fixed-size connectivity only. */
+int fh_color_parallel(fh_ctx*, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels);
 /* reuse a colouring computed elsewhere (colours are serialisable in the reference, paradis lib.rs:170) */
 int fh_set_colors(fh_ctx*, uint64_t num_colors, const uint64_t* color_offsets, const uint64_t* labels);
 

@@ -159,6 +159,31 @@ def test_coloring_identical_to_reference_algorithm(engine, oracle, kind):
         assert len(colors) == 8
 
 
+@pytest.mark.parametrize("kind", ["HEX8", "TET4", "QUAD4", "HEX27"])
+def test_parallel_coloring_is_a_valid_deterministic_coloring(engine, oracle, kind):
+    """fh_color_parallel: the colouring computed on the device -- every element once, ascending inside a colour, no two elements of a
+    colour sharing a node (the precondition of DisjointSubsets, fenris-paradis/src/lib.rs), the same result every time; and the
+    coloured scatter driven by it gives the oracle's matrix"""
+    asm, ref = _pair(engine, oracle, kind, "LAPLACE")
+    colors = asm.engine.color_parallel()
+    E = asm.num_elements()
+    assert sorted(colors.labels.tolist()) == list(range(E))
+    conn = np.asarray(asm.space.connectivity).astype(np.int64)
+    for c in range(len(colors)):
+        lab = colors.color(c).astype(np.int64)
+        assert np.all(np.diff(lab) > 0)
+        nodes = conn[lab].ravel()
+        assert len(np.unique(nodes)) == len(nodes)
+    again = asm.engine.color_parallel()
+    assert np.array_equal(again.color_offsets, colors.color_offsets) and np.array_equal(again.labels, colors.labels)
+    seq = fa.color_nodes(asm)
+    assert len(colors) >= len(seq) or len(colors) >= 1   # the sequential greedy colouring is not a lower bound, only a yardstick
+    k = fa.CsrParAssembler().assemble(colors, asm)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert np.array_equal(k.col_indices, oci)
+    assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
+
+
 def test_coloring_ragged(engine, oracle):
     mock = fa.MockElementAssembler(1, 6, MOCK, engine)
     colors = mock.engine.color()

@@ -337,26 +337,17 @@ def roofline_of(cfg, c, E, N, nnz, kernel_ms):
 
 
 def probe_placement(eng, values, flags, torch, tries):
-    """The better of several allocations of the values array (and, inside the library, of the element records): the time of the
-    owner-computes kernels follows how these buffers happen to be backed by device memory -- the same context and arguments run at one
-    of several levels up to 10 % apart for the life of an allocation (profiles/r03_affine_experiments.txt).  Done BEFORE the
-    timed region; every trial is three real assemblies.  Returns (values, report)."""
-    seen = [eng.time_assembly(values, flags)]
-    best, rejected = values, []
-    for _ in range(tries):
-        cand = torch.zeros_like(values)          # the previous candidates stay allocated: a new one gets other memory
-        t = eng.time_assembly(cand, flags)
-        if t < 0.98 * min(seen):
-            rejected.append(best)
-            best = cand
-        else:
-            rejected.append(cand)
-        seen.append(t)
-    before, after = eng.tune_placement(best, flags, tries)
-    del rejected
-    torch.cuda.empty_cache()
-    return best, {"values_ms_seen": [round(x, 4) for x in seen], "records_ms_before": round(before, 4), "records_ms_after": round(after, 4),
-                  "tries": tries}
+    """fenris_amd/placement.py: the better of several allocations of the values array and of the library's record buffer"""
+    from fenris_amd.placement import probe_placement as probe
+
+    return probe(eng, values, flags, tries)
+
+
+def settle_device(eng, values, flags, max_s=2.5, group=20):
+    """fenris_amd/placement.py: untimed assemblies until a fresh device has reached its steady rate (part of the set-up, like the probe)"""
+    from fenris_amd.placement import settle_device as settle
+
+    return settle(eng, values, flags, max_s, group)
 
 
 def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
@@ -416,9 +407,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configurations timed after the headline (N = 1, --config ns)")
-    ap.add_argument("--placement-tries", type=int, default=3,
+    ap.add_argument("--placement-tries", type=int, default=6,
                     help="N = 1: allocations of the values array (and of the library's record buffer) tried before the timed region, the "
                          "fastest kept; 0 = take the first (see probe_placement)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed assemblies that bring a fresh device to its steady rate (settle_device)")
     ap.add_argument("--no-module-warmup", action="store_true",
                     help="skip the tiny assembly that loads the code objects before anything is timed (profiling runs: its dispatches would "
                          "enter the per-kernel averages)")
@@ -539,11 +531,16 @@ def main():
         if rccl is not None and hasattr(slab_asm.exchange, "size"):
             rccl["fh_group_ranks"] = slab_asm.exchange.size()   # ncclCommCount of the library's own communicator
     t_pattern = time.perf_counter() - t0
+    if slab_asm is not None and slab_asm.placement is not None:
+        t_pattern -= slab_asm.placement.get("seconds", 0.0)   # the settle / placement probe inside SlabAssembly is reported on its own
     N = mesh.num_nodes()
     if args.scatter == "colored":
         eng.color()
     flags |= fa.ASSEMBLE_OVERWRITE
     placement = slab_asm.placement if slab_asm is not None else None   # N > 1: rank 0's (every rank probes its own buffers)
+    settle = None
+    if world == 1 and not args.no_settle and os.environ.get("FENRIS_BENCH_CHILD") != "1":
+        settle = settle_device(eng, values, flags)     # first: the probe below compares allocations, not a cold device with a warm one
     if world == 1 and args.placement_tries > 0 and args.scatter == "gather":
         values, placement = probe_placement(eng, values, flags, torch, args.placement_tries)
 
@@ -606,7 +603,7 @@ def main():
                        "name": cfg, "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
                        "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
-                       "pattern_build_s": t_pattern, "module_warmup_s": t_warm, "placement_probe": placement},
+                       "pattern_build_s": t_pattern, "module_warmup_s": t_warm, "placement_probe": placement, "device_settle": settle},
         }
         if world > 1:
             out["config"]["element_layers_per_rank"] = [l1 - l0 for l0, l1 in layers]

@@ -280,21 +280,16 @@ class SlabAssembly:
             # no collective, before anything is bound to the array
             from .assembly import ASSEMBLE_OVERWRITE, SCATTER_GATHER
 
+            from .placement import probe_placement, settle_device
+
+            import time
+
+            t0 = time.perf_counter()
             fl = SCATTER_GATHER | ASSEMBLE_OVERWRITE
-            seen, rejected = [self.main.time_assembly(self.values, fl)], []
-            for _ in range(placement_tries):
-                cand = torch.zeros_like(self.values)
-                t = self.main.time_assembly(cand, fl)
-                if t < 0.98 * min(seen):
-                    rejected.append(self.values)
-                    self.values = cand
-                else:
-                    rejected.append(cand)
-                seen.append(t)
-            before, after = self.main.tune_placement(self.values, fl, placement_tries)
-            del rejected
-            torch.cuda.empty_cache()
-            self.placement = {"values_ms_seen": [round(x, 4) for x in seen], "records_ms_before": round(before, 4), "records_ms_after": round(after, 4)}
+            settle = settle_device(self.main, self.values, fl)
+            self.values, self.placement = probe_placement(self.main, self.values, fl, placement_tries)
+            self.placement["device_settle"] = settle
+            self.placement["seconds"] = round(time.perf_counter() - t0, 3)   # (not part of the pattern build a caller may be timing)
         if overlap and (slab.send_nodes is not None or slab.recv_nodes is not None):
             self.comm = torch.cuda.Stream(device=device)
         if exchange == "abi":   # RCCL inside the library (fh_group_*); the torch path stays the test harness

@@ -608,6 +608,11 @@ def main():
         if world > 1:
             out["config"]["element_layers_per_rank"] = [l1 - l0 for l0, l1 in layers]
             out["config"]["exchange"] = "torch.distributed point-to-point" if (share or args.exchange == "torch") else "fh_group_* (RCCL behind the C ABI)"
+            ex = slab_asm.exchange
+            rb = getattr(ex, "recv_buf", None)
+            if rb is not None:   # what rank 0 receives from rank 1 per step (every interior interface carries the same amount)
+                out["config"]["interface_bytes_per_step"] = int(rb.numel() * rb.element_size())
+                out["config"]["interface_rows_packed"] = getattr(ex, "recv_idx", None) is not None
             out["rccl"] = rccl if rccl is not None else {"backend": "gloo (FENRIS_BENCH_SHARE_DEVICE validation mode)", "rccl_ranks": 0}
             out["rccl_ranks"] = out["rccl"]["rccl_ranks"]
         hbm = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",

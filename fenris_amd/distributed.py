@@ -109,15 +109,38 @@ def _box(cx, cy, cz, h):
 
 class InterfaceExchange:
     """Sends the partial rows of the bottom ghost plane to rank-1 and adds the rows received from rank+1 to the
-    owned top plane.  Works on any torch tensor (CUDA with nccl, CPU with gloo)."""
+    owned top plane.  Works on any torch tensor (CUDA with nccl, CPU with gloo).
 
-    def __init__(self, slab: SlabProblem, group=None):
-        self.slab, self.group = slab, group
+    ``pack`` (default): only the entries that can be non-zero travel.  The rows of an interface plane carry the complete global
+    pattern -- columns in the plane below, the plane itself and the plane above, the same number in each (the extended mesh has a
+    halo layer on either side) and in this order (columns are sorted, the numbering is plane-major) -- but the sender's own elements
+    lie ABOVE its ghost plane, so the first third of every scalar row is structurally zero: two thirds of the bytes go over the link
+    (Hex8 elasticity 216 x 216: 61 MB instead of 91.5 MB per interface and step), gathered into a send buffer on the transfer stream
+    and added through the same index list on the receiving side.  A row whose length is not a multiple of three switches packing off."""
+
+    def __init__(self, slab: SlabProblem, group=None, pack: bool = True):
+        self.slab, self.group, self.pack = slab, group, pack
         self.values = None
         self.send_seg = self.recv_seg = None
-        self.recv_buf = None
+        self.send_idx = self.recv_idx = None
+        self.send_buf = self.recv_buf = None
 
-    def bind_offsets(self, row_offsets: np.ndarray, solution_dim: int, values):
+    @staticmethod
+    def _upper_two_thirds(row_offsets, r0, r1, device):
+        """indices (int64 tensor) of the last two thirds of every scalar row r0 <= r < r1, or None when a row does not divide"""
+        import torch
+
+        ro = torch.as_tensor(np.asarray(row_offsets[r0:r1 + 1]).astype(np.int64), device=device)
+        length = ro[1:] - ro[:-1]
+        if int((length % 3).sum()) != 0 or int(length.sum()) == 0:
+            return None
+        n = 2 * (length // 3)
+        first = ro[:-1] + length // 3
+        start = torch.cumsum(n, 0) - n
+        return torch.repeat_interleave(first - start, n) + torch.arange(int(n.sum()), dtype=torch.int64, device=device)
+
+    def bind_offsets(self, row_offsets: np.ndarray, solution_dim: int, values, col_indices=None):
+        """``col_indices`` (optional, small cases / tests): checks that what packing leaves out are exactly the columns below the plane"""
         import torch
 
         s = solution_dim
@@ -127,8 +150,22 @@ class InterfaceExchange:
             return (int(row_offsets[s * nodes[0]]), int(row_offsets[s * nodes[1]])) if nodes else None
 
         self.send_seg, self.recv_seg = seg(self.slab.send_nodes), seg(self.slab.recv_nodes)
+        self.send_idx = self.recv_idx = None
+        if self.pack:
+            if self.slab.send_nodes:
+                self.send_idx = self._upper_two_thirds(row_offsets, s * self.slab.send_nodes[0], s * self.slab.send_nodes[1], values.device)
+            if self.slab.recv_nodes:
+                self.recv_idx = self._upper_two_thirds(row_offsets, s * self.slab.recv_nodes[0], s * self.slab.recv_nodes[1], values.device)
+            # both sides of an interface must take the same decision: they see the same rows (identical layouts), so they do
+            if col_indices is not None and self.send_idx is not None:
+                keep = np.zeros(self.send_seg[1] - self.send_seg[0], dtype=bool)
+                keep[self.send_idx.cpu().numpy() - self.send_seg[0]] = True
+                cols = np.asarray(col_indices[self.send_seg[0]:self.send_seg[1]]).astype(np.int64) // s
+                assert np.all(cols[~keep] < self.slab.send_nodes[0]) and np.all(cols[keep] >= self.slab.send_nodes[0]), \
+                    "packed exchange: the first third of a ghost row is not the plane below"
         if self.recv_seg:
-            self.recv_buf = torch.empty(self.recv_seg[1] - self.recv_seg[0], dtype=values.dtype, device=values.device)
+            n = self.recv_idx.numel() if self.recv_idx is not None else self.recv_seg[1] - self.recv_seg[0]
+            self.recv_buf = torch.empty(n, dtype=values.dtype, device=values.device)
         return self
 
     def bind(self, engine, values):
@@ -136,7 +173,9 @@ class InterfaceExchange:
         return self.bind_offsets(ro, engine.solution_dim(), values)
 
     def bytes_sent(self):
-        return 8 * (self.send_seg[1] - self.send_seg[0]) if self.send_seg else 0
+        if not self.send_seg:
+            return 0
+        return 8 * (self.send_idx.numel() if self.send_idx is not None else self.send_seg[1] - self.send_seg[0])
 
     def start(self, comm_stream=None):
         """Post the send of the bottom ghost plane and the receive for the owned top plane.  With a CUDA
@@ -146,19 +185,27 @@ class InterfaceExchange:
         import torch.distributed as dist
 
         self._reqs = []
-        ops = []
-        if self.send_seg:
-            ops.append(dist.P2POp(dist.isend, self.values[self.send_seg[0]:self.send_seg[1]], self.slab.rank - 1, self.group))
-        if self.recv_seg:
-            ops.append(dist.P2POp(dist.irecv, self.recv_buf, self.slab.rank + 1, self.group))
-        if not ops:
+        if not self.send_seg and not self.recv_seg:
             return
+
+        def post():
+            ops = []
+            if self.send_seg:
+                if self.send_idx is not None:
+                    self.send_buf = self.values.index_select(0, self.send_idx)   # (on the transfer stream when there is one)
+                    ops.append(dist.P2POp(dist.isend, self.send_buf, self.slab.rank - 1, self.group))
+                else:
+                    ops.append(dist.P2POp(dist.isend, self.values[self.send_seg[0]:self.send_seg[1]], self.slab.rank - 1, self.group))
+            if self.recv_seg:
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf, self.slab.rank + 1, self.group))
+            return dist.batch_isend_irecv(ops)
+
         if comm_stream is not None:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                self._reqs = dist.batch_isend_irecv(ops)
+                self._reqs = post()
         else:
-            self._reqs = dist.batch_isend_irecv(ops)
+            self._reqs = post()
 
     def finish(self):
         """Wait for the transfers (the current stream waits) and add the received rows to the owned top plane."""
@@ -166,7 +213,10 @@ class InterfaceExchange:
             req.wait()
         self._reqs = []
         if self.recv_seg:
-            self.values[self.recv_seg[0]:self.recv_seg[1]] += self.recv_buf
+            if self.recv_idx is not None:
+                self.values.index_add_(0, self.recv_idx, self.recv_buf)   # every index once: no two additions meet
+            else:
+                self.values[self.recv_seg[0]:self.recv_seg[1]] += self.recv_buf
 
     def run(self):
         self.start()

@@ -113,10 +113,20 @@ def _gloo_worker(rank, world, port, op_name, q, units_z=None, cells=2):
         units_z = units_z or world          # units_z * cells element layers over `world` ranks (uneven when not divisible)
         slab = fd.make_slab(1.0, 1, 1, units_z, cells, rank, world)
         ro, ci, vals = _oracle_partial(oracle, slab, op)
+        vals0 = vals.copy()                   # (values shares its memory with vals)
         values = torch.from_numpy(vals)
-        fd.InterfaceExchange(slab).bind_offsets(ro, s, values).run()
+        ex = fd.InterfaceExchange(slab).bind_offsets(ro, s, values, col_indices=ci)   # packed: the structurally zero third stays home
+        full = fd.InterfaceExchange(slab, pack=False).bind_offsets(ro, s, values)
+        if slab.send_nodes is not None:
+            assert ex.send_idx is not None and 3 * ex.bytes_sent() == 2 * full.bytes_sent() > 0
+        ex.run()
         gro, gci, gvals = _global_reference(oracle, units_z, cells, op)
         _check_owned_rows(slab, s, ro, ci, values.numpy(), gro, gci, gvals)
+        # the unpacked form gives the same owned rows bit for bit (what it adds on top are zeros)
+        values2 = torch.from_numpy(vals0)
+        fd.InterfaceExchange(slab, pack=False).bind_offsets(ro, s, values2).run()
+        lo, hi = int(ro[s * slab.owned_nodes[0]]), int(ro[s * slab.owned_nodes[1]])
+        assert np.array_equal(values.numpy()[lo:hi], values2.numpy()[lo:hi])
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

@@ -1664,6 +1664,14 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                          c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
             a.ub = std::max(c->p_us, 76);   // the X region of the layout (14 doubles per slot) holds the vertex table: 256 x 4 doubles
             a.nb_max = c->p_nbs;
+            if (c->has_mask && a.overwrite) {   // blocks without an active element have no lane: clear the range first (rows_kernel.hpp)
+                const int n_lo = (c->row_hi < 0) ? 0 : (int)std::min<long long>(c->row_lo, (long long)c->N);
+                const int n_hi = (c->row_hi < 0) ? (int)c->N : (int)std::min<long long>(c->row_hi, (long long)c->N);
+                if (n_hi > n_lo) {
+                    hipLaunchKernelGGL(k_zero_node_rows, dim3(2048), dim3(256), 0, c->stream, c->noff.p, n_lo, n_hi, c->S() * c->S(), values_dev);
+                    HIP_TRY(c, hipGetLastError());
+                }
+            }
             c->last_kernel += "k_gather_rows";
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);

@@ -404,6 +404,14 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
     for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
 }
 
+// With an element mask a block (I, J) of the pattern may have no active element and therefore no lane: k_gather_rows_tet4 writes every
+// OWNED block exactly once and nothing else, so in overwrite mode the values of the node range are cleared first (masked contexts only:
+// the multi-GPU partitions of fenris_amd/distributed.py are Hex8; found by tests/test_gpu_parity.py::test_overwrite_with_a_mask_...)
+__global__ void __launch_bounds__(256) k_zero_node_rows(const unsigned* noff, int n_lo, int n_hi, int ss, double* vals) {
+    const size_t lo = (size_t)ss * noff[n_lo], hi = (size_t)ss * noff[n_hi];
+    for (size_t k = lo + (size_t)blockIdx.x * 256 + threadIdx.x; k < hi; k += (size_t)gridDim.x * 256) vals[k] = 0.0;
+}
+
 // Unique vertices of every position for the Tet4 kernel (RowTablesS::vconn) from the per-slot connectivity of the pipelined tables
 // (p_conn: [npos][us * 4], node 0 in empty slots).  One wavefront per position: the node ids go through a hash table in LDS, the occupied
 // cells are numbered in table order, every slot gets the four numbers of its nodes.  Which cell a node lands in may depend on the order

@@ -397,6 +397,29 @@ def test_vector_async_matches_the_blocking_call_and_reports_through_poll(engine,
         engine.poll_status()
 
 
+@pytest.mark.parametrize("kind,op", [("TET4", "LINEAR_ELASTIC"), ("TET4", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("QUAD4", "LAPLACE")])
+def test_overwrite_with_a_mask_leaves_nothing_stale(engine, oracle, kind, op):
+    """FH_ASSEMBLE_OVERWRITE into an array full of garbage, with an element mask: blocks of the pattern that no ACTIVE element touches must
+    come out as zeros (the owner-computes kernels write every value of their rows exactly once and have no zero-fill pass)"""
+    import torch
+
+    asm, ref = _pair(engine, oracle, kind, op)
+    eng = asm.engine
+    nnz = eng.build_pattern()
+    E = asm.num_elements()
+    active = (np.arange(E) % 3 != 1)
+    eng.set_active_elements(active)
+    try:
+        want = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
+        got = torch.full((nnz,), 7.25, dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        w, g = want.cpu().numpy(), got.cpu().numpy()
+        assert np.abs(g - w).max() <= TOL * np.abs(w).max(), eng.last_kernel_name()
+    finally:
+        eng.set_active_elements(None)
+
+
 def test_residual_is_K_times_u_for_linear_operators(engine, oracle):
     asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", u_scale=1e-3)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm).to_scipy()

@@ -397,7 +397,9 @@ def test_vector_async_matches_the_blocking_call_and_reports_through_poll(engine,
         engine.poll_status()
 
 
-@pytest.mark.parametrize("kind,op", [("TET4", "LINEAR_ELASTIC"), ("TET4", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("QUAD4", "LAPLACE")])
+@pytest.mark.parametrize("kind,op", [("TET4", "LINEAR_ELASTIC"), ("TET4", "LAPLACE"), ("HEX8", "LINEAR_ELASTIC"), ("QUAD4", "LAPLACE"),
+                                     ("TRI3", "LINEAR_ELASTIC"), ("HEX8", "NEO_HOOKEAN"), ("TET4", "STVK"), ("HEX27", "LINEAR_ELASTIC"),
+                                     ("HEX27", "NEO_HOOKEAN")])
 def test_overwrite_with_a_mask_leaves_nothing_stale(engine, oracle, kind, op):
     """FH_ASSEMBLE_OVERWRITE into an array full of garbage, with an element mask: blocks of the pattern that no ACTIVE element touches must
     come out as zeros (the owner-computes kernels write every value of their rows exactly once and have no zero-fill pass)"""
@@ -418,6 +420,13 @@ def test_overwrite_with_a_mask_leaves_nothing_stale(engine, oracle, kind, op):
         assert np.abs(g - w).max() <= TOL * np.abs(w).max(), eng.last_kernel_name()
     finally:
         eng.set_active_elements(None)
+    # and without a mask
+    want = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
+    got = torch.full((nnz,), -3.5, dtype=torch.float64, device="cuda")
+    eng.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+    w, g = want.cpu().numpy(), got.cpu().numpy()
+    assert np.abs(g - w).max() <= TOL * np.abs(w).max(), eng.last_kernel_name()
 
 
 def test_residual_is_K_times_u_for_linear_operators(engine, oracle):
@@ -844,6 +853,41 @@ def test_host_path_overwrite_with_row_range_keeps_other_rows(engine, oracle):
             assert np.abs(buf[lo:hi] - vals[lo:hi]).max() <= TOL * np.abs(vals).max()
     engine.set_row_range(0, n)
     assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+
+
+@pytest.mark.parametrize("kind,op", [("TET4", "LINEAR_ELASTIC"), ("TET4", "LAPLACE"), ("QUAD4", "LINEAR_ELASTIC"), ("TRI3", "LAPLACE"),
+                                     ("HEX8", "NEO_HOOKEAN"), ("HEX27", "LINEAR_ELASTIC")])
+@pytest.mark.parametrize("masked", [False, True])
+def test_row_range_overwrite_on_the_device_other_kinds(engine, oracle, kind, op, masked):
+    """fh_set_row_range + FH_ASSEMBLE_OVERWRITE into garbage, device arrays, for the kernels the Hex8 tests do not reach (the Tet4
+    row-owner kernel, the planar pipelined forms, the two-pass path), with and without an element mask: rows in range = the atomic
+    assembly's rows, everything else untouched"""
+    import torch
+
+    asm, ref = _pair(engine, oracle, kind, op)
+    eng = asm.engine
+    nnz = eng.build_pattern()
+    ro, _ = eng.pattern(want_cols=False)
+    s = asm.solution_dim()
+    n = asm.num_nodes()
+    if masked:
+        eng.set_active_elements(np.arange(asm.num_elements()) % 4 != 2)
+    try:
+        want = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
+        w = want.cpu().numpy()
+        for lo_n, hi_n in ((n // 3, 2 * n // 3), (0, 2), (n - 3, n), (5, 5)):
+            eng.set_row_range(lo_n, hi_n)
+            got = torch.full((nnz,), 99.5, dtype=torch.float64, device="cuda")
+            eng.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+            g = got.cpu().numpy()
+            lo, hi = int(ro[s * lo_n]), int(ro[s * hi_n])
+            assert np.all(g[:lo] == 99.5) and np.all(g[hi:] == 99.5), (eng.last_kernel_name(), lo_n, hi_n)
+            if hi > lo:
+                assert np.abs(g[lo:hi] - w[lo:hi]).max() <= TOL * np.abs(w).max(), (eng.last_kernel_name(), lo_n, hi_n)
+    finally:
+        eng.set_row_range(0, n)
+        eng.set_active_elements(None)
 
 
 def test_quadrature_data_with_record_stride(engine, oracle):

@@ -965,7 +965,8 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
     unsigned char* pos_lds = reinterpret_cast<unsigned char*>(lds_i + L.o_pos);
     if (ent_in_lds) {
         for (int i = tid; i < m; i += nt) lds_i[L.o_ent + i] = (int)a.gt_ent[k0 + i];
-        for (int i = tid; i < m * N; i += nt) pos_lds[i] = a.gt_pos[(size_t)k0 * N + i];
+        if (a.gt_pos)   // (null when a row has 256 or more column blocks: the byte-wide slots do not exist, the columns are searched)
+            for (int i = tid; i < m * N; i += nt) pos_lds[i] = a.gt_pos[(size_t)k0 * N + i];
     }
     for (int i = tid; i < nacc; i += nt) acc[i] = 0.0;
     __syncthreads();

@@ -4,13 +4,14 @@
 // neighbour with a smaller (hashed) priority proposed the same" -- Luby-style, deterministic (no round reads what the same round writes),
 // O(log E) rounds in expectation.  Two elements are neighbours when they share a node; a colour is a set of pairwise non-neighbours, which
 // is all DisjointSubsets / CsrParAssembler need (fenris-paradis/src/lib.rs, global.rs:314-376).  It is generally NOT the sequential
-// greedy colouring: the colour count may be larger (a structured Hex8 mesh: 8 sequentially, typically 10 - 14 here).
+// greedy colouring: the colour count may be larger (a structured Hex8 mesh: 8 sequentially, 18 here).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace fenris_hip {
 
-constexpr int COLOR_MAX = 128;   // colours the proposal mask can express
+constexpr int COLOR_WINDOW = 128;      // colours one pass over the neighbours can mark
+constexpr int COLOR_LIMIT = 1 << 15;   // more would need more windows than anyone waits for (a node with > 32 k elements)
 
 __device__ __forceinline__ unsigned color_priority(unsigned e) {   // murmur3 finaliser: a fixed pseudo-random order of the elements
     e ^= e >> 16; e *= 0x85ebca6bu; e ^= e >> 13; e *= 0xc2b2ae35u; e ^= e >> 16;
@@ -23,18 +24,21 @@ __global__ void __launch_bounds__(256) k_color_propose(int E, int n, const int* 
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     if (color[e] >= 0) { tent[e] = -1; return; }
-    unsigned long long forb[2] = {0ull, 0ull};
-    for (int a = 0; a < n; ++a) {
-        const unsigned node = (unsigned)conn[(size_t)e * n + a];
-        for (unsigned k = n2e_off[node]; k < n2e_off[node + 1]; ++k) {
-            const int cf = color[n2e[k] / (unsigned)n];
-            if (cf >= 0) forb[cf >> 6] |= 1ull << (cf & 63);
+    int pick = -1;
+    // windows of 128 colours: almost always the first one holds a free colour; a node with hundreds of elements walks on
+    for (int wb = 0; wb < COLOR_LIMIT && pick < 0; wb += COLOR_WINDOW) {
+        unsigned long long forb[2] = {0ull, 0ull};
+        for (int a = 0; a < n; ++a) {
+            const unsigned node = (unsigned)conn[(size_t)e * n + a];
+            for (unsigned k = n2e_off[node]; k < n2e_off[node + 1]; ++k) {
+                const int cf = color[n2e[k] / (unsigned)n] - wb;
+                if (cf >= 0 && cf < COLOR_WINDOW) forb[cf >> 6] |= 1ull << (cf & 63);
+            }
         }
+        if (~forb[0]) pick = wb + __ffsll((long long)~forb[0]) - 1;
+        else if (~forb[1]) pick = wb + 64 + __ffsll((long long)~forb[1]) - 1;
     }
-    int pick;
-    if (~forb[0]) pick = __ffsll((long long)~forb[0]) - 1;
-    else if (~forb[1]) pick = 64 + __ffsll((long long)~forb[1]) - 1;
-    else { pick = -1; atomicOr(overflow, 1); }
+    if (pick < 0) atomicOr(overflow, 1);
     tent[e] = pick;
 }
 
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(256) k_color_resolve(int E, int n, const int* 
             if (pf < pe || (pf == pe && (int)f < e)) { keep = false; break; }
         }
     }
-    if (keep) color[e] = t;
+    if (keep) { color[e] = t; atomicMax(remaining + 1, (unsigned)t); }
     else atomicAdd(remaining, 1u);
 }
 

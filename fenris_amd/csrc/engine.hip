@@ -2601,15 +2601,16 @@ int fh_color_parallel(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, 
         HIP_TRY(c, ids.alloc(E));
         HIP_TRY(c, ids_s.alloc(E));
         HIP_TRY(c, flag.alloc(1));
-        HIP_TRY(c, remaining.alloc(1));
+        HIP_TRY(c, remaining.alloc(2));   // [0] elements still uncoloured after a round, [1] largest colour handed out
         HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), st));
         const int grid = (E + 255) / 256;
         hipLaunchKernelGGL(k_color_iota, dim3(grid), dim3(256), 0, st, E, ids.p, color.p, -1);
-        unsigned left = (unsigned)E;
+        HIP_TRY(c, hipMemsetAsync(remaining.p, 0, 2 * sizeof(unsigned), st));
+        unsigned left = (unsigned)E, max_color = 0;
         int rounds = 0, over = 0;
         while (left > 0) {
             if (++rounds > 4096) return c->fail(FH_HIP_ERROR, "fh_color_parallel: no progress");
-            HIP_TRY(c, hipMemsetAsync(remaining.p, 0, sizeof(unsigned), st));
+            HIP_TRY(c, hipMemsetAsync(remaining.p, 0, sizeof(unsigned), st));   // ([1] keeps its maximum over the rounds)
             hipLaunchKernelGGL(k_color_propose, dim3(grid), dim3(256), 0, st, E, n, c->conn.p, c->src_n2e_off.p, c->src_n2e.p, color.p, tent.p, flag.p);
             hipLaunchKernelGGL(k_color_resolve, dim3(grid), dim3(256), 0, st, E, n, c->conn.p, c->src_n2e_off.p, c->src_n2e.p, tent.p, color.p,
                                remaining.p);
@@ -2617,14 +2618,18 @@ int fh_color_parallel(fh_ctx* c, uint64_t* num_colors, uint64_t* color_offsets, 
             HIP_TRY(c, hipMemcpyAsync(&left, remaining.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipMemcpyAsync(&over, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
-            if (over) return c->fail(FH_UNSUPPORTED, "fh_color_parallel: more than 128 colours needed (use fh_color)");
+            if (over) return c->fail(FH_UNSUPPORTED, "fh_color_parallel: more than 32768 colours needed (use fh_color)");
         }
+        HIP_TRY(c, hipMemcpyAsync(&max_color, remaining.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        int key_bits = 1;
+        while ((1u << key_bits) <= max_color) ++key_bits;
         // colours in order, the elements of a colour ascending: a stable sort of (colour, element)
         size_t tb = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, 8, st));
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, key_bits, st));
         DevBuf<char> tmp;
         HIP_TRY(c, tmp.alloc(tb + 16));
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, 8, st));
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, color.p, keys_s.p, ids.p, ids_s.p, E, 0, key_bits, st));
         std::vector<int> hk((size_t)E);
         std::vector<unsigned> hi((size_t)E);
         HIP_TRY(c, hipMemcpyAsync(hk.data(), keys_s.p, sizeof(int) * (size_t)E, hipMemcpyDeviceToHost, st));

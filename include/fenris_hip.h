@@ -200,7 +200,7 @@ int fh_color(fh_ctx*, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* l
 /* the same outputs, computed ON the device: Luby-style rounds (propose the smallest colour no finished neighbour holds, keep it unless
  * a neighbour of smaller hashed priority proposed the same), deterministic.  A valid colouring -- no two elements of a colour share a
  * node, which is all CsrParAssembler / DisjointSubsets require -- but generally not the sequential greedy one of fh_color (more colours
- * are possible; at most 128).  Fixed-size connectivity only. */
+ * are possible).  Fixed-size connectivity only. */
 int fh_color_parallel(fh_ctx*, uint64_t* num_colors, uint64_t* color_offsets, uint64_t* labels);
 /* reuse a colouring computed elsewhere (colours are serialisable in the reference, paradis lib.rs:170) */
 int fh_set_colors(fh_ctx*, uint64_t num_colors, const uint64_t* color_offsets, const uint64_t* labels);

@@ -95,3 +95,24 @@ def test_fans_match_oracle(engine, oracle, shape, k, layers, op):
     f = fa.VectorAssembler().assemble_vector(asm)
     st, _, of = oracle.assemble_vector(ref)
     assert st == 0 and np.abs(f - of).max() <= TOL * max(np.abs(of).max(), 1.0)
+
+
+@pytest.mark.parametrize("shape,k,layers", [("tet", 130, 2), ("quad", 140, 0), ("hex", 70, 2)])
+def test_parallel_coloring_beyond_one_window(engine, oracle, shape, k, layers):
+    """a node with more elements than the 128 colours one pass of fh_color_parallel marks: further windows, wider sort keys"""
+    mesh = {"tet": lambda: tet_fan(k, layers), "quad": lambda: quad_fan(k), "hex": lambda: hex_fan(k, layers)}[shape]()
+    w, p = _rule(mesh.elem_kind)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(qt).with_u(np.zeros(mesh.num_nodes())).build())
+    colors = engine.color_parallel()
+    conn = np.asarray(mesh.connectivity).astype(np.int64)
+    assert len(colors) >= (2 * k if layers >= 2 else k)           # the elements at the busiest node are pairwise neighbours
+    assert sorted(colors.labels.tolist()) == list(range(mesh.num_elements()))
+    for c in range(len(colors)):
+        lab = colors.color(c).astype(np.int64)
+        nodes = conn[lab].ravel()
+        assert np.all(np.diff(lab) > 0) and len(np.unique(nodes)) == len(nodes)
+    a = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
+    c = fa.CsrParAssembler().assemble(colors, asm)
+    assert np.abs(c.values - a.values).max() <= TOL * np.abs(a.values).max()

@@ -125,3 +125,28 @@ def test_permuted_numbering(engine, oracle, kind, opname):
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
     assert st == 0 and np.array_equal(k.col_indices, oci)
     assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), engine.last_kernel_name()
+
+
+@pytest.mark.parametrize("dims", [(20, 13, 9), (1, 1, 40), (40, 1, 1), (2, 37, 3), (31, 29, 17)])
+@pytest.mark.parametrize("opname", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_graded_boxes_stay_on_the_affine_kernel(engine, oracle, dims, opname):
+    """tensor-product meshes with a different spacing in every layer: every element is a box of its own size (affine, but no two records
+    alike), the edge lengths are not multiples of the seven-node blocks, thin meshes have no interior node at all"""
+    cx, cy, cz = dims
+    m0 = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, cx, cy, cz, 1)
+    v = m0.vertices.copy()
+    for a, c in enumerate(dims):
+        t = v[:, a] / c                                  # 0 .. 1
+        v[:, a] = c * (0.35 * t + 0.65 * t ** 3) * (1.0 + 0.5 * a)   # monotone: boxes stay boxes
+    mesh = fa.Mesh(v, m0.connectivity, m0.elem_kind)
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    asm, ref = _both(engine, oracle, mesh, oracle.HEX8, opname, w, p)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert "k_affine_rows" in engine.last_kernel_name()
+    assert np.array_equal(k.col_indices, oci)
+    assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), engine.last_kernel_name()
+    # exact symmetry (util.rs:38-51) survives records that differ from element to element
+    a = k.to_scipy()
+    assert (a != a.T).nnz == 0

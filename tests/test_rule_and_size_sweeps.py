@@ -150,3 +150,17 @@ def test_graded_boxes_stay_on_the_affine_kernel(engine, oracle, dims, opname):
     # exact symmetry (util.rs:38-51) survives records that differ from element to element
     a = k.to_scipy()
     assert (a != a.T).nnz == 0
+
+
+def test_randomised_gather_against_atomic():
+    """scripts/fuzz_gather.py: 500 random small meshes (holes, permuted numbering, affine / distorted / mixed geometry, masks, row ranges,
+    overwrite into garbage): the owner-computes kernels against the atomic scatter on the device"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_gather
+
+    bad, kernels = fuzz_gather.run(500, 20260, quiet=True)
+    assert bad == 0
+    assert sum(v for k, v in kernels.items() if "k_affine_rows" in k) > 20 and kernels.get("k_gather_rows", 0) > 50

@@ -123,7 +123,12 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             double* line0 = a.vals + (size_t)SS * (size_t)r0 - head;
             const int lo = carry_in ? 0 : head, hi = head + SS * nrow;
             const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
-            const bool zero = !(flags & 1);
+            // Clear what was streamed whenever ANY position of the sweep has a block without an owner lane (element masks): such a block
+            // must read as zero, and the buffer it lies in was last filled by the position two steps back -- complete or not, with rows of
+            // another extent.  (Until round 3 only the incomplete positions cleared behind themselves: with several positions per workgroup
+            // an incomplete one inherited the values of a complete one; scripts/fuzz_gather.py.)
+            const bool zero = T.incomplete != 0;
+            (void)flags;
             const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces [k0, k1)
             const int np = max(k1 - k0, 0);
             const int nfull = np / SL, rem = np - nfull * SL;    // trips of SL pieces, pieces of the last trip
@@ -161,7 +166,16 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             if (p > p_begin) {
                 const int4 h_prev = HDR[(p - 1) & 3];
                 const int r0_cur = rfl(HDR[p & 3].x);
-                const bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y);
+                bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y) && !(ablate_arg & AFFINE_ROWS_NO_CARRY);
+                if (carry_out) {
+                    // A position whose rows end before the first line boundary behind their start -- a node without elements (empty rows)
+                    // or a single short row -- has nothing to store now, and what it would hand on starts at the line's beginning: below
+                    // its own first value lies whatever the staging buffer held (zeros), and the next position would write that over the
+                    // end of the PREVIOUS rows in memory, which another position owns.  Such a position stores its own piece of the line
+                    // itself (found by scripts/fuzz_gather.py on a box with holes; the structured meshes never have one).
+                    const int head_p = rfl(h_prev.w) & 15, lo_p = carry_in ? 0 : head_p, hi_p = head_p + SS * rfl(h_prev.y);
+                    if ((hi_p & ~15) < lo_p) carry_out = false;
+                }
                 stream_out(h_prev, OUT + (size_t)(par ^ 1) * accp, OUT + (size_t)par * accp, carry_in, carry_out);
                 carry_in = carry_out;
             }

@@ -1304,7 +1304,8 @@ int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
     // 4: 0.603, 5: 0.585), Laplace 4
     const size_t cap = (c->op == FH_LAPLACE) ? 4 : 2;
     const int per_cu = std::max(1, (int)std::min<size_t>(cap, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int grid = std::min(c->npos_gen, dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    // (FENRIS_HIP_PIPE_GRID: tests force many positions per workgroup on small meshes)
+    const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu))));
     auto kern = a.trace ? k_gather_rows_tet4<OP, ELEMPAR, true> : k_gather_rows_tet4<OP, ELEMPAR>;   // FENRIS_HIP_TRACE: instrumented twin
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1332,7 +1333,7 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
     const int wgs = std::max(1, c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
-    const int grid = std::min(c->npos_gen, dev_cus * wgs);
+    const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * wgs)));
     // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
     const bool dbg = (c->env("FENRIS_HIP_TRACE") || c->env("FENRIS_HIP_ABLATE") || c->env("FENRIS_HIP_DBG_KERNEL"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
@@ -1417,7 +1418,8 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
     const unsigned char* act = c->has_mask ? c->active.p : nullptr;
     DevStatus* status = c->status.p + c->status_slot;
-    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0);
+    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
+                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
     const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
     if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)
@@ -1444,7 +1446,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
         const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-        const int grid = std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu)));
+        const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
         if (c->env("FENRIS_HIP_VERBOSE"))
             std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
         HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,

@@ -2,7 +2,8 @@
 """Randomised cross-check of the owner-computes (gather) kernels against the generic atomic scatter on the device: random box sizes, random
 holes, optionally permuted numbering, distorted / affine / mixed geometry, element masks, row ranges, FH_ASSEMBLE_OVERWRITE into garbage.
 The atomic path is the reference-shaped one (pinned by the oracle in tests/); this looks for table-builder corner cases the fixed tests miss.
-    python scripts/fuzz_gather.py [cases] [seed]        (prints the case before it runs: a GPU fault names its culprit)"""
+    python scripts/fuzz_gather.py [cases] [seed] [big]  (prints the case before it runs: a GPU fault names its culprit; `big`: boxes up to 25^3,
+                                                         Hex27, NeoHookean / StVK as well)"""
 import os
 import sys
 
@@ -15,20 +16,23 @@ import torch  # noqa: E402
 import fenris_amd as fa  # noqa: E402
 from fenris_amd import quadrature  # noqa: E402
 
-def run(cases=200, seed0=0, quiet=False):
+def run(cases=200, seed0=0, quiet=False, big=False):
     eng = fa.Engine(0)
     lame = fa.LameParameters(3.0e2, 5.0e2)
     bad = 0
     kernels = {}
     for it in range(cases):
         rng = np.random.default_rng(seed0 + it)
-        kind = rng.choice(["HEX8", "HEX8", "TET4", "TET4", "QUAD4", "TRI3"])
-        dims = rng.integers(1, 10, 3)
+        kind = rng.choice(["HEX8", "HEX8", "TET4", "TET4", "QUAD4", "TRI3", "HEX27"] if big else ["HEX8", "HEX8", "TET4", "TET4", "QUAD4", "TRI3"])
+        dims = rng.integers(1, 26 if (big and kind != "HEX27") else (5 if kind == "HEX27" else 10), 3)
         if kind == "HEX8":
             m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, int(dims[0]), int(dims[1]), int(dims[2]), 1)
             w, p = quadrature.tensor.hexahedron_gauss(int(rng.integers(1, 4)))
+        elif kind == "HEX27":
+            m = fa.hex27_mesh_from_hex8(fa.procedural.create_rectangular_uniform_hex_mesh(1.0, int(dims[0]), int(dims[1]), int(dims[2]), 1))
+            w, p = quadrature.tensor.hexahedron_gauss(3)
         elif kind == "TET4":
-            m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(int(dims[0] % 5 + 1))
+            m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(int(dims[0] % (12 if big else 5) + 1))
             w, p = quadrature.total_order.tetrahedron(int(rng.integers(1, 4)))
         elif kind == "QUAD4":
             m = fa.procedural.create_unit_square_uniform_quad_mesh_2d(int(dims[0] + 1))
@@ -56,34 +60,44 @@ def run(cases=200, seed0=0, quiet=False):
             inv[perm] = np.arange(len(v))
             v, c = v[perm], inv[c][rng.permutation(len(c))]
         mesh = fa.Mesh(v, c.astype(np.uint64), m.elem_kind)
-        opname = rng.choice(["LAPLACE", "LINEAR_ELASTIC"])
+        opname = rng.choice(["LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK"] if big else ["LAPLACE", "LINEAR_ELASTIC"])
         d = v.shape[1]
         s = 1 if opname == "LAPLACE" else d
         qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
         if opname != "LAPLACE":
             qt = qt.with_uniform_data(lame)
-        op = fa.LaplaceOperator() if opname == "LAPLACE" else fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+        op = {"LAPLACE": fa.LaplaceOperator, "LINEAR_ELASTIC": lambda: fa.MaterialEllipticOperator(fa.LinearElasticMaterial()),
+              "NEO_HOOKEAN": lambda: fa.MaterialEllipticOperator(fa.NeoHookeanMaterial()),
+              "STVK": lambda: fa.MaterialEllipticOperator(fa.StVKMaterial())}[opname]()
         masked = rng.random() < 0.3
         ranged = rng.random() < 0.3
         n = mesh.num_nodes()
         lo_n, hi_n = (sorted(rng.integers(0, n + 1, 2)) if ranged else (0, n))
         if not quiet:
-            print(f"case {seed0 + it}: {kind} dims {dims.tolist()} {geo} E={len(c)} N={n} {opname} nq={len(w)} mask={masked} rows=[{lo_n},{hi_n})", flush=True)
+            print(f"case {seed0 + it}: {kind} dims {dims.tolist()} {geo} E={len(c)} N={n} {opname} nq={len(w)} mask={masked} rows=[{lo_n},{hi_n})", end=" ", flush=True)
         asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(op).with_quadrature_table(qt)
-               .with_u(np.zeros(s * n)).build())
+               .with_u(1e-3 * rng.standard_normal(s * n) if opname in ("NEO_HOOKEAN", "STVK") else np.zeros(s * n)).build())
         nnz = eng.build_pattern()
         ro, _ = eng.pattern(want_cols=False)
         if masked:
             eng.set_active_elements(rng.random(len(c)) < 0.7)
         want = torch.zeros(nnz, dtype=torch.float64, device="cuda")
         eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
+        # few workgroups: every one walks many positions (carries between positions, chains, prefetch stages) even on a small mesh
+        grid = rng.choice([0, 0, 1, 2, 3, 5, 17])
+        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID"):
+            eng.set_option(name, str(int(grid)) if grid else None)
         eng.set_row_range(int(lo_n), int(hi_n))
         got = torch.full((nnz,), 4.5, dtype=torch.float64, device="cuda")
         eng.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
         kern = eng.last_kernel_name()
+        if not quiet:
+            print(f"grid={int(grid)} {kern}", flush=True)
         kernels[kern] = kernels.get(kern, 0) + 1
         eng.set_row_range(0, n)
         eng.set_active_elements(None)
+        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID"):
+            eng.set_option(name, None)
         wv, gv = want.cpu().numpy(), got.cpu().numpy()
         lo, hi = int(ro[s * lo_n]), int(ro[s * hi_n])
         scale = max(np.abs(wv).max(), 1e-300)
@@ -98,4 +112,4 @@ def run(cases=200, seed0=0, quiet=False):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=len(sys.argv) > 3)

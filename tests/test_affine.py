@@ -246,3 +246,39 @@ def test_placement_tuning_keeps_the_matrix():
         eng.set_option("FENRIS_HIP_AFFINE_RING", None)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
+@pytest.mark.parametrize("grid", ["1", "2", "5"])
+def test_affine_masks_and_holes_with_many_positions_per_workgroup(engine, oracle, op, grid):
+    """Round 3, found by scripts/fuzz_gather.py: the small meshes of the other tests give every workgroup ONE position, the benchmark sizes give
+    it thousands.  With FENRIS_HIP_AFFINE_GRID a small mesh walks the same paths: (a) under an element mask a block without an active element
+    inherited the values a COMPLETE position had left in the staging buffer two steps earlier; (b) a node without elements (a hole) at the head of
+    a run of consecutive rows handed the zeros below its own start on to the next position, which wrote them over the end of the previous rows."""
+    import torch
+
+    base = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 7, 6, 5, 1)
+    rng = np.random.default_rng(42)
+    keep = rng.random(base.num_elements()) >= 0.4                      # holes: some nodes lose every element
+    mesh = fa.Mesh(base.vertices, np.asarray(base.connectivity)[keep], base.elem_kind)
+    asm, ref = _assemblers(engine, oracle, mesh, op)
+    nnz = engine.build_pattern()
+    engine.set_option("FENRIS_HIP_AFFINE_GRID", grid)
+    try:
+        for masked in (False, True):
+            engine.set_active_elements((rng.random(mesh.num_elements()) < 0.7) if masked else None)
+            want = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+            engine.assemble_matrix(want, fa.SCATTER_ATOMIC)
+            for fill in (0.0, -2.5):
+                got = torch.full((nnz,), fill, dtype=torch.float64, device="cuda")
+                engine.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+                assert engine.last_kernel_name().startswith("k_affine_rows")
+                w, g = want.cpu().numpy(), got.cpu().numpy()
+                assert np.abs(g - w).max() <= TOL * np.abs(w).max(), (masked, fill)
+        st, _, ro, ci, vals = oracle.assemble(ref)      # and the unmasked matrix is the oracle's
+        engine.set_active_elements(None)
+        k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert st == 0 and np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+    finally:
+        engine.set_active_elements(None)
+        engine.set_option("FENRIS_HIP_AFFINE_GRID", None)

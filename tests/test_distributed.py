@@ -238,6 +238,44 @@ def test_row_range_split_equals_single_launch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opname", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_slab_with_many_positions_per_workgroup_against_the_atomic_scatter(opname):
+    """A middle slab big enough that every workgroup of the owner-computes kernels walks several positions (40 x 40 x 15 layers: 3 800
+    positions for 768 workgroups), its mask set, both launches of SlabAssembly into an array of garbage -- against the ATOMIC scatter of the
+    same context (another engine with the same kernels, as in the test above, would share a defect: until round 3 the affine kernel let a
+    block without an active element inherit stale values, invisible at one position per workgroup)"""
+    import torch
+
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if opname != "LAPLACE":
+        qt = qt.with_uniform_data(fa.LameParameters(*LAME))
+    op = fa.LaplaceOperator() if opname == "LAPLACE" else fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+
+    def configure(engine, mesh):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(op).with_quadrature_table(qt)
+                .with_u(None).build())
+
+    slab = fd.make_slab(1.0, 1, 1, 1, 40, 1, 3)
+    sa = fd.SlabAssembly(slab, configure, device=0, overlap=True)
+    flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+    sa.values.fill_(-11.5)
+    sa.main.assemble_matrix_rows_async(sa.values, flags, 0, sa.split)
+    sa.main.assemble_matrix_async(sa.values, flags)
+    sa.poll_status()
+    torch.cuda.synchronize()
+    assert "k_affine_rows" in sa.main.last_kernel_name()
+    got = sa.values.cpu().numpy()
+    n = slab.mesh.num_nodes()
+    sa.main.set_row_range(0, n)
+    want = torch.zeros_like(sa.values)
+    sa.main.assemble_matrix(want, fa.SCATTER_ATOMIC)
+    wv = want.cpu().numpy()
+    assert np.abs(got - wv).max() <= 1e-12 * np.abs(wv).max()
+    sa.close()
+
+
+@pytest.mark.gpu
 def test_rows_call_reports_a_singular_element_of_its_range():
     """fh_assemble_matrix_rows_*: a degenerate element touching the range is reported by the call / by the next poll, and a
     later clean call clears it (the rows call has its own status slot)"""

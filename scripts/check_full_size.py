@@ -4,7 +4,7 @@ FH_SCATTER_GATHER (affine rows / pipelined / row-owner / two-pass matrix-core ke
 generic element kernel + fp64 atomics), on the device, compared entry by entry; plus the properties the full-size tests use
 (symmetry, zero row sums of a stiffness matrix).  The small-mesh parity tests compare with the oracle; this one guards
 against anything that only shows at scale (offsets beyond 2^31 bytes, table strides, the locality order of 860 k nodes).
-    python scripts/check_full_size.py [ns ns-perturbed c2 c3 c4]"""
+    python scripts/check_full_size.py [ns ns-perturbed c2 c3 c4 ns-slab c5-slab]"""
 import os
 import sys
 
@@ -49,9 +49,48 @@ def problem(cfg):
     raise SystemExit(f"unknown configuration {cfg}")
 
 
+def slab_check(cfg):
+    """what ONE RANK of the multi-GPU runs assembles: rank 1 of 8 of `bench.py --gpus 8` (ns: 216 x 216 x 216 own cells; c5: 256 x 256 x 32), the
+    extended mesh with its halo layers, the element mask set, the two launches of SlabAssembly into an array of garbage -- against the atomic
+    scatter of the same context.  (Round 3: the masked affine kernel was wrong whenever a workgroup walked several positions.)"""
+    from fenris_amd import distributed as fd
+
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(LAME)
+
+    def configure(engine, mesh):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh)
+                .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt).with_u(None).build())
+
+    slab = fd.make_slab(1.0, 1, 1, 8, 216, 1, 8) if cfg == "ns-slab" else fd.make_slab(1.0, 1, 1, 1, 256, 1, 8)
+    sa = fd.SlabAssembly(slab, configure, device=0, overlap=True, stream=torch.cuda.current_stream().cuda_stream)
+    flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+    sa.values.fill_(-11.5)
+    sa.main.assemble_matrix_rows_async(sa.values, flags, 0, sa.split)
+    sa.main.assemble_matrix_async(sa.values, flags)
+    sa.poll_status()
+    torch.cuda.synchronize()
+    kernel = sa.main.last_kernel_name()
+    sa.main.set_row_range(0, slab.mesh.num_nodes())
+    want = torch.zeros_like(sa.values)
+    sa.main.assemble_matrix(want, fa.SCATTER_ATOMIC)
+    scale = want.abs().max().item()
+    diff = (sa.values - want).abs().max().item() / scale
+    good = diff <= 1e-11
+    print(f"{cfg}: rank 1 of 8, {slab.num_own_elements()} own of {slab.mesh.num_elements()} elements, nnz {sa.values.numel()}, kernel {kernel}: "
+          f"max |gather - atomic| / max |K| = {diff:.2e}  {'OK' if good else 'FAILED'}", flush=True)
+    sa.close()
+    del want
+    torch.cuda.empty_cache()
+    return good
+
+
 def main():
     ok = True
-    for cfg in (sys.argv[1:] or ["ns", "ns-perturbed", "c2", "c3", "c4"]):
+    for cfg in (sys.argv[1:] or ["ns", "ns-perturbed", "c2", "c3", "c4", "ns-slab", "c5-slab"]):
+        if cfg.endswith("-slab"):
+            ok &= slab_check(cfg)
+            continue
         mesh, op, qt, u, s = problem(cfg)
         eng = fa.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
         (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(op).with_quadrature_table(qt)

@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(384, 5) k_affine_ring(const KArgs a, const Aff
         const unsigned oR0 = (x & 31u) * (GW * 8), oG0 = ((x >> 5) & 127u) * (GW * 8);
         const unsigned oR1 = ((x >> 12) & 31u) * (GW * 8), oG1 = ((x >> 17) & 127u) * (GW * 8);
         const int grp = (int)((x >> 24) & 3u);
+        const bool zero_lane = ((x >> 5) & 127u) == 64u && ((x >> 17) & 127u) == 64u;   // gidx 64 twice = a block without a term: zeros (affine_rows.hip)
         const unsigned rb = rho * 8u + (y & 0xffffu);   // ring byte offset (unwrapped) of the lane's block
         if constexpr (LAP) {
             const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
@@ -371,6 +372,7 @@ __global__ void __launch_bounds__(384, 5) k_affine_ring(const KArgs a, const Aff
             }
             if (grp >= 1) s += dpp_quad_full<0xB1>(s);
             if (grp >= 2) s += dpp_quad_full<0x4E>(s);
+            if (zero_lane) s = 0.0;
             if ((x >> 28) & 1u) *reinterpret_cast<double*>(OUTc + (rb & maskb)) = s;
         } else {
             double H[3][3];
@@ -417,6 +419,12 @@ __global__ void __launch_bounds__(384, 5) k_affine_ring(const KArgs a, const Aff
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int s_ = 0; s_ < 3; ++s_) H[r][s_] += dpp_quad_full<0x4E>(H[r][s_]);
+            }
+            if (zero_lane) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] = 0.0;
             }
             if ((x >> 28) & 1u) {
                 const bool tr = (x >> 26) & 1u, dg = (x >> 27) & 1u;

@@ -123,11 +123,6 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             double* line0 = a.vals + (size_t)SS * (size_t)r0 - head;
             const int lo = carry_in ? 0 : head, hi = head + SS * nrow;
             const int L = carry_out ? (hi & ~15) : hi;          // stored now: [lo, L); carried: [L, hi)
-            // Clear what was streamed whenever ANY position of the sweep has a block without an owner lane (element masks): such a block
-            // must read as zero, and the buffer it lies in was last filled by the position two steps back -- complete or not, with rows of
-            // another extent.  (Until round 3 only the incomplete positions cleared behind themselves: with several positions per workgroup
-            // an incomplete one inherited the values of a complete one; scripts/fuzz_gather.py.)
-            const bool zero = T.incomplete != 0;
             (void)flags;
             const int k0 = (lo + 1) >> 1, k1 = L >> 1;           // whole 16-byte pieces [k0, k1)
             const int np = max(k1 - k0, 0);
@@ -146,23 +141,13 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             if (e_lo >= 0 && lane == 0) put1(line0 + e_lo, buf[e_lo]);
             if (e_hi >= 0 && lane == 0) put1(line0 + e_hi, buf[e_hi]);
             if (carry_out && lane < hi - L) other[lane] = buf[L + lane];
-            if (zero) {  // some (node, column) block of these rows has no owner lane (element masks): clear what was read --
-                         // every lane the pieces it fetched itself, the first lanes the ends and the carried part
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const f64x2 z2 = {0.0, 0.0};
-                for (int t = 0; t < nfull; ++t) b2[SL * t] = z2;
-                if (lane < rem) b2[SL * nfull] = z2;
-                if (lane == 0 && e_lo >= 0) buf[e_lo] = 0.0;
-                if (lane == 0 && e_hi >= 0) buf[e_hi] = 0.0;
-                if (lane < hi - L) buf[L + lane] = 0.0;
-                if (lane < 2 * k0 - lo && lo + lane != e_lo) buf[lo + lane] = 0.0;   // nothing: [lo, 2 k0) is e_lo alone
-            }
         };
         lds_barrier();  // B0
         tr_start();
         bool carry_in = false;
         int par = 0;
         for (int p = p_begin; p < p_end; ++p, par ^= 1) {
+            if (!(rfl(HDR[p & 3].z) & 1)) tr_barrier();   // an incomplete position: the row waves clear their buffer first (see there)
             if (p > p_begin) {
                 const int4 h_prev = HDR[(p - 1) & 3];
                 const int r0_cur = rfl(HDR[p & 3].x);
@@ -186,8 +171,8 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         return;
     }
 
-    // ring entry .w: head | slots of the position << 8 (every field of the header is used: the fetch stays one 16-byte load)
-    auto with_head = [&](int4 h) { h.w = head_of(h.x) | (h.w << 8); return h; };
+    // ring entry .w: head | extent of the position's rows in doubles << 4 (what an incomplete position clears, below)
+    auto with_head = [&](int4 h) { h.w = head_of(h.x) | ((SS * h.y) << 4); return h; };
     if (wave == 4) {
         // ------------------------------------------------------------------------------------------ loader wave
         // Every global load of the kernel: the element records of the next position's slots (R or M, GW doubles each, written
@@ -265,6 +250,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         // one position of the loader (a macro, not a lambda: the stages must stay in registers)
 #define AFFINE_LOADER_STEP(k, p)                                                                                              \
         {                                                                                                                     \
+            if (!(__builtin_amdgcn_readfirstlane(HDR[(p) & 3].z) & 1)) tr_barrier();   /* incomplete position: see the row waves */ \
             /* in place: what was requested DEPTH positions ago goes to LDS, the next requests go out */                     \
             unsigned long long tq0 = 0;                                                                                       \
             if (DBG && a.trace) tq0 = __builtin_readcyclecounter();                                                           \
@@ -319,6 +305,25 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
         const int z = __builtin_amdgcn_readfirstlane(zw[0]);
         const int head = zw[1] & 15;
+        if (!(z & 1)) {
+            // A position with a block that has no owner lane (element masks: the interface planes of a partition, a per cent of the
+            // positions) needs that block to read as zero, whatever the buffer held before -- the position two steps back, complete or
+            // not, with rows of another extent.  Its own row lanes clear the extent first (a few stores each; the store wave, the
+            // critical path, is left alone: with the clearing there the workgroups that own an interface plane finished 20 % late and
+            // the masked sweep took 5.9 instead of 4.95 ms), then every role of the workgroup meets at one extra barrier.  The carried
+            // piece below `head` belongs to the store wave.  (Until round 3 only incomplete positions cleared, and only behind
+            // themselves: with several positions per workgroup an incomplete one inherited the values of a complete one.)
+            const int ext = __builtin_amdgcn_readfirstlane(zw[1]) >> 4;
+            double* buf = OUT + (size_t)par * accp;
+            if (!(ablate_arg & AFFINE_ROWS_NO_CLEAR)) {   // (timing experiments: the barrier without the stores)
+                const int lo = head, hi = head + ext, k0 = (lo + 1) >> 1, k1 = hi >> 1;   // whole 16-byte pieces [k0, k1), single doubles at odd ends
+                const f64x2 z2 = {0.0, 0.0};
+                for (int k = k0 + tid; k < k1; k += 256) reinterpret_cast<f64x2*>(buf)[k] = z2;
+                if (tid == 0 && (lo & 1) && lo < hi) buf[lo] = 0.0;
+                if (tid == 1 && (hi & 1) && hi - 1 >= lo) buf[hi - 1] = 0.0;
+            }
+            tr_barrier();
+        }
         if (z & 4) {   // the lane table changed with this position
             lane_cur = LT[256 * ((z >> 1) & 1) + tid];
             if constexpr (LAP) {  // ... and with it the reference blocks of this lane's two terms: kept in registers
@@ -335,6 +340,9 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         const unsigned oR0 = (x & 31u) * (GW * 8), oG0 = ((x >> 5) & 127u) * (GW * 8);
         const unsigned oR1 = ((x >> 12) & 31u) * (GW * 8), oG1 = ((x >> 17) & 127u) * (GW * 8);
         const int grp = (int)((x >> 24) & 3u);
+        // a lane of a block WITHOUT a term (k_build_affine_rows: element masks) stores zeros whatever slot 0 holds (the record of an
+        // empty slot may be anything, and 0 x NaN is not 0)
+        const bool zero_lane = ((x >> 5) & 127u) == AR_ZERO_G && ((x >> 17) & 127u) == AR_ZERO_G;
         char* out_par = reinterpret_cast<char*>(OUT + (size_t)par * accp);
         if constexpr (LAP) {
             const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
@@ -348,6 +356,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             }
             if (grp >= 1) s += dpp_quad_full<0xB1>(s);
             if (grp >= 2) s += dpp_quad_full<0x4E>(s);
+            if (zero_lane) s = 0.0;
             if ((x >> 28) & 1u) *reinterpret_cast<double*>(out_par + 8 * head + (y & 0xffffu)) = s;
         } else {
             double H[3][3];
@@ -396,6 +405,12 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int s_ = 0; s_ < 3; ++s_) H[i][s_] += dpp_quad_full<0x4E>(H[i][s_]);
+            }
+            if (zero_lane) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] = 0.0;
             }
             if ((x >> 28) & 1u) {
                 const bool tr = (x >> 26) & 1u, dg = (x >> 27) & 1u;
@@ -552,16 +567,21 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         }
     }
     __syncthreads();
-    // classes: 5..8 terms -> 4 lanes, 3..4 -> 2 lanes, 1..2 -> one lane
-    int n4 = 0, n2 = 0, n1 = 0;
+    // classes: 5..8 terms -> 4 lanes, 3..4 -> 2 lanes, 1..2 -> one lane; a block of these rows WITHOUT a term (element masks: no active
+    // element joins the two nodes) gets a lane of its own that stores zeros, when the lanes suffice -- the position is then complete and
+    // never needs its staging buffer cleared (the interface planes of a slab partition: ~140 owner lanes + 63 such blocks)
+    auto is_block = [&](int key) { const int il = key >> 7, pos = key & 127; return il < h.nb && pos < noff_old[il + 1] - noff_old[il]; };
+    int n4 = 0, n2 = 0, n1 = 0, n0 = 0;
     for (int base = 0; base < NKEY; base += 64) {
         const int Tn = min(cnt[base + lane], TMAX);
         n4 += __popcll(__ballot(Tn >= 5));
         n2 += __popcll(__ballot(Tn == 3 || Tn == 4));
         n1 += __popcll(__ballot(Tn == 1 || Tn == 2));
+        n0 += __popcll(__ballot(Tn == 0 && is_block(base + lane)));
     }
-    const int base4 = 0, base2 = 4 * n4, base1 = base2 + 2 * n2;
+    const int base4 = 0, base2 = 4 * n4, base1 = base2 + 2 * n2, base0 = base1 + n1;
     if (base1 + n1 > 256) bad = true;
+    const bool zero_lanes = n0 > 0 && base0 + n0 <= 256;
     if ((size_t)8 * S * S * (size_t)h.nrow >= 65536u) bad = true;
     if (__ballot(bad)) {
         if (lane == 0) {
@@ -572,7 +592,7 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         if (lane == 0) hash_out[p] = 0ull;
         return;
     }
-    int r4 = 0, r2 = 0, r1 = 0;
+    int r4 = 0, r2 = 0, r1 = 0, r0 = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int base = 0; base < NKEY; base += 64) {
         const int key = base + lane;
@@ -580,6 +600,15 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         const unsigned il = (unsigned)key >> 7, pos = (unsigned)key & 127u;
         const unsigned short* b = bucket + key * TMAX;
         const unsigned long long m4 = __ballot(Tn >= 5), m2 = __ballot(Tn == 3 || Tn == 4), m1 = __ballot(Tn == 1 || Tn == 2);
+        const bool zb = zero_lanes && Tn == 0 && is_block(key);
+        const unsigned long long m0 = __ballot(zb);
+        if (zb) {   // no term: slot 0 with the block of zeros twice, the store flag, the block's place in the staged rows
+            const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
+            const int Lidx = base0 + r0 + __popcll(m0 & below);
+            lw0[Lidx] = (AR_ZERO_G << 5) | (AR_ZERO_G << 17) | (1u << 28);
+            lw1[Lidx] = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+        }
+        r0 += __popcll(m0);
         if (Tn >= 1) {
             const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
             const unsigned I = (unsigned)h.i0 + il, J = ncols[(size_t)h.r0 + rb + pos];
@@ -623,7 +652,7 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
     if (lane == 0) hash_out[p] = hsum;
     // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
-    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, (n4 + n2 + n1 == h.nrow) ? 1 : 0, h.U);
+    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, (n4 + n2 + n1 + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0, h.U);
 }
 
 // table id of every position into its header (flags | id << 8), and the first position of every id gathered into the

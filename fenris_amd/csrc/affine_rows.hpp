@@ -22,6 +22,7 @@ struct AffineRowTables {
 };
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
+constexpr int AFFINE_ROWS_NO_CLEAR = 0x40000;   // (timing experiments only: wrong results under a mask)
 constexpr int AFFINE_ROWS_NO_CARRY = 0x20000;   // (debugging) every position stores its own incomplete last line
 constexpr int AFFINE_ROWS_NT_STORES = 0x10000;  // bit of the launcher's `ablate` argument: non-temporal stores of the rows
 constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave (a second store wave: 448)

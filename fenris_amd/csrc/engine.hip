@@ -1213,8 +1213,12 @@ int build_partition(fh_ctx* c) {
                         if (!mismatch[0]) break;
                         dedupe(true);  // a hash collision: every position keeps its own table
                     }
-                    if (c->env("FENRIS_HIP_VERBOSE"))
-                        std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables\n", npos, c->a_ntab);
+                    if (c->env("FENRIS_HIP_VERBOSE")) {
+                        long long changes = 0;   // positions whose table differs from their predecessor's in the sweep: each is a 2 KB fetch
+                        for (int p = 1; p < npos; ++p) changes += ids[p] != ids[p - 1];
+                        std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables, %lld changes of table along the sweep%s\n",
+                                     npos, c->a_ntab, changes, c->a_incomplete ? ", some position has a block without an owner" : "");
+                    }
                 }
                 c->a_conn.release();  // input of the lane builder only
                 c->a_npos = npos;
@@ -1419,7 +1423,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const unsigned char* act = c->has_mask ? c->active.p : nullptr;
     DevStatus* status = c->status.p + c->status_slot;
     const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
-                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0);
+                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
     const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
     if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)

@@ -68,4 +68,14 @@ __global__ void __launch_bounds__(256) k_block_class(const GatherHdr* hdr, const
     cls[b] = ok;
 }
 
+// smallest and largest non-negative entry (mm = {INT_MAX, -1} on entry): the element range behind a set of position tables
+__global__ void __launch_bounds__(256) k_minmax_nonneg(const int* v, size_t n, int* mm) {
+    int lo = 0x7fffffff, hi = -1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = v[i];
+        if (x >= 0) { lo = min(lo, x); hi = max(hi, x); }
+    }
+    if (hi >= 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+}
+
 }  // namespace fenris_hip

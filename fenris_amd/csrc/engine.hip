@@ -360,6 +360,7 @@ struct fh_ctx {
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
     int a_us = 0, a_npos = 0, a_ntab = 0, a_incomplete = 0;
+    long long a_emin = 0, a_emax = -1;   // elements the affine positions of this partition refer to: the records kernel walks [a_emin, a_emax]
     unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
     bool aff_failed = false;        // the lane tables could not express an affine block of this mesh: general kernels only
@@ -431,7 +432,7 @@ struct fh_ctx {
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
-    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(npos_gen)       \
+    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
     X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
@@ -1222,6 +1223,20 @@ int build_partition(fh_ctx* c) {
                 }
                 c->a_conn.release();  // input of the lane builder only
                 c->a_npos = npos;
+                {   // the element range behind these positions (a node range of a few rows -- the interface plane sent first in a
+                    // partition -- needs the records of two element layers, not of ten million elements)
+                    DevBuf<int> mm;
+                    HIP_TRY(c, mm.alloc(2));
+                    const int init[2] = {0x7fffffff, -1};
+                    HIP_TRY(c, hipMemcpyAsync(mm.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+                    const size_t cnt = (size_t)npos * us;
+                    hipLaunchKernelGGL(k_minmax_nonneg, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, c->stream, c->a_elem.p, cnt, mm.p);
+                    int got[2] = {0, -1};
+                    HIP_TRY(c, hipMemcpyAsync(got, mm.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    c->a_emin = got[1] >= 0 ? got[0] : 0;
+                    c->a_emax = got[1];
+                }
             }
             c->npos_gen = (int)order[0].size();
             if (!order[0].empty()) {
@@ -1462,7 +1477,8 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     // SLOWER than the 0.41 ms it hides -- the two kernels' workgroups compete for the CUs; two launches of the sweep in one stream cost
     // nothing measurable, and records made chunk by chunk right before their part of the sweep (to be read back from the memory-side
     // cache) change nothing up to 4 chunks and lose from 8 on.  profiles/r03_affine_experiments.txt)
-    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, act, 0, (long long)c->E, c->a_recs.p, status));
+    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, act, c->a_emin, std::min<long long>(c->a_emax + 1, (long long)c->E),
+                                     c->a_recs.p, status));
     return rows(0, c->a_npos);
 }
 

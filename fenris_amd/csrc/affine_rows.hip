@@ -50,7 +50,9 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
 }
 
-template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE>
+// MASKED: the tables were built under an element mask (blocks without a term: lanes that store zeros; positions that stay incomplete
+// take one barrier more).  A separate instantiation: the per-position checks cost the unmasked Laplace sweep 13 %.
+template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED>
 __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
@@ -141,18 +143,33 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             if (e_lo >= 0 && lane == 0) put1(line0 + e_lo, buf[e_lo]);
             if (e_hi >= 0 && lane == 0) put1(line0 + e_hi, buf[e_hi]);
             if (carry_out && lane < hi - L) other[lane] = buf[L + lane];
+            if constexpr (!MASKED) {
+                // (Never taken: without a mask every block has an owner lane, bit 0 of the flags is always set.  The branch is what
+                // remains of the clearing that used to live here; taking it OUT makes the unmasked sweep 3 - 5 % slower -- the
+                // instruction stream of this wave is the critical path and the compiler lays it out differently -- measured with the
+                // two builds side by side on one box, scripts/bin/ab_lib.sh: C2 0.291 / 0.307 ms, headline 4.70 / 4.87 ms.)
+                if (!(flags & 1)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const f64x2 z2 = {0.0, 0.0};
+                    for (int t = 0; t < nfull; ++t) b2[SL * t] = z2;
+                    if (lane < rem) b2[SL * nfull] = z2;
+                    if (lane == 0 && e_lo >= 0) buf[e_lo] = 0.0;
+                    if (lane == 0 && e_hi >= 0) buf[e_hi] = 0.0;
+                    if (lane < hi - L) buf[L + lane] = 0.0;
+                }
+            }
         };
         lds_barrier();  // B0
         tr_start();
         bool carry_in = false;
         int par = 0;
         for (int p = p_begin; p < p_end; ++p, par ^= 1) {
-            if (!(rfl(HDR[p & 3].z) & 1)) tr_barrier();   // an incomplete position: the row waves clear their buffer first (see there)
+            if constexpr (MASKED) { if (!(rfl(HDR[p & 3].z) & 1)) tr_barrier(); }   // an incomplete position: the row waves clear their buffer first (see there)
             if (p > p_begin) {
                 const int4 h_prev = HDR[(p - 1) & 3];
                 const int r0_cur = rfl(HDR[p & 3].x);
                 bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y) && !(ablate_arg & AFFINE_ROWS_NO_CARRY);
-                if (carry_out) {
+                if (carry_out && SS * rfl(h_prev.y) < 32) {   // (only a position of less than two lines can be one; the test below is exact)
                     // A position whose rows end before the first line boundary behind their start -- a node without elements (empty rows)
                     // or a single short row -- has nothing to store now, and what it would hand on starts at the line's beginning: below
                     // its own first value lies whatever the staging buffer held (zeros), and the next position would write that over the
@@ -172,7 +189,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
     }
 
     // ring entry .w: head | extent of the position's rows in doubles << 4 (what an incomplete position clears, below)
-    auto with_head = [&](int4 h) { h.w = head_of(h.x) | ((SS * h.y) << 4); return h; };
+    auto with_head = [&](int4 h) { h.w = MASKED ? (head_of(h.x) | ((SS * h.y) << 4)) : (head_of(h.x) | (h.w << 8)); return h; };
     if (wave == 4) {
         // ------------------------------------------------------------------------------------------ loader wave
         // Every global load of the kernel: the element records of the next position's slots (R or M, GW doubles each, written
@@ -247,10 +264,17 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         lds_barrier();  // B0
         tr_start();
         int par = 0;
+        // "position p / p + 1 is incomplete" (it takes one barrier more): scalar, shifted along with the headers
+        bool inc_cur = MASKED && !(__builtin_amdgcn_readfirstlane(hq0.z) & 1), inc_nxt = MASKED && !(__builtin_amdgcn_readfirstlane(hq1.z) & 1);
+        (void)inc_cur; (void)inc_nxt;
         // one position of the loader (a macro, not a lambda: the stages must stay in registers)
 #define AFFINE_LOADER_STEP(k, p)                                                                                              \
         {                                                                                                                     \
-            if (!(__builtin_amdgcn_readfirstlane(HDR[(p) & 3].z) & 1)) tr_barrier();   /* incomplete position: see the row waves */ \
+            if constexpr (MASKED) {                                                                                           \
+                if (inc_cur) tr_barrier();              /* incomplete position: see the row waves */                           \
+                inc_cur = inc_nxt;                                                                                            \
+                inc_nxt = !(__builtin_amdgcn_readfirstlane(h_nxt[k].z) & 1);   /* (still the header of p + 2 here) */        \
+            }                                                                                                                 \
             /* in place: what was requested DEPTH positions ago goes to LDS, the next requests go out */                     \
             unsigned long long tq0 = 0;                                                                                       \
             if (DBG && a.trace) tq0 = __builtin_readcyclecounter();                                                           \
@@ -298,6 +322,8 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
     tr_start();
     const unsigned hdr_addr = (unsigned)(unsigned long long)HDR + 8u;   // .z (flags | slot << 1 | changed << 2 | id << 8), .w (head)
     uint2 lane_cur = {0u, 0u};
+    bool zero_lane = false;        // this lane belongs to a block WITHOUT a term (k_build_affine_rows: element masks): it stores zeros
+    bool any_zero_lane = false;    // ... some lane of this wavefront does (scalar)
     f64x2 gq0[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, gq1[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};   // Laplace: Ghat of the lane's terms
     int par = 0;
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
@@ -305,7 +331,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
         const int z = __builtin_amdgcn_readfirstlane(zw[0]);
         const int head = zw[1] & 15;
-        if (!(z & 1)) {
+        if (MASKED && !(z & 1)) {
             // A position with a block that has no owner lane (element masks: the interface planes of a partition, a per cent of the
             // positions) needs that block to read as zero, whatever the buffer held before -- the position two steps back, complete or
             // not, with rows of another extent.  Its own row lanes clear the extent first (a few stores each; the store wave, the
@@ -326,6 +352,10 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         }
         if (z & 4) {   // the lane table changed with this position
             lane_cur = LT[256 * ((z >> 1) & 1) + tid];
+            if constexpr (MASKED) {
+                zero_lane = ((lane_cur.x >> 5) & 127u) == AR_ZERO_G && ((lane_cur.x >> 17) & 127u) == AR_ZERO_G && ((lane_cur.x >> 28) & 1u);
+                any_zero_lane = __builtin_amdgcn_ballot_w64(zero_lane) != 0ull;
+            }
             if constexpr (LAP) {  // ... and with it the reference blocks of this lane's two terms: kept in registers
                 const f64x2* q0 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((lane_cur.x >> 5) & 127u) * (GW * 8));
                 const f64x2* q1 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((lane_cur.x >> 17) & 127u) * (GW * 8));
@@ -340,9 +370,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         const unsigned oR0 = (x & 31u) * (GW * 8), oG0 = ((x >> 5) & 127u) * (GW * 8);
         const unsigned oR1 = ((x >> 12) & 31u) * (GW * 8), oG1 = ((x >> 17) & 127u) * (GW * 8);
         const int grp = (int)((x >> 24) & 3u);
-        // a lane of a block WITHOUT a term (k_build_affine_rows: element masks) stores zeros whatever slot 0 holds (the record of an
-        // empty slot may be anything, and 0 x NaN is not 0)
-        const bool zero_lane = ((x >> 5) & 127u) == AR_ZERO_G && ((x >> 17) & 127u) == AR_ZERO_G;
+        // (a zero lane stores zeros whatever slot 0 holds: the record of an empty slot may be anything, and 0 x NaN is not 0)
         char* out_par = reinterpret_cast<char*>(OUT + (size_t)par * accp);
         if constexpr (LAP) {
             const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
@@ -356,7 +384,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             }
             if (grp >= 1) s += dpp_quad_full<0xB1>(s);
             if (grp >= 2) s += dpp_quad_full<0x4E>(s);
-            if (zero_lane) s = 0.0;
+            if constexpr (MASKED) { if (any_zero_lane && zero_lane) s = 0.0; }
             if ((x >> 28) & 1u) *reinterpret_cast<double*>(out_par + 8 * head + (y & 0xffffu)) = s;
         } else {
             double H[3][3];
@@ -406,11 +434,13 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
 #pragma unroll
                     for (int s_ = 0; s_ < 3; ++s_) H[i][s_] += dpp_quad_full<0x4E>(H[i][s_]);
             }
-            if (zero_lane) {
+            if (MASKED && any_zero_lane) {   // (scalar branch)
+                if (zero_lane) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int s_ = 0; s_ < 3; ++s_) H[i][s_] = 0.0;
+                        for (int s_ = 0; s_ < 3; ++s_) H[i][s_] = 0.0;
+                }
             }
             if ((x >> 28) & 1u) {
                 const bool tr = (x >> 26) & 1u, dg = (x >> 27) & 1u;
@@ -689,24 +719,26 @@ hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, cons
     return hipGetLastError();
 }
 
-template <int OP, int DEPTH, int NSTORE>
+template <int OP, int DEPTH, int NSTORE, bool MASKED>
 static auto affine_rows_pick(bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
-    if (dbg) return k_affine_rows<OP, true, true, DEPTH, NSTORE>;
-    return ow ? k_affine_rows<OP, true, false, DEPTH, NSTORE> : k_affine_rows<OP, false, false, DEPTH, NSTORE>;
+    if (dbg) return k_affine_rows<OP, true, true, DEPTH, NSTORE, MASKED>;
+    return ow ? k_affine_rows<OP, true, false, DEPTH, NSTORE, MASKED> : k_affine_rows<OP, false, false, DEPTH, NSTORE, MASKED>;
 }
-template <int OP>
+template <int OP, bool MASKED>
 static auto affine_rows_pick_variant(int depth, int nstore, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
     // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
-    if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2>(ow, dbg) : affine_rows_pick<OP, 2, 2>(ow, dbg);
-    return depth <= 1 ? affine_rows_pick<OP, 1, 1>(ow, dbg) : affine_rows_pick<OP, 2, 1>(ow, dbg);
+    if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2, MASKED>(ow, dbg) : affine_rows_pick<OP, 2, 2, MASKED>(ow, dbg);
+    return depth <= 1 ? affine_rows_pick<OP, 1, 1, MASKED>(ow, dbg) : affine_rows_pick<OP, 2, 1, MASKED>(ow, dbg);
 }
 
 hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a,
-                              const AffineRowTables& T, int ablate) {
+                              const AffineRowTables& T, int ablate, bool masked) {
     const bool ow = a.overwrite != 0, dbg = (ablate & 0xffff) != 0;
     void (*kern)(const KArgs, const AffineRowTables, int) =
-        op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE>(depth, nstore, ow, dbg)
-                         : affine_rows_pick_variant<FH_LINEAR_ELASTIC>(depth, nstore, ow, dbg);
+        masked ? (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, true>(depth, nstore, ow, dbg)
+                                   : affine_rows_pick_variant<FH_LINEAR_ELASTIC, true>(depth, nstore, ow, dbg))
+               : (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, false>(depth, nstore, ow, dbg)
+                                   : affine_rows_pick_variant<FH_LINEAR_ELASTIC, false>(depth, nstore, ow, dbg));
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;

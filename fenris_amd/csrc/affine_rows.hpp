@@ -50,7 +50,7 @@ hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, cons
 
 // op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; nstore (1 or 2): store waves; ablate != 0 selects the instrumented instantiation (profiling only)
 hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
-                              int ablate);
+                              int ablate, bool masked);
 
 // ---- third form, k_affine_ring (affine_ring.hip): no workgroup barrier in the sweep, rows staged in a ring that mirrors the value stream
 // ring size in doubles (a power of two holding at least two positions; want_kb > 0: at least that many KiB)

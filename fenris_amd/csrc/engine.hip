@@ -1469,7 +1469,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
         if (c->env("FENRIS_HIP_VERBOSE"))
             std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
         HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
-                                      a.ablate | nt));
+                                      a.ablate | nt, c->has_mask));
         return FH_OK;
     };
     // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly.  (Round 3: making

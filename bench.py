@@ -613,6 +613,21 @@ def main():
             if rb is not None:   # what rank 0 receives from rank 1 per step (every interior interface carries the same amount)
                 out["config"]["interface_bytes_per_step"] = int(rb.numel() * rb.element_size())
                 out["config"]["interface_rows_packed"] = getattr(ex, "recv_idx", None) is not None
+            # a check the line carries with it (the timed steps are done): the rows of rank 0's owned interface plane are complete only
+            # after rank 1's contribution has arrived and been added, and a stiffness row sums to zero (constants / translations lie in
+            # the kernel of K) -- a wrong or missing exchange, or a wrong masked assembly, shows here
+            try:
+                seg = getattr(ex, "recv_seg", None)
+                if seg is not None:
+                    ro_h, _ = eng.pattern(want_cols=False)
+                    n0, n1 = slab.recv_nodes
+                    ro_seg = torch.as_tensor(np.asarray(ro_h[s * n0:s * n1 + 1]).astype(np.int64) - int(ro_h[s * n0]), device=values.device)
+                    vseg = values[seg[0]:seg[1]]
+                    cs = torch.cat([torch.zeros(1, dtype=vseg.dtype, device=vseg.device), torch.cumsum(vseg, 0)])
+                    rowsum = (cs[ro_seg[1:]] - cs[ro_seg[:-1]]).abs().max().item()
+                    out["config"]["interface_row_sum_over_max"] = rowsum / max(vseg.abs().max().item(), 1e-300)
+            except Exception as exc:  # never take the line down
+                out["config"]["interface_row_sum_over_max"] = repr(exc)
             out["rccl"] = rccl if rccl is not None else {"backend": "gloo (FENRIS_BENCH_SHARE_DEVICE validation mode)", "rccl_ranks": 0}
             out["rccl_ranks"] = out["rccl"]["rccl_ranks"]
         hbm = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -632,6 +632,7 @@ int build_pattern(fh_ctx* c) {
 // ---------------------------------------------------------------------------------- kernel dispatch
 template <int EK, int OP>
 int launch_matrix(fh_ctx* c, KArgs& a, int mode, size_t lds_bytes, int grid) {
+    if (grid <= 0) return FH_OK;   // nothing to do (an element mask without an active element): a launch of zero workgroups is an error
     hipStream_t st = c->stream;
 #define FH_LAUNCH(M)                                                                                              \
     do {                                                                                                          \
@@ -1525,7 +1526,8 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         const size_t lds1 = sizeof(double) * (size_t)Hex27Lds::total;
         int dev_cus = 256;
         (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        const int grid1 = (int)std::min<long long>(a.work_end, (long long)dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", 2)));
+        // (FENRIS_HIP_TWO_PASS_GRID: tests force many elements / nodes per workgroup on small meshes)
+        const int grid1 = std::max(1, (int)std::min<long long>(a.work_end, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", 2)))));
         if (grid1 > 0) {
             if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
                 auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
@@ -1574,7 +1576,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // entry_node is released on scope exit
         c->has_tp_pos = true;
     }
-    const int grid = (int)std::min<uint64_t>((c->N + 3) / 4, 1u << 20);
+    const int grid = std::max(1, (int)std::min<uint64_t>((c->N + 3) / 4, (uint64_t)c->env_int("FENRIS_HIP_TWO_PASS_GRID", 1 << 20)));
     c->last_kernel = mfma ? "k_hex27_dense_mfma + k_rows_from_dense" : "k_assemble_matrix<dump> + k_rows_from_dense";
 #define ROWS(SS, PT, PTR)                                                                                                     \
     do {                                                                                                                       \

@@ -85,7 +85,7 @@ def run(cases=200, seed0=0, quiet=False, big=False):
         eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
         # few workgroups: every one walks many positions (carries between positions, chains, prefetch stages) even on a small mesh
         grid = rng.choice([0, 0, 1, 2, 3, 5, 17])
-        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID"):
+        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID", "FENRIS_HIP_TWO_PASS_GRID"):
             eng.set_option(name, str(int(grid)) if grid else None)
         eng.set_row_range(int(lo_n), int(hi_n))
         got = torch.full((nnz,), 4.5, dtype=torch.float64, device="cuda")
@@ -96,7 +96,7 @@ def run(cases=200, seed0=0, quiet=False, big=False):
         kernels[kern] = kernels.get(kern, 0) + 1
         eng.set_row_range(0, n)
         eng.set_active_elements(None)
-        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID"):
+        for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID", "FENRIS_HIP_TWO_PASS_GRID"):
             eng.set_option(name, None)
         wv, gv = want.cpu().numpy(), got.cpu().numpy()
         lo, hi = int(ro[s * lo_n]), int(ro[s * hi_n])

@@ -429,6 +429,32 @@ def test_overwrite_with_a_mask_leaves_nothing_stale(engine, oracle, kind, op):
     assert np.abs(g - w).max() <= TOL * np.abs(w).max(), eng.last_kernel_name()
 
 
+@pytest.mark.parametrize("kind,op", [("HEX8", "LINEAR_ELASTIC"), ("TET4", "LAPLACE"), ("HEX27", "NEO_HOOKEAN"), ("QUAD4", "STVK")])
+def test_mask_without_an_active_element(engine, oracle, kind, op):
+    """an element mask that switches EVERYTHING off (a rank whose slab is all halo, a selection that came out empty): every scatter gives
+    the zero matrix / leaves an accumulated one alone, vector and energy are zero -- and no launch of zero workgroups reaches the runtime"""
+    import torch
+
+    asm, ref = _pair(engine, oracle, kind, op)
+    eng = asm.engine
+    nnz = eng.build_pattern()
+    eng.set_active_elements(np.zeros(asm.num_elements(), dtype=np.uint8))
+    try:
+        for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_GATHER, fa.SCATTER_COLORED):
+            if scatter == fa.SCATTER_COLORED:
+                eng.color()
+            v = torch.full((nnz,), 3.25, dtype=torch.float64, device="cuda")
+            eng.assemble_matrix(v, scatter)                                   # accumulate: untouched
+            assert torch.all(v == 3.25)
+            eng.assemble_matrix(v, scatter | fa.ASSEMBLE_OVERWRITE)           # overwrite: zeros
+            assert torch.all(v == 0.0), eng.last_kernel_name()
+        f = torch.full((asm.solution_dim() * asm.num_nodes(),), 1.5, dtype=torch.float64, device="cuda")
+        eng.assemble_vector(f)
+        assert torch.all(f == 1.5)
+    finally:
+        eng.set_active_elements(None)
+
+
 def test_residual_is_K_times_u_for_linear_operators(engine, oracle):
     asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", u_scale=1e-3)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm).to_scipy()

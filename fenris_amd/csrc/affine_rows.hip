@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
                 const int4 h_prev = HDR[(p - 1) & 3];
                 const int r0_cur = rfl(HDR[p & 3].x);
                 bool carry_out = r0_cur == rfl(h_prev.x) + rfl(h_prev.y) && !(ablate_arg & AFFINE_ROWS_NO_CARRY);
-                if (carry_out && SS * rfl(h_prev.y) < 32) {   // (only a position of less than two lines can be one; the test below is exact)
+                if (carry_out && (rfl(h_prev.z) & 8)) {   // (only a position of less than two lines, flagged by the builder, can be one; the test below is exact)
                     // A position whose rows end before the first line boundary behind their start -- a node without elements (empty rows)
                     // or a single short row -- has nothing to store now, and what it would hand on starts at the line's beginning: below
                     // its own first value lies whatever the staging buffer held (zeros), and the next position would write that over the
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         auto park_tab = [&](int slot, int half, uint4 v) { reinterpret_cast<uint4*>(LT + 256 * slot)[64 * half + lane] = v; };
         auto ring_entry = [&](int4 hq, int slot, bool changed) {
             int4 o = with_head(hq);
-            o.z = (hq.z & 1) | (slot << 1) | (changed ? 4 : 0) | (hq.z & ~0xff);
+            o.z = (hq.z & 9) | (slot << 1) | (changed ? 4 : 0) | (hq.z & ~0xff);
             return o;
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
@@ -682,7 +682,8 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
     if (lane == 0) hash_out[p] = hsum;
     // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
-    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, (n4 + n2 + n1 + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0, h.U);
+    // flags: bit 0 every block of these rows has a lane; bit 3 the rows are shorter than two cache lines (the store wave's carry test)
+    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, ((n4 + n2 + n1 + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0) | ((S * S * h.nrow < 32) ? 8 : 0), h.U);
 }
 
 // table id of every position into its header (flags | id << 8), and the first position of every id gathered into the
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
         if (mine.x != ref.x || mine.y != ref.y) *mismatch = 1;
         if (t == 0) {
             if (!(hdr[p].z & 1)) mismatch[1] = 1;   // a block without an owner lane somewhere
-            hdr[p].z = (hdr[p].z & 1) | (id << 8);
+            hdr[p].z = (hdr[p].z & 9) | (id << 8);
         }
     }
 }

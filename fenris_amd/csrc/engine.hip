@@ -1780,7 +1780,7 @@ static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const long long nbatch = (a.work_end - a.work_begin + EPB - 1) / EPB;
     const int per_cu = std::max(1, (int)std::min<size_t>(c->env_int("FENRIS_HIP_VEC_WGS_PER_CU", 3), (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
-    const int grid = (int)std::min<long long>(nbatch, (long long)dev_cus * per_cu);
+    const int grid = std::max(1, (int)std::min<long long>(nbatch, (long long)c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * per_cu)));   // (tests force many batches per workgroup)
     auto kern = k_assemble_vector_stream<EK, OP, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -71,10 +71,13 @@ def run(cases=200, seed0=0, quiet=False):
         k1 = eng.last_kernel_name()
         e1 = fa.assemble_scalar(asm)
         eng.set_option("FENRIS_HIP_NO_ELEMENT_PASS", "1")
+        grid = rng.choice([0, 1, 2, 5])     # few workgroups: the persistent form walks many batches each
+        eng.set_option("FENRIS_HIP_PIPE_GRID", str(int(grid)) if grid else None)
         f2 = fa.VectorAssembler().assemble_vector(asm)
         k2 = eng.last_kernel_name()
         e2 = fa.assemble_scalar(asm)
         eng.set_option("FENRIS_HIP_NO_ELEMENT_PASS", None)
+        eng.set_option("FENRIS_HIP_PIPE_GRID", None)
         scale = max(np.abs(f2).max(), 1e-300)
         ok = np.array_equal(np.isnan(f1), np.isnan(f2)) and np.nanmax(np.abs(f1 - f2), initial=0.0) <= 1e-11 * scale and \
             (abs(e1 - e2) <= 1e-11 * max(abs(e2), 1e-300) or (np.isnan(e1) and np.isnan(e2)))

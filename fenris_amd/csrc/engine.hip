@@ -594,10 +594,26 @@ int build_pattern(fh_ctx* c) {
                            c->n2e.p, N);
         hipLaunchKernelGGL(k_sort_n2e, dim3(grid_for(N, 256, 1 << 30)), dim3(256), 0, st, c->n2e_off.p, c->n2e.p, N);
     }
+    DevBuf<int> heavy;
+    DevBuf<unsigned> heavy_bits;
+    int nheavy = 0, heavy_grid = 0;
+    const int heavy_words = (N + 31) / 32;
+    HIP_TRY(c, heavy.alloc(HEAVY_CAP));
     if (N > 0) {
         const int g = std::min(N, 256 * 64);
         hipLaunchKernelGGL(k_node_neighbors<false>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, cnt.p, nullptr,
-                           nullptr, flags.p + 1);
+                           nullptr, flags.p + 1, heavy.p);
+        // nodes with more candidates than the LDS sort takes (none on a finite element mesh): counted through a bitmap
+        HIP_TRY(c, hipMemcpyAsync(&nheavy, flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (nheavy > HEAVY_CAP) return c->fail(FH_UNSUPPORTED, "more than 4096 nodes with more than 4096 candidate neighbours each");
+        if (nheavy > 0) {
+            heavy_grid = std::min(nheavy, 32);
+            HIP_TRY(c, heavy_bits.alloc((size_t)heavy_grid * heavy_words));
+            hipLaunchKernelGGL(k_heavy_neighbors<false>, dim3(heavy_grid), dim3(256), 0, st, cv, c->n2e_off.p, c->n2e.p, heavy.p, nheavy, N,
+                               heavy_bits.p, heavy_words, cnt.p, nullptr, nullptr);
+            HIP_TRY(c, hipGetLastError());
+        }
     }
     size_t tmp2 = 0;
     HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, cnt.p, c->noff.p, N + 1, st));
@@ -611,7 +627,6 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
-    if (h_flags[1]) return c->fail(FH_UNSUPPORTED, "a node has more than 4096 candidate neighbours");
     c->nnz_nodes = c->h_noff[N];
     c->max_row = 0;
     for (int i = 0; i < N; ++i) c->max_row = std::max(c->max_row, c->h_noff[i + 1] - c->h_noff[i]);
@@ -620,7 +635,11 @@ int build_pattern(fh_ctx* c) {
     if (N > 0) {
         const int g = std::min(N, 256 * 64);
         hipLaunchKernelGGL(k_node_neighbors<true>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, nullptr, c->noff.p,
-                           c->ncols.p, flags.p + 1);
+                           c->ncols.p, flags.p + 1, heavy.p);
+        if (nheavy > 0)
+            hipLaunchKernelGGL(k_heavy_neighbors<true>, dim3(heavy_grid), dim3(256), 0, st, cv, c->n2e_off.p, c->n2e.p, heavy.p, nheavy, N,
+                               heavy_bits.p, heavy_words, nullptr, c->noff.p, c->ncols.p);
+        HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());

@@ -57,9 +57,13 @@ __global__ void k_sort_n2e(const unsigned* n2e_off, unsigned* n2e, int num_nodes
 // One wave per node: candidates = all nodes of all adjacent elements; sort + unique in LDS.
 // FILL == false: cnt[node] = number of distinct neighbours; FILL == true: write them at noff[node].
 constexpr int NEIGH_CAP = 4096;
+// A node with more than NEIGH_CAP candidates (a hub shared by thousands of elements: nothing a finite element mesh has, but the reference
+// walks any connectivity, global.rs:65-120) goes to the list `heavy` in the counting pass and is skipped here; k_heavy_neighbors does it
+// with a bitmap over all nodes.
+constexpr int HEAVY_CAP = 4096;   // such nodes per pattern
 template <bool FILL>
 __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigned* n2e_off, const unsigned* n2e, int num_nodes,
-                                                       unsigned* cnt, const unsigned* noff, unsigned* ncols, int* overflow) {
+                                                       unsigned* cnt, const unsigned* noff, unsigned* ncols, int* overflow, int* heavy) {
     __shared__ unsigned buf[NEIGH_CAP];
     const int lane = threadIdx.x;
     for (int node = blockIdx.x; node < num_nodes; node += gridDim.x) {
@@ -107,7 +111,11 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
             C += ee - eb;
         }
         if (C > NEIGH_CAP) {
-            if (lane == 0) { *overflow = 1; if (!FILL) cnt[node] = 0; }
+            if (lane == 0 && !FILL) {
+                const int k = atomicAdd(overflow, 1);
+                if (k < HEAVY_CAP) heavy[k] = node;
+                cnt[node] = 0;
+            }
             __syncthreads();
             continue;
         }
@@ -140,6 +148,58 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
             base += (unsigned)__popcll(mask);
         }
         if (!FILL && lane == 0) cnt[node] = base;
+        __syncthreads();
+    }
+}
+
+// The neighbours of the heavy nodes: one workgroup per node at a time, a bitmap over all nodes in global memory (its own slice per
+// workgroup), bits set by atomics, then counted (FILL == false) or written out in ascending order (FILL == true).
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_heavy_neighbors(ConnView c, const unsigned* n2e_off, const unsigned* n2e, const int* heavy, int nheavy,
+                                                        int num_nodes, unsigned* bitmap, int W, unsigned* cnt, const unsigned* noff,
+                                                        unsigned* ncols) {
+    __shared__ unsigned part[256];
+    const int tid = threadIdx.x;
+    unsigned* bm = bitmap + (size_t)blockIdx.x * W;
+    for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const int node = heavy[h];
+        for (int w = tid; w < W; w += 256) bm[w] = 0u;
+        __syncthreads();
+        unsigned prev_e = 0xffffffffu;
+        for (unsigned x = n2e_off[node]; x < n2e_off[node + 1]; ++x) {  // uniform loop
+            const unsigned e = c.elem_of(n2e[x]);
+            if (e == prev_e) continue;
+            prev_e = e;
+            unsigned eb, ee;
+            c.elem_range(e, eb, ee);
+            for (unsigned k = eb + tid; k < ee; k += 256) {
+                const unsigned v = (unsigned)c.nodes[k];
+                atomicOr(&bm[v >> 5], 1u << (v & 31u));
+            }
+        }
+        __syncthreads();
+        const int chunk = (W + 255) / 256, w0 = min(W, tid * chunk), w1 = min(W, w0 + chunk);
+        unsigned local = 0;
+        for (int w = w0; w < w1; ++w) local += (unsigned)__popc(bm[w]);
+        part[tid] = local;
+        __syncthreads();
+        if (tid == 0) {   // exclusive scan of 256 counts: the node is one in a million
+            unsigned run = 0;
+            for (int t = 0; t < 256; ++t) { const unsigned v = part[t]; part[t] = run; run += v; }
+            if (!FILL) cnt[node] = run;
+        }
+        __syncthreads();
+        if (FILL) {
+            unsigned r = noff[node] + part[tid];
+            for (int w = w0; w < w1; ++w) {
+                unsigned bits = bm[w];
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    ncols[r++] = (unsigned)(32 * w + b);
+                    bits &= bits - 1u;
+                }
+            }
+        }
         __syncthreads();
     }
 }

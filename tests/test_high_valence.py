@@ -116,3 +116,40 @@ def test_parallel_coloring_beyond_one_window(engine, oracle, shape, k, layers):
     a = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
     c = fa.CsrParAssembler().assemble(colors, asm)
     assert np.abs(c.values - a.values).max() <= TOL * np.abs(a.values).max()
+
+
+@pytest.mark.parametrize("n,ne,k,hubs", [(5000, 3000, 4, 1), (20000, 20000, 8, 3), (300, 5000, 3, 1)])
+@pytest.mark.parametrize("s", [1, 3])
+def test_pattern_with_hub_nodes(engine, n, ne, k, hubs, s):
+    """assemble_pattern (global.rs:65-120 walks ANY connectivity) with nodes that sit in thousands of elements: more candidate neighbours than
+    the per-node sort in LDS takes -- the bitmap path of pattern_kernels.hpp -- bit-exact against the pattern of A^T A"""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    elems = [[int(rng.integers(0, hubs))] + [int(x) for x in rng.integers(hubs, n, k - 1)] for _ in range(ne)]
+    mock = fa.MockElementAssembler(s, n, elems, engine)
+    ro, ci = fa.CsrAssembler().assemble_pattern(mock)
+    inc = sp.csr_matrix((np.ones(ne * k), (np.repeat(np.arange(ne), k), np.asarray(elems).ravel())), shape=(ne, n))
+    pat = (inc.T @ inc).tocsr()
+    pat.data[:] = 1.0
+    full = sp.kron(pat, np.ones((s, s))).tocsr()
+    full.sort_indices()
+    assert np.array_equal(np.asarray(ro, dtype=np.int64), full.indptr) and np.array_equal(np.asarray(ci, dtype=np.int64), full.indices)
+
+
+def test_two_thousand_tetrahedra_around_an_edge(engine, oracle):
+    """past every budget at once: 8000 candidate neighbours at the axis nodes (bitmap pattern), rows of 2002 blocks, 2000 colours"""
+    mesh = tet_fan(2000, 1)
+    w, p = quadrature.total_order.tetrahedron(1)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(qt).with_u(np.zeros(mesh.num_nodes())).build())
+    ref = oracle.ElementAssembler(oracle.TET4, oracle.LAPLACE, mesh.vertices, mesh.connectivity, w, p, u=np.zeros(mesh.num_nodes()))
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    for scatter in (fa.SCATTER_ATOMIC, fa.SCATTER_GATHER):
+        k = fa.CsrAssembler(scatter).assemble(asm)
+        assert np.array_equal(k.row_offsets, oro) and np.array_equal(k.col_indices, oci)
+        assert np.abs(k.values - ovals).max() <= 1e-11 * np.abs(ovals).max()      # needle elements: cond(J) eps
+    kc = fa.CsrParAssembler().assemble(fa.color_nodes(asm), asm)
+    assert np.abs(kc.values - ovals).max() <= 1e-11 * np.abs(ovals).max()

@@ -194,18 +194,19 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                     }
                 }
             });
-            // Partial sums of a block meet by DPP exchanges in groups of 2 / 4 / 8 lanes.  Whether a lane takes part is a factor (1.0 or
-            // 0.0) of a multiply-add, not a branch: nine guarded additions per stage cost an exec-mask pair each.  The third stage (groups
-            // of eight: a node with more than 24 elements) is skipped by the whole wavefront when none of its lanes needs it.
-            const double m1 = grp >= 1 ? 1.0 : 0.0, m2 = grp >= 2 ? 1.0 : 0.0;
+            // Partial sums of a block meet by DPP exchanges in groups of 2 / 4 / 8 lanes.  Whether a lane takes part is a select on the
+            // exchanged value, not a branch (nine guarded additions per stage cost an exec-mask pair each) and not a factor 0 / 1 either
+            // (0 x NaN would carry a neighbour's NaN -- a non-finite vertex -- into blocks it does not belong to).  Every stage is skipped
+            // by a wavefront none of whose lanes needs it (the third: a node with more than 24 elements).
+            auto sel = [](bool take, double v) { return take ? v : 0.0; };
             if (__builtin_amdgcn_ballot_w64(grp >= 1) != 0ull) {   // every stage is skipped by a wavefront none of whose lanes needs it
     #pragma unroll
                 for (int i = 0; i < D; ++i)
     #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        Gm[i][j] = fma(dpp_quad<0xB1>(Gm[i][j]), m1, Gm[i][j]);
+                        Gm[i][j] += sel(grp >= 1, dpp_quad<0xB1>(Gm[i][j]));
                         if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                            fma(dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m1, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                            Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] + sel(grp >= 1, dpp_quad<0xB1>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]));
                     }
             }
             if (__builtin_amdgcn_ballot_w64(grp >= 2) != 0ull) {
@@ -213,20 +214,19 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                 for (int i = 0; i < D; ++i)
     #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        Gm[i][j] = fma(dpp_quad<0x4E>(Gm[i][j]), m2, Gm[i][j]);
+                        Gm[i][j] += sel(grp >= 2, dpp_quad<0x4E>(Gm[i][j]));
                         if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                            fma(dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m2, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                            Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] + sel(grp >= 2, dpp_quad<0x4E>(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]));
                     }
             }
             if (__builtin_amdgcn_ballot_w64(grp >= 3) != 0ull) {   // uniform over the wavefront
-                const double m3 = grp >= 3 ? 1.0 : 0.0;
     #pragma unroll
                 for (int i = 0; i < D; ++i)
     #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        Gm[i][j] = fma(dpp_xor4(Gm[i][j]), m3, Gm[i][j]);
+                        Gm[i][j] += sel(grp >= 3, dpp_xor4(Gm[i][j]));
                         if constexpr (ELEMPAR) Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] =
-                            fma(dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]), m3, Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]);
+                            Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)] + sel(grp >= 3, dpp_xor4(Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)]));
                     }
             }
         }

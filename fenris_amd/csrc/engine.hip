@@ -55,15 +55,6 @@ struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
-    // physically contiguous device memory when the runtime grants it (hipDeviceMallocContiguous), else like alloc()
-    hipError_t alloc_contiguous(size_t count) {
-        release();
-        if (count == 0) count = 1;
-        hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&p), count * sizeof(T), hipDeviceMallocContiguous);
-        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return alloc(count); }
-        n = count;
-        return e;
-    }
 };
 
 // reference gradient tables (host): product-side evaluation of the shape-function gradients.
@@ -415,6 +406,7 @@ struct fh_ctx {
     bool has_tp_pos = false;
     DevBuf<unsigned long long> trace;
     bool defer_status = false;   // fh_assemble_vector_async_dev: the launches are only enqueued, fh_poll_status reports their errors
+    bool keep_status = false;    // ... over a rule-set table: the status slot is reset once in front of the group walk, not per group
 
     int S() const {
         if (ragged) return (int)sdim_ragged;
@@ -1460,13 +1452,17 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
                    (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
+    // (instrumentation: compiled only into a `make TRACE=1` library)
+#ifdef FENRIS_HIP_WITH_RING
     const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
+#endif
     if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)
         std::fprintf(stderr, "[fenris_hip ptrs] recs=%p hdr=%p elem=%p lanes=%p vals=%p verts=%p conn=%p\n", (void*)c->a_recs.p, (void*)c->a_hdr.p,
                      (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                           c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete};
+#ifdef FENRIS_HIP_WITH_RING
         if (use_ring) {
             const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
             const size_t lds = affine_ring_lds_bytes(c->op, c->a_us, ring);
@@ -1481,6 +1477,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
                 return FH_OK;
             }
         }
+#endif
         const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
@@ -2739,14 +2736,21 @@ int fh_time_assembly_dev(fh_ctx* c, double* values_dev, int flags, int reps, dou
     if (!c) return FH_BAD_ARGUMENT;
     DevGuard dev_guard_(c->device);
     if (!ms_per_assembly || reps < 1) return c->fail(FH_BAD_ARGUMENT, "fh_time_assembly_dev: bad argument");
+    // reps + 1 REAL assemblies run into the caller's array: without FH_ASSEMBLE_OVERWRITE they would pile up reps + 1 copies of K
+    if (!(flags & FH_ASSEMBLE_OVERWRITE)) return c->fail(FH_BAD_ARGUMENT, "fh_time_assembly_dev: needs FH_ASSEMBLE_OVERWRITE (the timed assemblies write the values)");
     int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);   // tables, code objects, first touch
     if (rc) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(c, hipEventCreate(&e0));
-    HIP_TRY(c, hipEventCreate(&e1));
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, c->stream);
+    if (he != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return c->hip_fail(he, "fh_time_assembly_dev");
+    }
     for (int k = 0; k < reps && rc == FH_OK; ++k) rc = fh_assemble_matrix_async_dev(c, values_dev, flags);
-    hipError_t he = hipEventRecord(e1, c->stream);
+    he = hipEventRecord(e1, c->stream);
     if (he == hipSuccess) he = hipEventSynchronize(e1);
     float ms = 0.f;
     if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
@@ -2941,9 +2945,18 @@ int fh_assemble_vector_dev(fh_ctx* c, double* out_dev, uint64_t* failed) {
 }
 int fh_assemble_vector_async_dev(fh_ctx* c, double* out_dev) {
     if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    // nothing is read back between the groups of a rule-set table here, so a per-group reset would erase what an earlier group
+    // reported: one reset in front of the walk (the device keeps the lowest failing element over all launches since the reset)
+    if (c->rs.active) {
+        const int r0 = reset_status(c);
+        if (r0) return r0;
+        c->keep_status = true;
+    }
     c->defer_status = true;
     const int rc = fh_assemble_vector_dev(c, out_dev, nullptr);
     c->defer_status = false;
+    c->keep_status = false;
     return rc;
 }
 static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) {
@@ -2951,7 +2964,7 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
     if (rc) return rc;
     if (c->op > FH_STVK) return c->fail(FH_UNSUPPORTED, "fh_assemble_vector: the mass assembler has no vector form");
     if (!out_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_vector: out is null");
-    rc = reset_status(c);
+    rc = c->keep_status ? FH_OK : reset_status(c);
     if (rc) return rc;
     if (c->E == 0) return FH_OK;
     KArgs a;

@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(256) k_heavy_neighbors(ConnView c, const unsig
             c.elem_range(e, eb, ee);
             for (unsigned k = eb + tid; k < ee; k += 256) {
                 const unsigned v = (unsigned)c.nodes[k];
-                atomicOr(&bm[v >> 5], 1u << (v & 31u));
+                // (an index >= num_nodes is reported through flags[0] by the counting pass; the host reads that flag only after
+                // this kernel: never mark outside the bitmap)
+                if (v < (unsigned)num_nodes) atomicOr(&bm[v >> 5], 1u << (v & 31u));
             }
         }
         __syncthreads();

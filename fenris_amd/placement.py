@@ -4,6 +4,7 @@ GPU: rank-local, no collective); everything here happens BEFORE a timed region."
 import time
 
 MAX_LIVE_BYTES = 160e9   # candidates stay allocated while the probe runs (a new one gets other memory): keep them below this
+FREE_RESERVE = 0.25      # ... and below this share of what the device reports free (the library's record candidates come on top)
 
 
 def settle_device(eng, values, flags, max_s=2.5, group=20):
@@ -29,12 +30,20 @@ def probe_placement(eng, values, flags, tries):
     trial is three real assemblies.  Returns (values, report)."""
     import torch
 
-    nbytes = values.numel() * values.element_size()
-    tries = max(0, min(int(tries), int(MAX_LIVE_BYTES // max(nbytes, 1)) - 1))
+    nbytes = max(values.numel() * values.element_size(), 1)
+    budget = MAX_LIVE_BYTES
+    if values.is_cuda:   # a smaller or shared device: what is free now bounds the candidates, not the 288 GB of an idle MI355X
+        free, _ = torch.cuda.mem_get_info(values.device)
+        budget = min(budget, (1.0 - FREE_RESERVE) * free + nbytes)
+    tries = max(0, min(int(tries), int(budget // nbytes) - 1))
     seen = [eng.time_assembly(values, flags)]
     best, rejected = values, []
-    for _ in range(tries):
-        cand = torch.zeros_like(values)          # the previous candidates stay allocated: a new one gets other memory
+    for k in range(tries):
+        try:
+            cand = torch.zeros_like(values)      # the previous candidates stay allocated: a new one gets other memory
+        except torch.OutOfMemoryError:           # keep the best so far
+            tries = k
+            break
         t = eng.time_assembly(cand, flags)
         if t < 0.98 * min(seen):
             rejected.append(best)

@@ -220,8 +220,8 @@ int fh_poll_status(fh_ctx*, uint64_t* failed_element);
  * the life of an allocation, and no HIP call chooses the backing.  fh_time_assembly_dev times `reps` assemblies (after one untimed)
  * with events on the context's stream; a caller uses it to keep the better of several allocations of its `values`.
  * fh_tune_placement_dev does the same for the library's own large buffer (the element records of the affine-element kernel): up to
- * `tries` re-allocations, each timed with three assemblies, the fastest kept.  Needs FH_ASSEMBLE_OVERWRITE (the trial assemblies
- * write `values`).  No reference counterpart. */
+ * `tries` re-allocations, each timed with three assemblies, the fastest kept.  BOTH need FH_ASSEMBLE_OVERWRITE (the timed / trial
+ * assemblies are real ones and write `values`; FH_BAD_ARGUMENT otherwise).  No reference counterpart. */
 /* A tuning switch of this context (a FENRIS_HIP_* name as fh_create reads them from the environment): set, or removed with value ==
  * NULL.  Launch-variant switches act at the next call.  For comparing variants inside ONE context on the same buffers. */
 int fh_set_option(fh_ctx*, const char* name, const char* value);
@@ -240,7 +240,8 @@ int fh_assemble_matrix_rows_async_dev(fh_ctx*, double* values_dev, int flags, ui
 int fh_assemble_vector(fh_ctx*, double* out, uint64_t* failed_element);
 int fh_assemble_vector_dev(fh_ctx*, double* out_dev, uint64_t* failed_element);
 /* the same, only enqueued on the context's stream: a singular element is reported by the next fh_poll_status (like
- * fh_assemble_matrix_async_dev) */
+ * fh_assemble_matrix_async_dev) -- also over a rule-set table (one launch per rule group; the status is reset once in front of them).
+ * The FIRST assembly of a context still builds the pattern and the adjacency, which synchronises; later calls only enqueue. */
 int fh_assemble_vector_async_dev(fh_ctx*, double* out_dev);
 /* assemble_scalar (global.rs:697-711) with compute_element_elliptic_energy (elliptic.rs:551-605) */
 int fh_assemble_scalar(fh_ctx*, double* out, uint64_t* failed_element);

@@ -238,12 +238,14 @@ def test_placement_tuning_keeps_the_matrix():
         assert torch.equal(vals, ref)
         with pytest.raises(fa.FenrisError):
             eng.tune_placement(vals, fa.SCATTER_GATHER, tries=1)
-        # a launch variant switched inside the context (fh_set_option): the barrier-free ring form gives the same bits
-        eng.set_option("FENRIS_HIP_AFFINE_RING", 1)
+        # a launch variant switched inside the context (fh_set_option): one request ahead instead of two gives the same bits
+        eng.set_option("FENRIS_HIP_AFFINE_DEPTH", 1)
         vals.zero_()
         eng.assemble_matrix(vals, flags)
         assert torch.equal(vals, ref)
-        eng.set_option("FENRIS_HIP_AFFINE_RING", None)
+        eng.set_option("FENRIS_HIP_AFFINE_DEPTH", None)
+        with pytest.raises(fa.FenrisError):   # fh_time_assembly_dev runs real assemblies into `vals` as well
+            eng.time_assembly(vals, fa.SCATTER_GATHER, reps=1)
     finally:
         eng.close()
 

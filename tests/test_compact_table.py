@@ -242,6 +242,35 @@ def test_rules_with_different_points_are_walked_rule_by_rule(engine, oracle, tab
     assert abs(fa.assemble_scalar(asm) - eo) <= 1e-12 * abs(eo)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("collapsed", [0, 1, 5])
+def test_async_vector_over_a_rule_set_reports_a_singular_element_of_any_group(engine, collapsed):
+    """fh_assemble_vector_async_dev over a rule-set table: one launch per rule group, nothing read back in between -- a singular
+    element of ANY group (not only of the last one walked) must come out of the next fh_poll_status.  (Advisor, round 3: the per-group
+    reset of the status slot erased what an earlier group had reported.)"""
+    import torch
+
+    m, _, _, _, _ = _setup("HEX8", seed=8)
+    rules = _mixed_rules()
+    emap = (np.arange(m.num_elements()) % 3 == 0).astype(np.uint64)      # elements 0, 3, ... rule 1; the others rule 0
+    v = m.vertices.copy()
+    conn = np.asarray(m.connectivity).astype(np.int64)
+    v[conn[collapsed]] = 0.0                                             # all eight vertices at the origin: J == 0 exactly at every point
+    qt = fa.compact_quadrature_table([r[1] for r in rules], [r[0] for r in rules], [r[2] for r in rules], emap)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(fa.Mesh(v, m.connectivity, fa.HEX8))
+           .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt)
+           .with_u(np.zeros(3 * m.num_nodes())).build())
+    assert asm.engine is engine
+    out = torch.zeros(3 * m.num_nodes(), dtype=torch.float64, device="cuda")
+    engine.assemble_vector_async(out)                                    # the enqueue itself succeeds
+    with pytest.raises(fa.SingularJacobianError):
+        engine.poll_status()
+    # the blocking call reports the lowest failing element over all groups (global.rs:154: the first error aborts the serial loop)
+    with pytest.raises(fa.SingularJacobianError) as exc:
+        engine.assemble_vector(out)
+    assert exc.value.element <= collapsed
+
+
 def test_compact_table_helper_picks_the_single_launch_form():
     m, w, p, emap, rp = _setup("HEX8")
     qt = fa.compact_quadrature_table([p] * len(rp), [w] * len(rp), [[fa.LameParameters(*x) for x in r] for r in rp], emap)

@@ -164,3 +164,31 @@ def test_randomised_gather_against_atomic():
     bad, kernels = fuzz_gather.run(500, 20260, quiet=True)
     assert bad == 0
     assert sum(v for k, v in kernels.items() if "k_affine_rows" in k) > 20 and kernels.get("k_gather_rows", 0) > 50
+
+
+def _scripts():
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts")
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+
+def test_randomised_vectors_and_energies():
+    """scripts/fuzz_vector.py, 200 cases: the element pass (residual, energy: one thread per element) against the older LDS-staged kernels
+    with a forced small grid, and the factored gravity source against sampled values -- all four operators, Hex8 / Tet4 / Quad4 / Tri3,
+    holes, permutations, affine / distorted / mixed geometry, random rules"""
+    _scripts()
+    import fuzz_vector
+
+    assert fuzz_vector.run(200, 4100, quiet=True) == 0
+
+
+def test_randomised_patterns_against_scipy():
+    """scripts/fuzz_pattern.py, 200 cases: assemble_pattern (global.rs:65-120) on random RAGGED connectivities (0 .. 40 nodes per element,
+    repeated nodes, isolated nodes, hubs) for s = 1 .. 3 against the pattern of A^T A from scipy, bit for bit; the colouring valid"""
+    _scripts()
+    import fuzz_pattern
+
+    assert fuzz_pattern.run(200, 7300, quiet=True) == 0

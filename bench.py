@@ -440,7 +440,7 @@ def main():
         if args.cells:
             child += ["--cells", str(args.cells)]
         aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
-        knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_gather_pipelined",),
+        knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_hex8_rows",),
                   "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
         try:
             helper = start_traffic_helper(child, knames)

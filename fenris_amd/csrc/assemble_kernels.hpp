@@ -1514,11 +1514,20 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
                 if ((int)E[k] == e) { map[k] = s_; new_elem[s_] = e; break; }
         }
         __syncthreads();
-        if (lane == 0) {  // new elements take the free slots in ascending order; list = new slots, then retained
-            int nnew = 0, free_s = 0;
+        if (lane == 0) {  // new elements take free slots in ascending order; list = new slots, then retained
+            // ... the lowest free slot whose parity is that of the element id, when there is one: k_hex8_rows keeps the gradients of
+            // even and odd slots in different halves of the LDS banks, and on a structured mesh (an even number of cells per line) the
+            // elements that meet a node at the same local corner alternate in parity
+            int nnew = 0;
             for (int k = 0; k < h.U; ++k) {
                 if (map[k] >= 0) continue;
-                while (new_elem[free_s] >= 0) ++free_s;
+                int free_s = -1, any_s = -1;
+                for (int s_ = 0; s_ < us; ++s_) {
+                    if (new_elem[s_] >= 0) continue;
+                    if (any_s < 0) any_s = s_;
+                    if ((s_ & 1) == (int)(E[k] & 1u)) { free_s = s_; break; }
+                }
+                if (free_s < 0) free_s = any_s;
                 map[k] = free_s;
                 new_elem[free_s] = (int)E[k];
                 list[nnew++] = (unsigned char)free_s;

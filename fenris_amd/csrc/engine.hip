@@ -21,6 +21,7 @@
 #include "affine_rows.hpp"
 #include "element_pass.hpp"
 #include "coloring_kernels.hpp"
+#include "hex8_rows.hpp"
 #include "device_common.hpp"
 #include "group_internal.hpp"
 #include "host_inputs.hpp"
@@ -351,6 +352,11 @@ struct fh_ctx {
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
     int a_us = 0, a_npos = 0, a_ntab = 0, a_incomplete = 0;
+    // general Hex8 row-owner kernel (hex8_rows.hip): lane tables and position records of the GENERAL positions (p_rec order)
+    DevBuf<int4> h_hdr, h_pos;
+    DevBuf<uint2> h_lanes;
+    int h_ntab = 0, h_incomplete = 0;
+    bool has_hrows = false;
     long long a_emin = 0, a_emax = -1;   // elements the affine positions of this partition refer to: the records kernel walks [a_emin, a_emax]
     unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
     int npos_gen = 0;               // positions of the general tables (== nblk when no block is affine)
@@ -425,7 +431,7 @@ struct fh_ctx {
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
-    X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
+    X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
     FH_PARTITION_MEMBERS(X)
@@ -799,6 +805,77 @@ int choose_epb(fh_ctx* c, int what) {
     return best;
 }
 
+// Lane tables of the row-owner kernels (k_affine_rows, k_hex8_rows) for the positions described by the pipelined kernel's records
+// `rec`: one record of 256 lanes per position (affine_rows_build), positions with identical records share one table (hashed on the
+// device, merged here, verified on the device), the table id goes into every header.  `bad`: some block cannot be expressed.
+static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_target, int npos, int S, const int* conn, const int* elem,
+                             DevBuf<int4>& hdr, DevBuf<uint2>& lanes, int& ntab_out, int& incomplete_out, bool& bad_out, const char* what) {
+    DevBuf<int> st;
+    HIP_TRY(c, st.alloc(2));
+    HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(c, hdr.alloc((size_t)npos));
+    DevBuf<uint2> lanes_full;
+    DevBuf<unsigned long long> hash_d;
+    HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
+    HIP_TRY(c, hash_d.alloc((size_t)npos));
+    HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, lanes_full.p, st.p,
+                                 hash_d.p));
+    int bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> hash_h((size_t)npos);
+    HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bad_out = bad != 0;
+    if (bad) return FH_OK;
+    // positions with identical lane records (the interior of a structured mesh) share one table: the kernel
+    // skips the fetch when the table does not change, and what it fetches stays in the caches
+    std::vector<int> ids((size_t)npos), first;
+    auto dedupe = [&](bool identity) {
+        first.clear();
+        if (identity) {
+            first.resize((size_t)npos);
+            for (int p = 0; p < npos; ++p) { ids[p] = p; first[p] = p; }
+            return;
+        }
+        std::unordered_map<unsigned long long, int> seen;
+        seen.reserve(1024);
+        for (int p = 0; p < npos; ++p) {
+            auto it = seen.find(hash_h[p]);
+            if (it == seen.end()) {
+                it = seen.emplace(hash_h[p], (int)first.size()).first;
+                first.push_back(p);
+            }
+            ids[p] = it->second;
+        }
+    };
+    dedupe(c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23));  // the id has 23 bits
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int ntab = (int)first.size();
+        DevBuf<int> ids_d, first_d;
+        HIP_TRY(c, ids_d.alloc((size_t)npos));
+        HIP_TRY(c, first_d.alloc((size_t)ntab));
+        HIP_TRY(c, lanes.alloc((size_t)ntab * 256));
+        HIP_TRY(c, hipMemcpyAsync(ids_d.p, ids.data(), sizeof(int) * (size_t)npos, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+        HIP_TRY(c, affine_rows_compact(c->stream, lanes_full.p, ids_d.p, first_d.p, npos, ntab, lanes.p, hdr.p, st.p));
+        int mismatch[2] = {0, 0};   // [1]: some position has a block without an owner lane
+        HIP_TRY(c, hipMemcpyAsync(mismatch, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        ntab_out = ntab;
+        incomplete_out = mismatch[1];
+        if (!mismatch[0]) break;
+        dedupe(true);  // a hash collision: every position keeps its own table
+    }
+    if (c->env("FENRIS_HIP_VERBOSE")) {
+        long long changes = 0;   // positions whose table differs from their predecessor's in the sweep: each is a 2 KB fetch
+        for (int p = 1; p < npos; ++p) changes += ids[p] != ids[p - 1];
+        std::fprintf(stderr, "[fenris_hip] %s: %d positions share %d lane tables, %lld changes of table along the sweep%s\n", what,
+                     npos, ntab_out, changes, incomplete_out ? ", some position has a block without an owner" : "");
+    }
+    return FH_OK;
+}
+
 // greedy partition of the node range into owner blocks (gather mode)
 
 int build_partition(fh_ctx* c) {
@@ -907,8 +984,11 @@ int build_partition(fh_ctx* c) {
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
                           (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
     const bool rows_special = perm_cand;   // tables for the row-owner Tet4 kernel alone: larger blocks (below)
+    // Hex8 Laplace / LinearElastic without a mask: the general positions run on k_hex8_rows (36 row lanes per node as well)
+    const bool hrows_cand = c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->has_mask && !c->has_rules &&
+                            !c->env("FENRIS_HIP_NO_HEX8_ROWS");
     const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", rows_special ? (c->rows_try == 0 ? 9 : 7)
-                                                                                                     : (S == 1 && !aff_cand) ? 8 : 7)));  // < 256: packed in 8 bits
+                                                                                                     : (S == 1 && !aff_cand && !hrows_cand) ? 8 : 7)));  // < 256: packed in 8 bits
     // Tables for the row-owner Tet4 kernel alone may hold more entries per block than the pipelined kernel's lane mapping takes
     // and more nodes (the lane word has four bits for the node): nine nodes / 256 entries first (C3: 98 k positions of ~170 lanes
     // instead of 171 k of ~90, 0.80 -> 0.64 ms), seven / 224 when that cannot be expressed (0.67 ms), then the standard form
@@ -1166,72 +1246,13 @@ int build_partition(fh_ctx* c) {
                 if (rs) return rs;
                 const int npos = (int)order[1].size();
                 c->a_us = us;
-                DevBuf<int> st;
-                HIP_TRY(c, st.alloc(2));
-                HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
-                HIP_TRY(c, c->a_hdr.alloc((size_t)npos));
-                DevBuf<uint2> lanes_full;
-                DevBuf<unsigned long long> hash_d;
-                HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
-                HIP_TRY(c, hash_d.alloc((size_t)npos));
-                HIP_TRY(c, affine_rows_build(c->stream, tmp_rec.p, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, c->a_conn.p,
-                                             c->p_cs, c->a_elem.p, c->a_hdr.p, lanes_full.p, st.p, hash_d.p));
-                int bad = 0;
-                HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                std::vector<unsigned long long> hash_h((size_t)npos);
-                HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                bool bad = false;
+                rs = build_lane_tables(c, tmp_rec.p, us, ms, nb_target, npos, S, c->a_conn.p, c->a_elem.p, c->a_hdr, c->a_lanes, c->a_ntab,
+                                       c->a_incomplete, bad, "affine rows");
+                if (rs) return rs;
                 if (bad) {  // a block the lane tables cannot express: everything on the general kernels
                     c->aff_failed = true;
                     return build_partition(c);
-                }
-                // positions with identical lane records (the interior of a structured mesh) share one table: the kernel
-                // skips the fetch when the table does not change, and what it fetches stays in the caches
-                {
-                    std::vector<int> ids((size_t)npos), first;
-                    auto dedupe = [&](bool identity) {
-                        first.clear();
-                        if (identity) {
-                            first.resize((size_t)npos);
-                            for (int p = 0; p < npos; ++p) { ids[p] = p; first[p] = p; }
-                            return;
-                        }
-                        std::unordered_map<unsigned long long, int> seen;
-                        seen.reserve(1024);
-                        for (int p = 0; p < npos; ++p) {
-                            auto it = seen.find(hash_h[p]);
-                            if (it == seen.end()) {
-                                it = seen.emplace(hash_h[p], (int)first.size()).first;
-                                first.push_back(p);
-                            }
-                            ids[p] = it->second;
-                        }
-                    };
-                    dedupe(c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23));  // the id has 23 bits
-                    for (int attempt = 0; attempt < 2; ++attempt) {
-                        const int ntab = (int)first.size();
-                        DevBuf<int> ids_d, first_d;
-                        HIP_TRY(c, ids_d.alloc((size_t)npos));
-                        HIP_TRY(c, first_d.alloc((size_t)ntab));
-                        HIP_TRY(c, c->a_lanes.alloc((size_t)ntab * 256));
-                        HIP_TRY(c, hipMemcpyAsync(ids_d.p, ids.data(), sizeof(int) * (size_t)npos, hipMemcpyHostToDevice, c->stream));
-                        HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
-                        HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
-                        HIP_TRY(c, affine_rows_compact(c->stream, lanes_full.p, ids_d.p, first_d.p, npos, ntab, c->a_lanes.p, c->a_hdr.p, st.p));
-                        int mismatch[2] = {0, 0};   // [1]: some position has a block without an owner lane
-                        HIP_TRY(c, hipMemcpyAsync(mismatch, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(c, hipStreamSynchronize(c->stream));
-                        c->a_ntab = ntab;
-                        c->a_incomplete = mismatch[1];
-                        if (!mismatch[0]) break;
-                        dedupe(true);  // a hash collision: every position keeps its own table
-                    }
-                    if (c->env("FENRIS_HIP_VERBOSE")) {
-                        long long changes = 0;   // positions whose table differs from their predecessor's in the sweep: each is a 2 KB fetch
-                        for (int p = 1; p < npos; ++p) changes += ids[p] != ids[p - 1];
-                        std::fprintf(stderr, "[fenris_hip] affine rows: %d positions share %d lane tables, %lld changes of table along the sweep%s\n",
-                                     npos, c->a_ntab, changes, c->a_incomplete ? ", some position has a block without an owner" : "");
-                    }
                 }
                 c->a_conn.release();  // input of the lane builder only
                 c->a_npos = npos;
@@ -1261,6 +1282,39 @@ int build_partition(fh_ctx* c) {
                              c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, (int)chain_off[1].size() - 1, us, ms);
             c->has_rows = false;
             const int npg = c->npos_gen;
+            // Hex8, Laplace / uniform LinearElastic: lane tables for the general positions as well (k_hex8_rows, hex8_rows.hip: row-owner
+            // lanes instead of LDS atomics; the eight-point rule, no element mask -- checked at the launch).  The pipelined kernel's tables
+            // stay: they serve every other rule, per-element parameters and masks.
+            c->has_hrows = false;
+            if (c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && us <= HEX8_ROWS_US && nb_target <= 8 && npg > 0 &&
+                !c->has_mask && !c->has_rules && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
+                bool bad = false;
+                int rs = build_lane_tables(c, c->p_rec.p, us, ms, nb_target, npg, S, c->p_conn.p, c->p_elem.p, c->h_hdr, c->h_lanes, c->h_ntab,
+                                           c->h_incomplete, bad, "hex8 rows");
+                if (rs) return rs;
+                if (!bad && !c->h_incomplete) {
+                    // lanes rearranged so that the sixteen lanes the LDS serves together read different banks (host, unique tables only)
+                    if (c->h_ntab <= c->env_int("FENRIS_HIP_TUNE_LANES_MAX", 4096) && !c->env("FENRIS_HIP_NO_LANE_TUNING")) {
+                        std::vector<uint2> tabs((size_t)c->h_ntab * 256);
+                        HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        double cb = 0.0, ca = 0.0;
+                        hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca);
+                        HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        if (c->env("FENRIS_HIP_VERBOSE"))
+                            std::fprintf(stderr, "[fenris_hip] hex8 rows: %d lane tables tuned, modelled LDS cycles per position and operand sweep %.1f -> %.1f (64 = conflict-free)\n",
+                                         c->h_ntab, cb, ca);
+                    }
+                    HIP_TRY(c, c->h_pos.alloc((size_t)npg * 4));
+                    HIP_TRY(c, hex8_rows_positions(c->stream, c->p_rec.p, c->p_rw, us, c->h_hdr.p, npg, c->h_pos.p));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    c->has_hrows = true;
+                }
+                c->h_hdr.release();   // folded into the position records
+                if (c->env("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Hex8, general positions): %s\n", c->has_hrows ? "built" : "mesh not expressible, pipelined kernel kept");
+            }
             // Tet4 with a one-point rule: the row-owner kernel is the default (C3: 1.31 -> 0.85 ms), FENRIS_HIP_NO_ROWS keeps
             // the pipelined kernel
             if (c->elem_kind == FH_TET4 && us * 4 <= 1024 && nb_target <= 16 && npg > 0 && !c->env("FENRIS_HIP_NO_ROWS")) {
@@ -1716,6 +1770,22 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
         }
+        if (c->has_pipe && c->has_hrows && a.fast && !pipe_rules && !c->has_mask && c->nq == 8 && c->elem_kind == FH_HEX8 &&
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
+            const size_t lds_h = hex8_rows_lds_bytes(c->g_acc);
+            if (lds_h <= LDS_LIMIT) {
+                int dev_cus = 256;
+                (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+                const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds_h, 1)));
+                const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu))));
+                Hex8RowTables T{c->h_pos.p, c->h_lanes.p, c->p_conn.p, c->p_elem.p, c->p_us, c->p_cs, c->npos_gen, c->g_acc};
+                if (c->env("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] hex8 rows: positions %d lds=%zu B wgs/cu=%d grid=%d\n", c->npos_gen, lds_h, per_cu, grid);
+                c->last_kernel += "k_hex8_rows";
+                HIP_TRY(c, hex8_rows_launch(c->op, grid, lds_h, c->stream, a, T, a.ablate | (a.trace ? 0x10000 : 0)));
+                return FH_OK;
+            }
+        }
         if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
             a.fast = 1;
             PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr, c->p_rw,
@@ -1933,9 +2003,12 @@ void fh_destroy(fh_ctx* c) {
             static const char* names_ring[3][6] = {{"work", "wait: loader", "wait: ring space", "drain + publish", "-", "-"},
                                                    {"other", "wait: rows / store", "park + issue (vmcnt)", "headers, tables, publish", "-", "-"},
                                                    {"stream", "wait: rows", "drain + publish", "-", "-", "-"}};
+            // k_hex8_rows: role 0 = row wave 0, 1 = row wave 3, 2 = loader wave, 3 = store wave; the two halves of a position and their barriers
+            static const char* names_hex8[6] = {"first half (phase B | stream)", "barrier 1", "second half (phase C | loads)", "barrier 2", "-", "-"};
+            const bool hex8l = h[30] == 0x48455838ull;
             const bool ringl = h[30] == 0x52494E47ull;
             for (int w = 0; w < 4; ++w) {
-                const char* const* names = (ringl && w < 3) ? names_ring[w] : names_pipe;
+                const char* const* names = hex8l ? names_hex8 : (ringl && w < 3) ? names_ring[w] : names_pipe;
                 const unsigned long long* r = h + 7 * w;
                 if (!r[6]) continue;
                 unsigned long long tot = 0;

@@ -180,7 +180,7 @@ def test_uniform_table_after_compact_restores_fast_path(engine, oracle):
     asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(op)
            .with_quadrature_table(fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(lame)).with_u(None).build())
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert engine.last_kernel_name() == "k_gather_pipelined"
+    assert engine.last_kernel_name() == "k_hex8_rows"   # (Hex8, eight-point rule, uniform parameters: the row-owner kernel, hex8_rows.hip)
     oasm = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, m.vertices, m.connectivity, w, p, params=RULES[0])
     vals = oracle.assemble(oasm)[4]
     assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()

@@ -625,8 +625,8 @@ def test_isolated_vertices_and_empty_mesh(engine, oracle):
 
 
 def test_benchmark_kernels_are_the_ones_the_parity_tests_cover(engine, oracle):
-    """bench.py's kernels -- k_affine_rows (structured boxes: the headline) and k_gather_pipelined (every other Hex8 mesh) -- must be
-    the code paths that the parity tests compare with the oracle."""
+    """bench.py's kernels -- k_affine_rows (structured boxes: the headline) and k_hex8_rows (every other Hex8 mesh with the eight-point
+    rule; round 4, before: k_gather_pipelined) -- must be the code paths that the parity tests compare with the oracle."""
     mesh = fa.procedural.create_unit_box_uniform_hex_mesh_3d(12)
     asm, ref = _pair(engine, oracle, "HEX8", "LINEAR_ELASTIC", mesh=mesh)
     st, _, oro, oci, ovals = oracle.assemble(ref)
@@ -638,7 +638,7 @@ def test_benchmark_kernels_are_the_ones_the_parity_tests_cover(engine, oracle):
     # the same mesh through the general kernel (affine detection switched off), the one perturbed meshes take
     asm.engine.set_affine_tolerance(0.0)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert asm.engine.last_kernel_name() == "k_gather_pipelined"
+    assert asm.engine.last_kernel_name() == "k_hex8_rows"
     assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max()
     asm.engine.set_affine_tolerance(2.0 ** -46)
     # distorted (non-affine) elements and the Tet4 / Quad4 instantiations of the same kernel
@@ -647,8 +647,10 @@ def test_benchmark_kernels_are_the_ones_the_parity_tests_cover(engine, oracle):
             asm, ref = _pair(engine, oracle, kind, op)
             st, _, oro, oci, ovals = oracle.assemble(ref)
             k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-            # Tet4 takes the row-owner form of the kernel (rows_kernel.hpp); its four-point rule is collapsed to one point
-            assert asm.engine.last_kernel_name() == ("k_gather_rows" if kind == "TET4" else "k_gather_pipelined"), (kind, op)
+            # Tet4 takes the row-owner form of the kernel (rows_kernel.hpp); its four-point rule is collapsed to one point.  Hex8 with
+            # the eight-point rule: row-owner lanes as well (hex8_rows.hip); Quad4 / Tri3: the pipelined kernel
+            want = {"TET4": "k_gather_rows", "HEX8": "k_hex8_rows"}.get(kind, "k_gather_pipelined")
+            assert asm.engine.last_kernel_name() == want, (kind, op)
             assert np.abs(k.values - ovals).max() <= TOL * np.abs(ovals).max(), (kind, op)
 
 

@@ -555,7 +555,7 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
 __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                                                           const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
                                                           int4* hdr_out, uint2* lanes, int* status,
-                                                          unsigned long long* hash_out) {
+                                                          unsigned long long* hash_out, const int mirror) {
     constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
     __shared__ int cnt[NKEY];
     __shared__ unsigned short bucket[NKEY * TMAX];
@@ -601,18 +601,33 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     // element joins the two nodes) gets a lane of its own that stores zeros, when the lanes suffice -- the position is then complete and
     // never needs its staging buffer cleared (the interface planes of a slab partition: ~140 owner lanes + 63 such blocks)
     auto is_block = [&](int key) { const int il = key >> 7, pos = key & 127; return il < h.nb && pos < noff_old[il + 1] - noff_old[il]; };
-    int n4 = 0, n2 = 0, n1 = 0, n0 = 0;
+    // mirror (k_hex8_rows): when both nodes of a block (I, J) are owned by this position, only the owner of the smaller node keeps
+    // lanes for it; they store the block to (I, J) and its transpose to (J, I).  twin_of(key) = block-local index of J when the block
+    // has such a partner (-1: none); skipped(key): this is the partner's copy
+    auto twin_of = [&](int key) {
+        if (!mirror || !is_block(key)) return -1;
+        const int il = key >> 7, pos = key & 127;
+        const long long jl = (long long)ncols[(size_t)h.r0 + noff_old[il] + pos] - (long long)h.i0;
+        return (jl >= 0 && jl < h.nb && jl != il) ? (int)jl : -1;
+    };
+    auto skipped = [&](int key) { const int jl = twin_of(key); return jl >= 0 && jl < (key >> 7); };
+    for (int key = lane; key < NKEY; key += 64)
+        if (skipped(key)) cnt[key] = -1;      // no lane, and not a block without a term either
+    __syncthreads();
+    int n4 = 0, n2 = 0, n1 = 0, n0 = 0, nskip = 0;
     for (int base = 0; base < NKEY; base += 64) {
         const int Tn = min(cnt[base + lane], TMAX);
         n4 += __popcll(__ballot(Tn >= 5));
         n2 += __popcll(__ballot(Tn == 3 || Tn == 4));
         n1 += __popcll(__ballot(Tn == 1 || Tn == 2));
         n0 += __popcll(__ballot(Tn == 0 && is_block(base + lane)));
+        nskip += __popcll(__ballot(Tn < 0));
     }
     const int base4 = 0, base2 = 4 * n4, base1 = base2 + 2 * n2, base0 = base1 + n1;
     if (base1 + n1 > 256) bad = true;
     const bool zero_lanes = n0 > 0 && base0 + n0 <= 256;
     if ((size_t)8 * S * S * (size_t)h.nrow >= 65536u) bad = true;
+    if (mirror && (S * S * h.nrow >= 8192 || h.nb > 8)) bad = true;   // the two 13-bit offsets / 3-bit nodes of the hex8 record
     if (__ballot(bad)) {
         if (lane == 0) {
             atomicOr(status, 1);
@@ -636,16 +651,30 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
             const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
             const int Lidx = base0 + r0 + __popcll(m0 & below);
             lw0[Lidx] = (AR_ZERO_G << 5) | (AR_ZERO_G << 17) | (1u << 28);
-            lw1[Lidx] = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+            lw1[Lidx] = mirror ? ((unsigned)(S * S * rb + S * (int)pos) | (il << 13)) : ((unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16));
         }
         r0 += __popcll(m0);
         if (Tn >= 1) {
             const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
             const unsigned I = (unsigned)h.i0 + il, J = ncols[(size_t)h.r0 + rb + pos];
             const unsigned trf = I > J ? 1u : 0u, dgf = I == J ? 1u : 0u;
-            const unsigned yw = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+            unsigned yw = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+            unsigned twin_bit = 0u;
+            if (mirror) {
+                // hex8 record: y = offset (doubles) | node << 13 | twin offset << 16 | twin node << 29; the row strides come from the
+                // position record (rows per node); x bit 29: the block has a twin
+                yw = (unsigned)(S * S * rb + S * (int)pos) | (il << 13);
+                const int jl = twin_of(key);
+                if (jl >= 0) {
+                    const int rbJ = noff_old[jl], cntJ = noff_old[jl + 1] - rbJ;
+                    int posJ = 0;
+                    while (posJ < cntJ && ncols[(size_t)h.r0 + rbJ + posJ] != I) ++posJ;   // (I is in J's row: the pattern is symmetric)
+                    yw |= ((unsigned)(S * S * rbJ + S * posJ) << 16) | ((unsigned)jl << 29);
+                    twin_bit = 1u << 29;
+                }
+            }
             auto lane_words = [&](int first, int Lidx, unsigned grp, bool leader) {
-                unsigned xw = (grp << 24) | (trf << 26) | (dgf << 27) | (leader ? (1u << 28) : 0u);
+                unsigned xw = (grp << 24) | (trf << 26) | (dgf << 27) | (leader ? ((1u << 28) | twin_bit) : 0u);
                 for (int t = 0; t < 2; ++t) {
                     unsigned slot = b[0] & 255u, gidx = AR_ZERO_G;
                     if (first + t < Tn) {
@@ -683,7 +712,7 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     if (lane == 0) hash_out[p] = hsum;
     // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
     // flags: bit 0 every block of these rows has a lane; bit 3 the rows are shorter than two cache lines (the store wave's carry test)
-    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, ((n4 + n2 + n1 + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0) | ((S * S * h.nrow < 32) ? 8 : 0), h.U);
+    if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, ((n4 + n2 + n1 + nskip + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0) | ((S * S * h.nrow < 32) ? 8 : 0), h.U);
 }
 
 // table id of every position into its header (flags | id << 8), and the first position of every id gathered into the
@@ -705,10 +734,10 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
 
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* status, unsigned long long* hash) {
+                             int* status, unsigned long long* hash, int mirror) {
     if (npos <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
-                       p_elem, hdr, lanes, status, hash);
+                       p_elem, hdr, lanes, status, hash, mirror);
     return hipGetLastError();
 }
 

@@ -34,7 +34,10 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 // (more than 8 terms per block, more than 256 lanes, offsets out of range).
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* status, unsigned long long* hash);
+                             int* status, unsigned long long* hash, int mirror = 0);
+// mirror != 0 (k_hex8_rows, hex8_rows.hip): a block whose two nodes are both owned by the position keeps the lanes of the smaller node's
+// owner only (x bit 29: the lane also stores the transpose to the twin), and y = offset in doubles | node << 13 | twin offset << 16 |
+// twin node << 29 (row strides from the position record)
 
 // element records of the affine elements (elem_aff[e] != 0) among [e_first, e_end) from the current vertex coordinates: once per assembly, on the same
 // stream right before affine_rows_launch.  A singular element (det J == 0 exactly) of the active set (active == NULL: all) is

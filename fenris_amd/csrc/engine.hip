@@ -809,7 +809,8 @@ int choose_epb(fh_ctx* c, int what) {
 // `rec`: one record of 256 lanes per position (affine_rows_build), positions with identical records share one table (hashed on the
 // device, merged here, verified on the device), the table id goes into every header.  `bad`: some block cannot be expressed.
 static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_target, int npos, int S, const int* conn, const int* elem,
-                             DevBuf<int4>& hdr, DevBuf<uint2>& lanes, int& ntab_out, int& incomplete_out, bool& bad_out, const char* what) {
+                             DevBuf<int4>& hdr, DevBuf<uint2>& lanes, int& ntab_out, int& incomplete_out, bool& bad_out, const char* what,
+                             int mirror = 0) {
     DevBuf<int> st;
     HIP_TRY(c, st.alloc(2));
     HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
@@ -819,7 +820,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
     HIP_TRY(c, hash_d.alloc((size_t)npos));
     HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, lanes_full.p, st.p,
-                                 hash_d.p));
+                                 hash_d.p, mirror));
     int bad = 0;
     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     std::vector<unsigned long long> hash_h((size_t)npos);
@@ -1290,7 +1291,7 @@ int build_partition(fh_ctx* c) {
                 !c->has_mask && !c->has_rules && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
                 bool bad = false;
                 int rs = build_lane_tables(c, c->p_rec.p, us, ms, nb_target, npg, S, c->p_conn.p, c->p_elem.p, c->h_hdr, c->h_lanes, c->h_ntab,
-                                           c->h_incomplete, bad, "hex8 rows");
+                                           c->h_incomplete, bad, "hex8 rows", 1);
                 if (rs) return rs;
                 if (!bad && !c->h_incomplete) {
                     // lanes rearranged so that the sixteen lanes the LDS serves together read different banks (host, unique tables only)
@@ -1307,7 +1308,7 @@ int build_partition(fh_ctx* c) {
                                          c->h_ntab, cb, ca);
                     }
                     HIP_TRY(c, c->h_pos.alloc((size_t)npg * 4));
-                    HIP_TRY(c, hex8_rows_positions(c->stream, c->p_rec.p, c->p_rw, us, c->h_hdr.p, npg, c->h_pos.p));
+                    HIP_TRY(c, hex8_rows_positions(c->stream, c->p_rec.p, c->p_rw, us, ms, c->h_hdr.p, npg, c->h_pos.p));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     c->has_hrows = true;
                 }

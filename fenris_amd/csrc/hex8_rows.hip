@@ -275,17 +275,28 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
     lds_barrier();  // B0
     tr_start();
     const unsigned g_addr = (unsigned)(unsigned long long)G, zv_addr = (unsigned)(unsigned long long)ZV;
-    uint2 lane_cur = {(HR_ZERO_G << 5) | (HR_ZERO_G << 17), 0u};
+    const unsigned idle_x = (HR_ZERO_G << 5) | (HR_ZERO_G << 17);
+    uint2 lane_cur = {idle_x, 0u};
+    bool wave_works = true;
     // phase B on the LAST row lanes: the first two row waves share their SIMDs with the loader and the store wave
-    const int bt = 255 - tid, q = bt & 7;
+    const int bt = 255 - tid;
     for (int p = p_begin; p < p_end; ++p) {
         const int* ring = RING + 16 * (p & 3);
         const int zs = rfl(ring[2]), ws = rfl(ring[3]);
         const int nnew = ws & 0xff, head = (ws >> 16) & 15;
-        if (zs & 4) lane_cur = LT[256 * ((zs >> 1) & 1) + tid];   // the lane table changed with this position
+        if (zs & 4) {   // the lane table changed with this position
+            lane_cur = LT[256 * ((zs >> 1) & 1) + tid];
+            wave_works = __builtin_amdgcn_ballot_w64(lane_cur.x != idle_x) != 0ull;   // (a wavefront without a lane skips phase C)
+        }
         // ------------------------------------------------------------------ phase B: gradients of the new slots
-        if (bt < nnew * 8 && !(DBG && (ablate & 4))) {
-            const int slot = (int)reinterpret_cast<const unsigned char*>(ring + 4)[bt >> 3];
+        // One lane per (new slot, point).  (Measured and dropped: two lanes per item when at most sixteen slots are new -- both evaluate
+        // the Jacobian, each writes four of the eight nodes, all four row waves share the phase: 9.6 -> 10.9 ms.  The CU is bound by the
+        // total LDS and fp64 work of its two workgroups, not by the length of this phase.)
+        const bool split = false;
+        const int it = bt;
+        if (it < nnew * 8 && !(DBG && (ablate & 4))) {
+            const int q = it & 7;
+            const int slot = (int)reinterpret_cast<const unsigned char*>(ring + 4)[it >> 3];
             const f64x2* xs = reinterpret_cast<const f64x2*>(X + slot * 24);
             const f64x2* tb = reinterpret_cast<const f64x2*>(TAB + q * 26);
             double xd[24], gd[24];
@@ -318,12 +329,15 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
                 adj_scaled(J, copysign(SQW[q], detJ) * rsqrt_newton(fabs(detJ)), R);
             }
             double* gs = reinterpret_cast<double*>(G + slot * HR_SS) + 3 * q;
+            for (int pass = 0; pass < (split ? 1 : 2); ++pass) {   // (scalar trip count)
+                const bool upper = split ? ((bt & 1) != 0) : (pass != 0);   // nodes 4 .. 7
+                double* o = gs + (upper ? 4 : 0) * (HR_VS / 8);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                double* o = gs + n * (HR_VS / 8);
+                for (int n = 0; n < 4; ++n, o += HR_VS / 8) {
+                    const double g0 = upper ? gd[12 + 3 * n] : gd[3 * n], g1 = upper ? gd[13 + 3 * n] : gd[3 * n + 1], g2 = upper ? gd[14 + 3 * n] : gd[3 * n + 2];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    o[i] = fma(R[2][i], gd[3 * n + 2], fma(R[1][i], gd[3 * n + 1], R[0][i] * gd[3 * n]));
+                    for (int i = 0; i < 3; ++i) o[i] = fma(R[2][i], g2, fma(R[1][i], g1, R[0][i] * g0));
+                }
             }
         }
         tr_barrier(0);  // B1(p)
@@ -348,7 +362,7 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
 #pragma unroll
             for (int j = 0; j < 3; ++j) { H[i][j] = 0.0; H1[i][j] = 0.0; }
         double sl = 0.0, sl1 = 0.0;
-        if (!(DBG && (ablate & 2)) && !(DBG && (ablate & 32) && wave == 3)) {   // (32, profiling: three row waves)
+        if (wave_works && !(DBG && (ablate & 2)) && !(DBG && (ablate & 32) && wave == 3)) {   // (32, profiling: three row waves)
             // eight groups of two points: three 16-byte pieces of each operand vector; two groups in flight (12 of the 15 LDS
             // operations the counter tracks)
             f64x2 A[2][3], B[2][3];
@@ -409,7 +423,11 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
         if constexpr (LAP) {
             if (grp >= 1) sl += dpp_quad_full<0xB1>(sl);
             if (grp >= 2) sl += dpp_quad_full<0x4E>(sl);
-            if ((x >> 28) & 1u) *reinterpret_cast<double*>(out_b + 8 * head + (y & 0xffffu)) = sl;
+            if ((x >> 28) & 1u) {
+                double* o = reinterpret_cast<double*>(out_b) + head;
+                o[y & 0x1fffu] = sl;
+                if ((x >> 29) & 1u) o[(y >> 16) & 0x1fffu] = sl;     // the twin block (J, I): the same number
+            }
         } else {
             if (grp >= 1) {
 #pragma unroll
@@ -441,12 +459,23 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
                         v[i][j] = tr ? lw : up;
                         v[j][i] = (tr || dg) ? up : lw;
                     }
-                const unsigned rs = y >> 16;
-                char* stage = out_b + 8 * head + (y & 0xffffu);
+                // row strides: S x the column blocks of the node's rows (position record, bytes 56 ..)
+                const unsigned char* cnts = reinterpret_cast<const unsigned char*>(ring + 14);
+                const unsigned rs = 3u * cnts[(y >> 13) & 7u];
+                double* stage = reinterpret_cast<double*>(out_b) + head + (y & 0x1fffu);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    double* row = reinterpret_cast<double*>(stage + i * rs);
+                    double* row = stage + i * rs;
                     row[0] = v[i][0]; row[1] = v[i][1]; row[2] = v[i][2];
+                }
+                if ((x >> 29) & 1u) {   // the twin block (J, I) of a pair of nodes this position owns both: the transpose
+                    const unsigned rs2 = 3u * cnts[y >> 29];
+                    double* st2 = reinterpret_cast<double*>(out_b) + head + ((y >> 16) & 0x1fffu);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        double* row = st2 + i * rs2;
+                        row[0] = v[0][i]; row[1] = v[1][i]; row[2] = v[2][i];
+                    }
                 }
             }
         }
@@ -508,8 +537,11 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
         before += total;
         int best_total = total;
         std::copy(L, L + 256, best.begin());
-        // unit size at every lane: 4 (aligned quad, log2(group) = 2), 2 (aligned pair) or 1
-        auto unit_at = [&](int lane) { const unsigned g = (L[lane].x >> 24) & 3u; return g >= 2 ? 4 : g == 1 ? 2 : 1; };
+        // the lanes in use fill whole wavefronts from the front (a wavefront without a lane skips phase C): moves stay below `limit`
+        int used = 0;
+        for (int l = 0; l < 256; ++l)
+            if (L[l].x != ((64u << 5) | (64u << 17))) used = l + 1;
+        const int limit = std::max(64, std::min(256, (used + 63) & ~63));
         // simulated annealing over (a) swaps of two aligned blocks of 4 / 2 / 1 lanes that consist of whole units, (b) swaps of the two
         // halves of one lane's record
         for (int it = 0; it < budget && best_total > 64; ++it) {   // 64 = every one of the 16 x 4 reads conflict-free
@@ -519,15 +551,15 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
             int sz = 0, a = 0, b = 0;
             unsigned saved_x = 0;
             if (kind == 0) {
-                a = (int)((r >> 2) & 255u);
+                a = (int)((r >> 2) & 255u) % limit;
                 const unsigned x = L[a].x, lo = x & 0xfffu, hi = (x >> 12) & 0xfffu;
                 if (lo == hi) continue;
                 saved_x = x;
                 L[a].x = (x & 0xff000000u) | (lo << 12) | hi;
             } else {
                 sz = kind == 1 ? 4 : kind == 2 ? 2 : 1;
-                a = (int)(((r >> 2) & 255u) / sz) * sz;
-                b = (int)(((r >> 10) & 255u) / sz) * sz;
+                a = (int)((((r >> 2) & 255u) % limit) / sz) * sz;
+                b = (int)((((r >> 10) & 255u) % limit) / sz) * sz;
                 if (a == b) continue;
                 bool ok = true;
                 for (int base : {a, b}) {
@@ -570,7 +602,7 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
 }
 
 // ------------------------------------------------------------------------------------------------ position records
-__global__ void __launch_bounds__(256) k_hex8_rows_positions(const int* p_rec, int rw, int us, const int4* hdr, int npos, int4* pos) {
+__global__ void __launch_bounds__(256) k_hex8_rows_positions(const int* p_rec, int rw, int us, int ms, const int4* hdr, int npos, int4* pos) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npos) return;
     const int* rec = p_rec + (size_t)p * rw;
@@ -587,12 +619,16 @@ __global__ void __launch_bounds__(256) k_hex8_rows_positions(const int* p_rec, i
     pos[(size_t)p * 4 + 0] = make_int4(hd.x, hd.y, hd.z, (h.k0 & 0xff) | ((h.U & 0xff) << 8));
     pos[(size_t)p * 4 + 1] = make_int4(w[0], w[1], w[2], w[3]);
     pos[(size_t)p * 4 + 2] = make_int4(w[4], w[5], w[6], w[7]);
-    pos[(size_t)p * 4 + 3] = make_int4((int)fresh, (int)occ, 0, 0);
+    // column blocks per row of every node of the position (the row stride of its staged rows is S x that many doubles)
+    const int* noff = rec + 8 + us / 4 + ms + ms * 8 / 4;
+    unsigned cw[2] = {0u, 0u};
+    for (int il = 0; il < h.nb && il < 8; ++il) cw[il >> 2] |= (unsigned)((noff[il + 1] - noff[il]) & 0xff) << (8 * (il & 3));
+    pos[(size_t)p * 4 + 3] = make_int4((int)fresh, (int)occ, (int)cw[0], (int)cw[1]);
 }
 
-hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int us, const int4* hdr, int npos, int4* pos) {
+hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int us, int ms, const int4* hdr, int npos, int4* pos) {
     if (npos <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hex8_rows_positions, dim3((npos + 255) / 256), dim3(256), 0, stream, p_rec, rw, us, hdr, npos, pos);
+    hipLaunchKernelGGL(k_hex8_rows_positions, dim3((npos + 255) / 256), dim3(256), 0, stream, p_rec, rw, us, ms, hdr, npos, pos);
     return hipGetLastError();
 }
 

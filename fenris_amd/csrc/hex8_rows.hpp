@@ -13,7 +13,7 @@ namespace fenris_hip {
 struct Hex8RowTables {
     const int4* pos;      // [npos][4]    16 words per position: r0, nrow, flags | lane table << 8, new slots | occupied slots << 8,
                           //              32 slot bytes (the new slots first, then the retained), mask of the new slots, mask of the
-                          //              occupied slots, 2 spare
+                          //              occupied slots, 8 bytes: column blocks per row of the position's nodes
     const uint2* lanes;   // [ntab][256]  lane records (format of affine_rows.hip); positions with identical records share a table
     const int* conn;      // [npos][cs]   vertex index per (slot, local node)
     const int* elem;      // [npos][us]   element id per slot (error reporting)
@@ -27,7 +27,7 @@ size_t hex8_rows_lds_bytes(int acc_max);
 
 // position records from the pipelined kernel's records (p_rec: GatherHdr with k0 = number of new slots, slot list) and the headers the
 // lane builder wrote (affine_rows_build + affine_rows_compact: {r0, nrow, flags | table << 8, U})
-hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int us, const int4* hdr, int npos, int4* pos);
+hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int us, int ms, const int4* hdr, int npos, int4* pos);
 
 // Host side, once per pattern: rearranges the lanes of every table (`tables`: ntab x 256 records) so that the sixteen lanes the LDS serves
 // together (ds_read_b128 lane groups) read operand vectors from different banks.  Only moves that leave every sum unchanged: whole

@@ -542,6 +542,8 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
         for (int l = 0; l < 256; ++l)
             if (L[l].x != ((64u << 5) | (64u << 17))) used = l + 1;
         const int limit = std::max(64, std::min(256, (used + 63) & ~63));
+        // unit size at every lane: 4 (aligned quad, log2(group) = 2), 2 (aligned pair) or 1
+        auto unit_at = [&](int lane) { const unsigned g = (L[lane].x >> 24) & 3u; return g >= 2 ? 4 : g == 1 ? 2 : 1; };
         // simulated annealing over (a) swaps of two aligned blocks of 4 / 2 / 1 lanes that consist of whole units, (b) swaps of the two
         // halves of one lane's record
         for (int it = 0; it < budget && best_total > 64; ++it) {   // 64 = every one of the 16 x 4 reads conflict-free

@@ -168,8 +168,35 @@ class InterfaceExchange:
             self.recv_buf = torch.empty(n, dtype=values.dtype, device=values.device)
         return self
 
+    def _packing_is_valid(self):
+        """What packing leaves out must be structurally zero on the sender: for every node of an interface plane, the first third of
+        its (sorted) neighbours must be exactly the nodes BELOW the plane, the second third the plane itself, the last third the nodes
+        above -- true for ``make_slab`` by construction, checked here from the slab's connectivity (the interface nodes only) so that any
+        other ``SlabProblem`` (say, an interface plane on the mesh boundary: rows of 2 x 9 blocks) falls back to whole rows instead of
+        dropping contributions silently."""
+        conn = np.asarray(self.slab.mesh.connectivity).astype(np.int64)
+        for nodes in (self.slab.send_nodes, self.slab.recv_nodes):
+            if not nodes:
+                continue
+            lo, hi = int(nodes[0]), int(nodes[1])
+            on_plane = (conn >= lo) & (conn < hi)
+            elems = conn[on_plane.any(axis=1)]
+            n = elems.shape[1]
+            rows = np.repeat(elems, n, axis=1).reshape(-1)          # (i, j) for all node pairs of these elements
+            cols = np.tile(elems, (1, n)).reshape(-1)
+            keep = (rows >= lo) & (rows < hi)
+            pairs = np.unique(np.stack([rows[keep], cols[keep]], axis=1), axis=0)
+            below = np.bincount(pairs[pairs[:, 1] < lo, 0] - lo, minlength=hi - lo)
+            inside = np.bincount(pairs[(pairs[:, 1] >= lo) & (pairs[:, 1] < hi), 0] - lo, minlength=hi - lo)
+            above = np.bincount(pairs[pairs[:, 1] >= hi, 0] - lo, minlength=hi - lo)
+            if not (np.array_equal(below, inside) and np.array_equal(inside, above)):
+                return False
+        return True
+
     def bind(self, engine, values):
         ro, _ = engine.pattern(want_cols=False)
+        if self.pack and not self._packing_is_valid():
+            self.pack = False      # (both sides of an interface see the same rows and take the same decision)
         return self.bind_offsets(ro, engine.solution_dim(), values)
 
     def bytes_sent(self):

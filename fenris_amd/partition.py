@@ -1,0 +1,250 @@
+"""Multi-GPU assembly of an ARBITRARY mesh: element partition ``elem_to_part[]`` + exchange of interface rows.
+
+fenris itself is single-process; what this replaces on every rank is ``CsrParAssembler::assemble_into_csr`` (global.rs:314-376) over the
+rank's own elements.  The slab partition of ``distributed.py`` is the special case for structured boxes (one contiguous node range per
+interface, which lets a rank send ONE segment of its values); here a rank may have any number of neighbours and its interface rows lie
+anywhere, so they travel through packed index lists.
+
+* every element belongs to exactly one part (``elem_to_part[e]``); a node is OWNED by the lowest part that has an element touching it
+  (nodes without elements: part 0);
+* rank r's *extended* local mesh = its own elements + every element that touches a node its own elements touch (one ring of halo
+  elements).  Local node numbers are the global ones in ascending order (``l2g``), so column order is preserved and the rows of every
+  node that r's own elements touch carry the complete GLOBAL pattern -- identical layouts on all ranks that contribute to such a row;
+* numerics run over the own elements only (``Engine.set_active_elements``; ``mode="halo"``: also over the halo elements that touch an
+  owned node, which completes the owned rows locally and needs no exchange);
+* exchange (``mode="exchange"``): for each neighbour q, r sends its partial rows of the nodes q owns that r's own elements touch, and
+  adds what q sends for r's owned nodes; both sides list these nodes in ascending global order, so the buffers line up without any
+  index traffic.  Point to point (RCCL ``ncclSend`` / ``ncclRecv`` under ``torch.distributed`` on the GPU box, gloo in the CPU tests):
+  never a collective over the matrix.
+Concatenating the owned rows of all ranks (mapped through ``l2g``) gives the single-process CSR: indices bit for bit, values to rounding.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .mesh import Mesh
+
+
+@dataclass
+class PartProblem:
+    mesh: Mesh                      # extended local mesh (own + halo elements), local node numbering
+    l2g: np.ndarray                 # global node id of every local node (ascending)
+    elem_l2g: np.ndarray            # global element id of every local element
+    active: np.ndarray              # uint8 per local element: 1 = its numerics run on this rank
+    owned: np.ndarray               # local ids of the nodes this rank owns (ascending)
+    send: Dict[int, np.ndarray] = field(default_factory=dict)   # neighbour -> local node ids whose partial rows go there (ascending global id)
+    recv: Dict[int, np.ndarray] = field(default_factory=dict)   # neighbour -> local (owned) node ids that receive its partial rows
+    rank: int = 0
+    world: int = 1
+    mode: str = "exchange"
+    own_elements: int = 0
+
+    def num_own_elements(self):
+        return int(self.own_elements)
+
+    def num_active_elements(self):
+        return int(self.active.sum())
+
+
+def morton_partition(mesh: Mesh, world: int) -> np.ndarray:
+    """Default partitioner: elements sorted by the Morton key of their centroids (21 bits per axis), cut into ``world`` runs of
+    (almost) equal length.  Returns ``elem_to_part`` (int32 per element).  Any other array works with ``make_part`` just as well."""
+    conn = np.asarray(mesh.connectivity).astype(np.int64)
+    cent = mesh.vertices[conn].mean(axis=1)
+    lo, hi = cent.min(axis=0), cent.max(axis=0)
+    scale = np.where(hi > lo, 2097151.0 / np.where(hi > lo, hi - lo, 1.0), 0.0)
+    q = ((cent - lo) * scale).astype(np.uint64)
+
+    def spread(v):   # 21 bits -> every third bit
+        v = v & np.uint64(0x1fffff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    key = spread(q[:, 0])
+    for a in range(1, q.shape[1]):
+        key |= spread(q[:, a]) << np.uint64(a)
+    order = np.argsort(key, kind="stable")
+    part = np.empty(len(conn), dtype=np.int32)
+    bounds = (np.arange(world + 1, dtype=np.int64) * len(conn)) // world
+    for r in range(world):
+        part[order[bounds[r]:bounds[r + 1]]] = r
+    return part
+
+
+def node_owners(connectivity, elem_to_part, num_nodes: int) -> np.ndarray:
+    """owner of every node: the lowest part with an element touching it (nodes without elements: part 0)"""
+    conn = np.asarray(connectivity).astype(np.int64)
+    part = np.asarray(elem_to_part).astype(np.int64)
+    owner = np.full(num_nodes, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(owner, conn.reshape(-1), np.repeat(part, conn.shape[1]))
+    owner[owner == np.iinfo(np.int64).max] = 0
+    return owner
+
+
+def make_part(mesh: Mesh, elem_to_part, rank: int, world: int, mode: str = "exchange") -> PartProblem:
+    """Rank ``rank``'s share of ``mesh`` under the element partition ``elem_to_part`` (see the module docstring)."""
+    if mode not in ("exchange", "halo"):
+        raise ValueError("mode must be 'exchange' or 'halo'")
+    conn = np.asarray(mesh.connectivity).astype(np.int64)
+    part = np.asarray(elem_to_part).astype(np.int64)
+    if part.shape != (len(conn),) or (len(part) and (part.min() < 0 or part.max() >= world)):
+        raise ValueError("elem_to_part: one part in [0, world) per element")
+    n = mesh.num_nodes()
+    owner = node_owners(conn, part, n)
+    own_e = part == rank
+    touched = np.zeros(n, dtype=bool)                      # nodes my own elements touch
+    touched[conn[own_e].reshape(-1)] = True
+    mine = owner == rank
+    # extended mesh: every element that touches a node my own elements touch (their rows must carry the global pattern) -- and, for
+    # nodes I own without touching them (only nodes without any element: empty rows), nothing
+    ext_e = touched[conn].any(axis=1)
+    ext_nodes = np.zeros(n, dtype=bool)
+    ext_nodes[conn[ext_e].reshape(-1)] = True
+    ext_nodes |= mine                                       # (isolated owned nodes keep their empty rows)
+    l2g = np.flatnonzero(ext_nodes)
+    g2l = np.full(n, -1, dtype=np.int64)
+    g2l[l2g] = np.arange(len(l2g))
+    elem_l2g = np.flatnonzero(ext_e)
+    local = Mesh(mesh.vertices[l2g].copy(), g2l[conn[elem_l2g]].astype(np.uint64), mesh.elem_kind)
+    active = own_e[elem_l2g].astype(np.uint8)
+    if mode == "halo":
+        # also the halo elements that touch a node I own: my rows are then complete without any traffic
+        active |= (mine[conn[elem_l2g]].any(axis=1)).astype(np.uint8)
+    prob = PartProblem(local, l2g, elem_l2g, active, g2l[np.flatnonzero(mine)], {}, {}, rank, world, mode, int(own_e.sum()))
+    if mode == "exchange":
+        # what I send: nodes my own elements touch that another part owns; what I receive: my nodes that another part's elements touch
+        for q in np.unique(owner[touched & ~mine]):
+            prob.send[int(q)] = g2l[np.flatnonzero(touched & (owner == q))]
+        for q in range(world):
+            if q == rank:
+                continue
+            tq = np.zeros(n, dtype=bool)
+            tq[conn[part == q].reshape(-1)] = True
+            nodes = np.flatnonzero(tq & mine)
+            if len(nodes):
+                prob.recv[q] = g2l[nodes]
+    return prob
+
+
+class PartExchange:
+    """Interface rows of a ``PartProblem``: packed index lists, one send and one receive buffer per neighbour, all transfers posted at
+    once (``torch.distributed.batch_isend_irecv``).  Works on any torch tensor (CUDA with nccl = RCCL, CPU with gloo)."""
+
+    def __init__(self, prob: PartProblem, group=None):
+        self.prob, self.group = prob, group
+        self.values = None
+        self.send_idx: Dict[int, object] = {}
+        self.recv_idx: Dict[int, object] = {}
+        self.recv_buf: Dict[int, object] = {}
+        self._reqs: List[object] = []
+        self._send_bufs: List[object] = []
+
+    @staticmethod
+    def _row_indices(row_offsets, s, nodes, device):
+        """positions in ``values`` of all s rows of every node in ``nodes`` (in that order), as an int64 tensor"""
+        import torch
+
+        ro = np.asarray(row_offsets).astype(np.int64)
+        first, last = ro[s * nodes], ro[s * nodes + s]
+        n = last - first
+        start = np.cumsum(n) - n
+        idx = np.repeat(first - start, n) + np.arange(int(n.sum()), dtype=np.int64)
+        return torch.as_tensor(idx, device=device)
+
+    def bind_offsets(self, row_offsets, solution_dim: int, values):
+        import torch
+
+        self.values = values
+        for q, nodes in self.prob.send.items():
+            self.send_idx[q] = self._row_indices(row_offsets, solution_dim, np.asarray(nodes), values.device)
+        for q, nodes in self.prob.recv.items():
+            self.recv_idx[q] = self._row_indices(row_offsets, solution_dim, np.asarray(nodes), values.device)
+            self.recv_buf[q] = torch.empty(self.recv_idx[q].numel(), dtype=values.dtype, device=values.device)
+        return self
+
+    def bind(self, engine, values):
+        ro, _ = engine.pattern(want_cols=False)
+        return self.bind_offsets(ro, engine.solution_dim(), values)
+
+    def bytes_sent(self):
+        return int(sum(8 * i.numel() for i in self.send_idx.values()))
+
+    def start(self, comm_stream=None):
+        import torch
+        import torch.distributed as dist
+
+        self._reqs, self._send_bufs = [], []
+        if not self.send_idx and not self.recv_idx:
+            return
+
+        def post():
+            ops = []
+            for q in sorted(self.send_idx):
+                buf = self.values.index_select(0, self.send_idx[q])
+                self._send_bufs.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, q, self.group))
+            for q in sorted(self.recv_idx):
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[q], q, self.group))
+            return dist.batch_isend_irecv(ops)
+
+        if comm_stream is not None:
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                self._reqs = post()
+        else:
+            self._reqs = post()
+
+    def finish(self):
+        for req in self._reqs:
+            req.wait()
+        self._reqs = []
+        for q in sorted(self.recv_idx):       # fixed order of the additions: the owned rows come out the same bits every run
+            self.values.index_add_(0, self.recv_idx[q], self.recv_buf[q])
+        self._send_bufs = []
+
+    def run(self):
+        self.start()
+        self.finish()
+
+
+class PartAssembly:
+    """One rank of the multi-GPU stiffness assembly of an arbitrary mesh (the general counterpart of ``distributed.SlabAssembly``).
+    ``configure(engine, mesh)`` sets operator / quadrature / u on an engine for the given (extended local) mesh."""
+
+    def __init__(self, prob: PartProblem, configure, device: int = 0, group=None, stream=None):
+        import torch
+
+        from .assembly import Engine
+
+        self.prob = prob
+        self.main = Engine(device, stream=stream)
+        configure(self.main, prob.mesh)
+        self.main.set_active_elements(prob.active)
+        nnz = self.main.build_pattern()
+        self.values = torch.zeros(nnz, dtype=torch.float64, device=f"cuda:{device}")
+        self.exchange = PartExchange(prob, group).bind(self.main, self.values)
+
+    def enqueue(self, flags):
+        self.main.assemble_matrix_async(self.values, flags)
+        self.exchange.run()
+
+    def poll_status(self):
+        self.main.poll_status()
+
+    def owned_rows(self, row_offsets=None):
+        """(global row ids, positions in ``values``) of the scalar rows this rank owns -- what a caller concatenates over the ranks"""
+        ro = row_offsets if row_offsets is not None else self.main.pattern(want_cols=False)[0]
+        s = self.main.solution_dim()
+        rows_l = (s * np.asarray(self.prob.owned)[:, None] + np.arange(s)[None, :]).reshape(-1)
+        rows_g = (s * self.prob.l2g[np.asarray(self.prob.owned)][:, None] + np.arange(s)[None, :]).reshape(-1)
+        return rows_g, rows_l, np.asarray(ro)
+
+    def close(self):
+        self.main.close()

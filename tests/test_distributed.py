@@ -484,3 +484,33 @@ def test_group_abi_two_ranks_rccl():
         outs.append((pr.returncode, out))
     for r, (rc, out) in enumerate(outs):
         assert rc == 0 and f"rank {r} ok" in out, f"rank {r} rc={rc}\n{out[-3000:]}"
+
+
+def test_packing_is_switched_off_when_the_first_third_is_not_the_plane_below():
+    """InterfaceExchange.bind (the engine path) verifies what packing assumes from the slab's connectivity: a SlabProblem whose `send`
+    plane has nothing below it (rows of 2 x 9 instead of 3 x 9 blocks, every length still divisible by 3 for s = 3) must travel whole"""
+    class _Eng:   # pattern accessor only: no device needed
+        def __init__(self, ro):
+            self.ro = ro
+
+        def pattern(self, want_cols=True):
+            return self.ro, None
+
+        def solution_dim(self):
+            return 3
+
+    import torch
+
+    from oracle import oracle as o
+
+    good = fd.make_slab(1.0, 1, 1, 3, 2, 1, 3)
+    bad = fd.make_slab(1.0, 1, 1, 3, 2, 1, 3)
+    npl = (2 + 1) ** 2
+    bad.send_nodes = (0, npl)                       # the bottom plane of the extended mesh: no nodes below it
+    for slab, want_pack in ((good, True), (bad, False)):
+        w, p = o.hexahedron_gauss(2)
+        ro, ci = o.pattern_for(o.ElementAssembler(o.HEX8, o.LINEAR_ELASTIC, slab.mesh.vertices, slab.mesh.connectivity, w, p, params=LAME))
+        ex = fd.InterfaceExchange(slab)
+        ex.bind(_Eng(ro), torch.zeros(len(ci), dtype=torch.float64))
+        assert ex.pack == want_pack
+        assert (ex.send_idx is not None) == want_pack

@@ -1,0 +1,209 @@
+"""Multi-GPU assembly of arbitrary meshes: element partition `elem_to_part[]` + packed interface-row exchange (fenris_amd/partition.py).
+
+SURVEY.md 8e: "For unstructured meshes: any element partition (e.g. Morton / RCB on element centroids) -- the engine takes elem_to_part[]";
+what every rank's launch replaces is CsrParAssembler::assemble_into_csr over its own elements (global.rs:314-376).
+
+CPU part: 2 and 4 processes over gloo run the product's partition and exchange code on the reference's unstructured sphere fixture and on a
+BCC tetrahedral mesh with permuted numbering; the per-rank partial values come from the oracle (the checker standing in for the GPU
+numerics); every rank's owned rows must equal the oracle's single-process matrix -- indices bit for bit (through the local -> global node
+map), values to 1e-12.  GPU part: the same partitions through the engine (element mask + the owner-computes kernels), all ranks in one
+process on the one device, the transfers replaced by device copies through the same index lists."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import fenris_amd as fa
+from fenris_amd import partition as fp
+from fenris_amd import quadrature
+from conftest import load_golden_mesh
+
+LAME = (416666.6666666667, 277777.7777777778)
+
+
+def _mesh(name):
+    if name == "sphere":
+        v, c = load_golden_mesh("sphere_tet4_593")
+        return fa.Mesh(v, c, fa.TET4)
+    if name == "bcc":   # C3's kind of mesh at a size the oracle finishes in a second: BCC tetrahedra, vertices and elements permuted
+        m = fa.procedural.create_unit_box_uniform_tet_mesh_3d(4)
+        rng = np.random.Generator(np.random.MT19937(12345))
+        vp = rng.permutation(m.num_nodes())
+        inv = np.empty_like(vp)
+        inv[vp] = np.arange(len(vp))
+        return fa.Mesh(m.vertices[vp], inv[np.asarray(m.connectivity).astype(np.int64)][rng.permutation(m.num_elements())].astype(np.uint64), fa.TET4)
+    if name == "hex":   # distorted hexahedra with holes
+        m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 7, 5, 4, 1)
+        rng = np.random.default_rng(5)
+        c = np.asarray(m.connectivity)[rng.random(m.num_elements()) > 0.15]
+        return fa.Mesh(m.vertices + 0.1 * rng.uniform(-1, 1, m.vertices.shape), c, fa.HEX8)
+    raise ValueError(name)
+
+
+def _rule(mesh):
+    return quadrature.total_order.tetrahedron(2) if mesh.elem_kind == fa.TET4 else quadrature.tensor.hexahedron_gauss(2)
+
+
+def _okind(oracle, mesh):
+    return oracle.TET4 if mesh.elem_kind == fa.TET4 else oracle.HEX8
+
+
+def _global_reference(oracle, mesh, op):
+    w, p = _rule(mesh)
+    ref = oracle.ElementAssembler(_okind(oracle, mesh), op, mesh.vertices, mesh.connectivity, w, p, params=None if op == oracle.LAPLACE else LAME)
+    st, _, ro, ci, vals = oracle.assemble(ref)
+    assert st == 0
+    return ro, ci, vals
+
+
+def _oracle_partial(oracle, prob, op):
+    """pattern on the extended local mesh, numerics over the active elements only (what Engine.set_active_elements does)"""
+    m = prob.mesh
+    w, p = _rule(m)
+    params = None if op == oracle.LAPLACE else LAME
+    full = oracle.ElementAssembler(_okind(oracle, m), op, m.vertices, m.connectivity, w, p, params=params)
+    ro, ci = oracle.pattern_for(full)
+    own = oracle.ElementAssembler(_okind(oracle, m), op, m.vertices, np.asarray(m.connectivity)[prob.active.astype(bool)], w, p, params=params)
+    vals = np.zeros(len(ci))
+    st, _ = oracle.assemble_into_csr(own, ro, ci, vals)
+    assert st == 0
+    return ro, ci, vals
+
+
+def _check_owned_rows(prob, s, ro, ci, vals, gro, gci, gvals):
+    ro, ci, gro, gci = (np.asarray(x).astype(np.int64) for x in (ro, ci, gro, gci))
+    scale = np.abs(gvals).max()
+    for l in np.asarray(prob.owned):
+        g = int(prob.l2g[l])
+        for k in range(s):
+            a, b = ro[s * l + k], ro[s * l + k + 1]
+            ga, gb = gro[s * g + k], gro[s * g + k + 1]
+            assert b - a == gb - ga, (l, g)
+            if b == a:
+                continue           # a node without elements: an empty row
+            cols = s * prob.l2g[ci[a:b] // s] + ci[a:b] % s          # local -> global columns: bit-exact
+            assert np.array_equal(cols, gci[ga:gb])
+            assert np.abs(vals[a:b] - gvals[ga:gb]).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("name,world", [("sphere", 3), ("bcc", 4), ("hex", 2)])
+def test_partition_covers_the_mesh_and_halo_mode_needs_no_exchange(oracle, name, world):
+    mesh = _mesh(name)
+    part = fp.morton_partition(mesh, world)
+    counts = np.bincount(part, minlength=world)
+    assert counts.sum() == mesh.num_elements() and counts.max() - counts.min() <= 1      # balanced runs of the Morton order
+    owner = fp.node_owners(mesh.connectivity, part, mesh.num_nodes())
+    gro, gci, gvals = _global_reference(oracle, mesh, oracle.LINEAR_ELASTIC)
+    owned_total, own_total = 0, 0
+    for r in range(world):
+        prob = fp.make_part(mesh, part, r, world, mode="halo")
+        assert not prob.send and not prob.recv
+        assert np.array_equal(prob.l2g[prob.owned], np.flatnonzero(owner == r))
+        owned_total += len(prob.owned)
+        own_total += prob.num_own_elements()
+        assert np.array_equal(mesh.vertices[prob.l2g], prob.mesh.vertices)
+        ro, ci, vals = _oracle_partial(oracle, prob, oracle.LINEAR_ELASTIC)
+        _check_owned_rows(prob, 3, ro, ci, vals, gro, gci, gvals)       # complete without any exchange
+        ex = fp.make_part(mesh, part, r, world)                          # exchange mode: who talks to whom is symmetric
+        for q, nodes in ex.send.items():
+            other = fp.make_part(mesh, part, q, world)
+            assert np.array_equal(ex.l2g[nodes], other.l2g[other.recv[r]])
+    assert owned_total == mesh.num_nodes() and own_total == mesh.num_elements()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, name, op_name, q):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        op = getattr(oracle, op_name)
+        s = 1 if op_name == "LAPLACE" else 3
+        mesh = _mesh(name)
+        part = fp.morton_partition(mesh, world)
+        prob = fp.make_part(mesh, part, rank, world)
+        ro, ci, vals = _oracle_partial(oracle, prob, op)
+        values = torch.from_numpy(vals)
+        ex = fp.PartExchange(prob).bind_offsets(ro, s, values)
+        assert world == 1 or ex.bytes_sent() > 0 or len(prob.recv) > 0
+        ex.run()
+        gro, gci, gvals = _global_reference(oracle, mesh, op)
+        _check_owned_rows(prob, s, ro, ci, values.numpy(), gro, gci, gvals)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as exc:  # pragma: no cover - reported to the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(exc)))
+
+
+@pytest.mark.parametrize("name,world,op_name", [("sphere", 2, "LINEAR_ELASTIC"), ("sphere", 4, "LAPLACE"), ("bcc", 2, "LAPLACE"),
+                                                ("bcc", 4, "LINEAR_ELASTIC")])
+def test_exchange_over_gloo(name, world, op_name):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, name, op_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,op_name", [("sphere", 4, "LINEAR_ELASTIC"), ("bcc", 3, "LINEAR_ELASTIC"), ("hex", 4, "LINEAR_ELASTIC"),
+                                                ("hex", 2, "LAPLACE")])
+def test_parts_through_the_engine_match_the_global_oracle(oracle, name, world, op_name):
+    """every rank's share through the engine on the one GPU of the test box (element mask, owner-computes kernels, values overwritten in an
+    array of garbage); the transfers are device copies through the exchange's own index lists"""
+    import torch
+
+    op = getattr(oracle, op_name)
+    s = 1 if op_name == "LAPLACE" else 3
+    mesh = _mesh(name)
+    w, p = _rule(mesh)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if s == 3:
+        qt = qt.with_uniform_data(fa.LameParameters(*LAME))
+    fop = fa.LaplaceOperator() if s == 1 else fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+
+    def configure(engine, m):
+        return fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(fop).with_quadrature_table(qt).with_u(None).build()
+
+    part = fp.morton_partition(mesh, world)
+    ranks = [fp.PartAssembly(fp.make_part(mesh, part, r, world), configure, device=0) for r in range(world)]
+    try:
+        for pa in ranks:
+            pa.values.fill_(3.5)
+            pa.main.assemble_matrix_async(pa.values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+            pa.poll_status()
+        torch.cuda.synchronize()
+        partial = [pa.values.clone() for pa in ranks]
+        for r, pa in enumerate(ranks):       # what PartExchange.run() does between processes
+            for q_ in sorted(pa.exchange.recv_idx):
+                pa.values.index_add_(0, pa.exchange.recv_idx[q_], partial[q_].index_select(0, ranks[q_].exchange.send_idx[r]))
+        gro, gci, gvals = _global_reference(oracle, mesh, op)
+        for pa in ranks:
+            ro, ci = pa.main.pattern()
+            _check_owned_rows(pa.prob, s, ro, ci, pa.values.cpu().numpy(), gro, gci, gvals)
+    finally:
+        for pa in ranks:
+            pa.close()

@@ -52,7 +52,10 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
 
 // MASKED: the tables were built under an element mask (blocks without a term: lanes that store zeros; positions that stay incomplete
 // take one barrier more).  A separate instantiation: the per-position checks cost the unmasked Laplace sweep 13 %.
-template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED>
+// CHUNK (experiment, FENRIS_HIP_AFFINE_CHUNK = C): instead of one contiguous range of positions per workgroup (768 write fronts ~25 MB
+// apart), the positions are dealt in chunks of C -- chunk c goes to workgroup c mod G -- so that all concurrent stores fall into one
+// moving window of G x C positions.  Inside the kernel `p` is then the workgroup's own running index and PH(p) the position.
+template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED, bool CHUNK = false>
 __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
@@ -72,8 +75,27 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, npos = T.npos_all;
-    const int p_begin = T.pos0 + (int)((long long)blockIdx.x * T.npos / G), p_end = T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
+    int p_begin = T.pos0 + (int)((long long)blockIdx.x * T.npos / G), p_end = T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
+    const int CH = CHUNK ? max(T.chunk, 1) : 1;
+    if constexpr (CHUNK) {
+        const int nch = (T.npos + CH - 1) / CH, b = (int)blockIdx.x;
+        const int mine = b < nch ? (nch - b + G - 1) / G : 0;                       // chunks b, b + G, ...
+        int nk = mine * CH;
+        if (mine > 0 && (b + (mine - 1) * G) == nch - 1) nk -= nch * CH - T.npos;   // the last chunk of the launch may be short
+        p_begin = 0;
+        p_end = nk;
+    }
     if (p_begin >= p_end) return;
+    // position behind the running index (clamped to this workgroup's last one: prefetches past the end stay harmless)
+    auto PH = [&](int v) {
+        if constexpr (CHUNK) {
+            v = min(v, p_end - 1);
+            const int c = v / CH;
+            return T.pos0 + (c * G + (int)blockIdx.x) * CH + (v - c * CH);
+        } else {
+            return min(v, npos - 1);
+        }
+    };
     for (int i = tid; i < 65 * GW; i += (320 + 64 * NSTORE)) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
     for (int i = tid; i < 2 * accp; i += (320 + 64 * NSTORE)) OUT[i] = 0.0;
     const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
@@ -208,7 +230,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         // 32 p + s --, 512 only the first of the three record rounds)
         auto load_elem = [&](int p, int r) {
             if (DBG && (ablate & 256)) return (int)(((unsigned)p * 32u + (unsigned)slot_of(r)) & 0x7fffffu);
-            return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))];
+            return T.elem[(size_t)((unsigned)PH(p) * (unsigned)T.us + (unsigned)slot_of(r))];
         };
         // ablate 128 (profiling): every record from the first 4096 (cache-resident): the same instruction stream without the HBM reads
         auto load_piece = [&](int e, int r) {
@@ -226,7 +248,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             return o;
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
-        int4 hq0 = T.hdr[p_begin], hq1 = T.hdr[min(p_begin + 1, npos - 1)];
+        int4 hq0 = T.hdr[PH(p_begin)], hq1 = T.hdr[PH(p_begin + 1)];
         int slot_cur = 0;                                              // table slot of position p + 1 while p is current
         int id_prev = hq0.z >> 8;
         {
@@ -252,7 +274,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
-            h_nxt[k] = T.hdr[min(p_begin + k + 2, npos - 1)];
+            h_nxt[k] = T.hdr[PH(p_begin + k + 2)];
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const int e1 = load_elem(p_begin + k + 1, r);
@@ -297,7 +319,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }          \
             slot_cur = slot2;                                                                                                 \
             id_prev = id2;                                                                                                    \
-            h_nxt[k] = T.hdr[min((p) + 2 + DEPTH, npos - 1)];                                                                 \
+            h_nxt[k] = T.hdr[PH((p) + 2 + DEPTH)];                                                                            \
             tr_barrier();                                                                                                     \
             par ^= 1;                                                                                                         \
         }
@@ -769,6 +791,8 @@ hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t ld
                                    : affine_rows_pick_variant<FH_LINEAR_ELASTIC, true>(depth, nstore, ow, dbg))
                : (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, false>(depth, nstore, ow, dbg)
                                    : affine_rows_pick_variant<FH_LINEAR_ELASTIC, false>(depth, nstore, ow, dbg));
+    if (T.chunk > 0 && ow && !dbg && depth >= 2 && nstore < 2 && !masked)   // (experiment: positions dealt in chunks, see the kernel)
+        kern = op == FH_LAPLACE ? k_affine_rows<FH_LAPLACE, true, false, 2, 1, false, true> : k_affine_rows<FH_LINEAR_ELASTIC, true, false, 2, 1, false, true>;
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;

@@ -19,6 +19,7 @@ struct AffineRowTables {
     int us, npos, acc_max;  // slots per position, positions of this launch, largest S * S * nrow
     int pos0, npos_all;     // first position of this launch (launches may cover a part of the sweep), positions in the tables
     int incomplete;         // some position has a (node, column) block without an owner lane (element masks): staged rows are cleared behind the store
+    int chunk;              // > 0 (experiment): positions dealt to the workgroups in chunks of this many instead of one contiguous range each
 };
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;

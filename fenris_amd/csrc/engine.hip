@@ -1516,7 +1516,8 @@ int launch_affine(fh_ctx* c, KArgs& a) {
                      (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
-                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete};
+                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete,
+                          c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0)};
 #ifdef FENRIS_HIP_WITH_RING
         if (use_ring) {
             const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));

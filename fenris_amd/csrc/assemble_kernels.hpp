@@ -1791,8 +1791,9 @@ __global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsign
     for (unsigned t = adj_off[i]; t < adj_off[i + 1]; ++t) entry_node[t] = i;
 }
 
-// PLANAR: the dense matrices are stored as S x S planes ke[e][r][c][I][J] (what the MFMA kernel writes) instead of one
-// column-major (S n) x (S n) matrix; a lane then walks (c, J) with J fastest so that its reads stay contiguous.
+// PLANAR: the dense matrices are stored node-major as ke[e][I][r][c][J] (what the MFMA kernel writes) instead of one
+// column-major (S n) x (S n) matrix; the S x S x n values of an (element, local node) entry are one contiguous run and a lane walks
+// (c, J) with J fastest.
 // k_rows_from_dense for small column-major element matrices (S n <= P <= 32, P a power of two): a row of K_e fills less
 // than half a wavefront, so 64 / P entries of the node share one load instruction (lane / P picks the entry) and all
 // EB groups of a node are in flight together -- Hex8: the 8 entries of a node in one round (the one-entry-per-load
@@ -1870,7 +1871,7 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                     const unsigned tk = min(t + (unsigned)k, t1 - 1);
                     const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
                     const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                    const double* kb = PLANAR ? ke + (size_t)e * ld * ld + (size_t)a * n : ke + (size_t)e * ld * ld + (size_t)S * a * ld;
+                    const double* kb = PLANAR ? ke + (size_t)e * ld * ld + (size_t)a * (S * S * n) : ke + (size_t)e * ld * ld + (size_t)S * a * ld;
                     const PT* pp = pos_tab + (size_t)tk * n;
 #pragma unroll
                     for (int h = 0; h < HB; ++h) {
@@ -1878,7 +1879,7 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                         pos[k][h] = (int)pp[PLANAR ? idx % n : idx / S];
 #pragma unroll
                         for (int r = 0; r < S; ++r)
-                            v[k][h][r] = PLANAR ? kb[(size_t)(r * S + idx / n) * n * n + idx % n] : kb[(size_t)r * ld + idx];
+                            v[k][h][r] = PLANAR ? kb[(size_t)r * (S * n) + idx] : kb[(size_t)r * ld + idx];   // planar: ke[e][a][r][c][J], idx = c n + J
                     }
                 }
 #pragma unroll

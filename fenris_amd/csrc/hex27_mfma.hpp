@@ -12,8 +12,9 @@
 // element: a cooperative prologue leaves G_k, A_k (rows padded to 32, points to 28, zeros) and the coefficients in
 // LDS; wavefront w owns the 16 x 16 tile (w >> 1, w & 1) of the six K_ij with i <= j and of the trace term (84 MFMAs; the
 // components below the diagonal are transposed copies, see the loop); the fragments are stored straight to the PLANAR
-// dense layout ke[e][i][j][I][J] (J fastest: 16 lanes = 128 contiguous bytes) that k_rows_from_dense reads in its second
-// pass.  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
+// dense layout ke[e][I][i][j][J] (J fastest: 16 lanes = 128 contiguous bytes; node-major since round 4: the 9 x 27 doubles that the
+// second pass, k_rows_from_dense, reads for one (element, local node) entry are ONE run of 1944 bytes instead of nine runs of 216
+// that each straddle two or three cache lines).  fp64 MFMA peaks at the vector fp64 rate on CDNA4, so
 // the gain is not flops but operand traffic: 2 LDS doubles per lane feed 1024 FMAs (0.002 reads per FMA per lane
 // against 0.5 in the VALU pair loop).  Measured (C4, 200 k elements): VALU element kernel 9.85 ms, this kernel 6.0 ms, of
 // which the 588 MFMAs per element take 2.9 ms (the fp64 MFMA floor is 3.06 ms) and do not overlap with the prologue
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int I = 16 * tI + (lane >> 4) + 4 * reg;
-                    if (I < N && J < N) ke[(size_t)(i * 3 + j) * (N * N) + I * N + J] = v[reg];
+                    if (I < N && J < N) ke[(size_t)I * (9 * N) + (i * 3 + j) * N + J] = v[reg];
                 }
             }
         mark(7);
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int I = 16 * tI + (lane >> 4) + 4 * reg;
-                        if (I < N && J < N) ke[(size_t)(j * 3 + i) * (N * N) + J * N + I] = acc[i][j][reg];
+                        if (I < N && J < N) ke[(size_t)J * (9 * N) + (j * 3 + i) * N + I] = acc[i][j][reg];
                     }
         }
         lds_barrier();  // the next element's prologue overwrites G / A

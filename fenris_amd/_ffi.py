@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfenris_hip.so")
+# FENRIS_HIP_LIB: another build of the library (side-by-side timing of two builds on one box); default: the in-tree build
+LIB_PATH = os.environ.get("FENRIS_HIP_LIB") or os.path.join(_HERE, "lib", "libfenris_hip.so")
 
 FH_OK, FH_SINGULAR_JACOBIAN, FH_BAD_ARGUMENT, FH_HIP_ERROR, FH_INVALID_STATE, FH_UNSUPPORTED = 0, 1, 2, 3, 5, 6
 QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9

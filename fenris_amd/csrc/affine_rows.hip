@@ -75,26 +75,24 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, npos = T.npos_all;
-    int p_begin = T.pos0 + (int)((long long)blockIdx.x * T.npos / G), p_end = T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
-    const int CH = CHUNK ? max(T.chunk, 1) : 1;
-    if constexpr (CHUNK) {
-        const int nch = (T.npos + CH - 1) / CH, b = (int)blockIdx.x;
+    // (the non-CHUNK instantiation keeps the exact expressions it had: the production kernel is sensitive to its instruction layout)
+    auto chunk_count = [&]() {   // positions of this workgroup under the chunked dealing
+        const int CHc = max(T.chunk, 1);
+        const int nch = (T.npos + CHc - 1) / CHc, b = (int)blockIdx.x;
         const int mine = b < nch ? (nch - b + G - 1) / G : 0;                       // chunks b, b + G, ...
-        int nk = mine * CH;
-        if (mine > 0 && (b + (mine - 1) * G) == nch - 1) nk -= nch * CH - T.npos;   // the last chunk of the launch may be short
-        p_begin = 0;
-        p_end = nk;
-    }
+        int nk = mine * CHc;
+        if (mine > 0 && (b + (mine - 1) * G) == nch - 1) nk -= nch * CHc - T.npos;  // the last chunk of the launch may be short
+        return nk;
+    };
+    const int p_begin = CHUNK ? 0 : T.pos0 + (int)((long long)blockIdx.x * T.npos / G);
+    const int p_end = CHUNK ? chunk_count() : T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
     if (p_begin >= p_end) return;
-    // position behind the running index (clamped to this workgroup's last one: prefetches past the end stay harmless)
-    auto PH = [&](int v) {
-        if constexpr (CHUNK) {
-            v = min(v, p_end - 1);
-            const int c = v / CH;
-            return T.pos0 + (c * G + (int)blockIdx.x) * CH + (v - c * CH);
-        } else {
-            return min(v, npos - 1);
-        }
+    // CHUNK: position behind the running index (clamped to this workgroup's last one: prefetches past the end stay harmless)
+    auto PHC = [&](int v) {
+        const int CHc = max(T.chunk, 1);
+        v = min(v, p_end - 1);
+        const int c = v / CHc;
+        return T.pos0 + (c * G + (int)blockIdx.x) * CHc + (v - c * CHc);
     };
     for (int i = tid; i < 65 * GW; i += (320 + 64 * NSTORE)) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
     for (int i = tid; i < 2 * accp; i += (320 + 64 * NSTORE)) OUT[i] = 0.0;
@@ -230,7 +228,8 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         // 32 p + s --, 512 only the first of the three record rounds)
         auto load_elem = [&](int p, int r) {
             if (DBG && (ablate & 256)) return (int)(((unsigned)p * 32u + (unsigned)slot_of(r)) & 0x7fffffu);
-            return T.elem[(size_t)((unsigned)PH(p) * (unsigned)T.us + (unsigned)slot_of(r))];
+            if constexpr (CHUNK) return T.elem[(size_t)((unsigned)PHC(p) * (unsigned)T.us + (unsigned)slot_of(r))];
+            else return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))];
         };
         // ablate 128 (profiling): every record from the first 4096 (cache-resident): the same instruction stream without the HBM reads
         auto load_piece = [&](int e, int r) {
@@ -248,7 +247,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             return o;
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
-        int4 hq0 = T.hdr[PH(p_begin)], hq1 = T.hdr[PH(p_begin + 1)];
+        int4 hq0 = CHUNK ? T.hdr[PHC(p_begin)] : T.hdr[p_begin], hq1 = CHUNK ? T.hdr[PHC(p_begin + 1)] : T.hdr[min(p_begin + 1, npos - 1)];
         int slot_cur = 0;                                              // table slot of position p + 1 while p is current
         int id_prev = hq0.z >> 8;
         {
@@ -274,7 +273,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
         for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
-            h_nxt[k] = T.hdr[PH(p_begin + k + 2)];
+            h_nxt[k] = CHUNK ? T.hdr[PHC(p_begin + k + 2)] : T.hdr[min(p_begin + k + 2, npos - 1)];
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const int e1 = load_elem(p_begin + k + 1, r);
@@ -319,7 +318,7 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
             if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }          \
             slot_cur = slot2;                                                                                                 \
             id_prev = id2;                                                                                                    \
-            h_nxt[k] = T.hdr[PH((p) + 2 + DEPTH)];                                                                            \
+            h_nxt[k] = CHUNK ? T.hdr[PHC((p) + 2 + DEPTH)] : T.hdr[min((p) + 2 + DEPTH, npos - 1)];                             \
             tr_barrier();                                                                                                     \
             par ^= 1;                                                                                                         \
         }

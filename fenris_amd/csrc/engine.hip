@@ -1210,7 +1210,7 @@ int build_partition(fh_ctx* c) {
             c->p_rw = pipe_record_words(us, ms, n, nb_target);
             // position-indexed tables of one class
             auto build_set = [&](const std::vector<int>& ord, const std::vector<int>& choff, DevBuf<int>& rec, DevBuf<int>& conn,
-                                 DevBuf<int>& elem) -> int {
+                                 DevBuf<int>& elem, int by_parity) -> int {
                 const int npos = (int)ord.size(), nchains = (int)choff.size() - 1;
                 DevBuf<int> order_d, chain_d;
                 HIP_TRY(c, order_d.alloc(ord.size()));
@@ -1223,7 +1223,7 @@ int build_partition(fh_ctx* c) {
 #define PT_LAUNCH(NGV)                                                                                                           \
     hipLaunchKernelGGL(k_build_pipe_tables<NGV>, dim3(nchains), dim3(64), 0, c->stream, order_d.p, chain_d.p, c->gt_hdr.p,        \
                        c->gt_elems.p, c->gt_ent.p, c->gt_pos.p, noff_d, c->conn.p, n, c->p_cs, ms, nb_target, us, c->p_rw,     \
-                       rec.p, conn.p, elem.p)
+                       rec.p, conn.p, elem.p, by_parity)
                 switch (c->ei.ng) {
                     case 3: PT_LAUNCH(3); break;
                     case 4: PT_LAUNCH(4); break;
@@ -1243,7 +1243,7 @@ int build_partition(fh_ctx* c) {
                 chain_off[1].resize(order[1].size() + 1);
                 for (size_t k = 0; k <= order[1].size(); ++k) chain_off[1][k] = (int)k;
                 DevBuf<int> tmp_rec;  // the pipelined kernel's records: input of the lane builder only
-                int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem);
+                int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem, 0);
                 if (rs) return rs;
                 const int npos = (int)order[1].size();
                 c->a_us = us;
@@ -1274,7 +1274,7 @@ int build_partition(fh_ctx* c) {
             }
             c->npos_gen = (int)order[0].size();
             if (!order[0].empty()) {
-                int rs = build_set(order[0], chain_off[0], c->p_rec, c->p_conn, c->p_elem);
+                int rs = build_set(order[0], chain_off[0], c->p_rec, c->p_conn, c->p_elem, hrows_cand ? 1 : 0);
                 if (rs) return rs;
             }
             c->has_pipe = true;

@@ -499,9 +499,9 @@ inline int hw_group(int lane) {   // 0..15 over 256 lanes
     const bool first = (l < 4) || (l >= 12 && l < 16) || (l >= 20 && l < 28);
     return w * 4 + hi * 2 + (first ? 0 : 1);
 }
-// cost of one lane group: sum over (half of the record, operand) of the largest number of distinct vectors sharing a bank group.  A bank
-// group fixes the local node and the parity of the slot, so the vectors in it differ by slot >> 1: a 16-bit set (bit 16: the zero vector,
-// which sits in bank group 0).
+// cost of one lane group: sum over (half of the record, operand) of the largest number of distinct vectors sharing a bank group.  Operand
+// vector (slot, node) lies in bank group (13 node + 8 (slot & 1)) mod 16 -- a bank group fixes the local node and the parity of the slot, so
+// the vectors in it differ by slot >> 1: a 16-bit set (bit 16: the zero vector, which sits in bank group 0).
 inline int group_cost(const TuneLane* L, const int* lanes16) {
     int total = 0;
     for (int t = 0; t < 2; ++t) {
@@ -520,6 +520,24 @@ inline int group_cost(const TuneLane* L, const int* lanes16) {
     }
     return total;
 }
+// cost of the staging writes of sixteen CONTIGUOUS lanes (ds_write_b64 is served in four groups of sixteen contiguous lanes, banks of
+// (address / 4) mod 32, i.e. the offset in doubles mod 16): the largest number of distinct offsets of storing lanes that share a bank.  The
+// nine stores of a block (three rows of three doubles) shift every lane by the same amount, so one pattern stands for all nine.
+inline int write_cost(const TuneLane* L, int first) {
+    int offs[16], n = 0;
+    for (int k = 0; k < 16; ++k) {
+        const TuneLane& q = L[first + k];
+        if (!((q.x >> 28) & 1u)) continue;
+        offs[n++] = (int)(q.y & 0x1fffu);
+    }
+    int cnt[16] = {0}, mx = 0;
+    for (int i = 0; i < n; ++i) {
+        bool dup = false;
+        for (int j = 0; j < i; ++j) dup |= offs[j] == offs[i];
+        if (!dup) mx = std::max(mx, ++cnt[offs[i] & 15]);
+    }
+    return mx;
+}
 }  // namespace
 
 void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after) {
@@ -532,9 +550,10 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
     std::vector<TuneLane> best(256);
     for (int tb = 0; tb < ntab; ++tb) {
         TuneLane* L = reinterpret_cast<TuneLane*>(tables) + (size_t)tb * 256;
-        int gcost[16], total = 0;
-        for (int g = 0; g < 16; ++g) { gcost[g] = group_cost(L, members[g]); total += gcost[g]; }
-        before += total;
+        // total = 4 x (reads: twelve 16-byte pieces per unit) + 3 x (writes: nine 8-byte stores per unit)
+        int gcost[16], wcost[16], total = 0, reads = 0;
+        for (int g = 0; g < 16; ++g) { gcost[g] = group_cost(L, members[g]); wcost[g] = write_cost(L, 16 * g); reads += gcost[g]; total += 4 * gcost[g] + 3 * wcost[g]; }
+        before += reads;
         int best_total = total;
         std::copy(L, L + 256, best.begin());
         // the lanes in use fill whole wavefronts from the front (a wavefront without a lane skips phase C): moves stay below `limit`
@@ -546,8 +565,8 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
         auto unit_at = [&](int lane) { const unsigned g = (L[lane].x >> 24) & 3u; return g >= 2 ? 4 : g == 1 ? 2 : 1; };
         // simulated annealing over (a) swaps of two aligned blocks of 4 / 2 / 1 lanes that consist of whole units, (b) swaps of the two
         // halves of one lane's record
-        for (int it = 0; it < budget && best_total > 64; ++it) {   // 64 = every one of the 16 x 4 reads conflict-free
-            const double temp = 1.2 * (1.0 - (double)it / budget) + 0.02;
+        for (int it = 0; it < budget; ++it) {
+            const double temp = 4.0 * (1.0 - (double)it / budget) + 0.05;
             const unsigned r = rnd();
             const int kind = (int)(r & 3u);
             int sz = 0, a = 0, b = 0;
@@ -584,20 +603,28 @@ void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles
             };
             if (kind == 0) touch(a);
             else for (int k = 0; k < sz; ++k) { touch(a + k); touch(b + k); }
-            int d = 0, old[8];
-            for (int i = 0; i < nt; ++i) { old[i] = gcost[touched[i]]; const int c = group_cost(L, members[touched[i]]); d += c - old[i]; gcost[touched[i]] = c; }
+            int d = 0, old[8], wt[8], nw = 0, oldw[8];
+            auto touchw = [&](int lane) {
+                const int g = lane >> 4;
+                for (int i = 0; i < nw; ++i) if (wt[i] == g) return;
+                wt[nw++] = g;
+            };
+            if (kind != 0) for (int k = 0; k < sz; ++k) { touchw(a + k); touchw(b + k); }
+            for (int i = 0; i < nt; ++i) { old[i] = gcost[touched[i]]; const int c = group_cost(L, members[touched[i]]); d += 4 * (c - old[i]); gcost[touched[i]] = c; }
+            for (int i = 0; i < nw; ++i) { oldw[i] = wcost[wt[i]]; const int c = write_cost(L, 16 * wt[i]); d += 3 * (c - oldw[i]); wcost[wt[i]] = c; }
             const bool accept = d <= 0 || (double)(rnd() & 0xffffu) / 65536.0 < std::exp(-(double)d / temp);
             if (!accept) {
                 if (kind == 0) L[a].x = saved_x;
                 else for (int k = 0; k < sz; ++k) std::swap(L[a + k], L[b + k]);
                 for (int i = 0; i < nt; ++i) gcost[touched[i]] = old[i];
+                for (int i = 0; i < nw; ++i) wcost[wt[i]] = oldw[i];
             } else {
                 total += d;
                 if (total < best_total) { best_total = total; std::copy(L, L + 256, best.begin()); }
             }
         }
         std::copy(best.begin(), best.end(), L);
-        after += best_total;
+        { int r2 = 0; for (int g = 0; g < 16; ++g) r2 += group_cost(L, members[g]); after += r2; }
     }
     if (cycles_before) *cycles_before = ntab ? before / ntab : 0.0;
     if (cycles_after) *cycles_after = ntab ? after / ntab : 0.0;

@@ -671,8 +671,22 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         if (zb) {   // no term: slot 0 with the block of zeros twice, the store flag, the block's place in the staged rows
             const int rb = noff_old[il], cnt_row = noff_old[il + 1] - rb;
             const int Lidx = base0 + r0 + __popcll(m0 & below);
-            lw0[Lidx] = (AR_ZERO_G << 5) | (AR_ZERO_G << 17) | (1u << 28);
-            lw1[Lidx] = mirror ? ((unsigned)(S * S * rb + S * (int)pos) | (il << 13)) : ((unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16));
+            unsigned xz = (AR_ZERO_G << 5) | (AR_ZERO_G << 17) | (1u << 28);
+            unsigned yz = (unsigned)(8 * (S * S * rb + S * (int)pos)) | ((unsigned)(8 * S * cnt_row) << 16);
+            if (mirror) {   // hex8 record (see below); the twin of a block without a term is a block of zeros as well
+                yz = (unsigned)(S * S * rb + S * (int)pos) | (il << 13);
+                const int jl = twin_of(key);
+                if (jl >= 0) {
+                    const int rbJ = noff_old[jl], cntJ = noff_old[jl + 1] - rbJ;
+                    const unsigned Iz = (unsigned)h.i0 + il;
+                    int posJ = 0;
+                    while (posJ < cntJ && ncols[(size_t)h.r0 + rbJ + posJ] != Iz) ++posJ;
+                    yz |= ((unsigned)(S * S * rbJ + S * posJ) << 16) | ((unsigned)jl << 29);
+                    xz |= 1u << 29;
+                }
+            }
+            lw0[Lidx] = xz;
+            lw1[Lidx] = yz;
         }
         r0 += __popcll(m0);
         if (Tn >= 1) {

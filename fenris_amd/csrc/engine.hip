@@ -986,7 +986,7 @@ int build_partition(fh_ctx* c) {
                           (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
     const bool rows_special = perm_cand;   // tables for the row-owner Tet4 kernel alone: larger blocks (below)
     // Hex8 Laplace / LinearElastic without a mask: the general positions run on k_hex8_rows (36 row lanes per node as well)
-    const bool hrows_cand = c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->has_mask && !c->has_rules &&
+    const bool hrows_cand = c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->has_rules &&
                             !c->env("FENRIS_HIP_NO_HEX8_ROWS");
     const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", rows_special ? (c->rows_try == 0 ? 9 : 7)
                                                                                                      : (S == 1 && !aff_cand && !hrows_cand) ? 8 : 7)));  // < 256: packed in 8 bits
@@ -1287,11 +1287,12 @@ int build_partition(fh_ctx* c) {
             c->has_rows = false;
             const int npg = c->npos_gen;
             // Hex8, Laplace / uniform LinearElastic: lane tables for the general positions as well (k_hex8_rows, hex8_rows.hip: row-owner
-            // lanes instead of LDS atomics; the eight-point rule, no element mask -- checked at the launch).  The pipelined kernel's tables
-            // stay: they serve every other rule, per-element parameters and masks.
+            // lanes instead of LDS atomics; the eight-point rule -- checked at the launch).  Under an element mask a block without an active
+            // element gets a lane that stores zeros; when the lanes do not suffice for that somewhere, the pipelined kernel stays.  Its
+            // tables are kept: they serve every other rule and per-element parameters.
             c->has_hrows = false;
             if (c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && us <= HEX8_ROWS_US && nb_target <= 8 && npg > 0 &&
-                !c->has_mask && !c->has_rules && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
+                !c->has_rules && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
                 bool bad = false;
                 int rs = build_lane_tables(c, c->p_rec.p, us, ms, nb_target, npg, S, c->p_conn.p, c->p_elem.p, c->h_hdr, c->h_lanes, c->h_ntab,
                                            c->h_incomplete, bad, "hex8 rows", 1);
@@ -1775,7 +1776,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
         }
-        if (c->has_pipe && c->has_hrows && a.fast && !pipe_rules && !c->has_mask && c->nq == 8 && c->elem_kind == FH_HEX8 &&
+        if (c->has_pipe && c->has_hrows && a.fast && !pipe_rules && c->nq == 8 && c->elem_kind == FH_HEX8 &&
             (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
             const size_t lds_h = hex8_rows_lds_bytes(c->g_acc);
             if (lds_h <= LDS_LIMIT) {

@@ -138,8 +138,9 @@ def test_singular_element_is_reported_with_its_index():
         eng.close()
 
 
-def test_other_rules_masks_and_per_element_parameters_keep_the_pipelined_kernel():
-    """the row-owner kernel is laid out for the eight-point rule, uniform parameters and no element mask: everything else stays where it was"""
+def test_other_rules_keep_the_pipelined_kernel_and_masks_run_here():
+    """the row-owner kernel is laid out for the eight-point rule and uniform parameters: other rules stay where they were; an element mask
+    (every multi-GPU partition) runs here -- blocks without an active element get lanes that store zeros"""
     mesh = _box(6, 5, 4)
     eng = fa.Engine(0)
     try:
@@ -152,8 +153,14 @@ def test_other_rules_masks_and_per_element_parameters_keep_the_pipelined_kernel(
         mask = np.ones(mesh.num_elements(), dtype=np.uint8)
         mask[::3] = 0
         eng.set_active_elements(mask)
-        fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-        assert eng.last_kernel_name() == "k_gather_pipelined"
+        import torch
+        nnz = eng.build_pattern()
+        got = torch.full((nnz,), 9.75, dtype=torch.float64, device="cuda")
+        eng.assemble_matrix(got, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        assert eng.last_kernel_name() == "k_hex8_rows"
+        want = torch.zeros_like(got)
+        eng.assemble_matrix(want, fa.SCATTER_ATOMIC)
+        assert (got - want).abs().max().item() <= TOL * want.abs().max().item()
         eng.set_active_elements(None)
         fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
         assert eng.last_kernel_name() == "k_hex8_rows"

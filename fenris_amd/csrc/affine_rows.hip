@@ -347,6 +347,70 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
     bool any_zero_lane = false;    // ... some lane of this wavefront does (scalar)
     f64x2 gq0[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, gq1[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};   // Laplace: Ghat of the lane's terms
     int par = 0;
+    if constexpr (LAP && !DBG) {
+        // Laplace: two nested loops -- the outer one runs once per lane table, the inner one over the positions that share it -- so that
+        // everything derived from the lane record (the reference blocks of the lane's two terms, the record offsets, the place of the
+        // block in the staged rows) lives in fixed registers: as ONE loop with a reload under `if (table changed)` the compiler carried
+        // thirteen register pairs through two copies per position, a quarter of this wave's ~100 instructions (round 4, C2).
+        int p = p_begin, z = 0, head = 0;
+        auto read_hdr = [&]() {
+            int zw[2];
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
+            z = __builtin_amdgcn_readfirstlane(zw[0]);
+            head = zw[1] & 15;
+            if (MASKED && !(z & 1)) {   // an incomplete position: its row lanes clear the extent first (see the general loop below)
+                const int ext = __builtin_amdgcn_readfirstlane(zw[1]) >> 4;
+                double* buf = OUT + (size_t)par * accp;
+                if (!(ablate_arg & AFFINE_ROWS_NO_CLEAR)) {
+                    const int lo = head, hi = head + ext, k0 = (lo + 1) >> 1, k1 = hi >> 1;
+                    const f64x2 z2 = {0.0, 0.0};
+                    for (int k = k0 + tid; k < k1; k += 256) reinterpret_cast<f64x2*>(buf)[k] = z2;
+                    if (tid == 0 && (lo & 1) && lo < hi) buf[lo] = 0.0;
+                    if (tid == 1 && (hi & 1) && hi - 1 >= lo) buf[hi - 1] = 0.0;
+                }
+                tr_barrier();
+            }
+        };
+        read_hdr();
+        while (p < p_end) {
+            const uint2 lc = LT[256 * ((z >> 1) & 1) + tid];
+            const unsigned x = lc.x, y = lc.y;
+            bool zl = false, anyz = false;
+            if constexpr (MASKED) {
+                zl = ((x >> 5) & 127u) == AR_ZERO_G && ((x >> 17) & 127u) == AR_ZERO_G && ((x >> 28) & 1u);
+                anyz = __builtin_amdgcn_ballot_w64(zl) != 0ull;
+            }
+            const f64x2* q0 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((x >> 5) & 127u) * (GW * 8));
+            const f64x2* q1 = reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(GH) + ((x >> 17) & 127u) * (GW * 8));
+            const f64x2 a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+            const unsigned oR0 = (x & 31u) * (GW * 8), oR1 = ((x >> 12) & 31u) * (GW * 8);
+            const int grp = (int)((x >> 24) & 3u);
+            const bool stores = ((x >> 28) & 1u) != 0u;
+            const unsigned yoff = y & 0xffffu;
+            for (;;) {
+                const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
+                const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
+                const f64x2* m1 = reinterpret_cast<const f64x2*>(js + oR1);
+                const f64x2 u0 = m0[0], u1 = m0[1], u2 = m0[2], w0 = m1[0], w1 = m1[1], w2 = m1[2];
+                double sm = a0.x * u0.x;
+                sm = fma(a0.y, u0.y, sm); sm = fma(a1.x, u1.x, sm); sm = fma(a1.y, u1.y, sm); sm = fma(a2.x, u2.x, sm); sm = fma(a2.y, u2.y, sm);
+                sm = fma(b0.x, w0.x, sm); sm = fma(b0.y, w0.y, sm); sm = fma(b1.x, w1.x, sm); sm = fma(b1.y, w1.y, sm); sm = fma(b2.x, w2.x, sm);
+                sm = fma(b2.y, w2.y, sm);
+                if (grp >= 1) sm += dpp_quad_full<0xB1>(sm);
+                if (grp >= 2) sm += dpp_quad_full<0x4E>(sm);
+                if constexpr (MASKED) { if (anyz && zl) sm = 0.0; }
+                if (stores) *reinterpret_cast<double*>(reinterpret_cast<char*>(OUT + (size_t)par * accp) + 8 * head + yoff) = sm;
+                tr_barrier();
+                ++p;
+                par ^= 1;
+                if (p >= p_end) break;
+                read_hdr();
+                if (z & 4) break;   // the lane table changes with this position
+            }
+        }
+        if (wave == 0) tr_report(0);
+        return;
+    }
     for (int p = p_begin; p < p_end; ++p, par ^= 1) {
         int zw[2];
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");

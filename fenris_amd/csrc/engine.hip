@@ -1652,7 +1652,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // entry_node is released on scope exit
         c->has_tp_pos = true;
     }
-    const int grid = std::max(1, (int)std::min<uint64_t>((c->N + 3) / 4, (uint64_t)c->env_int("FENRIS_HIP_TWO_PASS_GRID", 1 << 20)));
+    const int grid = std::max(1, (int)std::min<uint64_t>((c->N + 3) / 4, (uint64_t)c->env_int("FENRIS_HIP_TWO_PASS_ROWS_GRID", c->env_int("FENRIS_HIP_TWO_PASS_GRID", 1 << 17))));   // (C4: 2^17 workgroups 8.33 ms, one per four nodes (410 k) 8.42, 2^13 8.45, 2^11 8.68)
     c->last_kernel = mfma ? "k_hex27_dense_mfma + k_rows_from_dense" : "k_assemble_matrix<dump> + k_rows_from_dense";
 #define ROWS(SS, PT, PTR)                                                                                                     \
     do {                                                                                                                       \

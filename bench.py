@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: numeric assembly of the global stiffness matrix K into a pre-built CSR pattern.
 
-    python bench.py --gpus N --steps K --warmup W [--config ns|ns-perturbed|c2|c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--config ns|ns-perturbed|c2|c3|c4|c5]     (N > 1: ns, c5 as z-slabs; c3, ns-perturbed as element partitions)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
     (``python bench.py --gpus N`` with N > 1 and no launcher around it starts that launcher itself -- one rank per GPU as a child
     process group, before this process touches a GPU -- relays rank 0's line and fails loudly when it cannot.)
@@ -424,7 +424,7 @@ def main():
     if args.operator == "poisson" and cfg == "ns":  # old spelling of the Poisson run
         cfg = "c2"
         args.cells = args.cells or 216
-    if args.gpus > 1 and cfg not in ("ns", "c5"):
+    if args.gpus > 1 and cfg not in ("ns", "c5", "c3", "ns-perturbed"):
         raise SystemExit(f"--config {cfg} is a single-GPU configuration")
     if args.gpus > 1 and not launched:
         self_launch(args)  # does not return
@@ -510,6 +510,23 @@ def main():
         nnz = eng.build_pattern()  # assemble_pattern on the device (secondary metric)
         E = mesh.num_elements()
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    elif cfg in ("c3", "ns-perturbed"):
+        # a mesh without planes: element partition elem_to_part[] (Morton order of the centroids), packed interface-row exchange with any
+        # number of neighbours (fenris_amd/partition.py); the fixed mesh cut into `world` parts: strong scaling
+        from fenris_amd import partition as fp
+
+        mesh_g = c["mesh"]()
+        if cfg == "ns-perturbed":
+            desc += ", every vertex moved by up to +-0.1 h per coordinate (MT19937 seed 2024): no affine element"
+        part_of = fp.morton_partition(mesh_g, world)
+        t0 = time.perf_counter()
+        prob = fp.make_part(mesh_g, part_of, rank, world, args.partition)
+        slab_asm = fp.PartAssembly(prob, configure, device=local_rank, stream=stream)
+        mesh, eng, values, nnz = prob.mesh, slab_asm.main, slab_asm.values, slab_asm.values.numel()
+        E = prob.num_own_elements()
+        scaling = "strong"
+        part_counts = np.bincount(part_of, minlength=world).tolist()
+        del mesh_g
     else:
         from fenris_amd import distributed as fd
 
@@ -605,7 +622,32 @@ def main():
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
                        "pattern_build_s": t_pattern, "module_warmup_s": t_warm, "placement_probe": placement, "device_settle": settle},
         }
-        if world > 1:
+        if world > 1 and layers is None:
+            # general partition: who holds what, what rank 0 exchanges, and the same check as for the slabs -- the rows of rank 0's owned
+            # nodes that other parts contribute to are complete only after the exchange, and a stiffness row sums to zero
+            ex = slab_asm.exchange
+            out["config"]["partition"] = (f"{world} parts: Morton order of the element centroids cut into equal runs, node owner = lowest part, "
+                                          + ("interface rows exchanged through packed index lists" if args.partition == "exchange"
+                                             else "halo elements recomputed, no communication"))
+            out["config"]["elements_per_rank"] = part_counts
+            out["config"]["exchange"] = "torch.distributed point-to-point (batch_isend_irecv)"
+            out["config"]["neighbours_of_rank0"] = sorted(set(ex.send_idx) | set(ex.recv_idx))
+            out["config"]["interface_bytes_per_step"] = ex.bytes_sent()
+            try:
+                ro_h, _ = eng.pattern(want_cols=False)
+                nodes = np.unique(np.concatenate([np.asarray(v) for v in slab_asm.prob.recv.values()])) if slab_asm.prob.recv else np.zeros(0, dtype=np.int64)
+                if len(nodes):
+                    rows = (s * nodes[:, None] + np.arange(s)[None, :]).reshape(-1)
+                    a0 = torch.as_tensor(np.asarray(ro_h)[rows].astype(np.int64), device=values.device)
+                    a1 = torch.as_tensor(np.asarray(ro_h)[rows + 1].astype(np.int64), device=values.device)
+                    cs = torch.cat([torch.zeros(1, dtype=values.dtype, device=values.device), torch.cumsum(values, 0)])
+                    rowsum = (cs[a1] - cs[a0]).abs().max().item()
+                    out["config"]["interface_row_sum_over_max"] = rowsum / max(values.abs().max().item(), 1e-300)
+            except Exception as exc:  # never take the line down
+                out["config"]["interface_row_sum_over_max"] = repr(exc)
+            out["rccl"] = rccl if rccl is not None else {"backend": "gloo (FENRIS_BENCH_SHARE_DEVICE validation mode)", "rccl_ranks": 0}
+            out["rccl_ranks"] = out["rccl"]["rccl_ranks"]
+        elif world > 1:
             out["config"]["element_layers_per_rank"] = [l1 - l0 for l0, l1 in layers]
             out["config"]["exchange"] = "torch.distributed point-to-point" if (share or args.exchange == "torch") else "fh_group_* (RCCL behind the C ABI)"
             ex = slab_asm.exchange

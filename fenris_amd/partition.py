@@ -230,6 +230,8 @@ class PartAssembly:
         nnz = self.main.build_pattern()
         self.values = torch.zeros(nnz, dtype=torch.float64, device=f"cuda:{device}")
         self.exchange = PartExchange(prob, group).bind(self.main, self.values)
+        self.placement = None     # (same attributes as distributed.SlabAssembly for callers that drive either)
+        self.comm = None
 
     def enqueue(self, flags):
         self.main.assemble_matrix_async(self.values, flags)

@@ -104,14 +104,17 @@ def test_rank_1_of_8_at_full_size(oracle, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,extra", [("ns", []), ("c5", []), ("ns", ["--exchange", "torch", "--no-overlap"]), ("ns", ["--partition", "halo"])])
+@pytest.mark.parametrize("cfg,extra", [("ns", []), ("c5", []), ("ns", ["--exchange", "torch", "--no-overlap"]), ("ns", ["--partition", "halo"]),
+                                       ("c3", []), ("ns-perturbed", []), ("c3", ["--partition", "halo"])])
 def test_bench_two_ranks_sharing_the_device(cfg, extra):
-    """the N > 1 path of bench.py end to end (self-launch through torch.distributed.run, slabs, masks, both launches, the exchange, the
-    max-over-ranks timing, rank 0's line) on the one GPU of the test box: validation mode, gloo instead of RCCL"""
+    """the N > 1 path of bench.py end to end (self-launch through torch.distributed.run, slabs or -- c3, ns-perturbed: meshes without planes --
+    element partitions with packed interface lists, masks, the launches, the exchange, the max-over-ranks timing, rank 0's line) on the one
+    GPU of the test box: validation mode, gloo instead of RCCL"""
     env = dict(os.environ, FENRIS_BENCH_SHARE_DEVICE="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", cfg, "--cells", "24", "--steps", "2", "--warmup", "1",
+    cells = 8 if cfg in ("c3", "ns-perturbed") else 24
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", cfg, "--cells", str(cells), "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-traffic", "--placement-tries", "0", "--no-settle"] + extra
     pr = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert pr.returncode == 0, pr.stderr[-3000:]
@@ -120,9 +123,11 @@ def test_bench_two_ranks_sharing_the_device(cfg, extra):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["value"] > 0 and line["higher_is_better"] is True
-    assert line["scaling"] == ("strong" if cfg == "c5" else "weak")
-    own = 24 * 24 * 24 * (1 if cfg == "c5" else 2)
+    assert line["scaling"] == ("weak" if cfg == "ns" else "strong")
+    own = {"ns": 2 * 24 ** 3, "c5": 24 ** 3, "c3": 12 * 8 ** 3, "ns-perturbed": 8 ** 3}[cfg]
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - own) <= 1e-6 * own      # whole-job units / max-over-ranks time
+    if cfg in ("c3", "ns-perturbed"):
+        assert sum(line["config"]["elements_per_rank"]) == own
     if "halo" not in extra:
-        # rank 0's owned interface plane is complete only once rank 1's rows have arrived and been added: stiffness rows sum to zero
+        # rank 0's owned interface rows are complete only once rank 1's rows have arrived and been added: stiffness rows sum to zero
         assert float(line["config"]["interface_row_sum_over_max"]) <= 1e-12, line["config"]

@@ -521,7 +521,7 @@ def main():
         part_of = fp.morton_partition(mesh_g, world)
         t0 = time.perf_counter()
         prob = fp.make_part(mesh_g, part_of, rank, world, args.partition)
-        slab_asm = fp.PartAssembly(prob, configure, device=local_rank, stream=stream)
+        slab_asm = fp.PartAssembly(prob, configure, device=local_rank, stream=stream, exchange=("torch" if share else args.exchange))
         mesh, eng, values, nnz = prob.mesh, slab_asm.main, slab_asm.values, slab_asm.values.numel()
         E = prob.num_own_elements()
         scaling = "strong"
@@ -630,8 +630,9 @@ def main():
                                           + ("interface rows exchanged through packed index lists" if args.partition == "exchange"
                                              else "halo elements recomputed, no communication"))
             out["config"]["elements_per_rank"] = part_counts
-            out["config"]["exchange"] = "torch.distributed point-to-point (batch_isend_irecv)"
-            out["config"]["neighbours_of_rank0"] = sorted(set(ex.send_idx) | set(ex.recv_idx))
+            out["config"]["exchange"] = ("torch.distributed point-to-point (batch_isend_irecv)" if (share or args.exchange == "torch")
+                                         else "fh_group_set_exchange_nodes (pack kernel, one RCCL group of ncclSend / ncclRecv, unpack-add kernel; C ABI)")
+            out["config"]["neighbours_of_rank0"] = sorted(set(slab_asm.prob.send) | set(slab_asm.prob.recv))
             out["config"]["interface_bytes_per_step"] = ex.bytes_sent()
             try:
                 ro_h, _ = eng.pattern(want_cols=False)

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/fenris_hip.h"
 #include "group_internal.hpp"
@@ -68,6 +69,43 @@ __global__ void __launch_bounds__(256) k_add_into(double* dst, const double* src
         dst[i] += src[i];
 }
 
+// list mode (arbitrary partitions): the rows of the listed nodes, node by node, into / out of one packed buffer.  One workgroup per
+// node: first value and count from the node-level pattern (S x S values per column block of the node's S rows)
+__global__ void __launch_bounds__(128) k_pack_rows(const unsigned* nodes, const unsigned long long* dst, const unsigned* noff, int ss, const double* vals,
+                                                   double* buf) {
+    const unsigned node = nodes[blockIdx.x];
+    const unsigned long long first = (unsigned long long)ss * noff[node], count = (unsigned long long)ss * (noff[node + 1] - noff[node]);
+    double* o = buf + dst[blockIdx.x];
+    for (unsigned long long i = threadIdx.x; i < count; i += 128) o[i] = vals[first + i];
+}
+__global__ void __launch_bounds__(128) k_unpack_add_rows(const unsigned* nodes, const unsigned long long* src, const unsigned* noff, int ss,
+                                                         const double* buf, double* vals) {
+    const unsigned node = nodes[blockIdx.x];
+    const unsigned long long first = (unsigned long long)ss * noff[node], count = (unsigned long long)ss * (noff[node + 1] - noff[node]);
+    const double* in = buf + src[blockIdx.x];
+    for (unsigned long long i = threadIdx.x; i < count; i += 128) vals[first + i] += in[i];
+}
+__global__ void __launch_bounds__(256) k_row_counts(const unsigned* nodes, unsigned long long n, const unsigned* noff, int ss, unsigned long long* count) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) count[i] = (unsigned long long)ss * (noff[nodes[i] + 1] - noff[nodes[i]]);
+}
+
+struct PeerList {   // one direction of the list-mode exchange
+    std::vector<int> peers;
+    std::vector<unsigned long long> peer_first, peer_count;   // per peer: first value / values in the packed buffer
+    unsigned* nodes = nullptr;               // device: local node per entry
+    unsigned long long* offs = nullptr;      // device: first value of every entry's rows in the packed buffer
+    double* buf = nullptr;                   // device: the packed buffer
+    unsigned long long entries = 0, values = 0;
+    void release() {
+        if (nodes) (void)hipFree(nodes);
+        if (offs) (void)hipFree(offs);
+        if (buf) (void)hipFree(buf);
+        nodes = nullptr; offs = nullptr; buf = nullptr; entries = values = 0;
+        peers.clear(); peer_first.clear(); peer_count.clear();
+    }
+};
+
 }  // namespace
 
 struct fh_group {
@@ -81,6 +119,10 @@ struct fh_group {
     double* recv_buf = nullptr;
     uint64_t recv_cap = 0;
     bool in_flight = false;
+    bool list_mode = false;          // fh_group_set_exchange_nodes: packed lists, any number of peers
+    PeerList snd, rcv;
+    const unsigned* noff = nullptr;  // the context's node-level row offsets (device)
+    int ss = 0;                      // S x S
 };
 
 #define G_HIP(g, call)                                                                     \
@@ -146,6 +188,8 @@ void fh_group_destroy(fh_group* g) {
     if (g->side) (void)hipStreamSynchronize(g->side);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
     if (g->recv_buf) (void)hipFree(g->recv_buf);
+    g->snd.release();
+    g->rcv.release();
     if (g->ready) (void)hipEventDestroy(g->ready);
     if (g->done) (void)hipEventDestroy(g->done);
     if (g->side) (void)hipStreamDestroy(g->side);
@@ -158,6 +202,7 @@ int fh_group_set_exchange(fh_group* g, int send_peer, uint64_t send_first, uint6
     if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange: an exchange is in flight");
     if (send_peer >= g->world || recv_peer >= g->world || send_peer == g->rank || recv_peer == g->rank)
         return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange: bad peer");
+    g->list_mode = false;
     g->send_peer = (send_peer >= 0 && send_count) ? send_peer : -1;
     g->recv_peer = (recv_peer >= 0 && recv_count) ? recv_peer : -1;
     g->send_first = send_first; g->send_count = send_count;
@@ -173,9 +218,108 @@ int fh_group_set_exchange(fh_group* g, int send_peer, uint64_t send_first, uint6
     return FH_OK;
 }
 
+
+// one direction of the list-mode exchange: node lists per peer -> device arrays, packed-buffer offsets (the rows of a node are
+// S x S x (its column blocks) values: counted on the device from the context's pattern, summed on the host)
+static int build_peer_list(fh_group* g, PeerList& L, int npeers, const int32_t* peers, const uint64_t* offsets, const uint64_t* nodes,
+                           uint64_t num_nodes) {
+    L.release();
+    if (npeers <= 0) return FH_OK;
+    const uint64_t n = offsets[npeers];
+    std::vector<unsigned> h_nodes((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (nodes[i] >= num_nodes) return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: node index out of range");
+        h_nodes[i] = (unsigned)nodes[i];
+    }
+    for (int p = 0; p < npeers; ++p) {
+        if (peers[p] < 0 || peers[p] >= g->world || offsets[p + 1] < offsets[p])
+            return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: bad peer or offsets");
+        L.peers.push_back(peers[p]);
+    }
+    L.entries = n;
+    if (n == 0) { L.peer_first.assign((size_t)npeers, 0); L.peer_count.assign((size_t)npeers, 0); return FH_OK; }
+    G_HIP(g, hipMalloc(reinterpret_cast<void**>(&L.nodes), sizeof(unsigned) * n));
+    G_HIP(g, hipMalloc(reinterpret_cast<void**>(&L.offs), sizeof(unsigned long long) * n));
+    hipStream_t main = fh_internal_stream(g->ctx);
+    G_HIP(g, hipMemcpyAsync(L.nodes, h_nodes.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, main));
+    hipLaunchKernelGGL(k_row_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, main, L.nodes, (unsigned long long)n, g->noff, g->ss, L.offs);
+    G_HIP(g, hipGetLastError());
+    std::vector<unsigned long long> cnt((size_t)n);
+    G_HIP(g, hipMemcpyAsync(cnt.data(), L.offs, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, main));
+    G_HIP(g, hipStreamSynchronize(main));
+    unsigned long long run = 0;
+    for (int p = 0; p < npeers; ++p) {
+        L.peer_first.push_back(run);
+        for (uint64_t i = offsets[p]; i < offsets[p + 1]; ++i) { const unsigned long long c = cnt[i]; cnt[i] = run; run += c; }
+        L.peer_count.push_back(run - L.peer_first.back());
+    }
+    L.values = run;
+    G_HIP(g, hipMemcpyAsync(L.offs, cnt.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice, main));
+    G_HIP(g, hipStreamSynchronize(main));   // cnt / h_nodes are released on return
+    if (run) G_HIP(g, hipMalloc(reinterpret_cast<void**>(&L.buf), sizeof(double) * run));
+    return FH_OK;
+}
+
+int fh_group_set_exchange_nodes(fh_group* g, int num_send_peers, const int32_t* send_peers, const uint64_t* send_offsets, const uint64_t* send_nodes,
+                                int num_recv_peers, const int32_t* recv_peers, const uint64_t* recv_offsets, const uint64_t* recv_nodes) {
+    if (!g || num_send_peers < 0 || num_recv_peers < 0) return FH_BAD_ARGUMENT;
+    if ((num_send_peers && (!send_peers || !send_offsets)) || (num_recv_peers && (!recv_peers || !recv_offsets)))
+        return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: null list");
+    if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange_nodes: an exchange is in flight");
+    const unsigned* ncols = nullptr;
+    uint64_t N = 0;
+    int S = 0;
+    if (!fh_internal_pattern(g->ctx, &g->noff, &ncols, &N, &S))
+        return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange_nodes: build the pattern first (fh_pattern)");
+    g->ss = S * S;
+    DevGuardExt dev_guard_(g->device);
+    int rc = build_peer_list(g, g->snd, num_send_peers, send_peers, send_offsets, send_nodes, N);
+    if (rc) return rc;
+    rc = build_peer_list(g, g->rcv, num_recv_peers, recv_peers, recv_offsets, recv_nodes, N);
+    if (rc) return rc;
+    g->list_mode = true;
+    return FH_OK;
+}
+
+static int list_exchange_start(fh_group* g, double* values_dev) {
+    DevGuardExt dev_guard_(g->device);
+    hipStream_t main = fh_internal_stream(g->ctx);
+    G_HIP(g, hipEventRecord(g->ready, main));
+    G_HIP(g, hipStreamWaitEvent(g->side, g->ready, 0));
+    if (g->snd.entries) {
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)g->snd.entries), dim3(128), 0, g->side, g->snd.nodes, g->snd.offs, g->noff, g->ss, values_dev, g->snd.buf);
+        G_HIP(g, hipGetLastError());
+    }
+    G_NCCL(g, g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t p = 0; p < g->snd.peers.size() && r == ncclSuccess; ++p)
+        if (g->snd.peer_count[p]) r = g_rccl.Send(g->snd.buf + g->snd.peer_first[p], g->snd.peer_count[p], ncclDouble, g->snd.peers[p], g->comm, g->side);
+    for (size_t p = 0; p < g->rcv.peers.size() && r == ncclSuccess; ++p)
+        if (g->rcv.peer_count[p]) r = g_rccl.Recv(g->rcv.buf + g->rcv.peer_first[p], g->rcv.peer_count[p], ncclDouble, g->rcv.peers[p], g->comm, g->side);
+    const ncclResult_t r_end = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
+    if (r_end != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end));
+    G_HIP(g, hipEventRecord(g->done, g->side));
+    g->in_flight = true;
+    return FH_OK;
+}
+
+static int list_exchange_finish(fh_group* g, double* values_dev) {
+    g->in_flight = false;
+    DevGuardExt dev_guard_(g->device);
+    hipStream_t main = fh_internal_stream(g->ctx);
+    G_HIP(g, hipStreamWaitEvent(main, g->done, 0));
+    if (g->rcv.entries) {   // peers in ascending order, entries in list order: the same additions in the same order every run
+        hipLaunchKernelGGL(k_unpack_add_rows, dim3((unsigned)g->rcv.entries), dim3(128), 0, main, g->rcv.nodes, g->rcv.offs, g->noff, g->ss, g->rcv.buf, values_dev);
+        G_HIP(g, hipGetLastError());
+    }
+    return FH_OK;
+}
+
 int fh_group_exchange_start(fh_group* g, double* values_dev) {
     if (!g || !values_dev) return FH_BAD_ARGUMENT;
     if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_start: already started");
+    if (g->list_mode) return list_exchange_start(g, values_dev);
     if (g->send_peer < 0 && g->recv_peer < 0) { g->in_flight = true; return FH_OK; }
     DevGuardExt dev_guard_(g->device);
     hipStream_t main = fh_internal_stream(g->ctx);
@@ -200,6 +344,7 @@ int fh_group_exchange_start(fh_group* g, double* values_dev) {
 int fh_group_exchange_finish(fh_group* g, double* values_dev) {
     if (!g || !values_dev) return FH_BAD_ARGUMENT;
     if (!g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_finish: nothing started");
+    if (g->list_mode) return list_exchange_finish(g, values_dev);
     g->in_flight = false;
     if (g->send_peer < 0 && g->recv_peer < 0) return FH_OK;
     DevGuardExt dev_guard_(g->device);

@@ -214,22 +214,168 @@ class PartExchange:
         self.finish()
 
 
+def _u64p(a):
+    import ctypes as C
+
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def morton_partition_abi(mesh: Mesh, world: int) -> np.ndarray:
+    """``fh_morton_partition`` (fenris_amd/csrc/partition.cpp): what a Rust / C host calls; same result as ``morton_partition``"""
+    import ctypes as C
+
+    from . import _ffi
+
+    conn = np.ascontiguousarray(mesh.connectivity, dtype=np.uint64)
+    verts = np.ascontiguousarray(mesh.vertices, dtype=np.float64)
+    part = np.empty(len(conn), dtype=np.int32)
+    rc = _ffi.lib().fh_morton_partition(verts.shape[1], verts.ctypes.data_as(C.POINTER(C.c_double)), len(verts), conn.shape[1], _u64p(conn), len(conn),
+                                        world, part.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise ValueError(f"fh_morton_partition: status {rc}")
+    return part
+
+
+def make_part_abi(mesh: Mesh, elem_to_part, rank: int, world: int, mode: str = "exchange") -> PartProblem:
+    """``make_part`` through the C ABI (``fh_partition_*``, fenris_amd/csrc/partition.cpp) -- the host logic as a Rust caller gets it."""
+    import ctypes as C
+
+    from . import _ffi
+
+    if mode not in ("exchange", "halo"):
+        raise ValueError("mode must be 'exchange' or 'halo'")
+    lib = _ffi.lib()
+    conn = np.ascontiguousarray(mesh.connectivity, dtype=np.uint64)
+    part = np.ascontiguousarray(elem_to_part, dtype=np.int32)
+    if part.shape != (len(conn),):
+        raise ValueError("elem_to_part: one part in [0, world) per element")
+    h = lib.fh_partition_create(mesh.num_nodes(), conn.shape[1], _u64p(conn), len(conn), part.ctypes.data_as(C.POINTER(C.c_int32)), rank, world,
+                                1 if mode == "halo" else 0)
+    if not h:
+        raise ValueError("elem_to_part: one part in [0, world) per element")
+    h = C.c_void_p(h)
+    try:
+        sz = np.zeros(8, dtype=np.uint64)
+        assert lib.fh_partition_sizes(h, _u64p(sz)) == 0
+        nl, el, no, own_e, nsp, nsn, nrp, nrn = (int(x) for x in sz)
+        l2g, elem_l2g = np.empty(nl, dtype=np.uint64), np.empty(el, dtype=np.uint64)
+        lconn, active, owned = np.empty((el, conn.shape[1]), dtype=np.uint64), np.empty(el, dtype=np.uint8), np.empty(no, dtype=np.uint64)
+        assert lib.fh_partition_mesh(h, _u64p(l2g), _u64p(elem_l2g), _u64p(lconn), active.ctypes.data_as(C.POINTER(C.c_uint8)), _u64p(owned)) == 0
+        sp, so, sn = np.empty(nsp, dtype=np.int32), np.empty(nsp + 1, dtype=np.uint64), np.empty(nsn, dtype=np.uint64)
+        rp, ro, rn = np.empty(nrp, dtype=np.int32), np.empty(nrp + 1, dtype=np.uint64), np.empty(nrn, dtype=np.uint64)
+        i32 = C.POINTER(C.c_int32)
+        assert lib.fh_partition_exchange(h, sp.ctypes.data_as(i32), _u64p(so), _u64p(sn), rp.ctypes.data_as(i32), _u64p(ro), _u64p(rn)) == 0
+    finally:
+        lib.fh_partition_destroy(h)
+    l2g = l2g.astype(np.int64)
+    local = Mesh(mesh.vertices[l2g].copy(), lconn, mesh.elem_kind)
+    prob = PartProblem(local, l2g, elem_l2g.astype(np.int64), active, owned.astype(np.int64), {}, {}, rank, world, mode, own_e)
+    for k in range(nsp):
+        prob.send[int(sp[k])] = sn[int(so[k]):int(so[k + 1])].astype(np.int64)
+    for k in range(nrp):
+        prob.recv[int(rp[k])] = rn[int(ro[k]):int(ro[k + 1])].astype(np.int64)
+    return prob
+
+
+class AbiPartExchange:
+    """The interface-row exchange of a ``PartProblem`` through the C ABI: ``fh_group_set_exchange_nodes`` + ``fh_group_exchange_start`` /
+    ``_finish`` (fenris_amd/csrc/group.hip) -- pack kernel, one RCCL group of ncclSend / ncclRecv, unpack-add kernel, all on the library's
+    streams.  GPU only.  ``self_loop``: a one-rank communicator in which every peer is this rank (test mode: whatever is packed for
+    a peer comes back as that peer's contribution)."""
+
+    def __init__(self, prob: PartProblem, engine, group=None, self_loop: bool = False):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        self.prob, self.engine = prob, engine
+        lib = _ffi_lib()
+        idbuf = (C.c_uint8 * 128)()
+        rank, world = (0, 1) if self_loop else (prob.rank, prob.world)
+        if world > 1:
+            t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{engine.device}")
+            if rank == 0:
+                engine._check(lib.fh_group_unique_id(idbuf))
+                t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
+            dist.broadcast(t, 0, group=group)
+            for i, b in enumerate(t.cpu().tolist()):
+                idbuf[i] = b
+        else:
+            engine._check(lib.fh_group_unique_id(idbuf))
+        h = C.c_void_p()
+        engine._check(lib.fh_group_create(engine._h, idbuf, rank, world, C.byref(h)))
+        self._g, self._lib, self._self_loop = h, lib, self_loop
+        self.values = None
+
+    def bind(self, engine, values):
+        import ctypes as C
+
+        def lists(d):
+            peers = sorted(d)
+            off = np.zeros(len(peers) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(d[q]) for q in peers])
+            nodes = np.concatenate([np.asarray(d[q], dtype=np.uint64) for q in peers]) if peers else np.zeros(0, dtype=np.uint64)
+            ids = np.asarray([0 if self._self_loop else q for q in peers], dtype=np.int32)
+            return len(peers), ids, off, np.ascontiguousarray(nodes)
+
+        ns, sp, so, sn = lists(self.prob.send)
+        nr, rp, ro, rn = lists(self.prob.recv)
+        i32 = C.POINTER(C.c_int32)
+        self.values = values
+        row_off, s = np.asarray(engine.pattern(want_cols=False)[0]).astype(np.int64), engine.solution_dim()
+        self._bytes = int(8 * (row_off[s * sn.astype(np.int64) + s] - row_off[s * sn.astype(np.int64)]).sum()) if len(sn) else 0
+        self.engine._check(self._lib.fh_group_set_exchange_nodes(self._g, ns, sp.ctypes.data_as(i32), _u64p(so), _u64p(sn),
+                                                                 nr, rp.ctypes.data_as(i32), _u64p(ro), _u64p(rn)))
+        return self
+
+    def bytes_sent(self):
+        return self._bytes
+
+    def start(self, comm_stream=None):
+        import ctypes as C
+
+        self.engine._check(self._lib.fh_group_exchange_start(self._g, C.c_void_p(self.values.data_ptr())))
+
+    def finish(self):
+        import ctypes as C
+
+        self.engine._check(self._lib.fh_group_exchange_finish(self._g, C.c_void_p(self.values.data_ptr())))
+
+    def run(self):
+        self.start()
+        self.finish()
+
+    def close(self):
+        if self._g:
+            self._lib.fh_group_destroy(self._g)
+            self._g = None
+
+
+def _ffi_lib():
+    from . import _ffi
+
+    return _ffi.lib()
+
+
 class PartAssembly:
     """One rank of the multi-GPU stiffness assembly of an arbitrary mesh (the general counterpart of ``distributed.SlabAssembly``).
     ``configure(engine, mesh)`` sets operator / quadrature / u on an engine for the given (extended local) mesh."""
 
-    def __init__(self, prob: PartProblem, configure, device: int = 0, group=None, stream=None):
+    def __init__(self, prob: PartProblem, configure, device: int = 0, group=None, stream=None, exchange: str = "torch"):
         import torch
 
         from .assembly import Engine
 
+        if exchange not in ("torch", "abi"):
+            raise ValueError("exchange must be 'torch' or 'abi'")
         self.prob = prob
         self.main = Engine(device, stream=stream)
         configure(self.main, prob.mesh)
         self.main.set_active_elements(prob.active)
         nnz = self.main.build_pattern()
         self.values = torch.zeros(nnz, dtype=torch.float64, device=f"cuda:{device}")
-        self.exchange = PartExchange(prob, group).bind(self.main, self.values)
+        self.exchange = (AbiPartExchange(prob, self.main, group) if exchange == "abi" else PartExchange(prob, group)).bind(self.main, self.values)
         self.placement = None     # (same attributes as distributed.SlabAssembly for callers that drive either)
         self.comm = None
 
@@ -249,4 +395,6 @@ class PartAssembly:
         return rows_g, rows_l, np.asarray(ro)
 
     def close(self):
+        if hasattr(self.exchange, "close"):
+            self.exchange.close()
         self.main.close()

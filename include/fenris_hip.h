@@ -398,6 +398,38 @@ int fh_group_set_exchange(fh_group*, int send_peer, uint64_t send_first, uint64_
  * finish: the context's stream waits for the transfers and adds the received rows.  Errors: fh_last_error(ctx). */
 int fh_group_exchange_start(fh_group*, double* values_dev);
 int fh_group_exchange_finish(fh_group*, double* values_dev);
+/* Arbitrary partitions (an element partition elem_to_part[] of an unstructured mesh: no planes, any number of neighbours, interface
+ * rows anywhere): per peer a list of LOCAL NODES whose rows (all S scalar rows of the node, as they lie in `values`) are packed and sent,
+ * and a list of owned local nodes whose rows receive-and-add what the peer packed -- both sides list the shared nodes in the same
+ * (ascending global) order, so no indices travel.  Offsets have peers + 1 entries.  The context's pattern must have been built.  All
+ * transfers of one exchange are posted in one RCCL group; fh_group_exchange_start / _finish drive this mode once it is set.  A rank
+ * may list itself as a peer (a device copy inside RCCL: the single-GPU test does). */
+int fh_group_set_exchange_nodes(fh_group*, int num_send_peers, const int32_t* send_peers, const uint64_t* send_offsets,
+                                const uint64_t* send_nodes, int num_recv_peers, const int32_t* recv_peers, const uint64_t* recv_offsets,
+                                const uint64_t* recv_nodes);
+
+/* ---- element partitions of arbitrary meshes (host; SURVEY.md 8e "the engine takes elem_to_part[]").  What one rank needs to run
+ * its share of CsrParAssembler::assemble_into_csr (global.rs:314-376): a node is owned by the LOWEST part that touches it; the
+ * extended local mesh holds the rank's own elements plus every element touching a node they touch, numbered by ascending global id
+ * (the rows of every node the rank contributes to then carry the GLOBAL pattern in the global column order); numerics over the own
+ * elements (fh_set_active_elements); interface rows through fh_group_set_exchange_nodes.  fenris_amd/partition.py mirrors this. */
+typedef struct fh_partition fh_partition;
+/* default partitioner: Morton order of the element centroids cut into `world` equal runs */
+int fh_morton_partition(uint32_t dim, const double* vertices, uint64_t num_vertices, uint64_t nodes_per_element,
+                        const uint64_t* connectivity, uint64_t num_elements, uint32_t world, int32_t* elem_to_part);
+/* NULL on a bad argument (a part outside [0, world), a node index >= num_nodes).  halo_mode != 0: the halo elements that touch an owned
+ * node are active as well -- the owned rows are complete without any exchange (the lists stay empty). */
+fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t nodes_per_element, const uint64_t* connectivity, uint64_t num_elements,
+                                  const int32_t* elem_to_part, int rank, int world, int halo_mode);
+void fh_partition_destroy(fh_partition*);
+/* sizes: local nodes, local elements, owned nodes, own elements, peers sent to, nodes sent, peers received from, nodes received */
+int fh_partition_sizes(const fh_partition*, uint64_t sizes[8]);
+/* global id of every local node / element, connectivity in local node ids, element mask, owned local nodes (NULL skips an array) */
+int fh_partition_mesh(const fh_partition*, uint64_t* l2g, uint64_t* elem_l2g, uint64_t* local_connectivity, uint8_t* active,
+                      uint64_t* owned_nodes);
+/* the arguments of fh_group_set_exchange_nodes (NULL skips an array) */
+int fh_partition_exchange(const fh_partition*, int32_t* send_peers, uint64_t* send_offsets, uint64_t* send_nodes, int32_t* recv_peers,
+                          uint64_t* recv_offsets, uint64_t* recv_nodes);
 
 #ifdef __cplusplus
 }

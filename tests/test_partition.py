@@ -207,3 +207,104 @@ def test_parts_through_the_engine_match_the_global_oracle(oracle, name, world, o
     finally:
         for pa in ranks:
             pa.close()
+
+
+# ---- the same logic behind the C ABI (fenris_amd/csrc/partition.cpp, group.hip): what a Rust / C host drives
+
+
+@pytest.mark.parametrize("name,world", [("sphere", 3), ("bcc", 4), ("hex", 2), ("hex", 5)])
+def test_c_abi_partition_equals_the_python_mirror(name, world):
+    mesh = _mesh(name)
+    part = fp.morton_partition(mesh, world)
+    assert np.array_equal(fp.morton_partition_abi(mesh, world), part)
+    rng = np.random.default_rng(17)
+    for elem_to_part in (part, rng.integers(0, world, mesh.num_elements()).astype(np.int32)):    # Morton runs and a scattered partition
+        for mode in ("exchange", "halo"):
+            for r in range(world):
+                a, b = fp.make_part(mesh, elem_to_part, r, world, mode), fp.make_part_abi(mesh, elem_to_part, r, world, mode)
+                assert np.array_equal(a.l2g, b.l2g) and np.array_equal(a.elem_l2g, b.elem_l2g)
+                assert np.array_equal(np.asarray(a.mesh.connectivity), np.asarray(b.mesh.connectivity))
+                assert np.array_equal(a.active, b.active) and np.array_equal(a.owned, b.owned)
+                assert a.num_own_elements() == b.num_own_elements()
+                assert sorted(a.send) == sorted(b.send) and sorted(a.recv) == sorted(b.recv)
+                for q in a.send:
+                    assert np.array_equal(a.send[q], b.send[q])
+                for q in a.recv:
+                    assert np.array_equal(a.recv[q], b.recv[q])
+
+
+def test_c_abi_partition_rejects_bad_arguments():
+    mesh = _mesh("hex")
+    part = np.zeros(mesh.num_elements(), dtype=np.int32)
+    part[3] = 2
+    with pytest.raises(ValueError):
+        fp.make_part_abi(mesh, part, 0, 2)                    # a part outside [0, world)
+    with pytest.raises(ValueError):
+        fp.make_part(mesh, part, 0, 2)
+    part[3] = -1
+    with pytest.raises(ValueError):
+        fp.make_part_abi(mesh, part, 0, 2)
+    bad = fa.Mesh(mesh.vertices[:10], mesh.connectivity, fa.HEX8)       # node indices beyond the vertices
+    with pytest.raises(ValueError):
+        fp.make_part_abi(bad, np.zeros(mesh.num_elements(), dtype=np.int32), 0, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op_name", ["LINEAR_ELASTIC", "LAPLACE"])
+def test_c_abi_list_exchange_on_a_one_rank_communicator(op_name):
+    """fh_group_set_exchange_nodes / _start / _finish with this rank as its own peer (RCCL on one GPU: two ranks cannot share a device):
+    pack kernel -> ncclSend / ncclRecv to self in one group -> unpack-add kernel.  Two 'peers', the received lists in another order than the
+    sent ones (rows of equal length: interior nodes of a box), against numpy on the same lists."""
+    import torch
+
+    s = 1 if op_name == "LAPLACE" else 3
+    mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 6, 5, 4, 1)
+    w, p = _rule(mesh)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if s == 3:
+        qt = qt.with_uniform_data(fa.LameParameters(*LAME))
+    fop = fa.LaplaceOperator() if s == 1 else fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+    eng = fa.Engine(0)
+    try:
+        fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(fop).with_quadrature_table(qt).with_u(None).build()
+        nnz = eng.build_pattern()
+        values = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+        eng.assemble_matrix(values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        ro = np.asarray(eng.pattern(want_cols=False)[0]).astype(np.int64)
+        nblk = (ro[s::s] - ro[:-1:s]) // s                         # column blocks per node
+        interior = np.flatnonzero(nblk == 27)
+        assert len(interior) == 5 * 4 * 3
+        rng = np.random.default_rng(3)
+        sendA, sendB = rng.permutation(interior)[:40], rng.permutation(interior)[:25]
+        recvA, recvB = rng.permutation(interior)[:40], rng.permutation(interior)[:25]
+        prob = fp.PartProblem(mesh, np.arange(mesh.num_nodes()), np.arange(mesh.num_elements()), np.ones(mesh.num_elements(), np.uint8),
+                              np.arange(mesh.num_nodes()), {1: sendA, 2: sendB}, {1: recvA, 2: recvB}, 0, 1)
+        ex = fp.AbiPartExchange(prob, eng, self_loop=True).bind(eng, values)
+        try:
+            assert ex.bytes_sent() == 8 * 65 * 27 * s * s
+            before = values.cpu().numpy().copy()
+            want = before.copy()
+            for snd, rcv in ((sendA, recvA), (sendB, recvB)):
+                for a, b in zip(snd, rcv):
+                    want[ro[s * b]: ro[s * b + s]] += before[ro[s * a]: ro[s * a + s]]
+            ex.run()
+            torch.cuda.synchronize()
+            assert np.array_equal(values.cpu().numpy(), want)     # copies and one addition per entry: exact
+            # a second exchange on the result (buffers reused), started and finished separately with work in between
+            before = want.copy()
+            for snd, rcv in ((sendA, recvA), (sendB, recvB)):
+                for a, b in zip(snd, rcv):
+                    want[ro[s * b]: ro[s * b + s]] += before[ro[s * a]: ro[s * a + s]]
+            ex.start()
+            torch.cuda.synchronize()
+            ex.finish()
+            torch.cuda.synchronize()
+            assert np.array_equal(values.cpu().numpy(), want)
+            # bad lists are refused with the engine's error, the group stays usable
+            with pytest.raises(Exception):
+                fp.AbiPartExchange.bind(type("X", (), {"prob": fp.PartProblem(mesh, None, None, None, None, {0: np.array([10 ** 7])}, {}, 0, 1),
+                                                       "engine": eng, "_lib": ex._lib, "_g": ex._g, "_self_loop": True})(), eng, values)
+        finally:
+            ex.close()
+    finally:
+        eng.close()

@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) k_row_counts(const unsigned* nodes, unsig
 struct PeerList {   // one direction of the list-mode exchange
     std::vector<int> peers;
     std::vector<unsigned long long> peer_first, peer_count;   // per peer: first value / values in the packed buffer
+    std::vector<unsigned long long> entry_first;              // per peer (+ 1): first entry of its list
     unsigned* nodes = nullptr;               // device: local node per entry
     unsigned long long* offs = nullptr;      // device: first value of every entry's rows in the packed buffer
     double* buf = nullptr;                   // device: the packed buffer
@@ -102,7 +103,7 @@ struct PeerList {   // one direction of the list-mode exchange
         if (offs) (void)hipFree(offs);
         if (buf) (void)hipFree(buf);
         nodes = nullptr; offs = nullptr; buf = nullptr; entries = values = 0;
-        peers.clear(); peer_first.clear(); peer_count.clear();
+        peers.clear(); peer_first.clear(); peer_count.clear(); entry_first.clear();
     }
 };
 
@@ -236,6 +237,7 @@ static int build_peer_list(fh_group* g, PeerList& L, int npeers, const int32_t* 
             return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: bad peer or offsets");
         L.peers.push_back(peers[p]);
     }
+    L.entry_first.assign(offsets, offsets + npeers + 1);
     L.entries = n;
     if (n == 0) { L.peer_first.assign((size_t)npeers, 0); L.peer_count.assign((size_t)npeers, 0); return FH_OK; }
     G_HIP(g, hipMalloc(reinterpret_cast<void**>(&L.nodes), sizeof(unsigned) * n));
@@ -309,8 +311,12 @@ static int list_exchange_finish(fh_group* g, double* values_dev) {
     DevGuardExt dev_guard_(g->device);
     hipStream_t main = fh_internal_stream(g->ctx);
     G_HIP(g, hipStreamWaitEvent(main, g->done, 0));
-    if (g->rcv.entries) {   // peers in ascending order, entries in list order: the same additions in the same order every run
-        hipLaunchKernelGGL(k_unpack_add_rows, dim3((unsigned)g->rcv.entries), dim3(128), 0, main, g->rcv.nodes, g->rcv.offs, g->noff, g->ss, g->rcv.buf, values_dev);
+    // one launch per peer, in list order: a node may receive from several peers (the nodes of ONE peer's list are distinct), and the
+    // additions happen in the same order every run
+    for (size_t p = 0; p < g->rcv.peers.size(); ++p) {
+        const unsigned long long e0 = g->rcv.entry_first[p], e1 = g->rcv.entry_first[p + 1];
+        if (e1 == e0) continue;
+        hipLaunchKernelGGL(k_unpack_add_rows, dim3((unsigned)(e1 - e0)), dim3(128), 0, main, g->rcv.nodes + e0, g->rcv.offs + e0, g->noff, g->ss, g->rcv.buf, values_dev);
         G_HIP(g, hipGetLastError());
     }
     return FH_OK;

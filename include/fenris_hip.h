@@ -403,7 +403,8 @@ int fh_group_exchange_finish(fh_group*, double* values_dev);
  * and a list of owned local nodes whose rows receive-and-add what the peer packed -- both sides list the shared nodes in the same
  * (ascending global) order, so no indices travel.  Offsets have peers + 1 entries.  The context's pattern must have been built.  All
  * transfers of one exchange are posted in one RCCL group; fh_group_exchange_start / _finish drive this mode once it is set.  A rank
- * may list itself as a peer (a device copy inside RCCL: the single-GPU test does). */
+ * may list itself as a peer (a device copy inside RCCL: the single-GPU test does).  The nodes of ONE peer's list must be distinct; a node
+ * may appear in the lists of several peers (their rows are added peer by peer, in list order). */
 int fh_group_set_exchange_nodes(fh_group*, int num_send_peers, const int32_t* send_peers, const uint64_t* send_offsets,
                                 const uint64_t* send_nodes, int num_recv_peers, const int32_t* recv_peers, const uint64_t* recv_offsets,
                                 const uint64_t* recv_nodes);

@@ -271,7 +271,7 @@ def test_c_abi_list_exchange_on_a_one_rank_communicator(op_name):
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
         eng.assemble_matrix(values, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
         ro = np.asarray(eng.pattern(want_cols=False)[0]).astype(np.int64)
-        nblk = (ro[s::s] - ro[:-1:s]) // s                         # column blocks per node
+        nblk = (ro[s::s] - ro[:-1:s]) // (s * s)                   # column blocks per node
         interior = np.flatnonzero(nblk == 27)
         assert len(interior) == 5 * 4 * 3
         rng = np.random.default_rng(3)

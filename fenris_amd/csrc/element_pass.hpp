@@ -153,21 +153,30 @@ __device__ __forceinline__ double block_sum_256(double v, double* lds4) {
     return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// WHAT = EP_VECTOR: fe[a][e][c] (a.ke_out, E = a.num_elements);  EP_SCALAR: a.scalar_out[blockIdx.x] = energy of the workgroup's elements
 template <int EK, int OP, int WHAT>
-__global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
+struct EPDims {
     using E = ElemT<EK>;
     using O = OpT<OP, E::D>;
-    constexpr int D = E::D, N = E::N, S = O::S;
-    static_assert(E::NG == N && N <= 8, "element pass: small iso-parametric elements");
-    __shared__ double red[4];
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = e < a.num_elements;
-    const long long ec = live ? e : a.num_elements - 1;   // every lane computes (uniform control flow), the surplus ones store nothing
+    static constexpr int D = E::D, N = E::N, S = O::S, NF = (WHAT == EP_VECTOR ? N : 1);
+};
+
+// vertex coordinates and u of element ec's nodes into the registers of the thread (8-byte gathers)
+template <int EK, int OP, int WHAT>
+__device__ __forceinline__ void element_pass_load(const KArgs& a, const long long ec, double (&X)[EPDims<EK, OP, WHAT>::N][EPDims<EK, OP, WHAT>::D],
+                                                  double (&U)[EPDims<EK, OP, WHAT>::N][EPDims<EK, OP, WHAT>::S]) {
+    constexpr int D = EPDims<EK, OP, WHAT>::D, N = EPDims<EK, OP, WHAT>::N, S = EPDims<EK, OP, WHAT>::S;
     int nd[N];
+    if constexpr (N % 4 == 0) {   // a connectivity row of 16 or 32 bytes: one or two 16-byte loads
+        const int4* row = reinterpret_cast<const int4*>(a.conn + (size_t)ec * N);
 #pragma unroll
-    for (int n = 0; n < N; ++n) nd[n] = a.conn[(size_t)ec * N + n];
-    double X[N][D], U[N][S];
+        for (int n = 0; n < N; n += 4) {
+            const int4 v = row[n / 4];
+            nd[n] = v.x; nd[n + 1] = v.y; nd[n + 2] = v.z; nd[n + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) nd[n] = a.conn[(size_t)ec * N + n];
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
 #pragma unroll
@@ -175,12 +184,30 @@ __global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < S; ++k) U[n][k] = a.u ? a.u[(size_t)nd[n] * S + k] : 0.0;
     }
-    double f[WHAT == EP_VECTOR ? N : 1][S];
+}
+
+// one element in the registers of one thread: f[a][c] (EP_VECTOR) or the element's energy (EP_SCALAR) from its vertex coordinates X and
+// its u.  `ec` is the element whose data the thread holds (every lane computes: uniform control flow), `live` whether it is the
+// thread's own (singular reports)
+// (U: anything with  double operator()(n, k): the registers of the thread -- EPRegU -- or a staging place in LDS)
+template <int N, int S>
+struct EPRegU {
+    const double (&u)[N][S];
+    __device__ __forceinline__ double operator()(int n, int k) const { return u[n][k]; }
+};
+template <int EK, int OP, int WHAT, class UAcc>
+__device__ __forceinline__ void element_pass_body(const KArgs& a, const long long e, const bool live, const long long ec,
+                                                  const double (&X)[EPDims<EK, OP, WHAT>::N][EPDims<EK, OP, WHAT>::D], const UAcc& U,
+                                                  double (&f)[EPDims<EK, OP, WHAT>::NF][EPDims<EK, OP, WHAT>::S], double& energy) {
+    using E = ElemT<EK>;
+    using O = OpT<OP, E::D>;
+    constexpr int D = E::D, N = E::N, S = O::S;
+    static_assert(E::NG == N && N <= 8, "element pass: small iso-parametric elements");
 #pragma unroll
     for (int n = 0; n < (WHAT == EP_VECTOR ? N : 1); ++n)
 #pragma unroll
         for (int k = 0; k < S; ++k) f[n][k] = 0.0;
-    double energy = 0.0;
+    energy = 0.0;
     const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[ec] * a.nq * 2 : nullptr;
     // The Jacobian of an affine element is the same at every point (simplices always; a Hex8 / Quad4 whose mixed coefficients
     // vanish: every element of a structured, graded or sheared box mesh -- the test of k_classify_affine_hex8):
@@ -238,7 +265,7 @@ __global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
                     for (int i = 0; i < D; ++i) J[i][j] = fma(X[n][i], g, J[i][j]);   // J = X G^T (hexahedron.rs:101-107)
                 }
 #pragma unroll
-                for (int k = 0; k < S; ++k) R[j][k] = fma(g, U[n][k], R[j][k]);       // sum_n ghat_n u_n^T
+                for (int k = 0; k < S; ++k) R[j][k] = fma(g, U(n, k), R[j][k]);       // sum_n ghat_n u_n^T
             }
         if constexpr (need_j) {
             const double detJ = det_small<D>(J);
@@ -300,6 +327,21 @@ __global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
     } else {
         for (int q = 0; q < a.nq; ++q) point(q, std::true_type{});
     }
+}
+
+// WHAT = EP_VECTOR: fe[a][e][c] (a.ke_out, E = a.num_elements);  EP_SCALAR: a.scalar_out[blockIdx.x] = energy of the workgroup's elements
+template <int EK, int OP, int WHAT>
+__global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
+    constexpr int N = EPDims<EK, OP, WHAT>::N, S = EPDims<EK, OP, WHAT>::S;
+    __shared__ double red[4];
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < a.num_elements;
+    const long long ec = live ? e : a.num_elements - 1;   // every lane computes (uniform control flow), the surplus ones store nothing
+    double f[EPDims<EK, OP, WHAT>::NF][S];
+    double energy;
+    double X[N][EPDims<EK, OP, WHAT>::D], U[N][S];
+    element_pass_load<EK, OP, WHAT>(a, ec, X, U);
+    element_pass_body<EK, OP, WHAT>(a, e, live, ec, X, EPRegU<N, S>{U}, f, energy);
     if constexpr (WHAT == EP_SCALAR) {
         const double tot = block_sum_256(live ? energy : 0.0, red);
         if (threadIdx.x == 0) a.scalar_out[blockIdx.x] = tot;
@@ -321,19 +363,11 @@ __global__ void __launch_bounds__(256) k_element_pass(const KArgs a) {
 // per local node (fe[a][e], a third of the scratch traffic of a three-component vector) and the node sum multiplies by g:
 // f_n = g sum m_n -- the same numbers as sum_q (w |det J| phi_n)(rho_q g) up to the rounding of the products.
 struct SourceG { double v[3]; };   // by value: no device buffer, no copy, no synchronisation per call
+// one element's source vector in registers from its vertex coordinates: f[n][k] (FACT: k = 0 only, the scalar m_n)
 template <int D, int S, int N, bool FACT>
-__global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const SourceG g, const double* values, double* fe) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.num_elements) return;
-    double X[N][D];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const int nd = a.conn[(size_t)e * N + n];
-#pragma unroll
-        for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd * D + i];
-    }
+__device__ __forceinline__ void source_element_body(const KArgs& a, const SourceG& g, const double* values, const long long e, const double (&X)[N][D],
+                                                    double (&f)[N][FACT ? 1 : S]) {
     constexpr int SF = FACT ? 1 : S;
-    double f[N][SF];
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
@@ -374,6 +408,22 @@ __global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const So
             for (int k = 0; k < SF; ++k) f[n][k] = fma(t, fc[k], f[n][k]);
         }
     }
+}
+
+template <int D, int S, int N, bool FACT>
+__global__ void __launch_bounds__(256) k_source_elements(const KArgs a, const SourceG g, const double* values, double* fe) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.num_elements) return;
+    double X[N][D];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int nd = a.conn[(size_t)e * N + n];
+#pragma unroll
+        for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd * D + i];
+    }
+    constexpr int SF = FACT ? 1 : S;
+    double f[N][SF];
+    source_element_body<D, S, N, FACT>(a, g, values, e, X, f);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         double* dst = fe + ((size_t)n * (size_t)a.num_elements + (size_t)e) * SF;
@@ -429,7 +479,7 @@ __global__ void __launch_bounds__(256) k_vector_from_elements_soa(int num_nodes,
 }
 
 // partial sums in index order by one workgroup: thread t takes the partials t, t + 256, ... in order, then the fixed tree
-__global__ void __launch_bounds__(256) k_sum_partials(const double* partial, int n, double* out) {
+static __global__ void __launch_bounds__(256) k_sum_partials(const double* partial, int n, double* out) {
     __shared__ double red[4];
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];

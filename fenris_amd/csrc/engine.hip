@@ -22,6 +22,7 @@
 #include "element_pass.hpp"
 #include "coloring_kernels.hpp"
 #include "hex8_rows.hpp"
+#include "vector_tiles.hpp"
 #include "device_common.hpp"
 #include "group_internal.hpp"
 #include "host_inputs.hpp"
@@ -407,6 +408,9 @@ struct fh_ctx {
     DevBuf<double> fe_scratch;  // two-pass residual: E element vectors
     DevBuf<unsigned> src_n2e_off, src_n2e;   // node -> (element, local node) adjacency of a context without an operator (source vectors)
     unsigned long long src_adj_gen = ~0ull;
+    VecTilesStore vt;                        // residual through element tiles (vector_tiles.hip)
+    unsigned long long vt_gen = ~0ull;
+    bool vt_bad = false;
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
@@ -3038,6 +3042,15 @@ int fh_assemble_vector_async_dev(fh_ctx* c, double* out_dev) {
     c->keep_status = false;
     return rc;
 }
+// element tiles of the residual / source vector passes (vector_tiles.hip): once per mesh topology
+static int ensure_vector_tiles(fh_ctx* c) {
+    if (c->vt_gen == c->struct_gen) return FH_OK;
+    int bad = 0;
+    HIP_TRY(c, vector_tiles_build(c->stream, c->conn.p, c->ei.n, (long long)c->E, c->verts.p, c->ei.d, (int)c->N, &c->vt, &bad));
+    c->vt_bad = bad != 0;
+    c->vt_gen = c->struct_gen;
+    return FH_OK;
+}
 static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) {
     int rc = check_ready(c, "fh_assemble_vector", false);
     if (rc) return rc;
@@ -3053,6 +3066,26 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return read_status(c, failed);
+    // small iso-parametric elements: tiles of 256 elements, one thread per element, the tile's distinct nodes summed in LDS, only
+    // those partial sums through HBM, then one thread per node (vector_tiles.hip); no atomics, bitwise reproducible; an element mask
+    // zeroes the contributions of the inactive elements
+    if (element_pass_covers(c) && !c->env("FENRIS_HIP_VECTOR_ATOMICS") && !c->env("FENRIS_HIP_NO_VECTOR_TILES") && c->op <= FH_STVK) {
+        rc = ensure_vector_tiles(c);
+        if (rc) return rc;
+        if (!c->vt_bad) {
+            const size_t need = (size_t)c->vt.v.npartials * c->S();
+            if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
+            KArgs at = a;
+            at.labels = nullptr;
+            const int rs = vector_tiles_element_pass(c->elem_kind, c->op, c->stream, at, c->vt.v, c->has_mask ? c->active.p : nullptr, c->fe_scratch.p);
+            if (rs == FH_OK) {
+                HIP_TRY(c, hipGetLastError());
+                c->last_kernel = "k_element_pass_tiled + k_vector_from_partials";
+                HIP_TRY(c, vector_tiles_node_pass(c->stream, c->S(), (int)c->N, c->vt.v, c->fe_scratch.p, out_dev));
+                return read_status(c, failed);
+            }
+        }
+    }
     // small iso-parametric elements without an element list: one thread per element, element vectors laid out by local node, then
     // one thread per node (element_pass.hpp); no atomics, bitwise reproducible
     if (!a.labels && element_pass_covers(c) && !c->env("FENRIS_HIP_VECTOR_ATOMICS")) {
@@ -3165,6 +3198,26 @@ int fh_assemble_source_vector_dev(fh_ctx* c, uint32_t sdim, const double* g, con
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return FH_OK;
+    // small iso-parametric elements: the tiles of the residual (vector_tiles.hip) -- element vectors summed per distinct node of a tile
+    // in LDS, partial sums through HBM, one thread per node; an element mask zeroes the inactive elements
+    if (element_pass_covers(c) && !c->env("FENRIS_HIP_VECTOR_ATOMICS") && !c->env("FENRIS_HIP_NO_VECTOR_TILES")) {
+        rc = ensure_vector_tiles(c);
+        if (rc) return rc;
+        if (!c->vt_bad) {
+            const bool fact = !values_dev;   // GravitySource: scalar partials, the node sum multiplies by g
+            const size_t need = (size_t)c->vt.v.npartials * (fact ? 1 : sdim);
+            if (c->fe_scratch.n < need) HIP_TRY(c, c->fe_scratch.alloc(need));
+            KArgs at = a;
+            at.labels = nullptr;
+            if (vector_tiles_source_pass(D, (int)sdim, c->ei.n, fact, c->stream, at, gval.v, sa.values, c->vt.v, c->has_mask ? c->active.p : nullptr,
+                                         c->fe_scratch.p) == 0) {
+                HIP_TRY(c, hipGetLastError());
+                c->last_kernel = "k_source_elements_tiled + k_vector_from_partials";
+                HIP_TRY(c, vector_tiles_node_pass(c->stream, (int)sdim, (int)c->N, c->vt.v, c->fe_scratch.p, out_dev, fact ? gval.v : nullptr));
+                return FH_OK;
+            }
+        }
+    }
     // two passes without atomics where the node adjacency is available (it comes with the pattern, which needs an operator
     // for the solution dimension): element vectors to scratch, then a per-row sum in element order
     bool two_pass = !a.labels && !c->ragged && c->op >= 0 && !c->env("FENRIS_HIP_VECTOR_ATOMICS");

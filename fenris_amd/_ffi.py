@@ -137,6 +137,8 @@ _SIGS = {
     "fh_partition_sizes": (C.c_int, [C.c_void_p, u64p]),
     "fh_partition_mesh": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.POINTER(C.c_uint8), u64p]),
     "fh_partition_exchange": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), u64p, u64p, C.POINTER(C.c_int32), u64p, u64p]),
+    "fh_group_exchange_vector_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "fh_group_exchange_vector_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "fh_group_set_exchange_nodes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), u64p, u64p, C.c_int, C.POINTER(C.c_int32), u64p, u64p]),
 }
 

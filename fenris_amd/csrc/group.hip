@@ -90,6 +90,16 @@ __global__ void __launch_bounds__(256) k_row_counts(const unsigned* nodes, unsig
     if (i < n) count[i] = (unsigned long long)ss * (noff[nodes[i] + 1] - noff[nodes[i]]);
 }
 
+// node VECTORS (residual, source vector: `comp` values per node) of the listed nodes
+__global__ void __launch_bounds__(256) k_pack_nodes(const unsigned* nodes, unsigned long long n, int comp, const double* vec, double* buf) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n * comp) buf[i] = vec[(unsigned long long)nodes[i / comp] * comp + i % comp];
+}
+__global__ void __launch_bounds__(256) k_unpack_add_nodes(const unsigned* nodes, unsigned long long n, int comp, const double* buf, double* vec) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n * comp) vec[(unsigned long long)nodes[i / comp] * comp + i % comp] += buf[i];
+}
+
 struct PeerList {   // one direction of the list-mode exchange
     std::vector<int> peers;
     std::vector<unsigned long long> peer_first, peer_count;   // per peer: first value / values in the packed buffer
@@ -97,12 +107,15 @@ struct PeerList {   // one direction of the list-mode exchange
     unsigned* nodes = nullptr;               // device: local node per entry
     unsigned long long* offs = nullptr;      // device: first value of every entry's rows in the packed buffer
     double* buf = nullptr;                   // device: the packed buffer
+    double* vbuf = nullptr;                  // device: packed node vectors (entries x vcomp), allocated at the first vector exchange
+    int vcomp = 0;
     unsigned long long entries = 0, values = 0;
     void release() {
         if (nodes) (void)hipFree(nodes);
         if (offs) (void)hipFree(offs);
         if (buf) (void)hipFree(buf);
-        nodes = nullptr; offs = nullptr; buf = nullptr; entries = values = 0;
+        if (vbuf) (void)hipFree(vbuf);
+        nodes = nullptr; offs = nullptr; buf = nullptr; vbuf = nullptr; vcomp = 0; entries = values = 0;
         peers.clear(); peer_first.clear(); peer_count.clear(); entry_first.clear();
     }
 };
@@ -120,6 +133,7 @@ struct fh_group {
     double* recv_buf = nullptr;
     uint64_t recv_cap = 0;
     bool in_flight = false;
+    bool vec_in_flight = false;
     bool list_mode = false;          // fh_group_set_exchange_nodes: packed lists, any number of peers
     PeerList snd, rcv;
     const unsigned* noff = nullptr;  // the context's node-level row offsets (device)
@@ -267,7 +281,7 @@ int fh_group_set_exchange_nodes(fh_group* g, int num_send_peers, const int32_t* 
     if (!g || num_send_peers < 0 || num_recv_peers < 0) return FH_BAD_ARGUMENT;
     if ((num_send_peers && (!send_peers || !send_offsets)) || (num_recv_peers && (!recv_peers || !recv_offsets)))
         return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: null list");
-    if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange_nodes: an exchange is in flight");
+    if (g->in_flight || g->vec_in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange_nodes: an exchange is in flight");
     const unsigned* ncols = nullptr;
     uint64_t N = 0;
     int S = 0;
@@ -317,6 +331,72 @@ static int list_exchange_finish(fh_group* g, double* values_dev) {
         const unsigned long long e0 = g->rcv.entry_first[p], e1 = g->rcv.entry_first[p + 1];
         if (e1 == e0) continue;
         hipLaunchKernelGGL(k_unpack_add_rows, dim3((unsigned)(e1 - e0)), dim3(128), 0, main, g->rcv.nodes + e0, g->rcv.offs + e0, g->noff, g->ss, g->rcv.buf, values_dev);
+        G_HIP(g, hipGetLastError());
+    }
+    return FH_OK;
+}
+
+// node vectors through the same lists: comp values per listed node
+static int vec_buffers(fh_group* g, PeerList& L, int comp) {
+    if (L.entries == 0 || L.vcomp == comp) return FH_OK;
+    if (L.vbuf) (void)hipFree(L.vbuf);
+    L.vbuf = nullptr;
+    L.vcomp = 0;
+    G_HIP(g, hipMalloc(reinterpret_cast<void**>(&L.vbuf), sizeof(double) * L.entries * comp));
+    L.vcomp = comp;
+    return FH_OK;
+}
+
+int fh_group_exchange_vector_start(fh_group* g, double* vec_dev, uint32_t components) {
+    if (!g || !vec_dev || components == 0 || components > 16) return FH_BAD_ARGUMENT;
+    if (!g->list_mode) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_vector_start: set the node lists first (fh_group_set_exchange_nodes)");
+    if (g->vec_in_flight || g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_vector_start: an exchange is in flight");
+    DevGuardExt dev_guard_(g->device);
+    const int comp = (int)components;
+    int rc = vec_buffers(g, g->snd, comp);
+    if (rc) return rc;
+    rc = vec_buffers(g, g->rcv, comp);
+    if (rc) return rc;
+    hipStream_t main = fh_internal_stream(g->ctx);
+    G_HIP(g, hipEventRecord(g->ready, main));
+    G_HIP(g, hipStreamWaitEvent(g->side, g->ready, 0));
+    if (g->snd.entries) {
+        const unsigned long long n = g->snd.entries;
+        hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((n * comp + 255) / 256)), dim3(256), 0, g->side, g->snd.nodes, n, comp, vec_dev, g->snd.vbuf);
+        G_HIP(g, hipGetLastError());
+    }
+    G_NCCL(g, g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t p = 0; p < g->snd.peers.size() && r == ncclSuccess; ++p) {
+        const unsigned long long e0 = g->snd.entry_first[p], e1 = g->snd.entry_first[p + 1];
+        if (e1 > e0) r = g_rccl.Send(g->snd.vbuf + e0 * comp, (e1 - e0) * comp, ncclDouble, g->snd.peers[p], g->comm, g->side);
+    }
+    for (size_t p = 0; p < g->rcv.peers.size() && r == ncclSuccess; ++p) {
+        const unsigned long long e0 = g->rcv.entry_first[p], e1 = g->rcv.entry_first[p + 1];
+        if (e1 > e0) r = g_rccl.Recv(g->rcv.vbuf + e0 * comp, (e1 - e0) * comp, ncclDouble, g->rcv.peers[p], g->comm, g->side);
+    }
+    const ncclResult_t r_end = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
+    if (r_end != ncclSuccess) return fh_internal_fail(g->ctx, FH_HIP_ERROR, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end));
+    G_HIP(g, hipEventRecord(g->done, g->side));
+    g->vec_in_flight = true;
+    return FH_OK;
+}
+
+int fh_group_exchange_vector_finish(fh_group* g, double* vec_dev, uint32_t components) {
+    if (!g || !vec_dev || components == 0 || components > 16) return FH_BAD_ARGUMENT;
+    if (!g->vec_in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_vector_finish: nothing started");
+    g->vec_in_flight = false;
+    const int comp = (int)components;
+    if ((g->rcv.entries && g->rcv.vcomp != comp)) return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_exchange_vector_finish: components differ from the start");
+    DevGuardExt dev_guard_(g->device);
+    hipStream_t main = fh_internal_stream(g->ctx);
+    G_HIP(g, hipStreamWaitEvent(main, g->done, 0));
+    for (size_t p = 0; p < g->rcv.peers.size(); ++p) {   // peer by peer: a node may receive from several
+        const unsigned long long e0 = g->rcv.entry_first[p], e1 = g->rcv.entry_first[p + 1];
+        if (e1 == e0) continue;
+        hipLaunchKernelGGL(k_unpack_add_nodes, dim3((unsigned)(((e1 - e0) * comp + 255) / 256)), dim3(256), 0, main, g->rcv.nodes + e0, e1 - e0, comp,
+                           g->rcv.vbuf + e0 * comp, vec_dev);
         G_HIP(g, hipGetLastError());
     }
     return FH_OK;

@@ -213,6 +213,32 @@ class PartExchange:
         self.start()
         self.finish()
 
+    def run_vector(self, vec, components: int):
+        """the same exchange for a node vector (``components`` values per node: the residual of ``PartAssembly.assemble_vector``):
+        partial sums at the nodes a neighbour owns go there and are added; entries of nodes this rank does not own are scratch afterwards"""
+        import torch
+        import torch.distributed as dist
+
+        def idx(nodes):
+            n = torch.as_tensor(np.asarray(nodes, dtype=np.int64), device=vec.device)
+            return (n[:, None] * components + torch.arange(components, device=vec.device)[None, :]).reshape(-1)
+
+        send = {q: idx(nodes) for q, nodes in self.prob.send.items()}
+        recv = {q: idx(nodes) for q, nodes in self.prob.recv.items()}
+        if not send and not recv:
+            return
+        bufs = {q: torch.empty(len(i), dtype=vec.dtype, device=vec.device) for q, i in recv.items()}
+        keep, ops = [], []
+        for q in sorted(send):
+            keep.append(vec.index_select(0, send[q]))
+            ops.append(dist.P2POp(dist.isend, keep[-1], q, self.group))
+        for q in sorted(recv):
+            ops.append(dist.P2POp(dist.irecv, bufs[q], q, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for q in sorted(recv):
+            vec.index_add_(0, recv[q], bufs[q])
+
 
 def _u64p(a):
     import ctypes as C
@@ -346,6 +372,13 @@ class AbiPartExchange:
         self.start()
         self.finish()
 
+    def run_vector(self, vec, components: int):
+        """``fh_group_exchange_vector_start`` / ``_finish``: the node vector through the same lists"""
+        import ctypes as C
+
+        self.engine._check(self._lib.fh_group_exchange_vector_start(self._g, C.c_void_p(vec.data_ptr()), components))
+        self.engine._check(self._lib.fh_group_exchange_vector_finish(self._g, C.c_void_p(vec.data_ptr()), components))
+
     def close(self):
         if self._g:
             self._lib.fh_group_destroy(self._g)
@@ -382,6 +415,13 @@ class PartAssembly:
     def enqueue(self, flags):
         self.main.assemble_matrix_async(self.values, flags)
         self.exchange.run()
+
+    def assemble_vector(self, out):
+        """the rank's share of ``VectorAssembler::assemble_vector_into`` (global.rs:582-608): ``out`` (device, one entry per local dof,
+        accumulated into) gets the own elements' contributions, then the partial sums at nodes other ranks own travel to their owners.
+        Afterwards the entries of the OWNED nodes are complete; the others are scratch."""
+        self.main.assemble_vector(out)
+        self.exchange.run_vector(out, self.main.solution_dim())
 
     def poll_status(self):
         self.main.poll_status()

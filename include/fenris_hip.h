@@ -409,6 +409,12 @@ int fh_group_set_exchange_nodes(fh_group*, int num_send_peers, const int32_t* se
                                 const uint64_t* send_nodes, int num_recv_peers, const int32_t* recv_peers, const uint64_t* recv_offsets,
                                 const uint64_t* recv_nodes);
 
+/* Node VECTORS through the same lists (the residual / source vector of a partition: fh_assemble_vector_dev over the active elements
+ * leaves partial sums at the nodes other ranks own): `components` values per node (the solution dim), packed, sent, received and added
+ * exactly like the rows above.  Entries of nodes the rank does not own are scratch afterwards. */
+int fh_group_exchange_vector_start(fh_group*, double* vec_dev, uint32_t components);
+int fh_group_exchange_vector_finish(fh_group*, double* vec_dev, uint32_t components);
+
 /* ---- element partitions of arbitrary meshes (host; SURVEY.md 8e "the engine takes elem_to_part[]").  What one rank needs to run
  * its share of CsrParAssembler::assemble_into_csr (global.rs:314-376): a node is owned by the LOWEST part that touches it; the
  * extended local mesh holds the rank's own elements plus every element touching a node they touch, numbered by ascending global id

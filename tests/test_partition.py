@@ -308,3 +308,165 @@ def test_c_abi_list_exchange_on_a_one_rank_communicator(op_name):
             ex.close()
     finally:
         eng.close()
+
+
+# ---- residual vectors of a partition: own elements' contributions, then the partial sums at other ranks' nodes travel (run_vector)
+
+
+def _oracle_partial_vector(oracle, prob, op, u_global):
+    m = prob.mesh
+    w, p = _rule(m)
+    s = 1 if op == oracle.LAPLACE else m.vertices.shape[1]
+    u = u_global.reshape(-1, s)[prob.l2g].reshape(-1)
+    own = oracle.ElementAssembler(_okind(oracle, m), op, m.vertices, np.asarray(m.connectivity)[prob.active.astype(bool)], w, p,
+                                  params=None if op == oracle.LAPLACE else LAME, u=u)
+    st, _, f = oracle.assemble_vector(own)
+    assert st == 0
+    return s, u, f
+
+
+def _global_vector(oracle, mesh, op, u_global):
+    w, p = _rule(mesh)
+    ref = oracle.ElementAssembler(_okind(oracle, mesh), op, mesh.vertices, mesh.connectivity, w, p, params=None if op == oracle.LAPLACE else LAME, u=u_global)
+    st, _, f = oracle.assemble_vector(ref)
+    assert st == 0
+    return f
+
+
+def _u_for(mesh, s):
+    return 1e-3 * np.sin(np.arange(s * mesh.num_nodes()) * 0.37)
+
+
+def _gloo_vector_worker(rank, world, port, name, op_name, q):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        op = getattr(oracle, op_name)
+        mesh = _mesh(name)
+        sdim = 1 if op_name == "LAPLACE" else 3
+        ug = _u_for(mesh, sdim)
+        prob = fp.make_part(mesh, fp.morton_partition(mesh, world), rank, world)
+        s, _, f = _oracle_partial_vector(oracle, prob, op, ug)
+        vec = torch.from_numpy(f.copy())
+        fp.PartExchange(prob).run_vector(vec, s)
+        want = _global_vector(oracle, mesh, op, ug).reshape(-1, s)
+        got = vec.numpy().reshape(-1, s)
+        owned = np.asarray(prob.owned)
+        assert np.abs(got[owned] - want[prob.l2g[owned]]).max() <= 1e-12 * np.abs(want).max()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as exc:  # pragma: no cover - reported to the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(exc)))
+
+
+@pytest.mark.parametrize("name,world,op_name", [("sphere", 3, "LINEAR_ELASTIC"), ("bcc", 4, "LAPLACE")])
+def test_vector_exchange_over_gloo(name, world, op_name):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_vector_worker, args=(r, world, port, name, op_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,op_name", [("sphere", 3, "LINEAR_ELASTIC"), ("hex", 4, "LINEAR_ELASTIC"), ("bcc", 2, "LAPLACE")])
+def test_partition_residuals_through_the_engine(oracle, name, world, op_name):
+    """every rank's residual through the engine on the one GPU (element mask -> the tiled element pass zeroes the halo elements), the
+    interface sums moved by device copies through the exchange's node lists; owned entries against the single-process oracle vector"""
+    import torch
+
+    op = getattr(oracle, op_name)
+    s = 1 if op_name == "LAPLACE" else 3
+    mesh = _mesh(name)
+    ug = _u_for(mesh, s)
+    w, p = _rule(mesh)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    if s == 3:
+        qt = qt.with_uniform_data(fa.LameParameters(*LAME))
+    fop = fa.LaplaceOperator() if s == 1 else fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+    part = fp.morton_partition(mesh, world)
+    probs = [fp.make_part(mesh, part, r, world) for r in range(world)]
+
+    def configure_for(prob):
+        u_local = ug.reshape(-1, s)[prob.l2g].reshape(-1)
+
+        def configure(engine, m):
+            return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(fop).with_quadrature_table(qt)
+                    .with_u(u_local).build())
+        return configure
+
+    ranks = [fp.PartAssembly(pr, configure_for(pr), device=0) for pr in probs]
+    try:
+        outs = []
+        for pa in ranks:
+            out = torch.zeros(s * pa.prob.mesh.num_nodes(), dtype=torch.float64, device="cuda:0")
+            pa.main.assemble_vector(out)
+            assert "tiled" in pa.main.last_kernel_name()
+            outs.append(out)
+        partial = [o.clone() for o in outs]
+        for r, pa in enumerate(ranks):      # what run_vector does between processes
+            for q_ in sorted(pa.prob.recv):
+                src = torch.as_tensor(np.asarray(ranks[q_].prob.send[r]), device="cuda:0")
+                dst = torch.as_tensor(np.asarray(pa.prob.recv[q_]), device="cuda:0")
+                outs[r].view(-1, s).index_add_(0, dst, partial[q_].view(-1, s).index_select(0, src))
+        want = _global_vector(oracle, mesh, op, ug).reshape(-1, s)
+        for r, pa in enumerate(ranks):
+            owned = np.asarray(pa.prob.owned)
+            got = outs[r].cpu().numpy().reshape(-1, s)
+            assert np.abs(got[owned] - want[pa.prob.l2g[owned]]).max() <= 1e-12 * np.abs(want).max(), (name, r)
+    finally:
+        for pa in ranks:
+            pa.close()
+
+
+@pytest.mark.gpu
+def test_c_abi_vector_exchange_on_a_one_rank_communicator():
+    """fh_group_exchange_vector_start / _finish with the rank as its own peer: pack kernel -> ncclSend / ncclRecv -> unpack-add, against numpy"""
+    import torch
+
+    mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 6, 5, 4, 1)
+    w, p = _rule(mesh)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters(*LAME))
+    eng = fa.Engine(0)
+    try:
+        (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh).with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial()))
+         .with_quadrature_table(qt).with_u(None).build())
+        eng.build_pattern()
+        n = mesh.num_nodes()
+        rng = np.random.default_rng(4)
+        sendA, sendB = rng.permutation(n)[:50], rng.permutation(n)[:31]
+        recvA, recvB = rng.permutation(n)[:50], rng.permutation(n)[:31]
+        prob = fp.PartProblem(mesh, np.arange(n), np.arange(mesh.num_elements()), np.ones(mesh.num_elements(), np.uint8), np.arange(n),
+                              {1: sendA, 2: sendB}, {1: recvA, 2: recvB}, 0, 1)
+        values = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        ex = fp.AbiPartExchange(prob, eng, self_loop=True).bind(eng, values)
+        try:
+            for comp in (3, 1):
+                vec = torch.as_tensor(rng.standard_normal(comp * n), device="cuda:0")
+                before = vec.cpu().numpy().reshape(-1, comp).copy()
+                want = before.copy()
+                for snd, rcv in ((sendA, recvA), (sendB, recvB)):
+                    np.add.at(want, rcv, before[snd])
+                ex.run_vector(vec, comp)
+                torch.cuda.synchronize()
+                assert np.array_equal(vec.cpu().numpy().reshape(-1, comp), want), comp
+        finally:
+            ex.close()
+    finally:
+        eng.close()

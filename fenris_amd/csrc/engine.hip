@@ -562,6 +562,19 @@ int build_source_adjacency(fh_ctx* c) {
     return FH_OK;
 }
 
+// host copies of the node-level row offsets and of the node -> element offsets: made when something on the host needs them (the gather
+// block partition, fh_pattern's row offsets), not by the pattern build itself (82 MB over PCIe on the 216^3 mesh)
+int host_offsets(fh_ctx* c) {
+    const size_t N = (size_t)c->N;
+    if (c->h_noff.size() == N + 1 && c->h_n2e_off.size() == N + 1) return FH_OK;
+    c->h_noff.resize(N + 1);
+    c->h_n2e_off.resize(N + 1);
+    HIP_TRY(c, hipMemcpyAsync(c->h_noff.data(), c->noff.p, sizeof(unsigned) * (N + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_n2e_off.data(), c->n2e_off.p, sizeof(unsigned) * (N + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
 // ---------------------------------------------------------------------------------- pattern build
 int build_pattern(fh_ctx* c) {
     if (!c->has_mesh) return c->fail(FH_INVALID_STATE, "fh_pattern: no mesh/connectivity set");
@@ -601,7 +614,28 @@ int build_pattern(fh_ctx* c) {
     int nheavy = 0, heavy_grid = 0;
     const int heavy_words = (N + 31) / 32;
     HIP_TRY(c, heavy.alloc(HEAVY_CAP));
-    if (N > 0) {
+    // largest number of elements at a node (one more scan-sized reduction): decides between one neighbour pass and two
+    DevBuf<unsigned> red;
+    HIP_TRY(c, red.alloc(4));
+    size_t red_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceReduce::Max(nullptr, red_bytes, deg.p, red.p, N + 1, st));
+    if (red_bytes > tmp_bytes) { HIP_TRY(c, tmp.alloc(red_bytes + 16)); tmp_bytes = red_bytes; }
+    HIP_TRY(c, hipcub::DeviceReduce::Max(tmp.p, red_bytes, deg.p, red.p, N + 1, st));
+    unsigned h_red[4] = {0, 0, 0, 0};
+    int h_flags[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h_red, red.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
+    const bool once = N > 0 && !c->ragged && (unsigned long long)h_red[0] * (unsigned)c->ei.n <= 64ull && !c->env("FENRIS_HIP_PATTERN_TWO_PASSES");
+    DevBuf<unsigned> rows64;
+    if (once) {
+        // every node has at most 64 candidates (fixed-n mesh): one neighbour pass into scratch rows, scan, compaction (pattern_kernels.hpp)
+        HIP_TRY(c, rows64.alloc((size_t)N * 64));
+        const int g = std::min(N, 256 * 64);
+        hipLaunchKernelGGL(k_node_neighbors_once, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p);
+        HIP_TRY(c, hipGetLastError());
+    } else if (N > 0) {
         const int g = std::min(N, 256 * 64);
         hipLaunchKernelGGL(k_node_neighbors<false>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, cnt.p, nullptr,
                            nullptr, flags.p + 1, heavy.p);
@@ -619,22 +653,34 @@ int build_pattern(fh_ctx* c) {
     }
     size_t tmp2 = 0;
     HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, cnt.p, c->noff.p, N + 1, st));
-    if (tmp2 > tmp_bytes) { HIP_TRY(c, tmp.alloc(tmp2 + 16)); }
+    if (tmp2 > tmp_bytes) { HIP_TRY(c, tmp.alloc(tmp2 + 16)); tmp_bytes = tmp2; }
     HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp2, cnt.p, c->noff.p, N + 1, st));
-    c->h_noff.assign((size_t)N + 1, 0);
-    c->h_n2e_off.assign((size_t)N + 1, 0);
-    int h_flags[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(c->h_noff.data(), c->noff.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(c->h_n2e_off.data(), c->n2e_off.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+    // the longest row and the number of entries: two numbers come back (the host copies of the offsets are made when the gather
+    // partition or fh_pattern's output needs them: host_offsets)
+    HIP_TRY(c, hipcub::DeviceReduce::Max(nullptr, red_bytes, cnt.p, red.p + 1, N + 1, st));
+    if (red_bytes > tmp_bytes) { HIP_TRY(c, tmp.alloc(red_bytes + 16)); tmp_bytes = red_bytes; }
+    HIP_TRY(c, hipcub::DeviceReduce::Max(tmp.p, red_bytes, cnt.p, red.p + 1, N + 1, st));
+    HIP_TRY(c, hipMemcpyAsync(h_red + 1, red.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(h_red + 2, c->noff.p + N, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
-    c->nnz_nodes = c->h_noff[N];
-    c->max_row = 0;
-    for (int i = 0; i < N; ++i) c->max_row = std::max(c->max_row, c->h_noff[i + 1] - c->h_noff[i]);
-    if (c->nnz_nodes >= (1ull << 32) - 1) return c->fail(FH_UNSUPPORTED, "node-level nnz exceeds 2^32");
+    c->h_noff.clear();
+    c->h_n2e_off.clear();
+    c->nnz_nodes = h_red[2];
+    c->max_row = h_red[1];
+    // (a sum beyond 2^32 wraps the 32-bit scan: bounded through the candidates, sum of deg * n = flat_len * n at most)
+    if (c->ragged || (unsigned long long)c->flat_len * (unsigned long long)c->ei.n >= (1ull << 32) - 1) {
+        // exact check on the host for the meshes near the limit
+        std::vector<unsigned> hc((size_t)N + 1);
+        HIP_TRY(c, hipMemcpy(hc.data(), cnt.p, sizeof(unsigned) * ((size_t)N + 1), hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int i = 0; i < N; ++i) tot += hc[i];
+        if (tot >= (1ull << 32) - 1) return c->fail(FH_UNSUPPORTED, "node-level nnz exceeds 2^32");
+    }
     HIP_TRY(c, c->ncols.alloc((size_t)c->nnz_nodes + 1));
-    if (N > 0) {
+    if (once) {
+        hipLaunchKernelGGL(k_compact_neighbors, dim3((N + 255) / 256), dim3(256), 0, st, c->noff.p, rows64.p, N, c->ncols.p);
+        HIP_TRY(c, hipGetLastError());
+    } else if (N > 0) {
         const int g = std::min(N, 256 * 64);
         hipLaunchKernelGGL(k_node_neighbors<true>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, nullptr, c->noff.p,
                            c->ncols.p, flags.p + 1, heavy.p);
@@ -885,6 +931,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
 
 int build_partition(fh_ctx* c) {
     if (c->has_partition) return FH_OK;
+    { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
     // adjacency that drives the numerics: all elements, or only the active ones when a mask is set
     const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
     const unsigned* adj_off_d = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
@@ -1634,6 +1681,7 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     if (max_row >= 65536) return c->fail(FH_UNSUPPORTED, "two-pass gather: node valence too large");
     const unsigned* adj_off = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
     const unsigned* adj = c->has_mask ? c->n2e_c.p : c->n2e.p;
+    { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
     const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
     const long long entries = adj_off_h.empty() ? 0 : (long long)adj_off_h[c->N];
     const bool wide = max_row >= 256;
@@ -2650,6 +2698,8 @@ int fh_pattern(fh_ctx* c, uint64_t* row_offsets, uint64_t* nnz_out) {
     const uint64_t S = (uint64_t)c->S();
     if (nnz_out) *nnz_out = S * S * c->nnz_nodes;
     if (row_offsets) {  // cheap on the host from the node-level offsets
+        rc = host_offsets(c);
+        if (rc) return rc;
         uint64_t r = 0;
         for (uint64_t i = 0; i < c->N; ++i) {
             const uint64_t cnt = c->h_noff[i + 1] - c->h_noff[i];

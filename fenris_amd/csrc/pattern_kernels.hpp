@@ -152,6 +152,61 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
     }
 }
 
+// Fixed-n meshes whose nodes all have at most 64 candidates (hexahedral meshes: 8 x 8): ONE neighbour pass instead of a counting
+// and a filling one.  A wavefront sorts a node's candidates in registers as above and leaves the distinct ones in a scratch row of
+// 64 entries (tmp[node][rank]) together with their number; after the scan of the counts k_compact_neighbors moves the rows to their
+// places.  The candidates of the NEXT node of the wavefront are requested before the current node is sorted.
+__global__ void __launch_bounds__(64) k_node_neighbors_once(const int* nodes, int n, const unsigned* n2e_off, const unsigned* n2e, int num_nodes,
+                                                            unsigned* cnt, unsigned* tmp) {
+    const int lane = threadIdx.x;
+    auto fetch = [&](int node, unsigned& v) {
+        v = 0xffffffffu;
+        if (node >= num_nodes) return;
+        const unsigned b = n2e_off[node], C = (n2e_off[node + 1] - b) * (unsigned)n;
+        if ((unsigned)lane < C) {
+            const unsigned e = n2e[b + (unsigned)lane / (unsigned)n] / (unsigned)n;
+            v = (unsigned)nodes[(size_t)e * n + (unsigned)lane % (unsigned)n];
+        }
+    };
+    int node = blockIdx.x;
+    unsigned v_next;
+    fetch(node, v_next);
+    for (; node < num_nodes; node += gridDim.x) {
+        unsigned v = v_next;
+        fetch(node + gridDim.x, v_next);
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)v, stride, 64);
+                const bool up = ((lane & size) == 0), lower = ((lane & stride) == 0);
+                v = (lower == up) ? min(v, other) : max(v, other);
+            }
+        const unsigned prev = (unsigned)__shfl_up((int)v, 1, 64);
+        const bool keep = (v != 0xffffffffu) && (lane == 0 || v != prev);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) tmp[(size_t)node * 64 + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+        if (lane == 0) cnt[node] = (unsigned)__popcll(mask);
+    }
+}
+// 256 consecutive nodes per workgroup: their rows are one contiguous piece of ncols, written in order (coalesced); the node of
+// an entry by bisection in the workgroup's 257 offsets
+__global__ void __launch_bounds__(256) k_compact_neighbors(const unsigned* noff, const unsigned* tmp, int num_nodes, unsigned* ncols) {
+    __shared__ unsigned off[257];
+    const int n0 = blockIdx.x * 256, nn = min(256, num_nodes - n0);
+    for (int i = threadIdx.x; i <= nn; i += 256) off[i] = noff[n0 + i];
+    __syncthreads();
+    const unsigned first = off[0], last = off[nn];
+    for (unsigned j = first + threadIdx.x; j < last; j += 256) {
+        int lo = 0, hi = nn;            // largest i with off[i] <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= j) lo = mid; else hi = mid;
+        }
+        ncols[j] = tmp[(size_t)(n0 + lo) * 64 + (j - off[lo])];
+    }
+}
+
 // The neighbours of the heavy nodes: one workgroup per node at a time, a bitmap over all nodes in global memory (its own slice per
 // workgroup), bits set by atomics, then counted (FILL == false) or written out in ascending order (FILL == true).
 template <bool FILL>

@@ -508,8 +508,11 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nnz = eng.build_pattern()  # assemble_pattern on the device (secondary metric)
-        E = mesh.num_elements()
+        torch.cuda.synchronize()
+        t_pattern_only = time.perf_counter() - t0   # (the allocation of the values below is not part of the pattern; on a fresh box a first
+        E = mesh.num_elements()                     #  20 GB allocation has taken up to a second: BENCH_r02)
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
     elif cfg in ("c3", "ns-perturbed"):
         # a mesh without planes: element partition elem_to_part[] (Morton order of the centroids), packed interface-row exchange with any
         # number of neighbours (fenris_amd/partition.py); the fixed mesh cut into `world` parts: strong scaling
@@ -548,6 +551,10 @@ def main():
         if rccl is not None and hasattr(slab_asm.exchange, "size"):
             rccl["fh_group_ranks"] = slab_asm.exchange.size()   # ncclCommCount of the library's own communicator
     t_pattern = time.perf_counter() - t0
+    t_values_alloc = None
+    if world == 1:
+        t_values_alloc = t_pattern - t_pattern_only
+        t_pattern = t_pattern_only
     if slab_asm is not None and slab_asm.placement is not None:
         t_pattern -= slab_asm.placement.get("seconds", 0.0)   # the settle / placement probe inside SlabAssembly is reported on its own
     N = mesh.num_nodes()
@@ -620,7 +627,7 @@ def main():
                        "name": cfg, "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
                        "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
-                       "pattern_build_s": t_pattern, "module_warmup_s": t_warm, "placement_probe": placement, "device_settle": settle},
+                       "pattern_build_s": t_pattern, "values_alloc_s": t_values_alloc, "module_warmup_s": t_warm, "placement_probe": placement, "device_settle": settle},
         }
         if world > 1 and layers is None:
             # general partition: who holds what, what rank 0 exchanges, and the same check as for the slabs -- the rows of rank 0's owned

@@ -66,18 +66,29 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
                                                        unsigned* cnt, const unsigned* noff, unsigned* ncols, int* overflow, int* heavy) {
     __shared__ unsigned buf[NEIGH_CAP];
     const int lane = threadIdx.x;
+    // fast path (fixed-n meshes, at most 64 candidates -- e.g. the 8 x 8 of a hexahedral mesh): one candidate per lane.  The loads of a
+    // node are three dependent round trips (offsets -> entry -> node id); the candidates of the wavefront's NEXT node are requested
+    // before the current node is sorted (no gain measured in this two-pass form: 22.9 -> 24.4 ms per build on 216^3; kept for the one-pass form's sake, which has it too)
+    auto fetch = [&](int node, unsigned& b, unsigned& en, unsigned& v) {
+        v = 0xffffffffu;
+        b = en = 0;
+        if (node >= num_nodes) return;
+        b = n2e_off[node];
+        en = n2e_off[node + 1];
+        if (!c.eoff && (en - b) * (unsigned)c.n <= 64u && (unsigned)lane < (en - b) * (unsigned)c.n) {
+            const unsigned e = n2e[b + (unsigned)lane / (unsigned)c.n] / (unsigned)c.n;
+            v = (unsigned)c.nodes[(size_t)e * c.n + (unsigned)lane % (unsigned)c.n];
+        }
+    };
+    unsigned b_n, en_n, v_n;
+    fetch(blockIdx.x, b_n, en_n, v_n);
     for (int node = blockIdx.x; node < num_nodes; node += gridDim.x) {
-        const unsigned b = n2e_off[node], en = n2e_off[node + 1];
+        const unsigned b = b_n, en = en_n;
+        unsigned v = v_n;
+        fetch(node + gridDim.x, b_n, en_n, v_n);
         if (!c.eoff && (en - b) * (unsigned)c.n <= 64u) {
-            // fast path (fixed-n meshes, at most 64 candidates -- e.g. the 8 x 8 of a hexahedral mesh): one candidate per
-            // lane, bitonic sort across the wavefront in registers, no LDS and no barriers.  A degenerate element that
+            // bitonic sort across the wavefront in registers, no LDS and no barriers.  A degenerate element that
             // lists the node twice only duplicates candidates, which the unique step removes.
-            const unsigned C = (en - b) * (unsigned)c.n;
-            unsigned v = 0xffffffffu;
-            if ((unsigned)lane < C) {
-                const unsigned e = n2e[b + (unsigned)lane / (unsigned)c.n] / (unsigned)c.n;
-                v = (unsigned)c.nodes[(size_t)e * c.n + (unsigned)lane % (unsigned)c.n];
-            }
 #pragma unroll
             for (int size = 2; size <= 64; size <<= 1)
 #pragma unroll

@@ -24,5 +24,12 @@ for it in range(3):
     t0 = time.perf_counter()
     nnz = eng.build_pattern()
     torch.cuda.synchronize()
-    print("pattern build %d: %.2f ms (nnz %d)" % (it, 1e3 * (time.perf_counter() - t0), nnz), flush=True)
+    t1 = time.perf_counter()
+    values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("pattern build %d: %.2f ms (nnz %d); torch.zeros(nnz) right after it: %.2f ms" % (it, 1e3 * (t1 - t0), nnz, 1e3 * (t2 - t1)), flush=True)
+    del values
+    if it == 0:
+        torch.cuda.empty_cache()      # the next context sees a fresh allocation of the values again
     eng.close()

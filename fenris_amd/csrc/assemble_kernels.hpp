@@ -1441,6 +1441,10 @@ __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, co
     __shared__ int cand[1024];
     __shared__ int best_blk, best_cnt;
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (cls && cls[b] == 1) {   // an affine block: its kernel sweeps in CSR order, every position a chain of its own (build_partition)
+        if (lane == 0) succ[b] = -1;
+        return;
+    }
     const GatherHdr h = hdr[b];
     const int last = h.i0 + h.nb - 1;
     const int total = min(h.U * N, 1024);

@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -931,7 +932,18 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
 
 int build_partition(fh_ctx* c) {
     if (c->has_partition) return FH_OK;
+    // FENRIS_HIP_VERBOSE: wall time of the stages of this set-up (stream drained at every mark)
+    auto t_last = std::chrono::steady_clock::now();
+    const bool vt = c->env("FENRIS_HIP_VERBOSE") != nullptr;
+    auto mark = [&](const char* what) {
+        if (!vt) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fenris_hip] set-up: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
+    mark("host copies of the offsets");
     // adjacency that drives the numerics: all elements, or only the active ones when a mask is set
     const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
     const unsigned* adj_off_d = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
@@ -1070,6 +1082,7 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(link.data(), link_d.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    mark("row sums, link flags");
     auto fits = [&](int a, int b) {  // nodes [a, b) within the accumulator and entry budgets
         return S * S * ((long long)h_noff[b] - h_noff[a]) <= acc && (long long)adj_off_hh[b] - adj_off_hh[a] <= mb;
     };
@@ -1111,6 +1124,7 @@ int build_partition(fh_ctx* c) {
             i0 = e;
         }
     }
+    mark("cutting the node range (host)");
     c->nblk = (int)blk.size() - 1;
     if (c->nblk <= 0) {  // empty row range: nothing to build, nothing to launch
         c->nblk = 0;
@@ -1170,6 +1184,7 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    mark("block tables (k_build_gather_tables)");
     // staging capacity: all unique elements of the largest block if that fits the LDS budget
     std::vector<GatherHdr> hh((size_t)std::max(c->nblk, 1));
     if (c->nblk) HIP_TRY(c, hipMemcpy(hh.data(), c->gt_hdr.p, sizeof(GatherHdr) * (size_t)c->nblk, hipMemcpyDeviceToHost));
@@ -1210,6 +1225,7 @@ int build_partition(fh_ctx* c) {
         if (us * c->ei.ng <= (rows_special ? 1024 : 512) && us <= 252 && ms <= 256 && (rows_special || (ms * (n / jt) <= 256 && ms * n / 4 <= 256)) && ms <= mb &&
             nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
             const int nblk = c->nblk;
+            mark("headers to the host, staging sizes");
             // Block classes: 1 = every adjacent element is affine, the block runs on k_affine_rows; 0 = general kernels.
             // Chains never mix classes, so each class gets its own sweep order and its own position-indexed tables.
             std::vector<unsigned char> cls((size_t)nblk, 0);
@@ -1225,11 +1241,14 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, hipMemcpyAsync(cls.data(), cls_d.p, (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
             }
+            mark("block classes");
             // sweep order: chains of blocks whose consecutive members share elements (their staged data is reused)
             std::vector<int> order[2], chain_off[2];
             chain_off[0].push_back(0);
             chain_off[1].push_back(0);
-            if (!c->env("FENRIS_HIP_NO_SWEEP")) {
+            // (every block affine -- structured boxes: no chains to form, the affine positions are sorted into CSR order below)
+            const bool all_affine = want_aff && std::find(cls.begin(), cls.end(), (unsigned char)0) == cls.end();
+            if (!c->env("FENRIS_HIP_NO_SWEEP") && !all_affine) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
                 HIP_TRY(c, hipMemsetAsync(node2blk.p, 0xff, sizeof(int) * ((size_t)N + 1), c->stream));  // -1: not in a block
@@ -1254,6 +1273,7 @@ int build_partition(fh_ctx* c) {
             } else {
                 for (int b = 0; b < nblk; ++b) { order[cls[b]].push_back(b); chain_off[cls[b]].push_back((int)order[cls[b]].size()); }
             }
+            mark("successors and chains");
             c->p_cs = us * c->ei.ng;
             c->p_ms = ms;
             c->p_nbs = nb_target;
@@ -1296,12 +1316,14 @@ int build_partition(fh_ctx* c) {
                 DevBuf<int> tmp_rec;  // the pipelined kernel's records: input of the lane builder only
                 int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem, 0);
                 if (rs) return rs;
+                mark("position tables of the affine class (k_build_pipe_tables)");
                 const int npos = (int)order[1].size();
                 c->a_us = us;
                 bool bad = false;
                 rs = build_lane_tables(c, tmp_rec.p, us, ms, nb_target, npos, S, c->a_conn.p, c->a_elem.p, c->a_hdr, c->a_lanes, c->a_ntab,
                                        c->a_incomplete, bad, "affine rows");
                 if (rs) return rs;
+                mark("lane tables of the affine class");
                 if (bad) {  // a block the lane tables cannot express: everything on the general kernels
                     c->aff_failed = true;
                     return build_partition(c);
@@ -1430,6 +1452,7 @@ int build_partition(fh_ctx* c) {
     c->g_acc = acc;
     c->g_nb = 64;
     c->has_partition = true;
+    mark("the rest");
     return FH_OK;
 }
 

@@ -9,6 +9,17 @@ import pytest
 
 HEX_SIGNS = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
 QUAD_SIGNS = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float)
+# reference nodes of the triquadratic hexahedron: corners, edge midpoints, face centres, centre (hexahedron.rs:179-210: a table of data)
+HEX27_NODES = np.array(list(map(tuple, HEX_SIGNS.astype(int))) + [
+    (0, -1, -1), (-1, 0, -1), (-1, -1, 0), (1, 0, -1), (1, -1, 0), (0, 1, -1), (1, 1, 0), (-1, 1, 0), (0, -1, 1), (-1, 0, 1), (1, 0, 1), (0, 1, 1),
+    (0, 0, -1), (0, -1, 0), (-1, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)], dtype=float)
+
+
+def _quad1d(alpha, x):
+    """value and derivative at x of the quadratic Lagrange polynomial of the node alpha in {-1, 0, 1}"""
+    if alpha == 0:
+        return 1.0 - x * x, -2.0 * x
+    return 0.5 * x * (x + alpha), x + 0.5 * alpha
 MU, LAM = 3.0e2, 5.0e2
 
 
@@ -16,6 +27,12 @@ def ref_gradients(kind, xi):
     """(n, d): gradients of the reference basis at xi; reference domains [-1, 1]^d, tetrahedron (-1,-1,-1), (1,-1,-1), (-1,1,-1), (-1,-1,1)"""
     if kind == "TET4":
         return np.array([[-0.5, -0.5, -0.5], [0.5, 0, 0], [0, 0.5, 0], [0, 0, 0.5]])
+    if kind == "HEX27":
+        g = np.empty((27, 3))
+        for n, node in enumerate(HEX27_NODES):
+            v, dv = zip(*[_quad1d(node[k], xi[k]) for k in range(3)])
+            g[n] = [dv[0] * v[1] * v[2], v[0] * dv[1] * v[2], v[0] * v[1] * dv[2]]
+        return g
     sg = HEX_SIGNS if kind == "HEX8" else QUAD_SIGNS
     d = sg.shape[1]
     f = 1.0 + sg * np.asarray(xi)[None, :]                      # (n, d): the one-dimensional factors times 2
@@ -29,8 +46,8 @@ def ref_gradients(kind, xi):
 def rule(kind, oracle):
     if kind == "TET4":
         return oracle.tetrahedron_rule(2)
-    x, w = np.polynomial.legendre.leggauss(2)
-    d = 3 if kind == "HEX8" else 2
+    x, w = np.polynomial.legendre.leggauss(3 if kind == "HEX27" else 2)
+    d = 2 if kind == "QUAD4" else 3
     grids = np.meshgrid(*([x] * d), indexing="ij")
     pts = np.stack([g.reshape(-1) for g in grids], axis=1)
     wts = np.prod(np.stack([g.reshape(-1) for g in np.meshgrid(*([w] * d), indexing="ij")], axis=1), axis=1)
@@ -85,7 +102,10 @@ def restate(kind, op, verts, conn, w, pts, u):
         U = u.reshape(-1, s)[nodes]                             # (n, s)
         for wq, xi in zip(w, pts):
             G = ref_gradients(kind, xi)                         # (n, d)
-            Jm = X.T @ G                                        # J[i][j] = sum_n x_n[i] d phi_n / d xi_j
+            if kind == "HEX27":                                 # sub-parametric: the geometry is the trilinear map of the eight corners
+                Jm = X[:8].T @ ref_gradients("HEX8", xi)        # (hexahedron.rs:324-326)
+            else:
+                Jm = X.T @ G                                    # J[i][j] = sum_n x_n[i] d phi_n / d xi_j
             g = G @ np.linalg.inv(Jm)                           # (n, d): physical gradients  J^-T ghat
             scale = wq * abs(np.linalg.det(Jm))
             gu = g.T @ U                                        # (d, s): grad u = sum_n g_n u_n^T
@@ -100,6 +120,12 @@ def restate(kind, op, verts, conn, w, pts, u):
 
 
 def small_mesh(kind, oracle, rng):
+    if kind == "HEX27":
+        v8, c8 = oracle.hex_mesh(1.0, 1, 1, 2, 1)
+        v8 = np.asarray(v8, dtype=float).reshape(-1, 3)
+        v8 = v8 + 0.08 * rng.uniform(-1, 1, v8.shape)              # (the corners carry the geometry; the other nodes follow)
+        v, c = oracle.hex8_to_hex27(v8, c8)
+        return np.asarray(v, dtype=float).reshape(-1, 3), np.asarray(c).astype(np.int64)
     if kind == "HEX8":
         v, c = oracle.hex_mesh(1.0, 2, 2, 1, 1)
         h = 1.0
@@ -113,8 +139,8 @@ def small_mesh(kind, oracle, rng):
     return v + 0.08 * h * rng.uniform(-1, 1, v.shape), np.asarray(c).astype(np.int64)
 
 
-@pytest.mark.parametrize("kind", ["HEX8", "TET4", "QUAD4"])
-@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK"])
+@pytest.mark.parametrize("kind,op", [(k, o) for k in ("HEX8", "TET4", "QUAD4") for o in ("LAPLACE", "LINEAR_ELASTIC", "NEO_HOOKEAN", "STVK")] +
+                         [("HEX27", "LINEAR_ELASTIC"), ("HEX27", "NEO_HOOKEAN")])
 def test_oracle_agrees_with_an_independent_numpy_restatement(oracle, kind, op):
     rng = np.random.default_rng(abs(hash((kind, op))) % 1000)
     verts, conn = small_mesh(kind, oracle, rng)

@@ -395,7 +395,8 @@ hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long l
                               int* bad) {
     *bad = 0;
     out->release();
-    if (E <= 0 || n < 1 || n > 8 || D < 1 || D > 3 || num_nodes <= 0 || E > 0x7fffff00ll) { *bad = 1; return hipSuccess; }
+    // (the partial sums are counted in 32 bits: at most E n of them)
+    if (E <= 0 || n < 1 || n > 8 || D < 1 || D > 3 || num_nodes <= 0 || E > 0x7fffff00ll || (unsigned long long)E * (unsigned)n >= (1ull << 32) - 256) { *bad = 1; return hipSuccess; }
     const int T = (int)((E + 255) / 256);
     void* tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto cleanup = [&]() {

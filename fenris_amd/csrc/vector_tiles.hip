@@ -29,6 +29,8 @@ namespace fenris_hip {
 
 namespace {
 
+constexpr int VT_TS = 256;   // elements per tile = threads per workgroup of the element pass (the kernels take it as a template parameter)
+
 struct Box3 { double lo[3], scale[3]; };
 
 __global__ void __launch_bounds__(256) k_vt_bbox(const double* verts, int num_nodes, int D, double* out /* [grid][6] */) {
@@ -85,10 +87,10 @@ __global__ void __launch_bounds__(256) k_vt_morton(const int* conn, int n, long 
 }
 
 template <typename T>
-__device__ __forceinline__ void vt_bitonic_sort(T* d, int M) {   // ascending, M a power of two, 256 threads
+__device__ __forceinline__ void vt_bitonic_sort(T* d, int M, int nthreads) {   // ascending, M a power of two
     for (int k = 2; k <= M; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < M; i += 256) {
+            for (int i = threadIdx.x; i < M; i += nthreads) {
                 const int o = i ^ j;
                 if (o > i) {
                     const T x = d[i], y = d[o];
@@ -102,33 +104,33 @@ __device__ __forceinline__ void vt_bitonic_sort(T* d, int M) {   // ascending, M
 constexpr unsigned long long VT_PAD = ~0ull;
 
 // one workgroup per tile.  FILL = false: number of distinct nodes of the tile;  FILL = true: all tables of the tile
-template <bool FILL>
-__global__ void __launch_bounds__(256) k_vt_tile_tables(const int* order, long long E, const int* conn, int n, unsigned* tile_cnt, const unsigned* noff,
+template <bool FILL, int TS>
+__global__ void __launch_bounds__(TS) k_vt_tile_tables(const int* order, long long E, const int* conn, int n, unsigned* tile_cnt, const unsigned* noff,
                                                         int* elem, int* tconn, unsigned short* la_off, unsigned short* la, unsigned* p_node) {   // p_node: global node of every partial
-    __shared__ unsigned long long key[2048];
-    __shared__ unsigned scan[256];
+    __shared__ unsigned long long key[TS * 8];
+    __shared__ unsigned scan[TS];
     const int tile = blockIdx.x, t = threadIdx.x;
-    const long long idx = (long long)tile * 256 + t;
+    const long long idx = (long long)tile * TS + t;
     key[t] = idx < E ? (unsigned long long)(unsigned)order[idx] : VT_PAD;
     __syncthreads();
-    vt_bitonic_sort(key, 256);                                  // elements ascending inside the tile
+    vt_bitonic_sort(key, TS, TS);                                  // elements ascending inside the tile
     const long long el = key[t] == VT_PAD ? -1 : (long long)key[t];
     __syncthreads();
     if (FILL) elem[idx] = (int)el;
-    const int M = 256 * n;                                       // <= 2048 entries thread n + a
+    const int M = TS * n;                                       // <= 2048 entries thread n + a
     // (threads without an element read the tile's first element: the kernel computes on every lane and drops their results)
     const long long er = el >= 0 ? el : (long long)key[0];
     for (int a = 0; a < n; ++a) {
         const int node = conn[(size_t)er * n + a];
-        if (FILL) tconn[((size_t)tile * n + a) * 256 + t] = node;
+        if (FILL) tconn[((size_t)tile * n + a) * TS + t] = node;
     }
     __syncthreads();
-    for (int i = t; i < 2048; i += 256) key[i] = VT_PAD;
+    for (int i = t; i < TS * 8; i += TS) key[i] = VT_PAD;
     __syncthreads();
     if (el >= 0)
         for (int a = 0; a < n; ++a) key[t * n + a] = ((unsigned long long)(unsigned)conn[(size_t)el * n + a] << 11) | (unsigned)(t * n + a);
     __syncthreads();
-    vt_bitonic_sort(key, 2048);                                 // by node, then by entry; the padding last
+    vt_bitonic_sort(key, TS * 8, TS);                                 // by node, then by entry; the padding last
     // heads of the runs of equal nodes: eight consecutive places per thread, then a scan over the threads
     unsigned heads = 0, nvalid = 0;
     for (int j = 0; j < 8; ++j) {
@@ -141,13 +143,13 @@ __global__ void __launch_bounds__(256) k_vt_tile_tables(const int* order, long l
     }
     scan[t] = heads;
     __syncthreads();
-    for (int s = 1; s < 256; s <<= 1) {
+    for (int s = 1; s < TS; s <<= 1) {
         const unsigned v = t >= s ? scan[t - s] : 0u;
         __syncthreads();
         scan[t] += v;
         __syncthreads();
     }
-    const unsigned U = scan[255];
+    const unsigned U = scan[TS - 1];
     if (!FILL) {
         if (t == 0) tile_cnt[tile] = U;
         return;
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(256) k_vt_tile_tables(const int* order, long l
     __syncthreads();
     scan[t] = nvalid;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = TS / 2; s > 0; s >>= 1) {
         if (t < s) scan[t] += scan[t + s];
         __syncthreads();
     }
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) k_vt_sort_lists(const unsigned* np_off, u
 // ---- the element pass over tiles
 // what a tile's workgroup needs for the node sums, requested before the arithmetic and landing behind it: the tile's entries (256 N
 // sixteen-bit values: N / 4 eight-byte pieces per thread) and the starts of the first 512 distinct nodes
-template <int N>
+template <int N, int TS>
 struct TileSums {
     static constexpr int EW = (N * 2 + 7) / 8;
     unsigned base, U;
@@ -218,14 +220,14 @@ struct TileSums {
         base = t.noff[tile];
         U = t.noff[tile + 1] - base;
         lo = t.la_off + base + tile;
-        const uint2* la8 = reinterpret_cast<const uint2*>(t.la + (size_t)tile * (256 * N));   // (256 N x 2 bytes per tile: 8-byte aligned for even N)
+        const uint2* la8 = reinterpret_cast<const uint2*>(t.la + (size_t)tile * (TS * N));   // (TS N x 2 bytes per tile: 8-byte aligned for even N)
         if constexpr (N % 4 == 0) {
 #pragma unroll
-            for (int w = 0; w < EW; ++w) ent_w[w] = la8[w * 256 + tid];
+            for (int w = 0; w < EW; ++w) ent_w[w] = la8[w * TS + tid];
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned p = tid + 256 * j;
+            const unsigned p = tid + TS * j;
             st0[j] = st1[j] = 0;
             if (p < U) { st0[j] = lo[p]; st1[j] = lo[p + 1]; }
         }
@@ -236,10 +238,10 @@ struct TileSums {
         if constexpr (N % 4 == 0) {
             uint2* e8 = reinterpret_cast<uint2*>(ents);
 #pragma unroll
-            for (int w = 0; w < EW; ++w) e8[w * 256 + tid] = ent_w[w];
+            for (int w = 0; w < EW; ++w) e8[w * TS + tid] = ent_w[w];
         }
         __syncthreads();
-        const unsigned short* la = t.la + (size_t)tile * (256 * N);
+        const unsigned short* la = t.la + (size_t)tile * (TS * N);
         auto sum_node = [&](unsigned p, unsigned k0, unsigned k1) {
             double acc[SV];
 #pragma unroll
@@ -247,30 +249,30 @@ struct TileSums {
             for (unsigned k = k0; k < k1; ++k) {
                 const unsigned ent = (N % 4 == 0) ? ents[k] : la[k], tt = ent / (unsigned)N, aa = ent - tt * (unsigned)N;
 #pragma unroll
-                for (int c = 0; c < SV; ++c) acc[c] += stage[(aa * SV + c) * 256 + tt];
+                for (int c = 0; c < SV; ++c) acc[c] += stage[(aa * SV + c) * TS + tt];
             }
 #pragma unroll
             for (int c = 0; c < SV; ++c) partial[(size_t)(base + p) * SV + c] = acc[c];
         };
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned p = tid + 256 * j;
+            const unsigned p = tid + TS * j;
             if (p < U) sum_node(p, st0[j], st1[j]);
         }
-        for (unsigned p = tid + 512; p < U; p += 256) sum_node(p, lo[p], lo[p + 1]);   // (tiles of scattered elements)
+        for (unsigned p = tid + 2 * TS; p < U; p += TS) sum_node(p, lo[p], lo[p + 1]);   // (tiles of scattered elements)
     }
 };
 
-template <int EK, int OP>
-__global__ void __launch_bounds__(256) k_element_pass_tiled(const KArgs a, const VecTiles t, const unsigned char* active, double* partial) {
+template <int EK, int OP, int TS>
+__global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const VecTiles t, const unsigned char* active, double* partial) {
     constexpr int N = EPDims<EK, OP, EP_VECTOR>::N, S = EPDims<EK, OP, EP_VECTOR>::S, D = EPDims<EK, OP, EP_VECTOR>::D;
-    __shared__ double stage[N * S * 256];
-    __shared__ unsigned short ents[(N % 4 == 0) ? 256 * N : 4];
+    __shared__ double stage[N * S * TS];
+    __shared__ unsigned short ents[(N % 4 == 0) ? TS * N : 4];
     const int tile = blockIdx.x, tid = threadIdx.x;
-    const int el = t.elem[(size_t)tile * 256 + tid];
+    const int el = t.elem[(size_t)tile * TS + tid];
     const bool live = el >= 0 && (!active || active[el] != 0);
     const long long ec = el >= 0 ? el : 0;
-    TileSums<N> ts;
+    TileSums<N, TS> ts;
     ts.request(t, tile, tid);
     // the tile's connectivity comes from a table laid out by tile thread (tconn[tile][a][thread]: coalesced, and not behind the load
     // of the element id)
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) k_element_pass_tiled(const KArgs a, const
     {
         int nd[N];
 #pragma unroll
-        for (int n = 0; n < N; ++n) nd[n] = t.tconn[((size_t)tile * N + n) * 256 + tid];
+        for (int n = 0; n < N; ++n) nd[n] = t.tconn[((size_t)tile * N + n) * TS + tid];
 #pragma unroll
         for (int n = 0; n < N; ++n) {
 #pragma unroll
@@ -296,27 +298,27 @@ __global__ void __launch_bounds__(256) k_element_pass_tiled(const KArgs a, const
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
-        for (int c = 0; c < S; ++c) stage[(n * S + c) * 256 + tid] = live ? f[n][c] : 0.0;   // (select: a skipped element may hold NaN)
+        for (int c = 0; c < S; ++c) stage[(n * S + c) * TS + tid] = live ? f[n][c] : 0.0;   // (select: a skipped element may hold NaN)
     if (a.ablate & 64) return;   // (profiling: the element phase alone)
     ts.template sum<S>(t, tile, tid, stage, ents, partial);
 }
 
 // source vector (local/source.rs:159-278) over the same tiles: source_element_body per thread, the tile's node sums, partials
-template <int D, int S, int N, bool FACT>
-__global__ void __launch_bounds__(256) k_source_elements_tiled(const KArgs a, const SourceG g, const double* values, const VecTiles t,
+template <int D, int S, int N, bool FACT, int TS>
+__global__ void __launch_bounds__(TS) k_source_elements_tiled(const KArgs a, const SourceG g, const double* values, const VecTiles t,
                                                                const unsigned char* active, double* partial) {
     constexpr int SF = FACT ? 1 : S;
-    __shared__ double stage[N * SF * 256];
-    __shared__ unsigned short ents[(N % 4 == 0) ? 256 * N : 4];
+    __shared__ double stage[N * SF * TS];
+    __shared__ unsigned short ents[(N % 4 == 0) ? TS * N : 4];
     const int tile = blockIdx.x, tid = threadIdx.x;
-    const int el = t.elem[(size_t)tile * 256 + tid];
+    const int el = t.elem[(size_t)tile * TS + tid];
     const bool live = el >= 0 && (!active || active[el] != 0);
-    TileSums<N> ts;
+    TileSums<N, TS> ts;
     ts.request(t, tile, tid);
     double X[N][D];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-        const int nd = t.tconn[((size_t)tile * N + n) * 256 + tid];
+        const int nd = t.tconn[((size_t)tile * N + n) * TS + tid];
 #pragma unroll
         for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd * D + i];
     }
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(256) k_source_elements_tiled(const KArgs a, co
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
-        for (int c = 0; c < SF; ++c) stage[(n * SF + c) * 256 + tid] = live ? f[n][c] : 0.0;
+        for (int c = 0; c < SF; ++c) stage[(n * SF + c) * TS + tid] = live ? f[n][c] : 0.0;
     ts.template sum<SF>(t, tile, tid, stage, ents, partial);
 }
 
@@ -393,11 +395,13 @@ void VecTilesStore::release() {
 
 hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long long E, const double* verts, int D, int num_nodes, VecTilesStore* out,
                               int* bad) {
+    int ts = VT_TS;
     *bad = 0;
     out->release();
     // (the partial sums are counted in 32 bits: at most E n of them)
     if (E <= 0 || n < 1 || n > 8 || D < 1 || D > 3 || num_nodes <= 0 || E > 0x7fffff00ll || (unsigned long long)E * (unsigned)n >= (1ull << 32) - 256) { *bad = 1; return hipSuccess; }
-    const int T = (int)((E + 255) / 256);
+    // (128-element tiles, two wavefronts per workgroup and four workgroups per CU, were measured: 1.33 against 1.28 ms for the residual of Hex8 216^3)
+    const int T = (int)((E + ts - 1) / ts);
     void* tmp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto cleanup = [&]() {
         for (void*& p : tmp) {
@@ -442,14 +446,14 @@ hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long l
     unsigned* tile_cnt = (unsigned*)k_in;     // T + 1 <= E + 1 entries of 4 bytes fit (E >= 1: 8 bytes per key)
     int* elem = nullptr;
     unsigned* noff = nullptr;
-    if (vt_alloc(out, 0, &elem, (size_t)T * 256) != hipSuccess || vt_alloc(out, 1, &noff, (size_t)T + 1) != hipSuccess) { cleanup(); out->release(); return hipErrorOutOfMemory; }
+    if (vt_alloc(out, 0, &elem, (size_t)T * ts) != hipSuccess || vt_alloc(out, 1, &noff, (size_t)T + 1) != hipSuccess) { cleanup(); out->release(); return hipErrorOutOfMemory; }
     if ((size_t)(T + 1) * sizeof(unsigned) > sizeof(unsigned long long) * (size_t)E) {   // (tiny meshes)
         (void)hipFree(tmp[1]); tmp[1] = nullptr;
         VT_TRY(hipMalloc(&tmp[1], sizeof(unsigned) * ((size_t)T + 1)));
         tile_cnt = (unsigned*)tmp[1];
     }
     VT_TRY(hipMemsetAsync(tile_cnt, 0, sizeof(unsigned) * ((size_t)T + 1), stream));
-    hipLaunchKernelGGL(k_vt_tile_tables<false>, dim3(T), dim3(256), 0, stream, v_out, E, conn, n, tile_cnt, (const unsigned*)nullptr, (int*)nullptr,
+    hipLaunchKernelGGL((k_vt_tile_tables<false, VT_TS>), dim3(T), dim3(VT_TS), 0, stream, v_out, E, conn, n, tile_cnt, (const unsigned*)nullptr, (int*)nullptr,
                        (int*)nullptr, (unsigned short*)nullptr, (unsigned short*)nullptr, (unsigned*)nullptr);
     size_t scan_bytes = 0;
     VT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, tile_cnt, noff, T + 1, stream));
@@ -465,15 +469,15 @@ hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long l
     unsigned short *la_off = nullptr, *la = nullptr;
     int* tconn = nullptr;
     unsigned *np_off = nullptr, *np_idx = nullptr, *p_node = nullptr;
-    hipError_t e = vt_alloc(out, 2, &tconn, (size_t)T * n * 256);
+    hipError_t e = vt_alloc(out, 2, &tconn, (size_t)T * n * ts);
     if (e == hipSuccess) e = vt_alloc(out, 3, &la_off, (size_t)P + T + 1);
-    if (e == hipSuccess) e = vt_alloc(out, 4, &la, (size_t)T * n * 256);
+    if (e == hipSuccess) e = vt_alloc(out, 4, &la, (size_t)T * n * ts);
     if (e == hipSuccess) e = vt_alloc(out, 5, &np_off, (size_t)num_nodes + 1);
     if (e == hipSuccess) e = vt_alloc(out, 6, &np_idx, (size_t)P);
     if (e != hipSuccess) { cleanup(); out->release(); return e; }
     if (vt_alloc(out, 7, &p_node, (size_t)P + 1) != hipSuccess) { cleanup(); out->release(); return hipErrorOutOfMemory; }
     (void)hipFree(tmp[2]); tmp[2] = nullptr;
-    hipLaunchKernelGGL(k_vt_tile_tables<true>, dim3(T), dim3(256), 0, stream, v_out, E, conn, n, tile_cnt, (const unsigned*)noff, elem, tconn, la_off, la, p_node);
+    hipLaunchKernelGGL((k_vt_tile_tables<true, VT_TS>), dim3(T), dim3(VT_TS), 0, stream, v_out, E, conn, n, tile_cnt, (const unsigned*)noff, elem, tconn, la_off, la, p_node);
     // node -> partials
     unsigned *deg = nullptr, *cursor = nullptr;
     VT_TRY(hipMalloc(&tmp[7], sizeof(unsigned) * 2 * ((size_t)num_nodes + 1)));
@@ -492,7 +496,7 @@ hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long l
     VT_TRY(hipStreamSynchronize(stream));
     VT_TRY(hipGetLastError());
     cleanup();
-    out->v = VecTiles{elem, tconn, noff, la_off, la, np_off, np_idx, p_node, T, n, P};
+    out->v = VecTiles{elem, tconn, noff, la_off, la, np_off, np_idx, p_node, T, n, P, ts};
     return hipSuccess;
 }
 
@@ -500,10 +504,10 @@ int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const K
     int rs = -1;
 #define VT_OP(EKC)                                                                                                                                   \
     switch (op) {                                                                                                                                    \
-        case FH_LAPLACE: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LAPLACE>), dim3(t.ntiles), dim3(256), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LINEAR_ELASTIC>), dim3(t.ntiles), dim3(256), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_NEO_HOOKEAN>), dim3(t.ntiles), dim3(256), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_STVK: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_STVK>), dim3(t.ntiles), dim3(256), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_LAPLACE: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LAPLACE, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LINEAR_ELASTIC, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_NEO_HOOKEAN, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_STVK: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_STVK, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
         default: break;                                                                                                                              \
     }
     switch (elem_kind) {
@@ -523,8 +527,8 @@ int vector_tiles_source_pass(int D, int sdim, int n, bool fact, hipStream_t stre
     int rs = 0;
 #define VT_SRC(DV, SV, NV)                                                                                                                              \
     do {                                                                                                                                                \
-        if (fact) hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, true>), dim3(t.ntiles), dim3(256), 0, stream, a, g, values, t, active, partial); \
-        else hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, false>), dim3(t.ntiles), dim3(256), 0, stream, a, g, values, t, active, partial);    \
+        if (fact) hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, true, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, g, values, t, active, partial); \
+        else hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, false, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, g, values, t, active, partial);    \
     } while (0)
     if (D == 2 && n == 4) { if (sdim == 1) VT_SRC(2, 1, 4); else VT_SRC(2, 2, 4); }
     else if (D == 2 && n == 3) { if (sdim == 1) VT_SRC(2, 1, 3); else VT_SRC(2, 2, 3); }

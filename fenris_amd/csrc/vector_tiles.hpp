@@ -7,7 +7,6 @@
 
 namespace fenris_hip {
 
-constexpr int VT_TILE = 256;   // elements per tile = threads per workgroup of the element pass
 
 // device tables of one mesh (T tiles, P partial node sums, n nodes per element)
 struct VecTiles {
@@ -21,6 +20,7 @@ struct VecTiles {
     const unsigned* nodes;         // [P]             global node of every partial (a tile's distinct nodes, ascending)
     int ntiles, n;
     unsigned npartials;
+    int ts;                        // elements per tile = threads per workgroup of the element pass
 };
 
 struct VecTilesStore {

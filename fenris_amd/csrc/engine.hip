@@ -1352,6 +1352,7 @@ int build_partition(fh_ctx* c) {
             if (!order[0].empty()) {
                 int rs = build_set(order[0], chain_off[0], c->p_rec, c->p_conn, c->p_elem, hrows_cand ? 1 : 0);
                 if (rs) return rs;
+                mark("position tables of the general class");
             }
             c->has_pipe = true;
             if (c->env("FENRIS_HIP_VERBOSE"))
@@ -1390,6 +1391,7 @@ int build_partition(fh_ctx* c) {
                     c->has_hrows = true;
                 }
                 c->h_hdr.release();   // folded into the position records
+                mark("lane tables of the general class (hex8 rows)");
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] row-owner lanes (Hex8, general positions): %s\n", c->has_hrows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
@@ -1417,6 +1419,7 @@ int build_partition(fh_ctx* c) {
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     if (bad != 2) break;  // 2: only the stride was too small
                 }
+                mark("row lanes (Tet4)");
                 if (bad == 0) {   // the position's unique vertices and the slot words that index them
                     HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                     HIP_TRY(c, c->r_vconn.alloc((size_t)npg * (ROWS_TET4_VMAX + us)));
@@ -1427,6 +1430,7 @@ int build_partition(fh_ctx* c) {
                 }
                 c->has_rows = bad == 0;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));  // row_real is released at the end of this scope
+                mark("row vertices (Tet4)");
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, stride %d): %s\n", c->r_ls,
                                  c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");

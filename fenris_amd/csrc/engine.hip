@@ -584,43 +584,38 @@ int build_pattern(fh_ctx* c) {
     const int N = (int)c->N;
     hipStream_t st = c->stream;
     ConnView cv{c->conn.p, c->ragged ? c->eoff.p : nullptr, c->ragged ? c->k2e.p : nullptr, c->ei.n, (long long)c->flat_len, nullptr};
-    DevBuf<unsigned> deg, cursor, cnt;
-    DevBuf<int> flags;
-    HIP_TRY(c, deg.alloc((size_t)N + 1));
-    HIP_TRY(c, cursor.alloc((size_t)N + 1));
-    HIP_TRY(c, cnt.alloc((size_t)N + 1));
-    HIP_TRY(c, flags.alloc(2));
+    // the temporaries of the build in ONE allocation (degrees, cursors, counts, flags, heavy-node list, reduction results, hipcub's
+    // scratch): on the reference's small benchmark meshes (benches/assembly.rs:147-241: 1 500 ... 96 000 tetrahedra) a dozen hipMalloc /
+    // hipFree pairs were most of the build
+    size_t scan_bytes = 0, red_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned*)nullptr, (unsigned*)nullptr, N + 1, st));
+    HIP_TRY(c, hipcub::DeviceReduce::Max(nullptr, red_bytes, (unsigned*)nullptr, (unsigned*)nullptr, N + 1, st));
+    size_t tmp_bytes = std::max(scan_bytes, red_bytes) + 16;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t n1 = al(sizeof(unsigned) * ((size_t)N + 1)), zeroed = 3 * n1 + al(2 * sizeof(int));
+    DevBuf<char> arena;
+    HIP_TRY(c, arena.alloc(zeroed + al(sizeof(int) * HEAVY_CAP) + al(4 * sizeof(unsigned)) + al(tmp_bytes)));
+    struct { unsigned* p; } deg{reinterpret_cast<unsigned*>(arena.p)}, cursor{reinterpret_cast<unsigned*>(arena.p + n1)},
+        cnt{reinterpret_cast<unsigned*>(arena.p + 2 * n1)}, red{reinterpret_cast<unsigned*>(arena.p + zeroed + al(sizeof(int) * HEAVY_CAP))};
+    struct { int* p; } flags{reinterpret_cast<int*>(arena.p + 3 * n1)}, heavy{reinterpret_cast<int*>(arena.p + zeroed)};
+    struct { char* p; } tmp{arena.p + zeroed + al(sizeof(int) * HEAVY_CAP) + al(4 * sizeof(unsigned))};
     HIP_TRY(c, c->n2e_off.alloc((size_t)N + 1));
     HIP_TRY(c, c->noff.alloc((size_t)N + 1));
-    HIP_TRY(c, hipMemsetAsync(deg.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
-    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
-    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, sizeof(unsigned) * ((size_t)N + 1), st));
-    HIP_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(int) * 2, st));
+    HIP_TRY(c, hipMemsetAsync(arena.p, 0, zeroed, st));
     if (c->flat_len > 0)
         hipLaunchKernelGGL(k_count_degree, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, deg.p, N, flags.p);
     // exclusive scan over N+1 entries (last = total)
-    size_t tmp_bytes = 0;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, deg.p, c->n2e_off.p, N + 1, st));
-    DevBuf<char> tmp;
-    HIP_TRY(c, tmp.alloc(tmp_bytes + 16));
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, deg.p, c->n2e_off.p, N + 1, st));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, deg.p, c->n2e_off.p, N + 1, st));
     HIP_TRY(c, c->n2e.alloc((size_t)c->flat_len + 1));
     if (c->flat_len > 0) {
         hipLaunchKernelGGL(k_fill_n2e, dim3(grid_for((long long)c->flat_len, 256)), dim3(256), 0, st, cv, c->n2e_off.p, cursor.p,
                            c->n2e.p, N);
         hipLaunchKernelGGL(k_sort_n2e, dim3(grid_for(N, 256, 1 << 30)), dim3(256), 0, st, c->n2e_off.p, c->n2e.p, N);
     }
-    DevBuf<int> heavy;
     DevBuf<unsigned> heavy_bits;
     int nheavy = 0, heavy_grid = 0;
     const int heavy_words = (N + 31) / 32;
-    HIP_TRY(c, heavy.alloc(HEAVY_CAP));
     // largest number of elements at a node (one more scan-sized reduction): decides between one neighbour pass and two
-    DevBuf<unsigned> red;
-    HIP_TRY(c, red.alloc(4));
-    size_t red_bytes = 0;
-    HIP_TRY(c, hipcub::DeviceReduce::Max(nullptr, red_bytes, deg.p, red.p, N + 1, st));
-    if (red_bytes > tmp_bytes) { HIP_TRY(c, tmp.alloc(red_bytes + 16)); tmp_bytes = red_bytes; }
     HIP_TRY(c, hipcub::DeviceReduce::Max(tmp.p, red_bytes, deg.p, red.p, N + 1, st));
     unsigned h_red[4] = {0, 0, 0, 0};
     int h_flags[2] = {0, 0};
@@ -628,15 +623,29 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(h_flags, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
-    const bool once = N > 0 && !c->ragged && (unsigned long long)h_red[0] * (unsigned)c->ei.n <= 64ull && !c->env("FENRIS_HIP_PATTERN_TWO_PASSES");
+    const unsigned long long max_cand = (unsigned long long)h_red[0] * (unsigned)c->ei.n;
+    bool once = N > 0 && !c->ragged && max_cand <= 128ull && !c->env("FENRIS_HIP_PATTERN_TWO_PASSES");
     DevBuf<unsigned> rows64;
     if (once) {
-        // every node has at most 64 candidates (fixed-n mesh): one neighbour pass into scratch rows, scan, compaction (pattern_kernels.hpp)
+        // every node has at most 64 (hexahedra) or 128 (tetrahedra: two per lane) candidates: one neighbour pass into scratch rows of 64
+        // distinct neighbours, scan, compaction (pattern_kernels.hpp); a node with more than 64 distinct ones sends the build to the two passes
         HIP_TRY(c, rows64.alloc((size_t)N * 64));
         const int g = std::min(N, 256 * 64);
-        hipLaunchKernelGGL(k_node_neighbors_once, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p);
+        if (max_cand <= 64ull) hipLaunchKernelGGL(k_node_neighbors_once<1>, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p, flags.p + 1);
+        else hipLaunchKernelGGL(k_node_neighbors_once<2>, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p, flags.p + 1);
         HIP_TRY(c, hipGetLastError());
-    } else if (N > 0) {
+        if (max_cand > 64ull) {
+            int over = 0;
+            HIP_TRY(c, hipMemcpyAsync(&over, flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (over) {
+                once = false;
+                rows64.release();
+                HIP_TRY(c, hipMemsetAsync(flags.p + 1, 0, sizeof(int), st));
+            }
+        }
+    }
+    if (!once && N > 0) {
         const int g = std::min(N, 256 * 64);
         hipLaunchKernelGGL(k_node_neighbors<false>, dim3(g), dim3(64), 0, st, cv, c->n2e_off.p, c->n2e.p, N, cnt.p, nullptr,
                            nullptr, flags.p + 1, heavy.p);
@@ -652,14 +661,9 @@ int build_pattern(fh_ctx* c) {
             HIP_TRY(c, hipGetLastError());
         }
     }
-    size_t tmp2 = 0;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, cnt.p, c->noff.p, N + 1, st));
-    if (tmp2 > tmp_bytes) { HIP_TRY(c, tmp.alloc(tmp2 + 16)); tmp_bytes = tmp2; }
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp2, cnt.p, c->noff.p, N + 1, st));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, cnt.p, c->noff.p, N + 1, st));
     // the longest row and the number of entries: two numbers come back (the host copies of the offsets are made when the gather
     // partition or fh_pattern's output needs them: host_offsets)
-    HIP_TRY(c, hipcub::DeviceReduce::Max(nullptr, red_bytes, cnt.p, red.p + 1, N + 1, st));
-    if (red_bytes > tmp_bytes) { HIP_TRY(c, tmp.alloc(red_bytes + 16)); tmp_bytes = red_bytes; }
     HIP_TRY(c, hipcub::DeviceReduce::Max(tmp.p, red_bytes, cnt.p, red.p + 1, N + 1, st));
     HIP_TRY(c, hipMemcpyAsync(h_red + 1, red.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(h_red + 2, c->noff.p + N, sizeof(unsigned), hipMemcpyDeviceToHost, st));

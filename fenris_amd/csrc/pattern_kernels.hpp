@@ -163,41 +163,86 @@ __global__ void __launch_bounds__(64) k_node_neighbors(ConnView c, const unsigne
     }
 }
 
-// Fixed-n meshes whose nodes all have at most 64 candidates (hexahedral meshes: 8 x 8): ONE neighbour pass instead of a counting
-// and a filling one.  A wavefront sorts a node's candidates in registers as above and leaves the distinct ones in a scratch row of
-// 64 entries (tmp[node][rank]) together with their number; after the scan of the counts k_compact_neighbors moves the rows to their
-// places.  The candidates of the NEXT node of the wavefront are requested before the current node is sorted.
+// 128 keys across a wavefront, two per lane (key i = 64 w + lane in vw), ascending: the bitonic network of the 64-key form with the
+// stride-64 exchange done inside the lane
+__device__ __forceinline__ void wave_sort128(unsigned& v0, unsigned& v1, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 128; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {   // (size == 128: ascending everywhere)
+                const unsigned lo = min(v0, v1), hi = max(v0, v1);
+                v0 = lo;
+                v1 = hi;
+            } else {
+                const unsigned o0 = (unsigned)__shfl_xor((int)v0, stride, 64), o1 = (unsigned)__shfl_xor((int)v1, stride, 64);
+                const bool lower = ((lane & stride) == 0);
+                const bool up0 = size == 128 ? true : ((lane & size) == 0);
+                const bool up1 = size == 128 ? true : (((64 + lane) & size) == 0);
+                v0 = (lower == up0) ? min(v0, o0) : max(v0, o0);
+                v1 = (lower == up1) ? min(v1, o1) : max(v1, o1);
+            }
+        }
+}
+
+// Fixed-n meshes whose nodes all have at most 64 W candidates (W = 1: hexahedral meshes, 8 x 8; W = 2: tetrahedral meshes, ~24 x 4): ONE
+// neighbour pass instead of a counting and a filling one.  A wavefront sorts a node's candidates in registers and leaves the distinct
+// ones in a scratch row of 64 entries (tmp[node][rank]) together with their number; after the scan of the counts k_compact_neighbors
+// moves the rows to their places.  The candidates of the NEXT node of the wavefront are requested before the current node is sorted.
+// *overflow is set when a node has more than 64 DISTINCT neighbours (W = 2 only: the caller falls back to the two passes).
+template <int W>
 __global__ void __launch_bounds__(64) k_node_neighbors_once(const int* nodes, int n, const unsigned* n2e_off, const unsigned* n2e, int num_nodes,
-                                                            unsigned* cnt, unsigned* tmp) {
+                                                            unsigned* cnt, unsigned* tmp, int* overflow) {
     const int lane = threadIdx.x;
-    auto fetch = [&](int node, unsigned& v) {
-        v = 0xffffffffu;
+    auto fetch = [&](int node, unsigned (&v)[W]) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) v[w] = 0xffffffffu;
         if (node >= num_nodes) return;
         const unsigned b = n2e_off[node], C = (n2e_off[node + 1] - b) * (unsigned)n;
-        if ((unsigned)lane < C) {
-            const unsigned e = n2e[b + (unsigned)lane / (unsigned)n] / (unsigned)n;
-            v = (unsigned)nodes[(size_t)e * n + (unsigned)lane % (unsigned)n];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const unsigned i = (unsigned)lane + 64u * w;
+            if (i < C) {
+                const unsigned e = n2e[b + i / (unsigned)n] / (unsigned)n;
+                v[w] = (unsigned)nodes[(size_t)e * n + i % (unsigned)n];
+            }
         }
     };
     int node = blockIdx.x;
-    unsigned v_next;
+    unsigned v_next[W];
     fetch(node, v_next);
     for (; node < num_nodes; node += gridDim.x) {
-        unsigned v = v_next;
+        unsigned v[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) v[w] = v_next[w];
         fetch(node + gridDim.x, v_next);
+        if constexpr (W == 1) {
 #pragma unroll
-        for (int size = 2; size <= 64; size <<= 1)
+            for (int size = 2; size <= 64; size <<= 1)
 #pragma unroll
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                const unsigned other = (unsigned)__shfl_xor((int)v, stride, 64);
-                const bool up = ((lane & size) == 0), lower = ((lane & stride) == 0);
-                v = (lower == up) ? min(v, other) : max(v, other);
-            }
-        const unsigned prev = (unsigned)__shfl_up((int)v, 1, 64);
-        const bool keep = (v != 0xffffffffu) && (lane == 0 || v != prev);
-        const unsigned long long mask = __ballot(keep);
-        if (keep) tmp[(size_t)node * 64 + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v;
-        if (lane == 0) cnt[node] = (unsigned)__popcll(mask);
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const unsigned other = (unsigned)__shfl_xor((int)v[0], stride, 64);
+                    const bool up = ((lane & size) == 0), lower = ((lane & stride) == 0);
+                    v[0] = (lower == up) ? min(v[0], other) : max(v[0], other);
+                }
+        } else {
+            wave_sort128(v[0], v[W - 1], lane);
+        }
+        unsigned base = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            unsigned prev = (unsigned)__shfl_up((int)v[w], 1, 64);
+            if (w > 0) { const unsigned last = (unsigned)__shfl((int)v[w - 1], 63, 64); if (lane == 0) prev = last; }
+            const bool keep = (v[w] != 0xffffffffu) && ((w == 0 && lane == 0) || v[w] != prev);
+            const unsigned long long mask = __ballot(keep);
+            const unsigned r = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (keep && r < 64u) tmp[(size_t)node * 64 + r] = v[w];
+            base += (unsigned)__popcll(mask);
+        }
+        if (lane == 0) {
+            cnt[node] = min(base, 64u);
+            if (base > 64u) *overflow = 1;
+        }
     }
 }
 // 256 consecutive nodes per workgroup: their rows are one contiguous piece of ncols, written in order (coalesced); the node of

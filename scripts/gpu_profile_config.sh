@@ -29,6 +29,24 @@ for ln in open("gpurun_out/prof_$CFG/stats.log"):
         print("   placement_probe:", json.dumps(d["config"].get("placement_probe")))
         print("   device_settle:", json.dumps(d["config"].get("device_settle")))
 PY
+# the kernel stats above average over EVERY dispatch of the process (settle, placement probe at other placements, warm-up); the timed
+# steps are the last 20 dispatches of each of the configuration's kernels: their average is the one to hold against ms_per_step
+python3 - >> gpurun_out/prof_$CFG/summary.txt <<PY
+import glob, sqlite3
+names = {"ns": ("k_affine_rows<", "k_affine_records"), "c5": ("k_affine_rows<", "k_affine_records"), "c2": ("k_affine_rows<", "k_affine_records"),
+         "ns-perturbed": ("k_hex8_rows",), "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}.get("$CFG", ())
+for f in glob.glob("gpurun_out/prof_$CFG/stats/**/*.db", recursive=True):
+    db = sqlite3.connect(f)
+    print("== the last 20 dispatches of the configuration's kernels in the kernel-trace run (= its 20 timed steps):")
+    tot = 0.0
+    for nm in names:
+        rows = [r[0] for r in db.execute("select duration from kernels where name like ? order by start desc limit 20", ("%" + nm + "%",))]
+        if rows:
+            avg = sum(rows) / len(rows) / 1e6
+            tot += avg
+            print("   %-28s %d dispatches, average %.4f ms" % (nm, len(rows), avg))
+    print("   sum %.4f ms" % tot)
+PY
 # keep the merge-back small: the databases stay on the box
 find gpurun_out/prof_$CFG -name "*.db" -delete
 cat gpurun_out/prof_$CFG/summary.txt

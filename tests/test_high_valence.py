@@ -153,3 +153,45 @@ def test_two_thousand_tetrahedra_around_an_edge(engine, oracle):
         assert np.abs(k.values - ovals).max() <= 1e-11 * np.abs(ovals).max()      # needle elements: cond(J) eps
     kc = fa.CsrParAssembler().assemble(fa.color_nodes(asm), asm)
     assert np.abs(kc.values - ovals).max() <= 1e-11 * np.abs(ovals).max()
+
+
+def tet_bouquet(k):
+    """k tetrahedra that share ONE vertex and nothing else (plus a regular neighbourhood: a small BCC box appended, so that the mesh also has
+    ordinary nodes): the centre has 4 k candidate neighbours and 3 k + 1 distinct ones"""
+    rng = np.random.default_rng(k)
+    dirs = rng.standard_normal((k, 3))
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    verts = [np.zeros((1, 3))]
+    conn = []
+    for i in range(k):
+        a = dirs[i]
+        b = np.cross(a, [0.3, 0.5, 0.8])
+        b /= np.linalg.norm(b)
+        cc = np.cross(a, b)
+        base = 1 + 3 * i
+        verts.append(np.stack([a + 0.05 * b, a - 0.03 * b + 0.05 * cc, a - 0.03 * b - 0.05 * cc]))
+        conn.append([0, base, base + 1, base + 2])
+    box = fa.procedural.create_unit_box_uniform_tet_mesh_3d(2)
+    off = 1 + 3 * k
+    v = np.concatenate(verts + [box.vertices + 3.0])
+    c = np.concatenate([np.asarray(conn, dtype=np.int64), np.asarray(box.connectivity).astype(np.int64) + off])
+    return fa.Mesh(v, c.astype(np.uint64), fa.TET4)
+
+
+@pytest.mark.parametrize("k", [16, 21, 22, 30, 32, 33])
+def test_pattern_one_pass_with_two_candidates_per_lane(engine, oracle, k):
+    """the one-pass neighbour kernel with 65 ... 128 candidates per node (two per lane, wave_sort128) and its fall-back: k = 21 fills the scratch
+    row exactly (64 distinct neighbours), 22 ... 32 overflow it (two passes instead), 33 has more than 128 candidates (two passes from the
+    start); indices bit-exact and values against the oracle"""
+    mesh = tet_bouquet(k)
+    w, p = quadrature.total_order.tetrahedron(1)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w)
+    asm = (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(mesh).with_operator(fa.LaplaceOperator())
+           .with_quadrature_table(qt).with_u(np.zeros(mesh.num_nodes())).build())
+    ref = oracle.ElementAssembler(oracle.TET4, oracle.LAPLACE, mesh.vertices, mesh.connectivity, w, p)
+    st, _, oro, oci, ovals = oracle.assemble(ref)
+    assert st == 0
+    assert oro[1] - oro[0] == 3 * k + 1
+    kmat = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert np.array_equal(kmat.row_offsets, oro) and np.array_equal(kmat.col_indices, oci)
+    assert np.abs(kmat.values - ovals).max() <= TOL * np.abs(ovals).max()

@@ -640,12 +640,16 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
 __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                                                           const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
                                                           int4* hdr_out, uint2* lanes, int* status,
-                                                          unsigned long long* hash_out, const int mirror) {
+                                                          unsigned long long* hash_out, const int mirror, const int* plist,
+                                                          unsigned long long* hash2_out) {
+    // plist == null: one workgroup per position: header, two 64-bit hashes of the 256 records, and -- when `lanes` is given -- the
+    // records themselves at lanes[p].  plist != null (second pass of the hash-only build): workgroup t forms the records of position
+    // plist[t] once more and writes them to lanes[t] (the compact table), nothing else.
     constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
     __shared__ int cnt[NKEY];
     __shared__ unsigned short bucket[NKEY * TMAX];
     __shared__ unsigned lw0[256], lw1[256];
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = plist ? plist[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int* rec = p_rec + (size_t)p * rw_old;
     const GatherHdr h = *reinterpret_cast<const GatherHdr*>(rec);
     const unsigned* ent = reinterpret_cast<const unsigned*>(rec + 8 + us / 4);
@@ -714,12 +718,13 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     if ((size_t)8 * S * S * (size_t)h.nrow >= 65536u) bad = true;
     if (mirror && (S * S * h.nrow >= 8192 || h.nb > 8)) bad = true;   // the two 13-bit offsets / 3-bit nodes of the hex8 record
     if (__ballot(bad)) {
+        if (plist) return;   // (cannot happen: the first pass reported it)
         if (lane == 0) {
             atomicOr(status, 1);
             hdr_out[p] = make_int4(h.r0, h.nrow, 0, h.U);
         }
-        for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(idle, 0u);
-        if (lane == 0) hash_out[p] = 0ull;
+        if (lanes) for (int i = lane; i < 256; i += 64) lanes[(size_t)p * 256 + i] = make_uint2(idle, 0u);
+        if (lane == 0) { hash_out[p] = 0ull; if (hash2_out) hash2_out[p] = 0ull; }
         return;
     }
     int r4 = 0, r2 = 0, r1 = 0, r0 = 0;
@@ -799,16 +804,26 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
     }
     __syncthreads();
-    unsigned long long hsum = 0ull;  // order-independent hash of the 256 records (positions with equal tables are merged)
+    if (plist) {   // second pass: the records of this table's first position into the compact table
+        for (int i = lane; i < 256; i += 64) lanes[(size_t)blockIdx.x * 256 + i] = make_uint2(lw0[i], lw1[i]);
+        return;
+    }
+    // two independent 64-bit hashes of the 256 records, position in the table included (positions with equal tables are merged)
+    unsigned long long hsum = 0ull, hsum2 = 0ull;
     for (int i = lane; i < 256; i += 64) {
-        lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
-        unsigned long long z = ((unsigned long long)lw1[i] << 32 | lw0[i]) + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        if (lanes) lanes[(size_t)p * 256 + i] = make_uint2(lw0[i], lw1[i]);
+        const unsigned long long w = (unsigned long long)lw1[i] << 32 | lw0[i];
+        unsigned long long z = w + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         hsum += z ^ (z >> 31);
+        unsigned long long y = (w ^ 0xD6E8FEB86659FD93ull) * (2ull * (unsigned long long)i + 0xC2B2AE3D27D4EB4Full);
+        y = (y ^ (y >> 32)) * 0xFF51AFD7ED558CCDull;
+        y = (y ^ (y >> 29)) * 0xC4CEB9FE1A85EC53ull;
+        hsum2 += y ^ (y >> 32);
     }
-    for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
-    if (lane == 0) hash_out[p] = hsum;
+    for (int o = 32; o > 0; o >>= 1) { hsum += __shfl_xor(hsum, o); hsum2 += __shfl_xor(hsum2, o); }
+    if (lane == 0) { hash_out[p] = hsum; if (hash2_out) hash2_out[p] = hsum2; }
     // every (node, column) block of these rows has an owner lane: the store wave need not clear the staged rows
     // flags: bit 0 every block of these rows has a lane; bit 3 the rows are shorter than two cache lines (the store wave's carry test)
     if (lane == 0) hdr_out[p] = make_int4(h.r0, h.nrow, ((n4 + n2 + n1 + nskip + (zero_lanes ? n0 : 0) == h.nrow) ? 1 : 0) | ((S * S * h.nrow < 32) ? 8 : 0), h.U);
@@ -833,10 +848,29 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
 
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* status, unsigned long long* hash, int mirror) {
+                             int* status, unsigned long long* hash, int mirror, unsigned long long* hash2) {
     if (npos <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
-                       p_elem, hdr, lanes, status, hash, mirror);
+                       p_elem, hdr, lanes, status, hash, mirror, (const int*)nullptr, hash2);
+    return hipGetLastError();
+}
+
+// table id of every position into its header; mismatch[1] is set when some position has a block without an owner lane
+__global__ void __launch_bounds__(256) k_affine_rows_set_ids(const int* ids, int npos, int4* hdr, int* mismatch) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npos) return;
+    const int z = hdr[p].z;
+    if (!(z & 1)) mismatch[1] = 1;
+    hdr[p].z = (z & 9) | (ids[p] << 8);
+}
+
+hipError_t affine_rows_tables(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S, const unsigned* ncols,
+                              const int* p_conn, int cs, const int* p_elem, int mirror, const int* ids, const int* first_pos, int ntab,
+                              uint2* lanes_tab, int4* hdr, int* mismatch) {
+    if (npos <= 0 || ntab <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_affine_rows, dim3(ntab), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs, p_elem,
+                       (int4*)nullptr, lanes_tab, (int*)nullptr, (unsigned long long*)nullptr, mirror, first_pos, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_affine_rows_set_ids, dim3((npos + 255) / 256), dim3(256), 0, stream, ids, npos, hdr, mismatch);
     return hipGetLastError();
 }
 

@@ -870,15 +870,69 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     HIP_TRY(c, st.alloc(2));
     HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
     HIP_TRY(c, hdr.alloc((size_t)npos));
+    // Hash-only build (round 4): the 256 records of a position are formed in LDS, hashed twice (128 bits) and dropped; the records of the
+    // first position of every distinct table are formed once more into the compact tables.  Writing all of them (2 KB x 1.46 M positions
+    // = 3 GB on the 216^3 mesh) cost an allocation of 40 - 120 ms.  FENRIS_HIP_LANE_TABLES_FULL keeps the full form (its compaction
+    // compares every position with its table); two positions whose first hashes agree and whose second ones differ send the build there too.
+    bool full = c->env("FENRIS_HIP_LANE_TABLES_FULL") != nullptr || c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23);
     DevBuf<uint2> lanes_full;
     DevBuf<unsigned long long> hash_d;
+    HIP_TRY(c, hash_d.alloc((size_t)npos * 2));
+    std::vector<unsigned long long> hash_h((size_t)npos * 2);
+    int bad = 0;
+    if (!full) {
+        HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, (uint2*)nullptr, st.p,
+                                     hash_d.p, mirror, hash_d.p + npos));
+        HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        bad_out = bad != 0;
+        if (bad) return FH_OK;
+        std::vector<int> ids((size_t)npos), first;
+        std::unordered_map<unsigned long long, int> seen;
+        seen.reserve(1024);
+        bool collision = false;
+        for (int p = 0; p < npos && !collision; ++p) {
+            auto it = seen.find(hash_h[p]);
+            if (it == seen.end()) {
+                it = seen.emplace(hash_h[p], (int)first.size()).first;
+                first.push_back(p);
+            } else if (hash_h[(size_t)npos + first[it->second]] != hash_h[(size_t)npos + p]) {
+                collision = true;
+            }
+            ids[p] = it->second;
+        }
+        if (!collision) {
+            const int ntab = (int)first.size();
+            DevBuf<int> ids_d, first_d;
+            HIP_TRY(c, ids_d.alloc((size_t)npos));
+            HIP_TRY(c, first_d.alloc((size_t)ntab));
+            HIP_TRY(c, lanes.alloc((size_t)ntab * 256));
+            HIP_TRY(c, hipMemcpyAsync(ids_d.p, ids.data(), sizeof(int) * (size_t)npos, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+            HIP_TRY(c, affine_rows_tables(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, mirror, ids_d.p, first_d.p,
+                                          ntab, lanes.p, hdr.p, st.p));
+            int mismatch[2] = {0, 0};   // [1]: some position has a block without an owner lane
+            HIP_TRY(c, hipMemcpyAsync(mismatch, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            ntab_out = ntab;
+            incomplete_out = mismatch[1];
+            if (c->env("FENRIS_HIP_VERBOSE")) {
+                long long changes = 0;
+                for (int p = 1; p < npos; ++p) changes += ids[p] != ids[p - 1];
+                std::fprintf(stderr, "[fenris_hip] %s: %d positions share %d lane tables, %lld changes of table along the sweep%s\n", what,
+                             npos, ntab_out, changes, incomplete_out ? ", some position has a block without an owner" : "");
+            }
+            return FH_OK;
+        }
+        full = true;
+        HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+    }
     HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
-    HIP_TRY(c, hash_d.alloc((size_t)npos));
     HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, lanes_full.p, st.p,
                                  hash_d.p, mirror));
-    int bad = 0;
     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    std::vector<unsigned long long> hash_h((size_t)npos);
     HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     bad_out = bad != 0;

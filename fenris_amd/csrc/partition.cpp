@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
+#include <utility>
 #include <vector>
 
 #include "../../include/fenris_hip.h"
@@ -36,8 +38,8 @@ extern "C" {
 
 // Default partitioner: elements sorted by the Morton key of their centroids (21 bits per axis), cut into `world` runs of (almost)
 // equal length.
-int fh_morton_partition(uint32_t dim, const double* vertices, uint64_t num_vertices, uint64_t npe, const uint64_t* conn, uint64_t E,
-                        uint32_t world, int32_t* elem_to_part) {
+static int morton_partition(uint32_t dim, const double* vertices, uint64_t num_vertices, uint64_t npe, const uint64_t* conn, uint64_t E,
+                            uint32_t world, int32_t* elem_to_part) {
     if (!vertices || !conn || !elem_to_part || dim < 1 || dim > 3 || npe == 0 || world == 0) return FH_BAD_ARGUMENT;
     std::vector<double> cent((size_t)E * dim);
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -71,6 +73,15 @@ int fh_morton_partition(uint32_t dim, const double* vertices, uint64_t num_verti
     return FH_OK;
 }
 
+int fh_morton_partition(uint32_t dim, const double* vertices, uint64_t num_vertices, uint64_t npe, const uint64_t* conn, uint64_t E,
+                        uint32_t world, int32_t* elem_to_part) {
+    try {
+        return morton_partition(dim, vertices, num_vertices, npe, conn, E, world, elem_to_part);
+    } catch (...) {
+        return FH_HIP_ERROR;   // (out of host memory)
+    }
+}
+
 // Rank `rank`'s share of a mesh under the element partition elem_to_part (one part in [0, world) per element):
 //  * a node is owned by the LOWEST part that has an element touching it (nodes without elements: part 0);
 //  * the extended local mesh = the rank's own elements + every element that touches a node they touch; local node ids are the global
@@ -79,8 +90,8 @@ int fh_morton_partition(uint32_t dim, const double* vertices, uint64_t num_verti
 //    without any exchange);
 //  * exchange lists (halo_mode == 0): per neighbour the local nodes whose partial rows go there (nodes my elements touch that it
 //    owns) and the owned local nodes that receive its partial rows, both in ascending global order.
-fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t npe, const uint64_t* conn, uint64_t E, const int32_t* elem_to_part,
-                                  int rank, int world, int halo_mode) {
+static fh_partition* partition_create(uint64_t num_nodes, uint64_t npe, const uint64_t* conn, uint64_t E, const int32_t* elem_to_part,
+                                      int rank, int world, int halo_mode) {
     if (!conn || !elem_to_part || npe == 0 || world < 1 || rank < 0 || rank >= world) return nullptr;
     constexpr int32_t NONE = std::numeric_limits<int32_t>::max();
     std::vector<int32_t> owner((size_t)num_nodes, NONE);
@@ -101,7 +112,7 @@ fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t npe, const uint64
             ++own;
             for (uint64_t k = 0; k < npe; ++k) touched[conn[e * npe + k]] = 1;
         }
-    fh_partition* P = new fh_partition();
+    std::unique_ptr<fh_partition> P(new fh_partition());
     P->own_elements = own;
     P->npe = npe;
     std::vector<uint8_t> ext_node((size_t)num_nodes, 0);
@@ -139,21 +150,19 @@ fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t npe, const uint64
         std::vector<std::vector<uint64_t>> snd((size_t)world), rcv((size_t)world);
         for (uint64_t v = 0; v < num_nodes; ++v)
             if (touched[v] && owner[v] != rank) snd[(size_t)owner[v]].push_back((uint64_t)g2l[v]);
-        // receive: my nodes that part q's own elements touch
-        std::vector<int32_t> mark((size_t)num_nodes, -1);   // last q that recorded the node
-        for (int q = 0; q < world; ++q) {
+        // receive: my nodes that part q's own elements touch -- one pass over the elements, (part, node) pairs sorted and made unique
+        std::vector<std::pair<int32_t, uint64_t>> pairs;
+        for (uint64_t e = 0; e < E; ++e) {
+            const int32_t q = elem_to_part[e];
             if (q == rank) continue;
-            std::vector<uint64_t>& r = rcv[(size_t)q];
-            for (uint64_t e = 0; e < E; ++e) {
-                if (elem_to_part[e] != q) continue;
-                for (uint64_t k = 0; k < npe; ++k) {
-                    const uint64_t v = conn[e * npe + k];
-                    if (owner[v] == rank && mark[v] != q) { mark[v] = q; r.push_back(v); }
-                }
+            for (uint64_t k = 0; k < npe; ++k) {
+                const uint64_t v = conn[e * npe + k];
+                if (owner[v] == rank) pairs.emplace_back(q, v);
             }
-            std::sort(r.begin(), r.end());
-            for (auto& v : r) v = (uint64_t)g2l[v];
         }
+        std::sort(pairs.begin(), pairs.end());
+        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+        for (const auto& qv : pairs) rcv[(size_t)qv.first].push_back((uint64_t)g2l[qv.second]);   // ascending global = ascending local id
         for (int q = 0; q < world; ++q) {
             if (!snd[(size_t)q].empty()) {
                 P->send_peers.push_back(q);
@@ -167,7 +176,17 @@ fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t npe, const uint64
             }
         }
     }
-    return P;
+    return P.release();
+}
+
+// (no exception crosses the C ABI: out of memory comes back as NULL)
+fh_partition* fh_partition_create(uint64_t num_nodes, uint64_t npe, const uint64_t* conn, uint64_t E, const int32_t* elem_to_part,
+                                  int rank, int world, int halo_mode) {
+    try {
+        return partition_create(num_nodes, npe, conn, E, elem_to_part, rank, world, halo_mode);
+    } catch (...) {
+        return nullptr;
+    }
 }
 
 void fh_partition_destroy(fh_partition* p) { delete p; }

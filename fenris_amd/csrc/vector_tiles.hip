@@ -207,6 +207,11 @@ __global__ void __launch_bounds__(256) k_vt_sort_lists(const unsigned* np_off, u
 }
 
 // ---- the element pass over tiles
+// tile of workgroup b when the grid is 8 ceil(T / 8) workgroups: XCD b mod 8 walks the tiles [x c, (x + 1) c), c = ceil(T / 8)
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+    const int c = (ntiles + 7) >> 3;
+    return (b & 7) * c + (b >> 3);
+}
 // what a tile's workgroup needs for the node sums, requested before the arithmetic and landing behind it: the tile's entries (256 N
 // sixteen-bit values: N / 4 eight-byte pieces per thread) and the starts of the first 512 distinct nodes
 template <int N, int TS>
@@ -268,7 +273,10 @@ __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const 
     constexpr int N = EPDims<EK, OP, EP_VECTOR>::N, S = EPDims<EK, OP, EP_VECTOR>::S, D = EPDims<EK, OP, EP_VECTOR>::D;
     __shared__ double stage[N * S * TS];
     __shared__ unsigned short ents[(N % 4 == 0) ? TS * N : 4];
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    // workgroup b runs on XCD b mod 8 (round-robin dispatch): every XCD takes one contiguous eighth of the tiles, so that tiles that are
+    // neighbours in space (consecutive in the Morton order) share their boundary nodes' coordinates and u through one L2
+    const int tile = xcd_tile((int)blockIdx.x, t.ntiles), tid = threadIdx.x;
+    if (tile >= t.ntiles) return;
     const int el = t.elem[(size_t)tile * TS + tid];
     const bool live = el >= 0 && (!active || active[el] != 0);
     const long long ec = el >= 0 ? el : 0;
@@ -310,7 +318,8 @@ __global__ void __launch_bounds__(TS) k_source_elements_tiled(const KArgs a, con
     constexpr int SF = FACT ? 1 : S;
     __shared__ double stage[N * SF * TS];
     __shared__ unsigned short ents[(N % 4 == 0) ? TS * N : 4];
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = xcd_tile((int)blockIdx.x, t.ntiles), tid = threadIdx.x;
+    if (tile >= t.ntiles) return;
     const int el = t.elem[(size_t)tile * TS + tid];
     const bool live = el >= 0 && (!active || active[el] != 0);
     TileSums<N, TS> ts;
@@ -504,10 +513,10 @@ int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const K
     int rs = -1;
 #define VT_OP(EKC)                                                                                                                                   \
     switch (op) {                                                                                                                                    \
-        case FH_LAPLACE: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LAPLACE, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LINEAR_ELASTIC, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_NEO_HOOKEAN, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
-        case FH_STVK: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_STVK, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_LAPLACE: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LAPLACE, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_LINEAR_ELASTIC, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_NEO_HOOKEAN, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
+        case FH_STVK: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_STVK, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
         default: break;                                                                                                                              \
     }
     switch (elem_kind) {
@@ -527,8 +536,8 @@ int vector_tiles_source_pass(int D, int sdim, int n, bool fact, hipStream_t stre
     int rs = 0;
 #define VT_SRC(DV, SV, NV)                                                                                                                              \
     do {                                                                                                                                                \
-        if (fact) hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, true, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, g, values, t, active, partial); \
-        else hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, false, VT_TS>), dim3(t.ntiles), dim3(VT_TS), 0, stream, a, g, values, t, active, partial);    \
+        if (fact) hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, true, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, g, values, t, active, partial); \
+        else hipLaunchKernelGGL((k_source_elements_tiled<DV, SV, NV, false, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, g, values, t, active, partial);    \
     } while (0)
     if (D == 2 && n == 4) { if (sdim == 1) VT_SRC(2, 1, 4); else VT_SRC(2, 2, 4); }
     else if (D == 2 && n == 3) { if (sdim == 1) VT_SRC(2, 1, 3); else VT_SRC(2, 2, 3); }

@@ -409,6 +409,7 @@ struct fh_ctx {
     DevBuf<double> fe_scratch;  // two-pass residual: E element vectors
     DevBuf<unsigned> src_n2e_off, src_n2e;   // node -> (element, local node) adjacency of a context without an operator (source vectors)
     unsigned long long src_adj_gen = ~0ull;
+    DevBuf<double> scalar_partial;           // workgroup partials of the energy (kept: no allocation per call)
     VecTilesStore vt;                        // residual through element tiles (vector_tiles.hip)
     unsigned long long vt_gen = ~0ull;
     bool vt_bad = false;
@@ -3506,6 +3507,26 @@ static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed) {
     a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     if (a.work_end == 0) return FH_OK;
+    // element tiles (vector_tiles.hip): the elements in the tiles' (space-compact) order -- what makes the gathers local on a numbering
+    // without locality (C3's permuted tetrahedra: 0.76 -> 0.20 ms per call); an element mask zeroes the inactive elements' energies
+    if (element_pass_covers(c) && !c->env("FENRIS_HIP_NO_VECTOR_TILES") && c->env_int("FENRIS_HIP_ENERGY_TILES", 1)) {
+        rc = ensure_vector_tiles(c);
+        if (rc) return rc;
+        if (!c->vt_bad) {
+            const int grid = vector_tiles_energy_partials(c->vt.v);
+            if (c->scalar_partial.n < (size_t)grid + 1) HIP_TRY(c, c->scalar_partial.alloc((size_t)grid + 1));
+            KArgs at = a;
+            at.labels = nullptr;
+            if (vector_tiles_energy_pass(c->elem_kind, c->op, c->stream, at, c->vt.v, c->has_mask ? c->active.p : nullptr, c->scalar_partial.p) == grid) {
+                HIP_TRY(c, hipGetLastError());
+                c->last_kernel = "k_element_energy_tiled";
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->scalar_partial.p, grid, c->scalar_partial.p + grid);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipMemcpyAsync(out, c->scalar_partial.p + grid, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                return read_status(c, failed);
+            }
+        }
+    }
     if (!a.labels && element_pass_covers(c)) {
         // one thread per element (element_pass.hpp), workgroup partials in a fixed tree, the partials summed in index order by one
         // workgroup: one double comes back (global.rs:703-709 sums element by element; same terms, fixed association)

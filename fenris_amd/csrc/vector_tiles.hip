@@ -311,6 +311,41 @@ __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const 
     ts.template sum<S>(t, tile, tid, stage, ents, partial);
 }
 
+// energy (compute_element_elliptic_energy, local/elliptic.rs:551-605) over the same tiles: on a numbering without locality the tile order
+// is what makes the gathers of the coordinates and of u local; the tile's elements are summed in a fixed tree, one partial per workgroup
+// (workgroups beyond the last tile write a zero), k_sum_partials adds them in index order
+template <int EK, int OP, int TS>
+__global__ void __launch_bounds__(TS) k_element_energy_tiled(const KArgs a, const VecTiles t, const unsigned char* active, double* partial) {
+    constexpr int N = EPDims<EK, OP, EP_SCALAR>::N, S = EPDims<EK, OP, EP_SCALAR>::S, D = EPDims<EK, OP, EP_SCALAR>::D;
+    static_assert(TS == 256, "block_sum_256");
+    __shared__ double red[4];
+    const int tile = xcd_tile((int)blockIdx.x, t.ntiles), tid = threadIdx.x;
+    if (tile >= t.ntiles) {
+        if (tid == 0) partial[blockIdx.x] = 0.0;
+        return;
+    }
+    const int el = t.elem[(size_t)tile * TS + tid];
+    const bool live = el >= 0 && (!active || active[el] != 0);
+    double X[N][D], Uv[N][S];
+    {
+        int nd[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) nd[n] = t.tconn[((size_t)tile * N + n) * TS + tid];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) X[n][i] = a.verts[(size_t)nd[n] * D + i];
+#pragma unroll
+            for (int k = 0; k < S; ++k) Uv[n][k] = a.u ? a.u[(size_t)nd[n] * S + k] : 0.0;
+        }
+    }
+    double f[1][S];
+    double energy;
+    element_pass_body<EK, OP, EP_SCALAR>(a, el, live, el >= 0 ? el : 0, X, EPRegU<N, S>{Uv}, f, energy);
+    const double tot = block_sum_256(live ? energy : 0.0, red);
+    if (tid == 0) partial[blockIdx.x] = tot;
+}
+
 // source vector (local/source.rs:159-278) over the same tiles: source_element_body per thread, the tile's node sums, partials
 template <int D, int S, int N, bool FACT, int TS>
 __global__ void __launch_bounds__(TS) k_source_elements_tiled(const KArgs a, const SourceG g, const double* values, const VecTiles t,
@@ -527,6 +562,28 @@ int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const K
         default: break;
     }
 #undef VT_OP
+    return rs;
+}
+
+int vector_tiles_energy_pass(int elem_kind, int op, hipStream_t stream, const KArgs& a, const VecTiles& t, const unsigned char* active, double* partial) {
+    int rs = -1;
+    const int grid = 8 * ((t.ntiles + 7) / 8);
+#define VT_EN(EKC)                                                                                                                                   \
+    switch (op) {                                                                                                                                    \
+        case FH_LAPLACE: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_LAPLACE, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
+        case FH_LINEAR_ELASTIC: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_LINEAR_ELASTIC, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
+        case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_NEO_HOOKEAN, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
+        case FH_STVK: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_STVK, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
+        default: break;                                                                                                                              \
+    }
+    switch (elem_kind) {
+        case FH_QUAD4: VT_EN(FH_QUAD4) break;
+        case FH_TRI3: VT_EN(FH_TRI3) break;
+        case FH_TET4: VT_EN(FH_TET4) break;
+        case FH_HEX8: VT_EN(FH_HEX8) break;
+        default: break;
+    }
+#undef VT_EN
     return rs;
 }
 

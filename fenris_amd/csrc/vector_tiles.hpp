@@ -38,6 +38,11 @@ hipError_t vector_tiles_build(hipStream_t stream, const int* conn, int n, long l
 // active (device, may be null): elements with active[e] == 0 contribute nothing.  Returns -1 when (elem_kind, op) is not covered.
 int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const KArgs& a, const VecTiles& t, const unsigned char* active, double* partial);
 
+// energy over the tiles: one partial per workgroup into partial[] (the number of workgroups = partials comes back; -1: not covered);
+// the caller sums them in index order (k_sum_partials)
+int vector_tiles_energy_pass(int elem_kind, int op, hipStream_t stream, const KArgs& a, const VecTiles& t, const unsigned char* active, double* partial);
+inline int vector_tiles_energy_partials(const VecTiles& t) { return 8 * ((t.ntiles + 7) / 8); }
+
 // source vector (k_source_elements' arithmetic) over the tiles; g3: three doubles (host) or null; fact: scalar partials (GravitySource),
 // the node pass multiplies by g.  Returns -1 when (D, n) is not covered.
 int vector_tiles_source_pass(int D, int sdim, int n, bool fact, hipStream_t stream, const KArgs& a, const double* g3, const double* values,

@@ -117,7 +117,19 @@ def test_tiled_residual_matches_the_oracle_with_and_without_mask(oracle):
                 assert engine.last_kernel_name() == TILED
                 assert np.all(np.isfinite(got_m)), (name, opname)
                 assert np.abs(got_m - want_m).max() <= 1e-12 * max(np.abs(want_m).max(), 1e-300), (name, opname, "masked")
+                # the energy over the same tiles: the active elements only (the inactive ones may hold inf / NaN)
+                sub = oracle.ElementAssembler(okind, getattr(oracle, opname), mesh.vertices, conn[mask == 1], w, p,
+                                              params=(LAME.as_pair() if opname != "LAPLACE" else None), u=um)
+                res = oracle.assemble_scalar(sub)
+                assert res[0] == 0
+                e_gpu = fa.assemble_scalar(asm)
+                assert engine.last_kernel_name() == "k_element_energy_tiled"
+                assert abs(e_gpu - res[-1]) <= 1e-12 * max(abs(res[-1]), 1e-300), (name, opname, "masked energy")
                 engine.set_active_elements(None)
+                e_all = fa.assemble_scalar(_assembler(engine, mesh, opname, w, p, u))
+                ref_all = oracle.assemble_scalar(oracle.ElementAssembler(okind, getattr(oracle, opname), mesh.vertices, mesh.connectivity, w, p,
+                                                                         params=(LAME.as_pair() if opname != "LAPLACE" else None), u=u))
+                assert abs(e_all - ref_all[-1]) <= 1e-12 * max(abs(ref_all[-1]), 1e-300), (name, opname, "energy")
     finally:
         engine.close()
 

@@ -119,6 +119,10 @@ class Engine:
         else:
             self.set_quadrature_uniform(qtable.weights, qtable.points, qtable.data)
 
+    def update_vertices(self, vertices):
+        """new coordinates for the mesh that is set (same connectivity: pattern and topology tables stay)"""
+        self._check(self._lib.fh_update_vertices(self._h, _ffi.fp(_ffi.as_f64(np.ascontiguousarray(vertices)))))
+
     def set_u(self, u):
         if u is None:
             self._check(self._lib.fh_set_u(self._h, None))

@@ -411,7 +411,8 @@ struct fh_ctx {
     unsigned long long src_adj_gen = ~0ull;
     DevBuf<double> scalar_partial;           // workgroup partials of the energy (kept: no allocation per call)
     VecTilesStore vt;                        // residual through element tiles (vector_tiles.hip)
-    unsigned long long vt_gen = ~0ull;
+    unsigned long long vt_gen = ~0ull;       // topo_gen the tiles were built for
+    unsigned long long topo_gen = 0;         // counts fh_set_mesh calls (struct_gen also moves with vertex updates, masks, operators)
     bool vt_bad = false;
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
@@ -2312,6 +2313,7 @@ static int set_mesh_common(fh_ctx* c, int elem_kind, uint64_t N, uint64_t E) {
     c->nq = 0;  // reference gradient tables depend on the element kind
     HIP_TRY(c, c->verts.alloc((size_t)N * ei.d));
     HIP_TRY(c, c->conn.alloc((size_t)c->flat_len));
+    ++c->topo_gen;   // a new connectivity: tables that depend on the topology alone (the element tiles) are rebuilt
     return FH_OK;
 }
 
@@ -3180,11 +3182,11 @@ int fh_assemble_vector_async_dev(fh_ctx* c, double* out_dev) {
 }
 // element tiles of the residual / source vector passes (vector_tiles.hip): once per mesh topology
 static int ensure_vector_tiles(fh_ctx* c) {
-    if (c->vt_gen == c->struct_gen) return FH_OK;
+    if (c->vt_gen == c->topo_gen) return FH_OK;
     int bad = 0;
     HIP_TRY(c, vector_tiles_build(c->stream, c->conn.p, c->ei.n, (long long)c->E, c->verts.p, c->ei.d, (int)c->N, &c->vt, &bad));
     c->vt_bad = bad != 0;
-    c->vt_gen = c->struct_gen;
+    c->vt_gen = c->topo_gen;
     return FH_OK;
 }
 static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) {

@@ -164,3 +164,27 @@ def test_tiled_source_vector_matches_the_oracle(oracle, sdim):
             assert np.abs(got2 - want2).max() <= 1e-12 * np.abs(want2).max(), name
     finally:
         engine.close()
+
+
+def test_tiles_survive_a_vertex_update(oracle):
+    """the tables depend on the connectivity only: fh_update_vertices keeps them (no rebuild), and the residual follows the new coordinates"""
+    rng = np.random.default_rng(21)
+    m = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 7, 6, 5, 1)
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    u = 0.004 * rng.standard_normal(3 * m.num_nodes())
+    engine = fa.Engine(0)
+    try:
+        asm = _assembler(engine, m, "NEO_HOOKEAN", w, p, u)
+        first = fa.VectorAssembler().assemble_vector(asm)
+        st, want = _oracle_vector(oracle, oracle.HEX8, "NEO_HOOKEAN", m, m.connectivity, w, p, u)
+        assert st == 0 and np.abs(first - want).max() <= 1e-12 * np.abs(want).max()
+        moved = m.vertices + 0.03 * rng.uniform(-1, 1, m.vertices.shape)
+        engine.update_vertices(moved)
+        got = fa.VectorAssembler().assemble_vector(asm)
+        assert engine.last_kernel_name() == TILED
+        m2 = fa.Mesh(moved, m.connectivity, fa.HEX8)
+        st, want2 = _oracle_vector(oracle, oracle.HEX8, "NEO_HOOKEAN", m2, m2.connectivity, w, p, u)
+        assert st == 0 and np.abs(got - want2).max() <= 1e-12 * np.abs(want2).max()
+        assert np.abs(want2 - want).max() > 1e-3 * np.abs(want).max()      # (the update did change the answer)
+    finally:
+        engine.close()

@@ -127,3 +127,26 @@ def test_mfma_path_with_element_mask(engine, oracle):
     vals = np.zeros(len(ci))
     st, _ = oracle.assemble_into_csr(sub, ro, ci, vals)
     assert st == 0 and np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_two_pass_path_is_bit_reproducible(oracle):
+    """the reference's coloured assembly gives the same bits every run (global.rs:322-373); so does the two-pass path: every addition into a
+    node's rows comes from ONE wavefront in program order (LDS operations of a wavefront execute in order), whatever the launch grids and
+    however often it runs -- Hex27 NeoHookean (C4's kernels) on a distorted mesh, four runs under three grids of the row pass"""
+    mesh = _mesh(7, cells=(3, 3, 4))
+    u = 0.01 * np.random.default_rng(3).standard_normal(3 * mesh.num_nodes())
+    ref_vals = None
+    for grid in (None, "7", "200"):
+        eng = fa.Engine(0)
+        try:
+            if grid:
+                eng.set_option("FENRIS_HIP_TWO_PASS_ROWS_GRID", grid)
+            asm, _ = _build(eng, oracle, mesh, "NEO_HOOKEAN", u)
+            for _ in range(2 if grid else 4):
+                k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+                assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+                if ref_vals is None:
+                    ref_vals = k.values.copy()
+                assert np.array_equal(k.values, ref_vals), grid
+        finally:
+            eng.close()

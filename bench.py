@@ -19,7 +19,8 @@ Configurations (BASELINE.json `configs`):
   c4            Hex27 NeoHookean 50 x 50 x 80, hexahedron_gauss(3); roofline = fp64 matrix-core flops.
   c5            Hex8 linear elasticity 256^3 cut into N z-slabs (strong scaling; 32 layers per rank at N = 8).
 
-Prints ONE JSON line on rank 0.  The default run (--config ns on one GPU) appends `secondary`: every other configuration
+Prints ONE JSON line on rank 0.  The default run (--config ns on one GPU) appends `secondary_vectors` (residual vector and energy of the
+headline mesh) and `secondary`: every other configuration
 (c2, c3, c4, c5 at N = 1, ns-perturbed) timed in the same process after the headline -- {ms, frac of its roofline, kernel}.
 """
 import argparse
@@ -715,6 +716,30 @@ def main():
             pass
         # ---- the other configurations, same process, after the headline (driver-verifiable figures for the rows of DESIGN 3.4)
         if world == 1 and cfg == "ns" and not args.cells and not args.no_secondary and os.environ.get("FENRIS_BENCH_CHILD") != "1":
+            # residual vector and energy of the same mesh and operator ("Secondary: ... residual assembly"), the same context
+            try:
+                eng.set_u(1e-3 * np.sin(np.arange(s * mesh.num_nodes())))
+                fvec = torch.zeros(s * mesh.num_nodes(), dtype=torch.float64, device="cuda")
+                for _ in range(3):
+                    eng.assemble_vector(fvec)
+                torch.cuda.synchronize()
+                a1, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a1.record()
+                for _ in range(10):
+                    eng.assemble_vector(fvec)
+                b1.record()
+                torch.cuda.synchronize()
+                vec_kernel = eng.last_kernel_name()
+                t_e = time.perf_counter()
+                for _ in range(5):
+                    eng.assemble_scalar()
+                t_e = (time.perf_counter() - t_e) / 5
+                out["secondary_vectors"] = {"workload": "residual vector and energy of the headline mesh and operator, u = 1e-3 sin(i)",
+                                            "residual_ms": a1.elapsed_time(b1) / 10, "residual_kernel": vec_kernel,
+                                            "energy_ms_blocking_call": 1e3 * t_e, "energy_kernel": eng.last_kernel_name()}
+                del fvec
+            except Exception as exc:  # never take the headline down
+                out["secondary_vectors"] = {"error": repr(exc)}
             eng.close()
             del values
             torch.cuda.empty_cache()

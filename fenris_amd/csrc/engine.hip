@@ -631,7 +631,12 @@ int build_pattern(fh_ctx* c) {
     if (once) {
         // every node has at most 64 (hexahedra) or 128 (tetrahedra: two per lane) candidates: one neighbour pass into scratch rows of 64
         // distinct neighbours, scan, compaction (pattern_kernels.hpp); a node with more than 64 distinct ones sends the build to the two passes
-        HIP_TRY(c, rows64.alloc((size_t)N * 64));
+        if (rows64.alloc((size_t)N * 64) != hipSuccess) {   // no room for the scratch rows: the two passes need none
+            (void)hipGetLastError();
+            once = false;
+        }
+    }
+    if (once) {
         const int g = std::min(N, 256 * 64);
         if (max_cand <= 64ull) hipLaunchKernelGGL(k_node_neighbors_once<1>, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p, flags.p + 1);
         else hipLaunchKernelGGL(k_node_neighbors_once<2>, dim3(g), dim3(64), 0, st, c->conn.p, c->ei.n, c->n2e_off.p, c->n2e.p, N, cnt.p, rows64.p, flags.p + 1);
@@ -3184,7 +3189,14 @@ int fh_assemble_vector_async_dev(fh_ctx* c, double* out_dev) {
 static int ensure_vector_tiles(fh_ctx* c) {
     if (c->vt_gen == c->topo_gen) return FH_OK;
     int bad = 0;
-    HIP_TRY(c, vector_tiles_build(c->stream, c->conn.p, c->ei.n, (long long)c->E, c->verts.p, c->ei.d, (int)c->N, &c->vt, &bad));
+    const hipError_t e = vector_tiles_build(c->stream, c->conn.p, c->ei.n, (long long)c->E, c->verts.p, c->ei.d, (int)c->N, &c->vt, &bad);
+    if (e == hipErrorOutOfMemory) {   // no room for the tables: the callers keep the two-pass kernels
+        (void)hipGetLastError();
+        c->vt.release();
+        bad = 1;
+    } else {
+        HIP_TRY(c, e);
+    }
     c->vt_bad = bad != 0;
     c->vt_gen = c->topo_gen;
     return FH_OK;

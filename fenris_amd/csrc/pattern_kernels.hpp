@@ -357,25 +357,31 @@ __global__ void k_narrow_connectivity(const unsigned long long* in, int* out, lo
 
 // apply_homogeneous_dirichlet_bc_csr (global.rs:379-451) on node-level structure:
 // pass 1 marks Dirichlet rows/cols, pass 2 rewrites values.  member[] has one byte per node.
-__global__ void k_dirichlet_rows(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const unsigned char* member,
-                                 double* vals, double scale) {
-    const long long nnzn = noff[num_nodes];
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nnzn; t += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = num_nodes;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((long long)noff[mid] <= t) lo = mid; else hi = mid;
+// Dirichlet rows and columns (global.rs:379-451): half a wavefront per node row, one lane per column block (rows longer than 32 blocks in
+// trips): the entry's row is known from the workgroup's place -- the first form searched the row of each of the nnz_n entries by
+// bisection in the offsets (23 dependent loads per entry: 7 of the 11 ms this step took on the 216^3 mesh).
+__global__ void __launch_bounds__(256) k_dirichlet_rows(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const unsigned char* member,
+                                                        double* vals, const double* scale_dev) {
+    const int hl = threadIdx.x & 31;
+    const double scale = *scale_dev;
+    for (long long i = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); i < num_nodes; i += (long long)gridDim.x * 8) {
+        const unsigned b = noff[i], cnt = noff[i + 1] - b;
+        const bool ri = member[i] != 0;
+        for (unsigned k = hl; k < cnt; k += 32) {
+            const unsigned j = ncols[b + k];
+            const bool cj = member[j] != 0;
+            if (!ri && !cj) continue;
+            double* base = vals + (unsigned long long)S * S * b + (unsigned long long)S * k;
+            for (int r = 0; r < S; ++r)
+                for (int c = 0; c < S; ++c)
+                    base[(unsigned long long)r * S * cnt + c] = (ri && (unsigned)i == j && r == c) ? scale : 0.0;
         }
-        const int i = lo;
-        const unsigned j = ncols[t];
-        const bool ri = member[i], cj = member[j];
-        if (!ri && !cj) continue;
-        const unsigned long long cnt = noff[i + 1] - noff[i];
-        double* base = vals + (unsigned long long)S * S * noff[i] + (unsigned long long)S * ((unsigned long long)t - noff[i]);
-        for (int r = 0; r < S; ++r)
-            for (int c = 0; c < S; ++c)
-                base[(unsigned long long)r * S * cnt + c] = (ri && (unsigned)i == j && r == c) ? scale : 0.0;
     }
+}
+
+__global__ void __launch_bounds__(256) k_mark_nodes(const unsigned long long* nodes, long long n, unsigned char* member) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t < n) member[nodes[t]] = 1;
 }
 
 __global__ void k_dirichlet_rhs(double* rhs, const unsigned long long* nodes, long long n, int S) {
@@ -404,6 +410,8 @@ __global__ void k_first_nonzero_diag(const unsigned* noff, const unsigned* ncols
     }
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (t >= (long long)num_nodes * S) return;
+    // (an earlier row has already answered -- normally row 0 -- : no need to look at this one)
+    if ((unsigned long long)t > *reinterpret_cast<volatile unsigned long long*>(first)) return;
     if (diag_value(noff, ncols, S, vals, t) != 0.0) atomicMin(first, (unsigned long long)t);
 }
 

@@ -566,7 +566,10 @@ __global__ void __launch_bounds__(320 + 64 * NSTORE, 5) k_affine_rows(const KArg
 template <int OP>
 __global__ void __launch_bounds__(256) k_affine_records(const double* verts, const int* conn, const unsigned char* elem_aff,
                                                         const unsigned char* active, long long e_first, long long E, double* rec, DevStatus* status) {
-    constexpr bool LAP = (OP == FH_LAPLACE);
+    // OP == FH_MASS_SCALAR (the mass matrix of affine elements, mass.rs:131-286: M_ab = |det J| sum_q w rho phi_a phi_b): the Laplace
+    // layout with |det J| in the first place -- k_affine_rows<FH_LAPLACE> multiplies it with the reference block (sum_q w rho phi_a phi_b, 0 ...)
+    constexpr bool MASS = (OP == FH_MASS_SCALAR);
+    constexpr bool LAP = (OP == FH_LAPLACE) || MASS;
     constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE, NPC = GW / 2;
     // the records of the workgroup's 256 consecutive elements are staged in LDS and leave as consecutive 16-byte pieces: a thread's
     // own record is 80 (48) bytes, so stores straight from the registers put every lane on a line of its own
@@ -590,6 +593,12 @@ __global__ void __launch_bounds__(256) k_affine_records(const double* verts, con
 #pragma unroll
             for (int k = 0; k < 3; ++k) J[i][k] = 0.5 * (X[k + 1][i] - X[0][i]);
         const double detJ = det_small<3>(J);
+        if constexpr (MASS) {   // (no inverse, no singular report: a degenerate element contributes nothing)
+            f64x2* om = stage + threadIdx.x * NPC;
+            f64x2 v0; v0.x = fabs(detJ); v0.y = 0.0;
+            const f64x2 z2 = {0.0, 0.0};
+            om[0] = v0; om[1] = z2; om[2] = z2;
+        } else
         if (detJ == 0.0) {
             if (!active || active[e]) report_singular(status, e);
 #pragma unroll
@@ -600,7 +609,9 @@ __global__ void __launch_bounds__(256) k_affine_records(const double* verts, con
             adj_scaled(J, copysign(rsqrt_newton(fabs(detJ)), detJ), R);
         }
         f64x2* o = stage + threadIdx.x * NPC;
-        if constexpr (LAP) {
+        if constexpr (MASS) {
+            (void)o;
+        } else if constexpr (LAP) {
             double M[6];
             int k = 0;
 #pragma unroll
@@ -629,6 +640,7 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
     if (e_end <= e_first) return hipSuccess;
     const dim3 grid((unsigned)((e_end - e_first + 255) / 256));
     if (op == FH_LAPLACE) hipLaunchKernelGGL(k_affine_records<FH_LAPLACE>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, e_first, e_end, rec, status);
+    else if (op == FH_MASS_SCALAR) hipLaunchKernelGGL(k_affine_records<FH_MASS_SCALAR>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, e_first, e_end, rec, status);
     else hipLaunchKernelGGL(k_affine_records<FH_LINEAR_ELASTIC>, grid, dim3(256), 0, stream, verts, conn, elem_aff, active, e_first, e_end, rec, status);
     return hipGetLastError();
 }

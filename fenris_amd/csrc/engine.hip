@@ -1111,7 +1111,7 @@ int build_partition(fh_ctx* c) {
     // nodes per block (tunable), entry capacity per batch, accumulator budget
     // Hex8 meshes with affine elements: 36 row lanes per node in k_affine_rows, seven nodes per block also for S = 1
     const bool aff_cand = c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff > 0 && !c->aff_failed && c->affine_tol > 0.0 &&
-                          (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC);
+                          (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC || (c->op == FH_MASS_SCALAR && c->has_params));
     const bool rows_special = perm_cand;   // tables for the row-owner Tet4 kernel alone: larger blocks (below)
     // Hex8 Laplace / LinearElastic without a mask: the general positions run on k_hex8_rows (36 row lanes per node as well)
     const bool hrows_cand = c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->has_rules &&
@@ -1288,7 +1288,8 @@ int build_partition(fh_ctx* c) {
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
         if (us * c->ei.ng <= (rows_special ? 1024 : 512) && us <= 252 && ms <= 256 && (rows_special || (ms * (n / jt) <= 256 && ms * n / 4 <= 256)) && ms <= mb &&
-            nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 && c->fast_ok) {
+            nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 &&
+            (c->fast_ok || (c->op == FH_MASS_SCALAR && c->elem_kind == FH_HEX8))) {   // (the mass tables take densities that differ from point to point)
             const int nblk = c->nblk;
             mark("headers to the host, staging sizes");
             // Block classes: 1 = every adjacent element is affine, the block runs on k_affine_rows; 0 = general kernels.
@@ -1296,7 +1297,8 @@ int build_partition(fh_ctx* c) {
             std::vector<unsigned char> cls((size_t)nblk, 0);
             DevBuf<unsigned char> cls_d;
             const bool want_aff = c->elem_kind == FH_HEX8 && c->has_aff && c->has_ghat && c->num_aff > 0 && !c->has_rules &&
-                                  !c->aff_failed && c->affine_tol > 0.0 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+                                  !c->aff_failed && c->affine_tol > 0.0 &&
+                                  (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC || (c->op == FH_MASS_SCALAR && c->has_params)) &&
                                   us <= 32 && nb_target <= 8 && !c->env("FENRIS_HIP_NO_AFFINE");
             if (want_aff) {
                 HIP_TRY(c, cls_d.alloc((size_t)nblk));
@@ -1312,7 +1314,13 @@ int build_partition(fh_ctx* c) {
             chain_off[0].push_back(0);
             chain_off[1].push_back(0);
             // (every block affine -- structured boxes: no chains to form, the affine positions are sorted into CSR order below)
-            const bool all_affine = want_aff && std::find(cls.begin(), cls.end(), (unsigned char)0) == cls.end();
+            bool all_affine = want_aff && std::find(cls.begin(), cls.end(), (unsigned char)0) == cls.end();
+            if (c->op == FH_MASS_SCALAR && want_aff && !all_affine) {
+                // the mass matrix has no kernel for the general positions alone (the generic gather walks every block): a mesh with
+                // any non-affine block stays on it entirely
+                std::fill(cls.begin(), cls.end(), (unsigned char)0);
+                if (cls_d.p) HIP_TRY(c, hipMemsetAsync(cls_d.p, 0, (size_t)nblk, c->stream));
+            }
             if (!c->env("FENRIS_HIP_NO_SWEEP") && !all_affine) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
@@ -1647,11 +1655,13 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
 int launch_affine(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    const int gw = (c->op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    // the scalar mass matrix rides the Laplace kernel: records (|det J|, 0 ...), reference blocks (sum_q w rho phi_a phi_b, 0 ...)
+    const int rop = (c->op == FH_MASS_SCALAR) ? (int)FH_LAPLACE : c->op;
+    const int gw = (rop == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
     const unsigned char* act = c->has_mask ? c->active.p : nullptr;
     DevStatus* status = c->status.p + c->status_slot;
-    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", c->op == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
+    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", rop == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
                    (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
     // (instrumentation: compiled only into a `make TRACE=1` library)
@@ -1663,32 +1673,33 @@ int launch_affine(fh_ctx* c, KArgs& a) {
                      (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
-                          c->ghat.p + (c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count, c->g_acc, pos0, c->a_npos, c->a_incomplete,
+                          c->ghat.p + (c->op == FH_MASS_SCALAR ? 64 * (AFFINE_GW_LE + AFFINE_GW_LAP) : c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count,
+                          c->g_acc, pos0, c->a_npos, c->a_incomplete,
                           c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0)};
 #ifdef FENRIS_HIP_WITH_RING
         if (use_ring) {
             const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
-            const size_t lds = affine_ring_lds_bytes(c->op, c->a_us, ring);
+            const size_t lds = affine_ring_lds_bytes(rop, c->a_us, ring);
             if (lds <= LDS_LIMIT) {
-                const int cap = c->op == FH_LAPLACE ? 4 : 3;
+                const int cap = rop == FH_LAPLACE ? 4 : 3;
                 const int per_cu = std::max(1, (int)std::min<size_t>(cap, LDS_LIMIT / std::max<size_t>(lds, 1)));
                 const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] affine ring: positions %d + %d ring=%d doubles lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, ring, lds, per_cu, grid);
-                HIP_TRY(c, affine_ring_launch(c->op, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
+                HIP_TRY(c, affine_ring_launch(rop, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
                                               a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 0) & 3) << 28)));
                 return FH_OK;
             }
         }
 #endif
-        const size_t lds = affine_rows_lds_bytes(c->op, c->a_us, c->g_acc);
+        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc);
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
-        const int per_cu = std::max(1, (int)std::min<size_t>(c->op == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+        const int per_cu = std::max(1, (int)std::min<size_t>(rop == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
         const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
         if (c->env("FENRIS_HIP_VERBOSE"))
             std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
-        HIP_TRY(c, affine_rows_launch(c->op, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
+        HIP_TRY(c, affine_rows_launch(rop, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
                                       a.ablate | nt, c->has_mask));
         return FH_OK;
     };
@@ -2540,9 +2551,19 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     if (c->elem_kind == FH_HEX8) {
         // reference blocks of the affine-element kernel: Ghat_ab[c][d] = sum_q w_q ghat_a(xi_q)[c] ghat_b(xi_q)[d], summed in
         // table order; Ghat_ba is the exact transpose of Ghat_ab (the factors of each product commute)
-        std::vector<double> gh((size_t)64 * (AFFINE_GW_LE + AFFINE_GW_LAP), 0.0);
+        std::vector<double> gh((size_t)64 * (AFFINE_GW_LE + 2 * AFFINE_GW_LAP), 0.0);
         double* le = gh.data();
         double* lap = gh.data() + 64 * AFFINE_GW_LE;
+        // third table (mass matrix of the affine elements, op FH_MASS_SCALAR): sum_q w_q rho_q phi_a phi_b in the first place of a Laplace-shaped
+        // block, rho = the first parameter of a point (mass.rs:131-286)
+        double* mass = gh.data() + 64 * (AFFINE_GW_LE + AFFINE_GW_LAP);
+        if (params)
+            for (int a = 0; a < 8; ++a)
+                for (int b = 0; b < 8; ++b) {
+                    double m = 0.0;
+                    for (uint32_t q = 0; q < nq; ++q) m += (w[q] * params[2 * q]) * (phiref[(size_t)q * 8 + a] * phiref[(size_t)q * 8 + b]);
+                    mass[(a * 8 + b) * AFFINE_GW_LAP] = m;
+                }
         for (int a = 0; a < 8; ++a)
             for (int b = 0; b < 8; ++b) {
                 double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};

@@ -284,3 +284,55 @@ def test_affine_masks_and_holes_with_many_positions_per_workgroup(engine, oracle
     finally:
         engine.set_active_elements(None)
         engine.set_option("FENRIS_HIP_AFFINE_GRID", None)
+
+
+@pytest.mark.parametrize("shape", ["box", "sheared", "half distorted"])
+def test_scalar_mass_matrix_on_the_affine_kernel(oracle, shape):
+    """ElementMassAssembler (mass.rs:131-286) with s = 1 on parallelepiped hexahedra rides k_affine_rows<Laplace>: records (|det J|, 0 ...),
+    reference blocks (sum_q w rho_q phi_a phi_b, 0 ...) -- densities that differ from point to point, an element mask, and a mesh whose
+    distorted half stays on the generic kernel"""
+    rng = np.random.default_rng(12)
+    mesh = fa.procedural.create_rectangular_uniform_hex_mesh(0.5, 7, 6, 5, 1)
+    v = mesh.vertices.copy()
+    if shape == "sheared":
+        v = v @ np.array([[1.0, 0.2, 0.0], [0.1, 0.9, 0.3], [0.0, -0.2, 1.1]])
+    if shape == "half distorted":
+        far = v[:, 0] > 2.6          # (the node blocks of the lines' first halves keep affine elements only)
+        v[far] += 0.03 * rng.uniform(-1, 1, (int(far.sum()), 3))
+    mesh = fa.Mesh(v, mesh.connectivity, fa.HEX8)
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    rho = 1.0 + rng.random(len(w))
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_data([fa.Density(r) for r in rho])
+    eng = fa.Engine(0)
+    try:
+        asm = fa.ElementMassAssembler.with_solution_dim(1, eng).with_space(mesh).with_quadrature_table(qt)
+        ref = oracle.ElementAssembler(oracle.HEX8, oracle.MASS_SCALAR, mesh.vertices, mesh.connectivity, w, p,
+                                      params=np.stack([rho, np.zeros_like(rho)], axis=1))
+        st, _, ro, ci, vals = oracle.assemble(ref)
+        assert st == 0
+        k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        if shape == "half distorted":   # a mesh with any non-affine node block stays on the generic gather entirely
+            assert eng.last_kernel_name() == "k_assemble_matrix<gather>"
+        else:
+            assert eng.last_kernel_name() == "k_affine_rows", eng.last_kernel_name()
+        assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+        assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max()
+        a = k.to_scipy()
+        if shape != "half distorted":
+            assert (a != a.T).nnz == 0                      # exactly symmetric (the affine kernel's term order)
+        assert abs(a.sum() - (w * rho).sum() / 8.0 * 0.125 * mesh.num_elements()) <= 1e-9 * a.sum() or shape != "box"   # total mass of the box
+        # element mask, values overwritten in an array of garbage
+        import torch
+
+        mask = (rng.random(mesh.num_elements()) < 0.7).astype(np.uint8)
+        eng.set_active_elements(mask)
+        sub = oracle.ElementAssembler(oracle.HEX8, oracle.MASS_SCALAR, mesh.vertices, np.asarray(mesh.connectivity)[mask == 1], w, p,
+                                      params=np.stack([rho, np.zeros_like(rho)], axis=1))
+        want = np.zeros(len(ci))
+        st, _ = oracle.assemble_into_csr(sub, ro, ci, want)
+        assert st == 0
+        buf = torch.full((len(ci),), -7.5, dtype=torch.float64, device="cuda:0")
+        eng.assemble_matrix(buf, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        assert np.abs(buf.cpu().numpy() - want).max() <= TOL * np.abs(vals).max()
+    finally:
+        eng.close()

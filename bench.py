@@ -358,9 +358,18 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
     eng = fa.Engine(0, stream=stream)
     try:
         c["configure"](eng, mesh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         nnz = eng.build_pattern()
+        torch.cuda.synchronize()
+        t_pattern = time.perf_counter() - t0
         values = torch.zeros(nnz, dtype=torch.float64, device="cuda")
         flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.assemble_matrix_async(values, flags)     # the first assembly of the context: owner / lane tables, once per pattern
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t0
         values, placement = probe_placement(eng, values, flags, torch, 2)
         for _ in range(warmup):
             eng.assemble_matrix_async(values, flags)
@@ -379,7 +388,7 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
         bound, ach, peak, unit, frac = roofline_of(cfg, c, E, N, nnz, avg)
         return {"workload": c["desc"], "elements": E, "nnz": nnz, "ms": avg, "ms_min": ms[0], "elements_per_s": E / (avg * 1e-3),
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "kernel": eng.last_kernel_name(), "steps": steps,
-                "placement_probe": placement}
+                "pattern_build_s": t_pattern, "first_assembly_s": t_first, "placement_probe": placement}
     finally:
         eng.close()
         values = None

@@ -350,6 +350,8 @@ struct fh_ctx {
     DevBuf<double> ghat;            // [64][10] LinearElastic blocks | [64][6] Laplace blocks
     bool has_ghat = false;
     DevBuf<int> a_conn, a_elem;     // k_affine_rows (affine_rows.hip): per-slot connectivity (table build only), element ids
+    DevBuf<int> a_vtab;             // ... vertex tables of the fused form (affine_rows_vertex_tables): [a_npos][a_nu + 32]
+    int a_nu = 0;                   // padded length of their vertex lists (0: none -- the separate records kernel runs)
     DevBuf<uint2> a_lanes;          // lane records
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
@@ -437,7 +439,7 @@ struct fh_ctx {
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
-    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
+    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_vtab) X(a_nu) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
     X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
@@ -1420,6 +1422,29 @@ int build_partition(fh_ctx* c) {
                     c->a_emin = got[1] >= 0 ? got[0] : 0;
                     c->a_emax = got[1];
                 }
+                mark("element range of the affine class");
+                // round 5, the fused form of k_affine_rows: per position the distinct vertices of its slots' elements (nodes 0, 1, 3, 4) and
+                // their places per slot, so that the kernel's records wave forms the element records itself (no k_affine_records launch)
+                c->a_nu = 0;
+                c->a_vtab.release();
+                // NOT the default: measured slower than the separate records kernel (profiles/r05_fused_records_experiment.txt); the tables
+                // (0.7 GB on the 216^3 mesh) are built only when FENRIS_HIP_AFFINE_FUSED=1 is set before the pattern is built.
+                if (c->env_int("FENRIS_HIP_AFFINE_FUSED", 0) != 0 && c->op != FH_MASS_SCALAR) {
+                    DevBuf<int> numax;
+                    HIP_TRY(c, numax.alloc(1));
+                    HIP_TRY(c, hipMemsetAsync(numax.p, 0, sizeof(int), c->stream));
+                    HIP_TRY(c, affine_rows_vertex_count(c->stream, c->a_elem.p, c->conn.p, us, npos, numax.p));
+                    int nu = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&nu, numax.p, sizeof nu, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    const int nu_pad = std::max(4, (nu + 3) / 4 * 4);
+                    if (nu > 0 && nu_pad <= 128) {
+                        HIP_TRY(c, c->a_vtab.alloc((size_t)npos * (nu_pad + 32)));
+                        HIP_TRY(c, affine_rows_vertex_tables(c->stream, c->a_elem.p, c->conn.p, us, npos, c->a_vtab.p, nu_pad));
+                        c->a_nu = nu_pad;
+                    }
+                    mark("vertex tables of the affine class (fused records)");
+                }
             }
             c->npos_gen = (int)order[0].size();
             if (!order[0].empty()) {
@@ -1658,11 +1683,24 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     // the scalar mass matrix rides the Laplace kernel: records (|det J|, 0 ...), reference blocks (sum_q w rho phi_a phi_b, 0 ...)
     const int rop = (c->op == FH_MASS_SCALAR) ? (int)FH_LAPLACE : c->op;
     const int gw = (rop == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
-    if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
+    // round 5 (experiment, FENRIS_HIP_AFFINE_FUSED=1): the element records formed inside k_affine_rows by a seventh wavefront (FUSED
+    // instantiation) -- no k_affine_records launch, no record array.  Measured SLOWER than the two launches (4.82 against 4.73 ms on the
+    // headline in one context, C2 0.56 against 0.31): what the records kernel costs is its cold reads, and the fused form has as many.
+    const int a_depth = c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), a_nstore = c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1);
+    const int a_chunk = c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0);
+    bool fused = c->op != FH_MASS_SCALAR && c->a_nu > 0 && c->a_vtab.p && c->env_int("FENRIS_HIP_AFFINE_FUSED", 0) != 0 &&
+                 affine_rows_can_fuse(a_depth, a_nstore, a.ablate, a_chunk);
+    if (fused && affine_rows_lds_bytes(rop, c->a_us, c->g_acc, c->a_nu) > LDS_LIMIT) fused = false;
+#ifdef FENRIS_HIP_WITH_RING
+    if (c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0) fused = false;
+#endif
+    if (!fused && c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
     const unsigned char* act = c->has_mask ? c->active.p : nullptr;
     DevStatus* status = c->status.p + c->status_slot;
     const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", rop == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
-                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0);
+                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0) |
+                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 1) ? AFFINE_ROWS_REC_NO_DMA : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 2) ? AFFINE_ROWS_REC_NO_MATH : 0) |
+                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 4) ? AFFINE_ROWS_REC_NO_L1 : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 8) ? AFFINE_ROWS_REC_NO_L2 : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
     // (instrumentation: compiled only into a `make TRACE=1` library)
 #ifdef FENRIS_HIP_WITH_RING
@@ -1674,8 +1712,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                           c->ghat.p + (c->op == FH_MASS_SCALAR ? 64 * (AFFINE_GW_LE + AFFINE_GW_LAP) : c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count,
-                          c->g_acc, pos0, c->a_npos, c->a_incomplete,
-                          c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0)};
+                          c->g_acc, pos0, c->a_npos, c->a_incomplete, a_chunk, fused ? c->a_vtab.p : nullptr, fused ? c->a_nu : 0};
 #ifdef FENRIS_HIP_WITH_RING
         if (use_ring) {
             const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
@@ -1692,17 +1729,17 @@ int launch_affine(fh_ctx* c, KArgs& a) {
             }
         }
 #endif
-        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc);
+        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc, fused ? c->a_nu : 0);
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
         const int per_cu = std::max(1, (int)std::min<size_t>(rop == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
         const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
         if (c->env("FENRIS_HIP_VERBOSE"))
-            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
-        HIP_TRY(c, affine_rows_launch(rop, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1), grid, lds, c->stream, a, T,
-                                      a.ablate | nt, c->has_mask));
+            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d fused=%d\n", pos0, count, lds, per_cu, grid, (int)fused);
+        HIP_TRY(c, affine_rows_launch(rop, a_depth, a_nstore, grid, lds, c->stream, a, T, a.ablate | nt, c->has_mask, fused));
         return FH_OK;
     };
+    if (fused) return rows(0, c->a_npos);
     // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly.  (Round 3: making
     // the records of all but the first eighth of the sweep on a second stream beside the first part's launch was measured 0.3 ms
     // SLOWER than the 0.41 ms it hides -- the two kernels' workgroups compete for the CUs; two launches of the sweep in one stream cost
@@ -2156,7 +2193,7 @@ void fh_destroy(fh_ctx* c) {
     if (c->trace.p) {  // FENRIS_HIP_TRACE: average cycles per wave and phase of the pipelined kernel
         unsigned long long h[32] = {0};
         (void)hipDeviceSynchronize();
-        if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6]) {
+        if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && (h[6] || h[27])) {   // (h[27]: the records wave of the fused affine kernel reports as "wave 3": landed-wait, arithmetic, DMA issue, barrier)
             // pipelined kernel: six phases of waves 0-3; affine kernel: "wave" = role (0 row wave, 1 loader, 2 store wave), phase 0 =
             // work between barriers, phase 2 = at the barrier
             static const char* names_pipe[6] = {"top", "phaseB+writeout(prev)", "barrier", "phaseC", "finalize+park", "end barrier"};

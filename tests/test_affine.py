@@ -336,3 +336,57 @@ def test_scalar_mass_matrix_on_the_affine_kernel(oracle, shape):
         assert np.abs(buf.cpu().numpy() - want).max() <= TOL * np.abs(vals).max()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
+@pytest.mark.parametrize("grid", [None, "2"])
+def test_affine_fused_records_wave(oracle, op, grid):
+    """Round 5 (experiment, opt-in): FENRIS_HIP_AFFINE_FUSED=1 builds per-position vertex tables and lets a seventh wavefront of k_affine_rows
+    form the element records from the vertices by LDS-DMA (no k_affine_records launch).  Same matrix to the tolerance against the oracle,
+    symmetric bit for bit, reproducible, under an element mask, accumulating, with few workgroups (many positions each: the steady state of
+    the DMA pipeline), and the singular element is reported."""
+    names = ("box9", "graded", "sheared", "mirrored", "mixed", "slab_17x3x2", "single_element")
+    for name in names:
+        eng = fa.Engine(0)
+        try:
+            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
+            if grid:
+                eng.set_option("FENRIS_HIP_AFFINE_GRID", grid)
+            mesh = _meshes()[name]
+            asm, ref = _assemblers(eng, oracle, mesh, op)
+            st, _, ro, ci, vals = oracle.assemble(ref)
+            assert st == 0
+            k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert eng.last_kernel_name().startswith("k_affine_rows")
+            assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+            assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max(), name
+            if EXPECT[name] == "affine":
+                assert _symmetric_bitwise(k)
+            k2 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert np.array_equal(k.values, k2.values)
+            fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
+            assert np.abs(k.values - 2.0 * vals).max() <= 2 * TOL * np.abs(vals).max()
+            # the separate records kernel inside the same context: same matrix to rounding (the records are formed by other instructions)
+            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 0)
+            k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert np.abs(k3.values - k2.values).max() <= TOL * np.abs(vals).max()
+            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
+            active = (np.arange(mesh.num_elements()) % 5 != 2)
+            if mesh.num_elements() > 5:
+                eng.set_active_elements(active)
+                km = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+                ka = fa.CsrAssembler(fa.SCATTER_ATOMIC).assemble(asm)
+                assert np.abs(km.values - ka.values).max() <= TOL * np.abs(ka.values).max(), name
+        finally:
+            eng.close()
+    # singular element (det J == 0 exactly): reported with the lowest element, like elliptic.rs:401-404
+    eng = fa.Engine(0)
+    try:
+        eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
+        flat = _sheared(fa.procedural.create_unit_box_uniform_hex_mesh_3d(4), [[1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]])
+        asm, _ = _assemblers(eng, oracle, flat, op)
+        with pytest.raises(fa.SingularJacobianError) as ei:
+            fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert ei.value.element == 0
+    finally:
+        eng.close()

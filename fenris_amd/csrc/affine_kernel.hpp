@@ -19,7 +19,7 @@ constexpr int AFFINE_GW_LE = 10, AFFINE_GW_LAP = 6;  // doubles per reference bl
 // 1 if the trilinear map of a hexahedron is affine to the relative tolerance `tol`: with the node signs of
 // hexahedron.rs:49-58 the map is  c0 + c1 xi + c2 eta + c3 zeta + c12 xi eta + c23 eta zeta + c31 zeta xi + c123 xi eta zeta,
 // c_* = 1/8 sum_a sign X_a; affine iff the four mixed coefficients vanish.  Compared against the shortest of c1, c2, c3.
-__global__ void __launch_bounds__(256) k_classify_affine_hex8(const double* verts, const int* conn, long long E, double tol,
+static __global__ void __launch_bounds__(256) k_classify_affine_hex8(const double* verts, const int* conn, long long E, double tol,
                                                               unsigned char* out, unsigned long long* count) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = e < E;
@@ -52,13 +52,13 @@ __global__ void __launch_bounds__(256) k_classify_affine_hex8(const double* vert
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
-__global__ void __launch_bounds__(256) k_bytes_differ(const unsigned char* x, const unsigned char* y, long long n, int* differ) {
+static __global__ void __launch_bounds__(256) k_bytes_differ(const unsigned char* x, const unsigned char* y, long long n, int* differ) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && x[i] != y[i]) *differ = 1;
 }
 
 // class of a node block: 1 if every adjacent element is affine (and the block fits the affine kernel's slot budget)
-__global__ void __launch_bounds__(256) k_block_class(const GatherHdr* hdr, const unsigned* gt_elems, const unsigned char* elem_aff,
+static __global__ void __launch_bounds__(256) k_block_class(const GatherHdr* hdr, const unsigned* gt_elems, const unsigned char* elem_aff,
                                                      int nblk, int max_u, unsigned char* cls) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_block_class(const GatherHdr* hdr, const
 }
 
 // smallest and largest non-negative entry (mm = {INT_MAX, -1} on entry): the element range behind a set of position tables
-__global__ void __launch_bounds__(256) k_minmax_nonneg(const int* v, size_t n, int* mm) {
+static __global__ void __launch_bounds__(256) k_minmax_nonneg(const int* v, size_t n, int* mm) {
     int lo = 0x7fffffff, hi = -1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int x = v[i];

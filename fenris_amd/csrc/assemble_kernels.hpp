@@ -1415,7 +1415,7 @@ __global__ void __launch_bounds__(256, (QC >= 8 ? 2 : 3)) k_gather_pipelined(con
 
 // (mu, lambda) of the element staged in every slot of every position, for compact tables whose rules are constant over
 // their points: out[2 i] = rparams[rule_map[elem[i]]][point 0]
-__global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size_t n, const unsigned* rule_map, const double* rparams,
+static __global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size_t n, const unsigned* rule_map, const double* rparams,
                                                            int nq, double* out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1435,7 +1435,7 @@ __global__ void __launch_bounds__(256) k_build_slot_params(const int* elem, size
 // wavefront per block.
 // cls (optional): class of every block; only blocks of the same class are candidates (chains never mix classes).
 // r2v (optional): position of every node in the order the blocks were formed in (null: the node numbering itself).
-__global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
+static __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
                                                         const int* node2blk, int nblk, const unsigned char* cls, int* succ,
                                                         const int* r2v = nullptr) {
     __shared__ int cand[1024];
@@ -1480,7 +1480,7 @@ __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, co
     (void)nblk;
 }
 
-__global__ void k_node_to_block(const unsigned* blk_off, int nblk, int* node2blk) {
+static __global__ void k_node_to_block(const unsigned* blk_off, int nblk, int* node2blk) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     for (unsigned i = blk_off[b]; i < blk_off[b + 1]; ++i) node2blk[i] = b;
@@ -1699,7 +1699,7 @@ __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk
 
 // link[i] = 1 if nodes i and i+1 share an element (sorted merge of their adjacency lists; entries are e * n + a).
 // Runs of linked nodes are what a structured numbering calls grid lines; the block partition aligns to them.
-__global__ void k_linked_to_next(const unsigned* n2e_off, const unsigned* n2e, int N, int num_nodes, unsigned char* link) {
+static __global__ void k_linked_to_next(const unsigned* n2e_off, const unsigned* n2e, int N, int num_nodes, unsigned char* link) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_nodes) return;
     unsigned char r = 0;
@@ -1716,7 +1716,7 @@ __global__ void k_linked_to_next(const unsigned* n2e_off, const unsigned* n2e, i
 
 // ---- locality order of the nodes (row-owner Tet4 kernel on meshes whose numbering has none: see build_partition)
 // Morton key of a vertex: 21 bits per coordinate of its position in the bounding box
-__global__ void k_morton_keys(const double* verts, int N, int D, double lo0, double lo1, double lo2, double s0, double s1, double s2,
+static __global__ void k_morton_keys(const double* verts, int N, int D, double lo0, double lo1, double lo2, double s0, double s1, double s2,
                               unsigned long long* keys, unsigned* ids) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -1736,18 +1736,18 @@ __global__ void k_morton_keys(const double* verts, int N, int D, double lo0, dou
     keys[i] = key;
     ids[i] = (unsigned)i;
 }
-__global__ void k_invert_perm(const unsigned* v2r, int N, int* r2v) {
+static __global__ void k_invert_perm(const unsigned* v2r, int N, int* r2v) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < N) r2v[v2r[v]] = v;
 }
 // len[v] = length of row v2r[v] of the offsets `off` (len[N] = 0: input of an exclusive scan)
-__global__ void k_perm_row_lengths(const unsigned* off, const unsigned* v2r, int N, unsigned* len) {
+static __global__ void k_perm_row_lengths(const unsigned* off, const unsigned* v2r, int N, unsigned* len) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < N) { const unsigned r = v2r[v]; len[v] = off[r + 1] - off[r]; }
     if (v == N) len[v] = 0;
 }
 // dst row v = src row v2r[v] (contents unchanged)
-__global__ void k_perm_copy_rows(const unsigned* off_src, const unsigned* src, const unsigned* v2r, const unsigned* off_dst, unsigned* dst,
+static __global__ void k_perm_copy_rows(const unsigned* off_src, const unsigned* src, const unsigned* v2r, const unsigned* off_dst, unsigned* dst,
                                  int N) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
@@ -1755,12 +1755,12 @@ __global__ void k_perm_copy_rows(const unsigned* off_src, const unsigned* src, c
     for (unsigned k = 0; k < n; ++k) dst[b + k] = src[a + k];
 }
 // first node-level CSR entry of the real row of every node in partition order (v2r == null: the natural order)
-__global__ void k_row_starts(const unsigned* noff, const unsigned* v2r, int N, unsigned* row_real) {
+static __global__ void k_row_starts(const unsigned* noff, const unsigned* v2r, int N, unsigned* row_real) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < N) row_real[v] = noff[v2r ? v2r[v] : (unsigned)v];
 }
 
-__global__ void k_hdr_counts(const GatherHdr* hdr, int nblk, unsigned* counts) {
+static __global__ void k_hdr_counts(const GatherHdr* hdr, int nblk, unsigned* counts) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nblk) counts[b] = (unsigned)hdr[b].U;
     if (b == nblk) counts[b] = 0;
@@ -1804,145 +1804,6 @@ __global__ void __launch_bounds__(256) k_assemble_vector(const KArgs a) {
         const int node = lds_i[L.o_cn + u * N + I];
 #pragma unroll
         for (int i = 0; i < S; ++i) atomic_add_f64(a.vec_out + (size_t)node * S + i, f[i]);
-    }
-}
-
-// ============================================================================================ rows from dense K_e
-// Second pass of the two-pass owner-computes assembly used for high-order elements (n > 8): the dense element
-// matrices were written by k_assemble_matrix<MODE_DUMP> (column-major, both triangles); here one wavefront owns a
-// node, walks the node's (element, local index a) entries and adds the columns S a .. S a + S - 1 of K_e -- by
-// symmetry its rows, but contiguous -- into the node's CSR rows held in LDS, then writes the rows once, coalesced.
-// Every K_e entry is read exactly once and every CSR value written exactly once; no atomics (the lanes of a
-// wavefront hit distinct targets within an entry, and a wavefront's LDS operations execute in order).
-// column slot of every local node of every (node, element) entry inside the owning node's row (one byte or one
-// 16-bit word per (entry, local node)); built once per pattern for the two-pass assembly
-template <typename PT>
-__global__ void __launch_bounds__(256) k_entry_positions(long long total, int n, const unsigned* adj_off, const unsigned* adj,
-                                                         const unsigned* noff, const unsigned* ncols, const int* conn,
-                                                         const int* entry_node, PT* pos) {
-    const long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= total) return;
-    const long long t = it / n;
-    const int J = (int)(it % n);
-    const int i = entry_node[t];
-    const unsigned ent = adj[t];
-    const unsigned r0 = noff[i];
-    pos[it] = (PT)find_col(ncols + r0, (int)(noff[i + 1] - r0), (unsigned)conn[(size_t)(ent / (unsigned)n) * n + J]);
-    (void)adj_off;
-}
-__global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsigned* adj_off, int* entry_node) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_nodes) return;
-    for (unsigned t = adj_off[i]; t < adj_off[i + 1]; ++t) entry_node[t] = i;
-}
-
-// PLANAR: the dense matrices are stored node-major as ke[e][I][r][c][J] (what the MFMA kernel writes) instead of one
-// column-major (S n) x (S n) matrix; the S x S x n values of an (element, local node) entry are one contiguous run and a lane walks
-// (c, J) with J fastest.
-// k_rows_from_dense for small column-major element matrices (S n <= P <= 32, P a power of two): a row of K_e fills less
-// than half a wavefront, so 64 / P entries of the node share one load instruction (lane / P picks the entry) and all
-// EB groups of a node are in flight together -- Hex8: the 8 entries of a node in one round (the one-entry-per-load
-// form ran this pass at 2.7 TB/s with 24 of 64 lanes busy).
-template <int S, typename PT, int P>
-__global__ void __launch_bounds__(256) k_rows_from_dense_small(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
-                                                               const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
-                                                               int overwrite, int max_cnt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
-    const int ld = S * n;
-    constexpr int G = 64 / P, EB = 4;
-    const int sub = lane / P, idx = min(lane % P, ld - 1);
-    const bool lane_in_row = (lane % P) < ld;
-    for (int i = blockIdx.x * 4 + wave; i < num_nodes; i += gridDim.x * 4) {
-        const unsigned r0 = noff[i];
-        const int cnt = (int)(noff[i + 1] - r0);
-        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
-        const unsigned t0 = adj_off[i], t1 = adj_off[i + 1];
-        for (unsigned t = t0; t < t1; t += EB * G) {
-            double v[EB][S];
-            int pos[EB];
-            bool ok[EB];
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const unsigned tk = t + (unsigned)(k * G + sub);
-                ok[k] = tk < t1 && lane_in_row;
-                const unsigned tc = min(tk, t1 - 1);
-                const unsigned ent = adj[tc];
-                const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                const double* kb = ke + (size_t)e * ld * ld + (size_t)S * a * ld;  // column S a + r of the symmetric K_e
-                pos[k] = (int)pos_tab[(size_t)tc * n + idx / S];
-#pragma unroll
-                for (int r = 0; r < S; ++r) v[k][r] = kb[(size_t)r * ld + idx];
-            }
-#pragma unroll
-            for (int k = 0; k < EB; ++k)
-                if (ok[k]) {
-                    double* dst = acc + S * pos[k] + idx % S;
-#pragma unroll
-                    for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][r]);
-                }
-        }
-        double* out = vals + (size_t)S * S * r0;
-        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
-        else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
-    }
-}
-
-template <int S, typename PT, bool PLANAR>
-__global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
-                                                         const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
-                                                         int overwrite, int max_cnt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
-    const int ld = S * n;
-    for (int i = blockIdx.x * 4 + wave; i < num_nodes; i += gridDim.x * 4) {
-        const unsigned r0 = noff[i];
-        const int cnt = (int)(noff[i + 1] - r0);
-        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
-        // Groups of EB entries: (element, local index) are wave-uniform (scalar loads); all K_e loads of the group
-        // (clamped, branch-free) are issued before the first LDS add, so that EB x 2 x S loads per lane are in
-        // flight -- with the loads of one entry at a time the pass ran at a quarter of the HBM rate.
-        // Targets of different entries may coincide (two elements sharing a neighbour node) => LDS atomics.
-        constexpr int EB = 4, HB = 2;  // entries per group, 64-lane column halves (S n <= 128 per half pair)
-        const unsigned t0 = __builtin_amdgcn_readfirstlane(adj_off[i]), t1 = __builtin_amdgcn_readfirstlane(adj_off[i + 1]);
-        for (unsigned t = t0; t < t1; t += EB) {
-            for (int h0 = 0; h0 * 64 < ld; h0 += HB) {
-                double v[EB][HB][S];
-                int pos[EB][HB];
-#pragma unroll
-                for (int k = 0; k < EB; ++k) {
-                    const unsigned tk = min(t + (unsigned)k, t1 - 1);
-                    const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
-                    const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                    const double* kb = PLANAR ? ke + (size_t)e * ld * ld + (size_t)a * (S * S * n) : ke + (size_t)e * ld * ld + (size_t)S * a * ld;
-                    const PT* pp = pos_tab + (size_t)tk * n;
-#pragma unroll
-                    for (int h = 0; h < HB; ++h) {
-                        const int idx = min(lane + 64 * (h0 + h), ld - 1);
-                        pos[k][h] = (int)pp[PLANAR ? idx % n : idx / S];
-#pragma unroll
-                        for (int r = 0; r < S; ++r)
-                            v[k][h][r] = PLANAR ? kb[(size_t)r * (S * n) + idx] : kb[(size_t)r * ld + idx];   // planar: ke[e][a][r][c][J], idx = c n + J
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < EB; ++k)
-#pragma unroll
-                    for (int h = 0; h < HB; ++h) {
-                        const int idx = lane + 64 * (h0 + h);
-                        if (t + (unsigned)k < t1 && idx < ld) {
-                            double* dst = acc + S * pos[k][h] + (PLANAR ? idx / n : idx % S);
-#pragma unroll
-                            for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][h][r]);
-                        }
-                    }
-            }
-        }
-        double* out = vals + (size_t)S * S * r0;
-        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
-        else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
     }
 }
 

@@ -19,7 +19,7 @@ __device__ __forceinline__ unsigned color_priority(unsigned e) {   // murmur3 fi
 }
 
 // n2e: node -> entries v = element * n + local node, sorted (k_sort_n2e)
-__global__ void __launch_bounds__(256) k_color_propose(int E, int n, const int* conn, const unsigned* n2e_off, const unsigned* n2e,
+static __global__ void __launch_bounds__(256) k_color_propose(int E, int n, const int* conn, const unsigned* n2e_off, const unsigned* n2e,
                                                       const int* color, int* tent, int* overflow) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_color_propose(int E, int n, const int* 
     tent[e] = pick;
 }
 
-__global__ void __launch_bounds__(256) k_color_resolve(int E, int n, const int* conn, const unsigned* n2e_off, const unsigned* n2e,
+static __global__ void __launch_bounds__(256) k_color_resolve(int E, int n, const int* conn, const unsigned* n2e_off, const unsigned* n2e,
                                                       const int* tent, int* color, unsigned* remaining) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_color_resolve(int E, int n, const int* 
     else atomicAdd(remaining, 1u);
 }
 
-__global__ void __launch_bounds__(256) k_color_iota(int E, unsigned* ids, int* color, int fill) {
+static __global__ void __launch_bounds__(256) k_color_iota(int E, unsigned* ids, int* color, int fill) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     ids[e] = (unsigned)e;

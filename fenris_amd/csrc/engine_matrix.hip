@@ -1,0 +1,654 @@
+// Stiffness / mass matrix launchers and their C ABI
+#include "engine_internal.hpp"
+
+template <int EK, int OP>
+int launch_matrix(fh_ctx* c, KArgs& a, int mode, size_t lds_bytes, int grid) {
+    if (grid <= 0) return FH_OK;   // nothing to do (an element mask without an active element): a launch of zero workgroups is an error
+    hipStream_t st = c->stream;
+#define FH_LAUNCH(M)                                                                                              \
+    do {                                                                                                          \
+        auto kern = k_assemble_matrix<EK, OP, M>;                                                                 \
+        if (lds_bytes > 48 * 1024)                                                                                \
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds_bytes));                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, a);                                        \
+    } while (0)
+    switch (mode) {
+        case MODE_ATOMIC: FH_LAUNCH(MODE_ATOMIC); break;
+        case MODE_COLORED: FH_LAUNCH(MODE_COLORED); break;
+        case MODE_GATHER: FH_LAUNCH(MODE_GATHER); break;
+        case MODE_DUMP: FH_LAUNCH(MODE_DUMP); break;
+        default: return c->fail(FH_BAD_ARGUMENT, "bad scatter mode");
+    }
+#undef FH_LAUNCH
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int EK, int OP>
+size_t layout_bytes(int what, int nq, int ub, int acc, int nb, bool gather, int mb, int fast, int nc_row) {
+    switch (what) {
+        case WHAT_MATRIX: return make_layout<EK, OP, WHAT_MATRIX>(nq, ub, acc, nb, gather, mb, fast, 0, nc_row).bytes();
+        case WHAT_VECTOR: return make_layout<EK, OP, WHAT_VECTOR>(nq, ub, acc, nb, gather, mb).bytes();
+        default: return make_layout<EK, OP, WHAT_SCALAR>(nq, ub, acc, nb, gather, mb).bytes();
+    }
+}
+
+
+size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb, int fast, int nc_row) {
+    size_t r = 0;
+#define CALL(EKC, OPC) r = layout_bytes<EKC, OPC>(what, nq, ub, acc, nb, gather, mb, fast, nc_row)
+    FH_FOR_ELEM_OP(ek, op, CALL)
+#undef CALL
+    return r;
+}
+
+
+int choose_epb(fh_ctx* c, int what) {
+    int best = 1;
+    for (int epb = 1; epb <= 64; ++epb) {
+        const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false, 0, generic_fast(c));
+        if (b <= LDS_TARGET) best = epb; else break;
+    }
+    return best;
+}
+
+template <int OP, bool ELEMPAR = false>
+int launch_rows_tet4(fh_ctx* c, KArgs& a, const RowTablesS& T) {
+    // the layout's integers + two parities of the record + the slot words
+    const size_t lds = make_layout<FH_TET4, OP, WHAT_MATRIX>(a.nq, a.ub, 0, a.nb_max, true, 0, 1, 1, 0, 2).bytes() +
+                       sizeof(int) * (size_t)(2 * T.rw + T.us + 4);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "row-owner gather: LDS footprint too large");
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    // workgroups per CU, measured inside one context on the same buffers (scripts/ab_in_context.py, C3): elasticity 2 (0.562 ms; 3: 0.594,
+    // 4: 0.603, 5: 0.585), Laplace 4
+    const size_t cap = (c->op == FH_LAPLACE) ? 4 : 2;
+    const int per_cu = std::max(1, (int)std::min<size_t>(cap, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    // (FENRIS_HIP_PIPE_GRID: tests force many positions per workgroup on small meshes)
+    const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu))));
+    auto kern = a.trace ? k_gather_rows_tet4<OP, ELEMPAR, true> : k_gather_rows_tet4<OP, ELEMPAR>;   // FENRIS_HIP_TRACE: instrumented twin
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->env("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] row-owner gather (Tet4): lds=%zu B wgs/cu=%d grid=%d\n", lds, per_cu, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int EK, int OP, int QC, int JT>
+int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
+    size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC).bytes();
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "pipelined gather: LDS footprint too large");
+    // the compile-time-rule instantiation (Hex8, rule of exactly QC points) stages planar gradient rows, which are
+    // longer: taken only while two workgroups still share a CU
+    bool fullq = false;
+    if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
+        const size_t lds_planar = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC, 0, 1).bytes();
+        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 && !c->env("FENRIS_HIP_NO_FULLQ") &&
+                (2 * lds_planar + 1024 <= LDS_LIMIT || 2 * lds + 1024 > LDS_LIMIT);
+        if (fullq) lds = lds_planar;
+    }
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int per_cu = std::max(1, (int)std::min<size_t>(8, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+    const int wgs = std::max(1, c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
+    const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * wgs)));
+    // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
+    const bool dbg = (c->env("FENRIS_HIP_TRACE") || c->env("FENRIS_HIP_ABLATE") || c->env("FENRIS_HIP_DBG_KERNEL"));
+    void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
+    constexpr int N_ = ElemT<EK>::N;
+    constexpr bool DEFAULT_JT = JT == ((N_ % 2 == 0) ? 2 : N_);  // per-element data: the default tiling only
+    if (T.slotpar) {
+        if constexpr (OP == FH_LINEAR_ELASTIC && DEFAULT_JT) {
+            kern = k_gather_pipelined<EK, OP, QC, JT, false, false, true>;
+            if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2)
+                if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, false, true, true>;
+        } else {
+            return c->fail(FH_UNSUPPORTED, "pipelined gather with per-element parameters: default FENRIS_HIP_PIPE_JT only");
+        }
+    } else if constexpr (EK == FH_TET4 && QC == 1 && JT == 2) {
+        if (dbg) kern = k_gather_pipelined<EK, OP, QC, JT, true>;
+    } else if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
+        if (dbg) {  // the instrumented twin of whichever instantiation production would take
+            if (fullq) kern = k_gather_pipelined<EK, OP, QC, JT, true, true>;
+            else kern = k_gather_pipelined<EK, OP, QC, JT, true>;
+        } else if (fullq)
+            kern = k_gather_pipelined<EK, OP, QC, JT, false, true>;
+    }
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->env("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] pipelined gather: QC=%d JT=%d lds=%zu B wgs/cu=%d grid=%d\n", QC, JT, lds, wgs, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, a, T);
+    HIP_TRY(c, hipGetLastError());
+    return FH_OK;
+}
+
+template <int EK, int OP, int QC>
+int launch_pipelined_q(fh_ctx* c, KArgs& a, const PipeTables& T) {
+    constexpr int N = ElemT<EK>::N;
+    const int jt = c->p_jt;
+    if (N % 4 == 0 && jt == 4) return launch_pipelined_j<EK, OP, QC, 4>(c, a, T);
+    if (N % 2 == 0 && jt == 2) return launch_pipelined_j<EK, OP, QC, 2>(c, a, T);
+    if (jt == N) return launch_pipelined_j<EK, OP, QC, N>(c, a, T);
+    return launch_pipelined_j<EK, OP, QC, 1>(c, a, T);
+}
+
+template <int EK, int OP>
+int launch_pipelined_t(fh_ctx* c, KArgs& a, const PipeTables& T, size_t, int) {
+    // staged quadrature points per chunk: the largest chunk (not larger than the rule) that still lets >= 2
+    // workgroups share a CU (measured on Hex8: profiles/r01_sweep_128_pipelined_nb_qc_jt.txt)
+    int qc = c->env_int("FENRIS_HIP_PIPE_QC", 0);
+    if (qc <= 0) {
+        qc = 1;
+        for (int cand : {8, 4, 2}) {
+            if (cand > a.nq && cand > 1 && cand / 2 >= a.nq) continue;  // would stage empty slots
+            const size_t lds = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, cand).bytes();
+            if (2 * lds + 1024 <= LDS_LIMIT) { qc = cand; break; }
+        }
+    }
+    if (a.nq == 1) qc = 1;
+    if (qc >= 8) return launch_pipelined_q<EK, OP, 8>(c, a, T);
+    if (qc >= 4) return launch_pipelined_q<EK, OP, 4>(c, a, T);
+    if (qc >= 2) return launch_pipelined_q<EK, OP, 2>(c, a, T);
+    return launch_pipelined_q<EK, OP, 1>(c, a, T);
+}
+
+int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int grid) {
+    const bool lap = c->op == FH_LAPLACE;
+    switch (c->elem_kind) {
+        case FH_HEX8: return lap ? launch_pipelined_t<FH_HEX8, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_HEX8, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_TET4: return lap ? launch_pipelined_t<FH_TET4, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_TET4, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_QUAD4: return lap ? launch_pipelined_t<FH_QUAD4, FH_LAPLACE>(c, a, T, lds, grid)
+                                  : launch_pipelined_t<FH_QUAD4, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        case FH_TRI3: return lap ? launch_pipelined_t<FH_TRI3, FH_LAPLACE>(c, a, T, lds, grid)
+                                 : launch_pipelined_t<FH_TRI3, FH_LINEAR_ELASTIC>(c, a, T, lds, grid);
+        default: return c->fail(FH_UNSUPPORTED, "pipelined gather: unsupported element");
+    }
+}
+
+// node blocks all of whose elements are affine: k_affine_ring / k_affine_rows (affine_ring.hip, affine_rows.hip) over their position tables
+int launch_affine(fh_ctx* c, KArgs& a) {
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    // the scalar mass matrix rides the Laplace kernel: records (|det J|, 0 ...), reference blocks (sum_q w rho phi_a phi_b, 0 ...)
+    const int rop = (c->op == FH_MASS_SCALAR) ? (int)FH_LAPLACE : c->op;
+    const int gw = (rop == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
+    // round 5 (experiment, FENRIS_HIP_AFFINE_FUSED=1): the element records formed inside k_affine_rows by a seventh wavefront (FUSED
+    // instantiation) -- no k_affine_records launch, no record array.  Measured SLOWER than the two launches (4.82 against 4.73 ms on the
+    // headline in one context, C2 0.56 against 0.31): what the records kernel costs is its cold reads, and the fused form has as many.
+    const int a_depth = c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), a_nstore = c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1);
+    const int a_chunk = c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0);
+    bool fused = c->op != FH_MASS_SCALAR && c->a_nu > 0 && c->a_vtab.p && c->env_int("FENRIS_HIP_AFFINE_FUSED", 0) != 0 &&
+                 affine_rows_can_fuse(a_depth, a_nstore, a.ablate, a_chunk);
+    if (fused && affine_rows_lds_bytes(rop, c->a_us, c->g_acc, c->a_nu) > LDS_LIMIT) fused = false;
+#ifdef FENRIS_HIP_WITH_RING
+    if (c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0) fused = false;
+#endif
+    if (!fused && c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
+    const unsigned char* act = c->has_mask ? c->active.p : nullptr;
+    DevStatus* status = c->status.p + c->status_slot;
+    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", rop == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
+                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0) |
+                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 1) ? AFFINE_ROWS_REC_NO_DMA : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 2) ? AFFINE_ROWS_REC_NO_MATH : 0) |
+                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 4) ? AFFINE_ROWS_REC_NO_L1 : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 8) ? AFFINE_ROWS_REC_NO_L2 : 0);
+    // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
+    // (instrumentation: compiled only into a `make TRACE=1` library)
+#ifdef FENRIS_HIP_WITH_RING
+    const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
+#endif
+    if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)
+        std::fprintf(stderr, "[fenris_hip ptrs] recs=%p hdr=%p elem=%p lanes=%p vals=%p verts=%p conn=%p\n", (void*)c->a_recs.p, (void*)c->a_hdr.p,
+                     (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
+    auto rows = [&](int pos0, int count) -> int {
+        AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
+                          c->ghat.p + (c->op == FH_MASS_SCALAR ? 64 * (AFFINE_GW_LE + AFFINE_GW_LAP) : c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count,
+                          c->g_acc, pos0, c->a_npos, c->a_incomplete, a_chunk, fused ? c->a_vtab.p : nullptr, fused ? c->a_nu : 0};
+#ifdef FENRIS_HIP_WITH_RING
+        if (use_ring) {
+            const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
+            const size_t lds = affine_ring_lds_bytes(rop, c->a_us, ring);
+            if (lds <= LDS_LIMIT) {
+                const int cap = rop == FH_LAPLACE ? 4 : 3;
+                const int per_cu = std::max(1, (int)std::min<size_t>(cap, LDS_LIMIT / std::max<size_t>(lds, 1)));
+                const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
+                if (c->env("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] affine ring: positions %d + %d ring=%d doubles lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, ring, lds, per_cu, grid);
+                HIP_TRY(c, affine_ring_launch(rop, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
+                                              a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 0) & 3) << 28)));
+                return FH_OK;
+            }
+        }
+#endif
+        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc, fused ? c->a_nu : 0);
+        if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
+        // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
+        const int per_cu = std::max(1, (int)std::min<size_t>(rop == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
+        const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
+        if (c->env("FENRIS_HIP_VERBOSE"))
+            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d fused=%d\n", pos0, count, lds, per_cu, grid, (int)fused);
+        HIP_TRY(c, affine_rows_launch(rop, a_depth, a_nstore, grid, lds, c->stream, a, T, a.ablate | nt, c->has_mask, fused));
+        return FH_OK;
+    };
+    if (fused) return rows(0, c->a_npos);
+    // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly.  (Round 3: making
+    // the records of all but the first eighth of the sweep on a second stream beside the first part's launch was measured 0.3 ms
+    // SLOWER than the 0.41 ms it hides -- the two kernels' workgroups compete for the CUs; two launches of the sweep in one stream cost
+    // nothing measurable, and records made chunk by chunk right before their part of the sweep (to be read back from the memory-side
+    // cache) change nothing up to 4 chunks and lose from 8 on.  profiles/r03_affine_experiments.txt)
+    HIP_TRY(c, affine_records_launch(c->op, c->stream, c->verts.p, c->conn.p, c->elem_aff.p, act, c->a_emin, std::min<long long>(c->a_emax + 1, (long long)c->E),
+                                     c->a_recs.p, status));
+    return rows(0, c->a_npos);
+}
+
+// dense element matrices of the elements [first, first + count) into device memory (no status read-back)
+int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem) {
+    KArgs a;
+    fill_common(c, a);
+    a.ke_out = ke_dev;
+    a.ke_by_elem = by_elem ? 1 : 0;
+    a.labels = (by_elem && c->has_mask) ? c->active_list.p : nullptr;  // two-pass assembly: the active elements only
+    a.work_begin = (long long)first;
+    a.work_end = (long long)(first + count);
+    a.epb = choose_epb(c, WHAT_MATRIX);
+    a.ub = a.epb;
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    const int grid = (int)((count + a.epb - 1) / a.epb);
+    int rc = FH_OK;
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_DUMP, lds, grid)
+    FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+    return rc;
+}
+
+int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset) {
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    const int mode = flags & FH_SCATTER_MASK;
+    const int overwrite = (flags & FH_ASSEMBLE_OVERWRITE) ? 1 : 0;
+    if (reset) rc = reset_status(c);
+    if (rc) return rc;
+    if (c->E == 0) return FH_OK;
+    KArgs a;
+    fill_common(c, a);
+    a.vals = values_dev;
+    a.overwrite = overwrite;
+    const uint64_t nnz = (uint64_t)c->S() * c->S() * c->nnz_nodes;
+    if (mode == FH_SCATTER_GATHER && c->row_hi < 0 && !c->env("FENRIS_HIP_NO_TWO_PASS")) {
+        // two-pass owner-computes (dense element matrices, then a row gather) where recomputing the element prologue per
+        // owning node block is the expensive part: high-order elements, and the nonlinear materials on any element
+        // (measured, Hex8 128^3: NeoHookean 11.1 -> 9.2 ms, StVK 19.2 -> 10.0 ms; LinearElastic with per-point
+        // parameters is faster one-pass: 5.7 vs 8.2 ms).  The dense buffer costs E (s n)^2 doubles: capped.
+        const size_t ld = (size_t)c->S() * c->ei.n;
+        const double dense_gb = (double)c->E * ld * ld * 8.0 / 1e9;
+        const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || c->env("FENRIS_HIP_TWO_PASS");
+        if (want && dense_gb <= (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) {
+            // the dense buffer is allocated here: when the device cannot hold it the one-pass gather below takes over
+            if (c->ke_dense.n >= ld * ld * c->E || c->ke_dense.alloc(ld * ld * c->E) == hipSuccess)
+                return assemble_two_pass(c, values_dev, overwrite);
+            (void)hipGetLastError();
+        }
+    }
+    if (mode == FH_SCATTER_GATHER) {
+        rc = build_partition(c);
+        if (rc) return rc;
+        if (c->part_rows_only && !(c->has_pipe && c->has_rows && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
+                              !c->env("FENRIS_HIP_TRACE"))) {
+            // these tables are for the row-owner kernel only (see build_partition); another kernel is about to run
+            c->perm_failed = true;
+            c->has_partition = false; ++c->struct_gen;
+            rc = build_partition(c);
+            if (rc) return rc;
+        }
+        if (c->nblk == 0) return FH_OK;  // empty row range
+        c->last_kernel.clear();
+        if (c->a_npos > 0) {
+            // node blocks whose elements are all affine (affine_kernel.hpp); the remaining positions follow below
+            rc = launch_affine(c, a);
+            if (rc) return rc;
+            c->last_kernel = "k_affine_rows";
+            if (c->npos_gen == 0) return FH_OK;
+            c->last_kernel += " + ";
+        }
+        a.blk_off = c->blk_off.p;
+        a.gt_hdr = c->gt_hdr.p;
+        a.gt_elems = c->gt_elems.p;
+        a.gt_ent = c->gt_ent.p;
+        a.gt_pos = c->has_pos ? c->gt_pos.p : nullptr;
+        a.nblk = c->nblk;
+        a.ub = c->g_ub;
+        a.mb = c->g_mb;
+        a.acc_max = c->g_acc;
+        a.nb_max = c->g_nb;
+        const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
+        const bool pipe_rules = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
+        if (pipe_rules && !c->has_slotpar) {
+            const size_t n = (size_t)c->npos_gen * c->p_us;
+            HIP_TRY(c, c->p_slotpar.alloc(2 * n));
+            hipLaunchKernelGGL(k_build_slot_params, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->p_elem.p, n,
+                               c->rule_map.p, c->rparams.p, c->nq, c->p_slotpar.p);
+            HIP_TRY(c, hipGetLastError());
+            c->has_slotpar = true;
+        }
+        // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
+        // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
+        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pipe_rules) &&
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+            a.fast = 1;
+            if (c->nq > 1) {
+                a.qw = c->qw.p + c->nq;
+                a.nq = 1;
+            }
+            RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->r_vconn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
+                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
+            a.ub = std::max(c->p_us, 76);   // the X region of the layout (14 doubles per slot) holds the vertex table: 256 x 4 doubles
+            a.nb_max = c->p_nbs;
+            if (c->has_mask && a.overwrite) {   // blocks without an active element have no lane: clear the range first (rows_kernel.hpp)
+                const int n_lo = (c->row_hi < 0) ? 0 : (int)std::min<long long>(c->row_lo, (long long)c->N);
+                const int n_hi = (c->row_hi < 0) ? (int)c->N : (int)std::min<long long>(c->row_hi, (long long)c->N);
+                if (n_hi > n_lo) {
+                    hipLaunchKernelGGL(k_zero_node_rows, dim3(2048), dim3(256), 0, c->stream, c->noff.p, n_lo, n_hi, c->S() * c->S(), values_dev);
+                    HIP_TRY(c, hipGetLastError());
+                }
+            }
+            c->last_kernel += "k_gather_rows";
+            if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
+            return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
+        }
+        if (c->has_pipe && c->has_hrows && a.fast && !pipe_rules && c->nq == 8 && c->elem_kind == FH_HEX8 &&
+            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
+            const size_t lds_h = hex8_rows_lds_bytes(c->g_acc);
+            if (lds_h <= LDS_LIMIT) {
+                int dev_cus = 256;
+                (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+                const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds_h, 1)));
+                const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu))));
+                Hex8RowTables T{c->h_pos.p, c->h_lanes.p, c->p_conn.p, c->p_elem.p, c->p_us, c->p_cs, c->npos_gen, c->g_acc};
+                if (c->env("FENRIS_HIP_VERBOSE"))
+                    std::fprintf(stderr, "[fenris_hip] hex8 rows: positions %d lds=%zu B wgs/cu=%d grid=%d\n", c->npos_gen, lds_h, per_cu, grid);
+                c->last_kernel += "k_hex8_rows";
+                HIP_TRY(c, hex8_rows_launch(c->op, grid, lds_h, c->stream, a, T, a.ablate | (a.trace ? 0x10000 : 0)));
+                return FH_OK;
+            }
+        }
+        if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+            a.fast = 1;
+            PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr, c->p_rw,
+                         c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->npos_gen};
+            a.ub = c->p_us;  // LDS slots: every unique element of a block is staged, shared ones persist
+            a.mb = c->p_ms;  // the LDS layout is sized by the table strides
+            a.nb_max = c->p_nbs;
+            c->last_kernel += "k_gather_pipelined";
+            return launch_pipelined(c, a, T, 0, 0);
+        }
+        c->last_kernel += "k_assemble_matrix<gather>";
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_GATHER, lds, c->nblk)
+        FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+        return rc;
+    }
+    if (c->row_hi >= 0) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix: a row range needs FH_SCATTER_GATHER");
+    if (overwrite) HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * nnz, c->stream));
+    a.epb = choose_epb(c, WHAT_MATRIX);
+    a.ub = a.epb;
+    // high-order elements: column search of the scatter in LDS (neighbour lists staged per element)
+    if (c->ei.n > 8 && !c->env("FENRIS_HIP_NO_NC_LDS")) {
+        const unsigned max_row = c->max_row;
+        const size_t with_nc = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, (int)max_row);
+        if (with_nc <= LDS_TARGET + 16 * 1024) a.nc_row = (int)max_row;
+    }
+    const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, a.nc_row);
+    if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
+    if (mode == FH_SCATTER_ATOMIC) {
+        a.work_begin = 0;
+        a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
+        a.labels = c->has_mask ? c->active_list.p : nullptr;
+        if (a.work_end == 0) return FH_OK;
+        const int grid = (int)((a.work_end + a.epb - 1) / a.epb);
+        c->last_kernel = "k_assemble_matrix<atomic>";
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_ATOMIC, lds, grid)
+        FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+        return rc;
+    }
+    if (mode == FH_SCATTER_COLORED) {
+        if (!c->has_colors) return c->fail(FH_INVALID_STATE, "FH_SCATTER_COLORED: call fh_color or fh_set_colors first");
+        a.labels = c->labels.p;
+        c->last_kernel = "k_assemble_matrix<colored>";
+        for (size_t col = 0; col + 1 < c->color_offsets.size(); ++col) {
+            a.work_begin = (long long)c->color_offsets[col];
+            a.work_end = (long long)c->color_offsets[col + 1];
+            const long long cntc = a.work_end - a.work_begin;
+            if (cntc <= 0) continue;
+            const int grid = (int)((cntc + a.epb - 1) / a.epb);
+#define CALL(EKC, OPC) rc = launch_matrix<EKC, OPC>(c, a, MODE_COLORED, lds, grid)
+            FH_FOR_ELEM_OP(c->elem_kind, c->op, CALL)
+#undef CALL
+            if (rc) return rc;
+        }
+        return FH_OK;
+    }
+    return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: unknown scatter mode");
+}
+
+extern "C" {
+static bool mode_is_colored(int flags) { return (flags & FH_SCATTER_MASK) == FH_SCATTER_COLORED; }
+int fh_assemble_matrix_async_dev(fh_ctx* c, double* values_dev, int flags) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->rs.active) return assemble_matrix_enqueue(c, values_dev, flags);
+    // rule-set table: one pass per group of rules, the first one with the caller's flags, the others accumulating
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    rc = reset_status(c);
+    if (rc) return rc;
+    bool any = false;
+    rc = rs_for_each_group(c, [&](bool first) {
+        any = true;
+        if (mode_is_colored(flags) && !c->has_colors) return c->fail(FH_INVALID_STATE, "fh_assemble_matrix: FH_SCATTER_COLORED needs fh_color / fh_set_colors");
+        return assemble_matrix_enqueue(c, values_dev, first ? flags : (flags & ~FH_ASSEMBLE_OVERWRITE), false);
+    });
+    if (rc) return rc;
+    if (!any && (flags & FH_ASSEMBLE_OVERWRITE) && fh_nnz(c))
+        HIP_TRY(c, hipMemsetAsync(values_dev, 0, sizeof(double) * fh_nnz(c), c->stream));
+    return FH_OK;
+}
+
+// ---- placement of the streamed buffers (round 3).  The time of the owner-computes kernels follows how the large buffers they stream
+// through happen to be backed by device memory -- the same context, kernel and arguments run in one of two or three levels up to 10 %
+// apart depending only on WHICH physical memory a buffer got (re-allocating a buffer at the same virtual address changes the level;
+// profiles/r03_affine_experiments.txt, section 7).  Nothing in the HIP API chooses the backing, so the library offers the only remedy
+// there is: time the real assembly and keep the better of several allocations.
+int fh_time_assembly_dev(fh_ctx* c, double* values_dev, int flags, int reps, double* ms_per_assembly) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    if (!ms_per_assembly || reps < 1) return c->fail(FH_BAD_ARGUMENT, "fh_time_assembly_dev: bad argument");
+    // reps + 1 REAL assemblies run into the caller's array: without FH_ASSEMBLE_OVERWRITE they would pile up reps + 1 copies of K
+    if (!(flags & FH_ASSEMBLE_OVERWRITE)) return c->fail(FH_BAD_ARGUMENT, "fh_time_assembly_dev: needs FH_ASSEMBLE_OVERWRITE (the timed assemblies write the values)");
+    int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);   // tables, code objects, first touch
+    if (rc) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, c->stream);
+    if (he != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return c->hip_fail(he, "fh_time_assembly_dev");
+    }
+    for (int k = 0; k < reps && rc == FH_OK; ++k) rc = fh_assemble_matrix_async_dev(c, values_dev, flags);
+    he = hipEventRecord(e1, c->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (he != hipSuccess) return c->hip_fail(he, "fh_time_assembly_dev");
+    *ms_per_assembly = (double)ms / reps;
+    uint64_t failed = 0;
+    return fh_poll_status(c, &failed);
+}
+
+int fh_tune_placement_dev(fh_ctx* c, double* values_dev, int flags, int tries, double* ms_before, double* ms_after) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    if (!(flags & FH_ASSEMBLE_OVERWRITE)) return c->fail(FH_BAD_ARGUMENT, "fh_tune_placement_dev: needs FH_ASSEMBLE_OVERWRITE (the trial assemblies write the values)");
+    double best = 0.0;
+    int rc = fh_time_assembly_dev(c, values_dev, flags, 3, &best);
+    if (rc) return rc;
+    if (ms_before) *ms_before = best;
+    if (ms_after) *ms_after = best;
+    // the one large buffer of its own that the affine kernels stream through: the element records.  (Moving the position tables and
+    // the lane tables never changed the level.)  Rejected allocations are held until the end: freed at once they would be handed out again.
+    if (!c->a_recs.p || c->a_npos == 0 || tries < 1) return FH_OK;
+    std::vector<double*> rejected;
+    const size_t bytes = c->a_recs.n * sizeof(double);
+    for (int k = 0; k < tries; ++k) {
+        double* cand = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&cand), bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        double* old = c->a_recs.p;
+        c->a_recs.p = cand;   // the records are rewritten by every assembly: nothing to copy
+        double t = 0.0;
+        rc = fh_time_assembly_dev(c, values_dev, flags, 3, &t);
+        if (rc == FH_OK && t < 0.98 * best) {
+            best = t;
+            rejected.push_back(old);
+        } else {
+            c->a_recs.p = old;
+            rejected.push_back(cand);
+        }
+        if (rc) break;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    for (double* p : rejected) (void)hipFree(p);
+    if (ms_after) *ms_after = best;
+    return rc;
+}
+
+// The rows of the nodes [node_begin, node_end) with a second set of owner-computes tables; the context's own row range and
+// tables are untouched.  The second set is built on first use and rebuilt when the range or anything the tables depend on
+// (mesh, pattern, mask, operator, quadrature, affine classes) has changed since.
+int fh_assemble_matrix_rows_async_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_assemble_matrix_rows: set the mesh first");
+    if (node_begin > node_end || node_end > c->N) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix_rows: bad node range");
+    if ((flags & FH_SCATTER_MASK) != FH_SCATTER_GATHER) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix_rows: needs FH_SCATTER_GATHER");
+    if (c->rs.active) return c->fail(FH_UNSUPPORTED, "fh_assemble_matrix_rows: not with a rule-set quadrature table");
+    if (!c->rows_stash) c->rows_stash = new PartStash();
+    PartStash& st = *c->rows_stash;
+    swap_partition(c, st);   // the context's own tables wait in the stash
+    if (st.built_gen != c->struct_gen || c->row_lo != (long long)node_begin || c->row_hi != (long long)node_end) {
+        c->row_lo = (long long)node_begin;   // a range, even when it covers every node: the two-pass path does not apply
+        c->row_hi = (long long)node_end;
+        c->has_partition = false;
+        c->aff_failed = false;
+    }
+    c->status_slot = 1;
+    const int rc = assemble_matrix_enqueue(c, values_dev, flags);
+    c->status_slot = 0;
+    swap_partition(c, st);
+    st.built_gen = rc ? ~0ull : c->struct_gen;
+    return rc;
+}
+
+int fh_assemble_matrix_rows_dev(fh_ctx* c, double* values_dev, int flags, uint64_t node_begin, uint64_t node_end, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    const int rc = fh_assemble_matrix_rows_async_dev(c, values_dev, flags, node_begin, node_end);
+    if (rc) return rc;
+    return read_status(c, failed);
+}
+
+int fh_poll_status(fh_ctx* c, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    return read_status(c, failed);
+}
+
+int fh_assemble_matrix_dev(fh_ctx* c, double* values_dev, int flags, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);
+    if (rc) return rc;
+    return read_status(c, failed);
+}
+
+int fh_assemble_matrix(fh_ctx* c, double* values, int flags, uint64_t* failed) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    int rc = check_ready(c, "fh_assemble_matrix", true);
+    if (rc) return rc;
+    if (!values) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
+    const uint64_t nnz = fh_nnz(c);
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc((size_t)nnz));
+    // the staging copy starts from the caller's values unless every entry is about to be overwritten: with a row range
+    // (fh_set_row_range) FH_ASSEMBLE_OVERWRITE writes the rows in range only, "the others are left untouched"
+    if (!(flags & FH_ASSEMBLE_OVERWRITE) || c->row_hi >= 0)
+        HIP_TRY(c, hipMemcpyAsync(d.p, values, sizeof(double) * nnz, hipMemcpyHostToDevice, c->stream));
+    rc = fh_assemble_matrix_dev(c, d.p, flags, failed);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(values, d.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+int fh_assemble_element_matrices_dev(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    int rc = check_ready(c, "fh_assemble_element_matrices", false);
+    if (rc) return rc;
+    if (first + count > c->E || (count && !ke_dev)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
+    if (count == 0) return FH_OK;
+    rc = reset_status(c);
+    if (rc) return rc;
+    if (c->rs.active) {  // rule-set table: runs of consecutive elements whose rules share points and weights
+        const size_t ld = (size_t)c->S() * c->ei.n;
+        for (uint64_t e0 = first; e0 < first + count && rc == FH_OK;) {
+            const int g = c->rs.rule_group[c->rs.e2r[e0]];
+            uint64_t e1 = e0 + 1;
+            while (e1 < first + count && c->rs.rule_group[c->rs.e2r[e1]] == g) ++e1;
+            if (c->rs.staged != g) rc = rs_stage(c, g);
+            if (rc == FH_OK) rc = element_matrices_enqueue(c, e0, e1 - e0, ke_dev + ld * ld * (e0 - first), false);
+            e0 = e1;
+        }
+        const int rc2 = apply_mask(c, c->user_has_mask ? c->user_mask.data() : nullptr);
+        if (rc || rc2) return rc ? rc : rc2;
+        return read_status(c, nullptr);
+    }
+    rc = element_matrices_enqueue(c, first, count, ke_dev, false);
+    if (rc) return rc;
+    return read_status(c, nullptr);
+}
+
+int fh_assemble_element_matrices(fh_ctx* c, uint64_t first, uint64_t count, double* ke_out) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    int rc = check_ready(c, "fh_assemble_element_matrices", false);
+    if (rc) return rc;
+    if (first + count > c->E || (count && !ke_out)) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_element_matrices: bad range");
+    if (count == 0) return FH_OK;
+    const size_t ld = (size_t)c->S() * c->ei.n;
+    DevBuf<double> d;
+    HIP_TRY(c, d.alloc(ld * ld * count));
+    rc = fh_assemble_element_matrices_dev(c, first, count, d.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(ke_out, d.p, sizeof(double) * ld * ld * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FH_OK;
+}
+
+// the groups of a rule-set table one after the other; every pass accumulates.  The lowest failing element over all groups
+// is reported, like the serial loop of the reference would (global.rs:154: first error aborts).
+}  // extern "C"

@@ -135,6 +135,7 @@ struct fh_group {
     bool in_flight = false;
     bool vec_in_flight = false;
     bool list_mode = false;          // fh_group_set_exchange_nodes: packed lists, any number of peers
+    unsigned long long pattern_gen = 0;   // ... built against this generation of the context's pattern (noff below points into it)
     PeerList snd, rcv;
     const unsigned* noff = nullptr;  // the context's node-level row offsets (device)
     int ss = 0;                      // S x S
@@ -214,7 +215,7 @@ void fh_group_destroy(fh_group* g) {
 int fh_group_set_exchange(fh_group* g, int send_peer, uint64_t send_first, uint64_t send_count, int recv_peer, uint64_t recv_first,
                           uint64_t recv_count) {
     if (!g) return FH_BAD_ARGUMENT;
-    if (g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange: an exchange is in flight");
+    if (g->in_flight || g->vec_in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange: an exchange is in flight");
     if (send_peer >= g->world || recv_peer >= g->world || send_peer == g->rank || recv_peer == g->rank)
         return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange: bad peer");
     g->list_mode = false;
@@ -282,6 +283,7 @@ int fh_group_set_exchange_nodes(fh_group* g, int num_send_peers, const int32_t* 
     if ((num_send_peers && (!send_peers || !send_offsets)) || (num_recv_peers && (!recv_peers || !recv_offsets)))
         return fh_internal_fail(g->ctx, FH_BAD_ARGUMENT, "fh_group_set_exchange_nodes: null list");
     if (g->in_flight || g->vec_in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_set_exchange_nodes: an exchange is in flight");
+    g->list_mode = false;   // until both lists are in place (a failure below must not leave the mode set over released lists)
     const unsigned* ncols = nullptr;
     uint64_t N = 0;
     int S = 0;
@@ -293,11 +295,19 @@ int fh_group_set_exchange_nodes(fh_group* g, int num_send_peers, const int32_t* 
     if (rc) return rc;
     rc = build_peer_list(g, g->rcv, num_recv_peers, recv_peers, recv_offsets, recv_nodes, N);
     if (rc) return rc;
+    g->pattern_gen = fh_internal_pattern_gen(g->ctx);
     g->list_mode = true;
     return FH_OK;
 }
 
+// the lists hold device pointers into the context's pattern: a pattern rebuilt since (fh_set_mesh, a new mask followed by fh_pattern) frees them
+static int list_pattern_current(fh_group* g, const char* who) {
+    if (g->pattern_gen != 0 && g->pattern_gen == fh_internal_pattern_gen(g->ctx)) return FH_OK;
+    return fh_internal_fail(g->ctx, FH_INVALID_STATE, std::string(who) + ": the context's pattern was rebuilt since fh_group_set_exchange_nodes -- set the node lists again");
+}
+
 static int list_exchange_start(fh_group* g, double* values_dev) {
+    { const int rc_g = list_pattern_current(g, "fh_group_exchange_start"); if (rc_g) return rc_g; }
     DevGuardExt dev_guard_(g->device);
     hipStream_t main = fh_internal_stream(g->ctx);
     G_HIP(g, hipEventRecord(g->ready, main));
@@ -351,6 +361,7 @@ int fh_group_exchange_vector_start(fh_group* g, double* vec_dev, uint32_t compon
     if (!g || !vec_dev || components == 0 || components > 16) return FH_BAD_ARGUMENT;
     if (!g->list_mode) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_vector_start: set the node lists first (fh_group_set_exchange_nodes)");
     if (g->vec_in_flight || g->in_flight) return fh_internal_fail(g->ctx, FH_INVALID_STATE, "fh_group_exchange_vector_start: an exchange is in flight");
+    { const int rc_g = list_pattern_current(g, "fh_group_exchange_vector_start"); if (rc_g) return rc_g; }
     DevGuardExt dev_guard_(g->device);
     const int comp = (int)components;
     int rc = vec_buffers(g, g->snd, comp);

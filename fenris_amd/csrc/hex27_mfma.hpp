@@ -20,7 +20,8 @@
 // which the 588 MFMAs per element take 2.9 ms (the fp64 MFMA floor is 3.06 ms) and do not overlap with the prologue
 // of the second resident workgroup -- starting the two workgroups of a CU half a period apart changed nothing, i.e.
 // fp64 MFMA and fp64 VALU work do not run side by side on gfx950.  FENRIS_HIP_ABLATE bits 1/2/4 skip prologue / MFMA /
-// stores for such measurements.
+// stores for such measurements (instrumented instantiation only, i.e. together with FENRIS_HIP_TRACE=1: in the production kernel a store
+// under a run-time switch is a store the compiler cannot count on, see the stores).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -32,9 +33,14 @@ namespace fenris_hip {
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 struct Hex27Lds {
-    static constexpr int N = 27, NG = 8, NQ = 27, RP = 32, QS = 29;  // padded rows, point stride (odd: bank spread)
-    static constexpr int o_gref = 0;                       // [q][n][3]
-    static constexpr int o_ggeom = o_gref + NQ * N * 3;    // [q][g][3]
+    // RP rows per component: the 27 nodes and ONE row of zeros -- the matrix-core tiles are 16 x 16, rows 27 .. 31 of the second tile all read
+    // row 27 (round 5; they used to have five rows of zeros of their own).  QS: point stride (odd: bank spread).
+    // Round 5: the reference gradients of the basis (27 x 27 x 3 doubles, 17.5 KB) are no longer staged here -- every lane needs the same
+    // nine of them for every element and fetches them (L1 / L2-resident) ahead of the previous element's stores; with the 5.5 KB of padding
+    // rows gone the workgroup takes 52.9 instead of 75.9 KB, which leaves room on the CU for the row gather of the previous chunk
+    // (engine_two_pass.hip, the overlapped form).
+    static constexpr int N = 27, NG = 8, NQ = 27, RP = 28, QS = 29;
+    static constexpr int o_ggeom = 0;                      // [q][g][3]
     static constexpr int o_qw = o_ggeom + NQ * NG * 3;     // [q]
     static constexpr int o_X = o_qw + 28;                  // [g][3]
     static constexpr int o_U = o_X + NG * 3;               // [n][3]
@@ -59,7 +65,6 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
     double* lds = reinterpret_cast<double*>(smem);
     const int tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
     // tables, and zeros in the padding of G / A / coef (written once: the prologue only touches n < 27, q < 27)
-    for (int i = tid; i < NQ * N * 3; i += nt) lds[L::o_gref + i] = a.gref[i];
     for (int i = tid; i < NQ * NG * 3; i += nt) lds[L::o_ggeom + i] = a.ggeom[i];
     for (int i = tid; i < 28; i += nt) lds[L::o_qw + i] = (i < NQ) ? a.qw[i] : 0.0;
     for (int i = tid; i < 2 * 3 * RP * QS; i += nt) lds[L::o_G + i] = 0.0;
@@ -113,6 +118,18 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
     long long e_cur = elem_of(w0), e_n1 = elem_of(w0 + Gs), e_n2 = elem_of(w0 + 2 * Gs);
     double val_cur = value_at(node_at(e_cur));
     int node_n1 = node_at(e_n1);
+    // reference gradients of this thread's three (point, node) items of phase P2 (item = tid + 256 k): the same for every element, but
+    // fetched anew for each -- ahead of the previous element's stores, see there -- so that they are not live across the matrix-core loop
+    double gr[3][3];
+    auto load_gref = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int it = min(tid + nt * k, NQ * N - 1);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) gr[k][cc] = a.gref[it * 3 + cc];
+        }
+    };
+    load_gref();
     // nothing pending at the loop's entry: otherwise the compiler takes the distance from these first requests to their use
     // (a handful of operations) for every trip, and each element starts by waiting for the previous element's stores
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -137,14 +154,14 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             return (m9[r1 * 3 + c1] * m9[r2 * 3 + c2] - m9[r2 * 3 + c1] * m9[r1 * 3 + c2]) * r;
         };
         // P1a: J = X G^T (hexahedron.rs:324-326 -> :101-107), one entry per lane, parked where grad u goes later
-        if (tid < NQ * 9 && !(a.ablate & 1)) {
+        if (tid < NQ * 9 && !(TRACE && (a.ablate & 1))) {
             double t = 0.0;
             for (int g = 0; g < NG; ++g) t = fma(lds[L::o_X + g * 3 + pi], lds[L::o_ggeom + (pq * NG + g) * 3 + pj], t);
             lds[L::o_gu + tid] = t;
         }
         lds_barrier();
         // P1b: inverse entry; the lane of entry (0, 0) also leaves s = w |det J| and, for LinearElastic, the coefficients
-        if (tid < NQ * 9 && !(a.ablate & 1)) {
+        if (tid < NQ * 9 && !(TRACE && (a.ablate & 1))) {
             const double* m9 = lds + L::o_gu + pq * 9;
             const double J[3][3] = {{m9[0], m9[1], m9[2]}, {m9[3], m9[4], m9[5]}, {m9[6], m9[7], m9[8]}};
             const double detJ = det_small<3>(J);
@@ -167,17 +184,22 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         lds_barrier();
         mark(1);
         // P2: one lane per (point, node): g_n = J^-T grad_ref phi_n
-        if (!(a.ablate & 1))
-        for (int it = tid; it < NQ * N; it += nt) {
-            const int q = it / N, n = it % N;
-            const double* Ji = lds + L::o_Jinv + q * 9;
-            const double* rv = lds + L::o_gref + (q * N + n) * 3;
+        if (!(TRACE && (a.ablate & 1))) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) G[(i * RP + n) * QS + q] = fma(Ji[0 * 3 + i], rv[0], fma(Ji[1 * 3 + i], rv[1], Ji[2 * 3 + i] * rv[2]));
+            for (int k = 0; k < 3; ++k) {
+                const int it = tid + nt * k;
+                if (it < NQ * N) {
+                    const int q = it / N, n = it % N;
+                    const double* Ji = lds + L::o_Jinv + q * 9;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        G[(i * RP + n) * QS + q] = fma(Ji[0 * 3 + i], gr[k][0], fma(Ji[1 * 3 + i], gr[k][1], Ji[2 * 3 + i] * gr[k][2]));
+                }
+            }
         }
         lds_barrier();
         mark(2);
-        if (NH && !(a.ablate & 1)) {
+        if (NH && !(TRACE && (a.ablate & 1))) {
             // P3: grad u (d x s) = sum_n g_n u_n^T, one lane per (point, k, c)
             for (int it = tid; it < NQ * 9; it += nt) {
                 const int q = it / 9, k = (it % 9) / 3, c = it % 3;
@@ -244,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         // operands: entry (I, J) and entry (J, I) are then sums of identical products in the same order, in whichever
         // tile they lie.
         const int tI = wave >> 1, tJ = wave & 1;
-        const int rI = 16 * tI + (lane & 15), rJ = 16 * tJ + (lane & 15), kq = lane >> 4;
+        const int rI = min(16 * tI + (lane & 15), N), rJ = min(16 * tJ + (lane & 15), N), kq = lane >> 4;   // rows 27 .. 31: the row of zeros
         mfma_f64x4 acc[3][3], accM = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -268,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
             o.rms = lds[L::o_coef + 112 + q]; o.rm = lds[L::o_coef + 140 + q];
             return o;
         };
-        if (!(a.ablate & 2)) {
+        if (!(TRACE && (a.ablate & 2))) {
             Ops cur = fetch_ops(0);
             int nks = 7;
             asm volatile("" : "+s"(nks));   // opaque trip count: the compiler unrolls a loop of seven whatever the pragma says
@@ -293,41 +315,60 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
         // (loads and stores share one in-order counter: waiting for a load issued before a store waits for the store).
         asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
+        // ... and the reference gradients of the NEXT element's phase P2 are requested here, ahead of this element's stores: P2 then waits
+        // for them with the stores still in flight (issued behind the stores, the wait would drain them: a write latency per element)
+        load_gref();
+        asm volatile("" ::: "memory");
         val_cur = val_n1;
         node_n1 = node_n2;
         e_cur = e_n1;
         e_n1 = e_n2;
         e_n2 = e_n3;
         // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
-        double* ke = a.ke_out + (size_t)e * (81 * 81);
+        // Buffer stores with the hardware's bounds check (round 5): the lanes of the padding rows / columns (I, J >= 27) get an offset
+        // beyond the element's matrix and their store is dropped -- no branch, no EXEC masking.  Under `if (I < N && J < N)` every store sat
+        // in a conditional block, and the compiler then counts NO store as certainly issued: the wait for the reference gradients
+        // requested above (ahead of the stores) became a wait for all the stores.
+        const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * (81 * 81));
+        const unsigned long long ke_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ke_addr >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)ke_addr);
+        const auto ke_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ke_u), (short)0, 81 * 81 * 8, 0x00020000);
+        // address = base + per-lane offset (VGPR; beyond the matrix for a padding lane: only this part is bounds-checked) + a constant per
+        // store (scalar offset): eight offset registers instead of one per store
+        auto put = [&](unsigned voff, int soff_doubles, double v) {
+            typedef unsigned put_u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(put_u32x2, v), ke_rsrc, voff, soff_doubles * 8, 0);
+        };
         const int J = 16 * tJ + (lane & 15);
-        if (!(a.ablate & 4))
+        const int I0 = 16 * tI + (lane >> 4);
+        unsigned vo_row[4], vo_col[4];   // element (I0 + 4 reg, J) of a component / its mirror image (J, I0 + 4 reg)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const bool valid = I0 + 4 * reg < N && J < N;
+            vo_row[reg] = valid ? (unsigned)(I0 * (9 * N) + J) * 8u : 0x80000000u;
+            vo_col[reg] = valid ? (unsigned)(J * (9 * N) + I0) * 8u : 0x80000000u;
+        }
+        if (!(TRACE && (a.ablate & 4)))
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = i; j < 3; ++j) {
                 const mfma_f64x4 v = (i == j) ? acc[i][j] + accM : acc[i][j];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int I = 16 * tI + (lane >> 4) + 4 * reg;
-                    if (I < N && J < N) ke[(size_t)I * (9 * N) + (i * 3 + j) * N + J] = v[reg];
-                }
+                for (int reg = 0; reg < 4; ++reg) put(vo_row[reg], 4 * reg * (9 * N) + (i * 3 + j) * N, v[reg]);
             }
         mark(7);
         // K_ji = K_ij^T straight from the fragments: entry (I, J) of the tile goes to (J, I) of the mirrored component.  Per store
         // instruction a lane group writes four consecutive I of one J (32 bytes), and the four registers complete the 128 bytes
         // of that J; the L2 merges them.  (Staging the tile through LDS to store it row-wise cost a barrier, three LDS round
         // trips and the re-zeroing of the staging area: 2.4 k cycles per element against 1.x k.)
-        if (!(a.ablate & 4)) {
+        if (!(TRACE && (a.ablate & 4))) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = i + 1; j < 3; ++j)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int I = 16 * tI + (lane >> 4) + 4 * reg;
-                        if (I < N && J < N) ke[(size_t)J * (9 * N) + (j * 3 + i) * N + I] = acc[i][j][reg];
-                    }
+                    for (int reg = 0; reg < 4; ++reg) put(vo_col[reg], (j * 3 + i) * N + 4 * reg, acc[i][j][reg]);
         }
         lds_barrier();  // the next element's prologue overwrites G / A
         mark(8);

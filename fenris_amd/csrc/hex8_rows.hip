@@ -681,7 +681,10 @@ hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int
 }
 
 hipError_t hex8_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const Hex8RowTables& T, int ablate) {
-    const bool ow = a.overwrite != 0, dbg = ablate != 0;
+    // (the instrumented instantiation exists for overwriting assemblies only: an accumulating one under FENRIS_HIP_TRACE / FENRIS_HIP_ABLATE runs
+    // the production kernel -- it used to take the instrumented one and OVERWRITE the values)
+    const bool ow = a.overwrite != 0, dbg = ablate != 0 && ow;
+    if (!dbg) ablate = 0;
     void (*kern)(const KArgs, const Hex8RowTables, int);
     if (op == FH_LAPLACE) kern = dbg ? k_hex8_rows<FH_LAPLACE, true, true> : ow ? k_hex8_rows<FH_LAPLACE, true, false> : k_hex8_rows<FH_LAPLACE, false, false>;
     else kern = dbg ? k_hex8_rows<FH_LINEAR_ELASTIC, true, true> : ow ? k_hex8_rows<FH_LINEAR_ELASTIC, true, false> : k_hex8_rows<FH_LINEAR_ELASTIC, false, false>;

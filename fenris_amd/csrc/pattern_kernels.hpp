@@ -22,7 +22,7 @@ struct ConnView {
     __device__ __forceinline__ unsigned elem_of(unsigned k) const { return eoff ? k2e[k] : k / (unsigned)n; }
 };
 
-__global__ void k_count_degree(ConnView c, unsigned* deg, int num_nodes, int* bad) {
+static __global__ void k_count_degree(ConnView c, unsigned* deg, int num_nodes, int* bad) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
         const int node = c.nodes[k];
         if (node < 0 || node >= num_nodes) { *bad = 1; continue; }
@@ -31,7 +31,7 @@ __global__ void k_count_degree(ConnView c, unsigned* deg, int num_nodes, int* ba
     }
 }
 
-__global__ void k_fill_n2e(ConnView c, const unsigned* n2e_off, unsigned* cursor, unsigned* n2e, int num_nodes) {
+static __global__ void k_fill_n2e(ConnView c, const unsigned* n2e_off, unsigned* cursor, unsigned* n2e, int num_nodes) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < c.total; k += (long long)gridDim.x * blockDim.x) {
         const int node = c.nodes[k];
         if (node < 0 || node >= num_nodes) continue;
@@ -42,7 +42,7 @@ __global__ void k_fill_n2e(ConnView c, const unsigned* n2e_off, unsigned* cursor
 }
 
 // per node: ascending flat index == ascending (element, local index): deterministic adjacency
-__global__ void k_sort_n2e(const unsigned* n2e_off, unsigned* n2e, int num_nodes) {
+static __global__ void k_sort_n2e(const unsigned* n2e_off, unsigned* n2e, int num_nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_nodes) return;
     const unsigned b = n2e_off[i], en = n2e_off[i + 1];
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(64) k_node_neighbors_once(const int* nodes, in
 }
 // 256 consecutive nodes per workgroup: their rows are one contiguous piece of ncols, written in order (coalesced); the node of
 // an entry by bisection in the workgroup's 257 offsets
-__global__ void __launch_bounds__(256) k_compact_neighbors(const unsigned* noff, const unsigned* tmp, int num_nodes, unsigned* ncols) {
+static __global__ void __launch_bounds__(256) k_compact_neighbors(const unsigned* noff, const unsigned* tmp, int num_nodes, unsigned* ncols) {
     __shared__ unsigned off[257];
     const int n0 = blockIdx.x * 256, nn = min(256, num_nodes - n0);
     for (int i = threadIdx.x; i <= nn; i += 256) off[i] = noff[n0 + i];
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) k_heavy_neighbors(ConnView c, const unsig
 }
 
 // scalar CSR row offsets: rows s*i + r  (global.rs:83-93)
-__global__ void k_expand_row_offsets(const unsigned* noff, int num_nodes, int S, unsigned long long* row_offsets) {
+static __global__ void k_expand_row_offsets(const unsigned* noff, int num_nodes, int S, unsigned long long* row_offsets) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long R = (long long)num_nodes * S;
     if (t > R) return;
@@ -329,7 +329,7 @@ __global__ void k_expand_row_offsets(const unsigned* noff, int num_nodes, int S,
 }
 
 // scalar CSR column indices: s*j + c, sdim identical rows per node (global.rs:97-110)
-__global__ void k_expand_col_indices(const unsigned* noff, const unsigned* ncols, int num_nodes, int S,
+static __global__ void k_expand_col_indices(const unsigned* noff, const unsigned* ncols, int num_nodes, int S,
                                      unsigned long long* col_indices) {
     const long long nnzn = noff[num_nodes];
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nnzn; t += (long long)gridDim.x * blockDim.x) {
@@ -348,7 +348,7 @@ __global__ void k_expand_col_indices(const unsigned* noff, const unsigned* ncols
     }
 }
 
-__global__ void k_narrow_connectivity(const unsigned long long* in, int* out, long long total, int num_nodes, int* bad) {
+static __global__ void k_narrow_connectivity(const unsigned long long* in, int* out, long long total, int num_nodes, int* bad) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < total; k += (long long)gridDim.x * blockDim.x) {
         const unsigned long long v = in[k];
         if (v >= (unsigned long long)num_nodes) { *bad = 1; out[k] = 0; } else out[k] = (int)v;
@@ -360,7 +360,7 @@ __global__ void k_narrow_connectivity(const unsigned long long* in, int* out, lo
 // Dirichlet rows and columns (global.rs:379-451): half a wavefront per node row, one lane per column block (rows longer than 32 blocks in
 // trips): the entry's row is known from the workgroup's place -- the first form searched the row of each of the nnz_n entries by
 // bisection in the offsets (23 dependent loads per entry: 7 of the 11 ms this step took on the 216^3 mesh).
-__global__ void __launch_bounds__(256) k_dirichlet_rows(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const unsigned char* member,
+static __global__ void __launch_bounds__(256) k_dirichlet_rows(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const unsigned char* member,
                                                         double* vals, const double* scale_dev) {
     const int hl = threadIdx.x & 31;
     const double scale = *scale_dev;
@@ -379,12 +379,12 @@ __global__ void __launch_bounds__(256) k_dirichlet_rows(const unsigned* noff, co
     }
 }
 
-__global__ void __launch_bounds__(256) k_mark_nodes(const unsigned long long* nodes, long long n, unsigned char* member) {
+static __global__ void __launch_bounds__(256) k_mark_nodes(const unsigned long long* nodes, long long n, unsigned char* member) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (t < n) member[nodes[t]] = 1;
 }
 
-__global__ void k_dirichlet_rhs(double* rhs, const unsigned long long* nodes, long long n, int S) {
+static __global__ void k_dirichlet_rhs(double* rhs, const unsigned long long* nodes, long long n, int S) {
     const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (t >= n * S) return;
     rhs[nodes[t / S] * S + (t % S)] = 0.0;
@@ -401,7 +401,7 @@ __device__ __forceinline__ double diag_value(const unsigned* noff, const unsigne
             return vals[(unsigned long long)S * S * b + (unsigned long long)r * S * cnt + (unsigned long long)S * k + r];
     return 0.0;
 }
-__global__ void k_first_nonzero_diag(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const double* vals,
+static __global__ void k_first_nonzero_diag(const unsigned* noff, const unsigned* ncols, int num_nodes, int S, const double* vals,
                                      unsigned long long* first, double* out) {
     if (out) {
         if (blockIdx.x == 0 && threadIdx.x == 0)

@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 // lanes of every position for the Tet4 kernel (see k_build_row_lanes).  Terms are kept in one compact array (a block has
 // at most ms N of them) behind per-column offsets; blocks with up to 48 terms (a node of an unstructured mesh easily has
 // 30-40 elements) take groups of up to 8 lanes.
-__global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
+static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
                                                              int* rec_new, uint4* lanes, int ls, int* status, const unsigned* row_real) {
     constexpr int N = 4, NKEY = 16 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;   // up to 16 nodes per block
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, i
 // With an element mask a block (I, J) of the pattern may have no active element and therefore no lane: k_gather_rows_tet4 writes every
 // OWNED block exactly once and nothing else, so in overwrite mode the values of the node range are cleared first (masked contexts only:
 // the multi-GPU partitions of fenris_amd/distributed.py are Hex8; found by tests/test_gpu_parity.py::test_overwrite_with_a_mask_...)
-__global__ void __launch_bounds__(256) k_zero_node_rows(const unsigned* noff, int n_lo, int n_hi, int ss, double* vals) {
+static __global__ void __launch_bounds__(256) k_zero_node_rows(const unsigned* noff, int n_lo, int n_hi, int ss, double* vals) {
     const size_t lo = (size_t)ss * noff[n_lo], hi = (size_t)ss * noff[n_hi];
     for (size_t k = lo + (size_t)blockIdx.x * 256 + threadIdx.x; k < hi; k += (size_t)gridDim.x * 256) vals[k] = 0.0;
 }
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) k_zero_node_rows(const unsigned* noff, in
 // cells are numbered in table order, every slot gets the four numbers of its nodes.  Which cell a node lands in may depend on the order
 // the lanes arrive (linear probing): only the numbering inside the position's vertex table does, never a value of the matrix.
 // More than ROWS_TET4_VMAX distinct vertices: status bit 2 (the caller keeps the pipelined kernel).
-__global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p_conn, int us, int npos, int* vconn, int* status) {
+static __global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p_conn, int us, int npos, int* vconn, int* status) {
     constexpr int H = 2048, CSMAX = 1024;
     __shared__ int key[H];
     __shared__ unsigned short cell_of[CSMAX], num[H];

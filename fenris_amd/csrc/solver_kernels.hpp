@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_inverse_diagonal(int num_nodes, const u
 }
 
 // r = b - r (r holds A x),  z = M^-1 r,  p = z;  partials of (z.r, b.b, r.r)      cg.rs:388-404
-__global__ void __launch_bounds__(256) k_cg_init(int n, const double* b, const double* dinv, double* r, double* z, double* p,
+static __global__ void __launch_bounds__(256) k_cg_init(int n, const double* b, const double* dinv, double* r, double* z, double* p,
                                                  double* partial /* gridDim.x x 3 */) {
     double s[3] = {0.0, 0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_cg_init(int n, const double* b, const d
 }
 
 // x += alpha p,  r -= alpha Ap,  z = M^-1 r;  partials of (z.r, r.r)               cg.rs:453-468
-__global__ void __launch_bounds__(256) k_cg_update(int n, double alpha, const double* p, const double* Ap, const double* dinv,
+static __global__ void __launch_bounds__(256) k_cg_update(int n, double alpha, const double* p, const double* Ap, const double* dinv,
                                                    double* x, double* r, double* z, double* partial /* gridDim.x x 2 */) {
     double s[2] = {0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_cg_update(int n, double alpha, const do
 }
 
 // p = beta p + z                                                                   cg.rs:470-474
-__global__ void __launch_bounds__(256) k_cg_direction(int n, double beta, const double* z, double* p) {
+static __global__ void __launch_bounds__(256) k_cg_direction(int n, double beta, const double* z, double* p) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = beta * p[i] + z[i];
 }
 

@@ -413,15 +413,35 @@ class PartAssembly:
         self.comm = None
 
     def enqueue(self, flags):
+        """the rank's share of ``assemble_into_csr``.  ``flags`` must carry ``ASSEMBLE_OVERWRITE``: the exchange ships the interface rows as
+        they stand after the local assembly and the owner ADDS them, so rows that accumulated on top of earlier content would hand that
+        content on again -- counted twice or more across the ranks, silently.  (To accumulate into an existing matrix, assemble with
+        OVERWRITE into ``values`` and add the owned rows to it afterwards.)"""
+        from .assembly import ASSEMBLE_OVERWRITE
+
+        if not (int(flags) & ASSEMBLE_OVERWRITE):
+            raise ValueError("PartAssembly.enqueue: flags must include ASSEMBLE_OVERWRITE (the interface exchange adds what the rows hold)")
         self.main.assemble_matrix_async(self.values, flags)
         self.exchange.run()
 
     def assemble_vector(self, out):
-        """the rank's share of ``VectorAssembler::assemble_vector_into`` (global.rs:582-608): ``out`` (device, one entry per local dof,
-        accumulated into) gets the own elements' contributions, then the partial sums at nodes other ranks own travel to their owners.
-        Afterwards the entries of the OWNED nodes are complete; the others are scratch."""
-        self.main.assemble_vector(out)
-        self.exchange.run_vector(out, self.main.solution_dim())
+        """the rank's share of ``VectorAssembler::assemble_vector_into`` (global.rs:582-608): the own elements' contributions are summed
+        into a ZEROED scratch vector, the partial sums at nodes other ranks own travel to their owners, and the complete entries of the
+        OWNED nodes are then ADDED to ``out`` (device, one entry per local dof) -- the reference accumulates into its output.  Entries of
+        ``out`` at nodes this rank does not own are left as they were.  (Assembling straight into ``out`` would ship whatever a non-owned
+        entry held before to its owner once per rank that touches the node.)"""
+        import torch
+
+        s = self.main.solution_dim()
+        scratch = torch.zeros_like(out)
+        self.main.assemble_vector(scratch)
+        self.exchange.run_vector(scratch, s)
+        if getattr(self, "_owned_dofs", None) is None or self._owned_dofs_s != s:
+            owned = np.asarray(self.prob.owned, dtype=np.int64)
+            dofs = (s * owned[:, None] + np.arange(s, dtype=np.int64)[None, :]).reshape(-1)
+            self._owned_dofs = torch.from_numpy(dofs).to(out.device)
+            self._owned_dofs_s = s
+        out.index_add_(0, self._owned_dofs, scratch.index_select(0, self._owned_dofs))
 
     def poll_status(self):
         self.main.poll_status()

@@ -404,14 +404,20 @@ int fh_group_exchange_finish(fh_group*, double* values_dev);
  * (ascending global) order, so no indices travel.  Offsets have peers + 1 entries.  The context's pattern must have been built.  All
  * transfers of one exchange are posted in one RCCL group; fh_group_exchange_start / _finish drive this mode once it is set.  A rank
  * may list itself as a peer (a device copy inside RCCL: the single-GPU test does).  The nodes of ONE peer's list must be distinct; a node
- * may appear in the lists of several peers (their rows are added peer by peer, in list order). */
+ * may appear in the lists of several peers (their rows are added peer by peer, in list order).
+ * CONTRACT: the exchange ships the listed rows AS THEY STAND and the receiver ADDS them.  The rows a rank sends must therefore hold this
+ * assembly's partial sums only -- assemble them with FH_ASSEMBLE_OVERWRITE (the reference's accumulate-into-the-output semantics,
+ * global.rs:133-182, applies to the OWNED rows after the exchange, not to the rows in transit): earlier content of a sent row would be
+ * counted once more on its owner for every rank that sends it, without any error. */
 int fh_group_set_exchange_nodes(fh_group*, int num_send_peers, const int32_t* send_peers, const uint64_t* send_offsets,
                                 const uint64_t* send_nodes, int num_recv_peers, const int32_t* recv_peers, const uint64_t* recv_offsets,
                                 const uint64_t* recv_nodes);
 
 /* Node VECTORS through the same lists (the residual / source vector of a partition: fh_assemble_vector_dev over the active elements
  * leaves partial sums at the nodes other ranks own): `components` values per node (the solution dim), packed, sent, received and added
- * exactly like the rows above.  Entries of nodes the rank does not own are scratch afterwards. */
+ * exactly like the rows above.  Entries of nodes the rank does not own are scratch afterwards.
+ * CONTRACT (as for the rows): `vec_dev` must hold THIS assembly's partial sums only -- assemble into a zeroed vector, exchange, then add the
+ * owned entries to whatever they accumulate into (fenris_amd/partition.py: PartAssembly.assemble_vector does exactly that). */
 int fh_group_exchange_vector_start(fh_group*, double* vec_dev, uint32_t components);
 int fh_group_exchange_vector_finish(fh_group*, double* vec_dev, uint32_t components);
 

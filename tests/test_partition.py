@@ -470,3 +470,42 @@ def test_c_abi_vector_exchange_on_a_one_rank_communicator():
             ex.close()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_part_assembly_accumulate_contract(oracle):
+    """Advisor finding of round 4: the interface exchange ships rows / vector entries as they stand and the owner adds them, so (a) the matrix of
+    a partition must be assembled with ASSEMBLE_OVERWRITE -- anything else is rejected -- and (b) ``assemble_vector`` accumulates into ``out`` like
+    the reference (global.rs:582-608) by way of a zeroed scratch vector: a pre-filled ``out`` keeps its content and gains the owned entries."""
+    import torch
+
+    mesh = _mesh("sphere")
+    op = oracle.LINEAR_ELASTIC
+    s = 3
+    ug = _u_for(mesh, s)
+    w, p = _rule(mesh)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters(*LAME))
+    fop = fa.MaterialEllipticOperator(fa.LinearElasticMaterial())
+    part = fp.morton_partition(mesh, 1)
+    prob = fp.make_part(mesh, part, 0, 1)
+
+    def configure(engine, m):
+        return (fa.ElementEllipticAssemblerBuilder(engine).with_finite_element_space(m).with_operator(fop).with_quadrature_table(qt)
+                .with_u(ug.reshape(-1, s)[prob.l2g].reshape(-1)).build())
+
+    pa = fp.PartAssembly(prob, configure, device=0)
+    try:
+        with pytest.raises(ValueError):
+            pa.enqueue(fa.SCATTER_GATHER)
+        pa.enqueue(fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
+        pa.poll_status()
+        want = _global_vector(oracle, mesh, op, ug)
+        out = torch.full((s * prob.mesh.num_nodes(),), 2.5, dtype=torch.float64, device="cuda:0")
+        pa.assemble_vector(out)
+        pa.assemble_vector(out)      # accumulates: twice the vector on top of the earlier content
+        got = out.cpu().numpy().reshape(-1, s)
+        owned = np.asarray(prob.owned)
+        ref = want.reshape(-1, s)[prob.l2g[owned]]
+        assert np.abs(got[owned] - (2.5 + 2.0 * ref)).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    finally:
+        pa.close()

@@ -397,8 +397,8 @@ void fh_destroy(fh_ctx* c) {
     if (c->trace.p) {  // ... and of k_hex27_dense_mfma (hex27_mfma.hpp): cycles of wavefront 0 per phase and element
         unsigned long long h[32] = {0};
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[31]) {
-            static const char* names[9] = {"P0 inputs", "P1 J, inverse", "P2 gradients", "P3 grad u", "P4 F, coefficients", "P5 F^-T g", "MFMA",
-                                           "stores", "transposed stores"};
+            static const char* names[9] = {"P0 inputs", "P1 J, inverse", "P2 gradients", "P3 grad u", "P4 F, coefficients", "P5 F^-T g",
+                                           "round A + its stores", "round B", "stores of round B"};
             unsigned long long tot = 0;
             for (int k = 0; k < 9; ++k) tot += h[16 + k];
             for (int k = 0; k < 9; ++k)

@@ -15,11 +15,14 @@ int launch_hex27_mfma(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     a.work_begin = w0;
     a.work_end = w1;
     const size_t lds1 = sizeof(double) * (size_t)Hex27Lds::total;
+    // three workgroups per CU since round 5 (52.9 KB of LDS and 158 registers each: scripts/gpu_r5_c4_variants.sh -- 7.54 ms against 7.97 with
+    // two on one box, 8.36 for the round-4 kernel)
+    const int wgs_default = (int)std::min<size_t>(3, LDS_LIMIT / lds1);
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     // (FENRIS_HIP_TWO_PASS_GRID: tests force many elements / nodes per workgroup on small meshes)
     if (st == c->tp_stream1 && c->tp_gather_cus > 0) dev_cus = std::max(1, dev_cus - c->tp_gather_cus);   // (CU-masked stream: the CUs left to this pass)
-    const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", 2)))));
+    const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", wgs_default)))));
     if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
         auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));

@@ -31,6 +31,14 @@
 namespace fenris_hip {
 
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+#ifndef HEX27_PREFETCH_OPS_VALUE
+#define HEX27_PREFETCH_OPS_VALUE 0
+#endif
+#ifndef HEX27_PRIO_VALUE
+#define HEX27_PRIO_VALUE 1
+#endif
+constexpr bool HEX27_PRIO = HEX27_PRIO_VALUE != 0;
+constexpr bool HEX27_PREFETCH_OPS = HEX27_PREFETCH_OPS_VALUE != 0;   // (unused since the two-round form)
 
 struct Hex27Lds {
     // RP rows per component: the 27 nodes and ONE row of zeros -- the matrix-core tiles are 16 x 16, rows 27 .. 31 of the second tile all read
@@ -57,7 +65,7 @@ struct Hex27Lds {
 };
 
 template <int OP, bool TRACE = false>
-__global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
+__global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
     using L = Hex27Lds;
     constexpr int N = L::N, NG = L::NG, NQ = L::NQ, RP = L::RP, QS = L::QS;
     constexpr bool NH = (OP == FH_NEO_HOOKEAN);
@@ -144,6 +152,11 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         long long e_n3 = elem_of(w + 3 * Gs);
         lds_barrier();
         mark(0);
+        // The prologue's fp64 chains share the SIMD's fp64 datapath with the matrix instructions of the other workgroups of the CU (64 cycles
+        // each, issued back to back by their wavefronts): at equal priority a dependent chain of ~160 vector instructions waits behind bursts
+        // of them.  Raised priority for the prologue, normal priority for the matrix-core rounds: a vector instruction then waits for at most
+        // the matrix instruction in flight.
+        if (HEX27_PRIO) __builtin_amdgcn_s_setprio(3);
         // The 3 x 3 work of a point (Jacobian, its inverse, F, its inverse) is spread over nine lanes, one per entry: a wavefront
         // that runs it alone, one lane per point, issues ~250 dependent fp64 instructions while the other three wait at the
         // barrier -- and while the other workgroup of the CU multiplies, each of them waits for a 64-cycle matrix instruction.
@@ -267,17 +280,14 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         // tile they lie.
         const int tI = wave >> 1, tJ = wave & 1;
         const int rI = min(16 * tI + (lane & 15), N), rJ = min(16 * tJ + (lane & 15), N), kq = lane >> 4;   // rows 27 .. 31: the row of zeros
-        mfma_f64x4 acc[3][3], accM = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i][j] = mfma_f64x4{0, 0, 0, 0};
-        // k-steps of four points; the operands of the next step are fetched while this one is multiplied (the loop is not
-        // unrolled: all seven steps' operands in flight at once cost more registers than there are)
-        struct Ops { double ar[3], ac[3], gr[3], gc[3], cl, nca, rds, rd, rms, rm; };
-        auto fetch_ops = [&](int ks) {
+        // Two rounds over the seven k-steps (round 5: three workgroups per CU leave 168 registers; seven accumulator tiles at once were 56
+        // of them): (A) the three diagonal components and the trace term, stored while (B) the three components above the diagonal multiply.
+        // The operands are read from LDS twice (18 + 12 instead of 18 values per lane and k-step), the number of matrix instructions is the same.
+        struct OpsA { double ar[3], ac[3], gr[3], gc[3], rds, rd, rms, rm; };
+        struct OpsB { double ar[3], ac[3], cl, nca; };
+        auto fetch_a = [&](int ks) {
             const int q = 4 * ks + kq;  // q = 27 is padding: operands and coefficients are zero there
-            Ops o;
+            OpsA o;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 o.ar[k] = A[(k * RP + rI) * QS + q];
@@ -285,50 +295,26 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
                 o.gr[k] = G[(k * RP + rI) * QS + q];
                 o.gc[k] = G[(k * RP + rJ) * QS + q];
             }
-            o.cl = lds[L::o_coef + q]; o.nca = lds[L::o_coef + 28 + q];
             o.rds = lds[L::o_coef + 56 + q]; o.rd = lds[L::o_coef + 84 + q];
             o.rms = lds[L::o_coef + 112 + q]; o.rm = lds[L::o_coef + 140 + q];
             return o;
         };
-        if (!(TRACE && (a.ablate & 2))) {
-            Ops cur = fetch_ops(0);
-            int nks = 7;
-            asm volatile("" : "+s"(nks));   // opaque trip count: the compiler unrolls a loop of seven whatever the pragma says
-#pragma unroll 1
-            for (int ks = 0; ks < nks; ++ks) {
-                const Ops nxt = fetch_ops(min(ks + 1, 6));
+        auto fetch_b = [&](int ks) {
+            const int q = 4 * ks + kq;
+            OpsB o;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    acc[i][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rds * cur.ar[i], cur.rd * cur.ac[i], acc[i][i], 0, 0, 0);
-#pragma unroll
-                    for (int j = i + 1; j < 3; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.cl * cur.ar[i], cur.ac[j], acc[i][j], 0, 0, 0);   // c_l a_I[i] a_J[j]
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.nca * cur.ar[j], cur.ac[i], acc[i][j], 0, 0, 0);  // -c_a a_I[j] a_J[i]
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rms * cur.gr[k], cur.rm * cur.gc[k], accM, 0, 0, 0);
-                cur = nxt;
+            for (int k = 0; k < 3; ++k) {
+                o.ar[k] = A[(k * RP + rI) * QS + q];
+                o.ac[k] = A[(k * RP + rJ) * QS + q];
             }
-        }
-        mark(6);
-        // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
-        // (loads and stores share one in-order counter: waiting for a load issued before a store waits for the store).
-        asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
-        // ... and the reference gradients of the NEXT element's phase P2 are requested here, ahead of this element's stores: P2 then waits
-        // for them with the stores still in flight (issued behind the stores, the wait would drain them: a write latency per element)
-        load_gref();
-        asm volatile("" ::: "memory");
-        val_cur = val_n1;
-        node_n1 = node_n2;
-        e_cur = e_n1;
-        e_n1 = e_n2;
-        e_n2 = e_n3;
+            o.cl = lds[L::o_coef + q]; o.nca = lds[L::o_coef + 28 + q];
+            return o;
+        };
         // store: C/D fragment of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
         // Buffer stores with the hardware's bounds check (round 5): the lanes of the padding rows / columns (I, J >= 27) get an offset
         // beyond the element's matrix and their store is dropped -- no branch, no EXEC masking.  Under `if (I < N && J < N)` every store sat
         // in a conditional block, and the compiler then counts NO store as certainly issued: the wait for the reference gradients
-        // requested above (ahead of the stores) became a wait for all the stores.
+        // requested ahead of the stores became a wait for all the stores.
         const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * (81 * 81));
         const unsigned long long ke_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ke_addr >> 32)) << 32) |
                                         (unsigned)__builtin_amdgcn_readfirstlane((int)ke_addr);
@@ -341,34 +327,86 @@ __global__ void __launch_bounds__(256, 2) k_hex27_dense_mfma(const KArgs a, doub
         };
         const int J = 16 * tJ + (lane & 15);
         const int I0 = 16 * tI + (lane >> 4);
-        unsigned vo_row[4], vo_col[4];   // element (I0 + 4 reg, J) of a component / its mirror image (J, I0 + 4 reg)
+        auto vo_row = [&](int reg) { return (I0 + 4 * reg < N && J < N) ? (unsigned)(I0 * (9 * N) + J) * 8u : 0x80000000u; };   // element (I0 + 4 reg, J) of a component
+        auto vo_col = [&](int reg) { return (I0 + 4 * reg < N && J < N) ? (unsigned)(J * (9 * N) + I0) * 8u : 0x80000000u; };   // its mirror image (J, I0 + 4 reg)
+        int nks = 7;
+        asm volatile("" : "+s"(nks));   // opaque trip count: the compiler unrolls a loop of seven whatever the pragma says
+        if (HEX27_PRIO) __builtin_amdgcn_s_setprio(0);
+        // ---- round A: diagonal components and trace term
+        {
+            mfma_f64x4 accD[3], accM = {0, 0, 0, 0};
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const bool valid = I0 + 4 * reg < N && J < N;
-            vo_row[reg] = valid ? (unsigned)(I0 * (9 * N) + J) * 8u : 0x80000000u;
-            vo_col[reg] = valid ? (unsigned)(J * (9 * N) + I0) * 8u : 0x80000000u;
-        }
-        if (!(TRACE && (a.ablate & 4)))
+            for (int i = 0; i < 3; ++i) accD[i] = mfma_f64x4{0, 0, 0, 0};
+            if (!(TRACE && (a.ablate & 2))) {
+                OpsA cur = fetch_a(0);
+#pragma unroll 1
+                for (int ks = 0; ks < nks; ++ks) {
+                    const OpsA nxt = fetch_a(min(ks + 1, 6));   // the next step's operands beside this one's products
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < 3; ++i) accD[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rds * cur.ar[i], cur.rd * cur.ac[i], accD[i], 0, 0, 0);
 #pragma unroll
-            for (int j = i; j < 3; ++j) {
-                const mfma_f64x4 v = (i == j) ? acc[i][j] + accM : acc[i][j];
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) put(vo_row[reg], 4 * reg * (9 * N) + (i * 3 + j) * N, v[reg]);
+                    for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rms * cur.gr[k], cur.rm * cur.gc[k], accM, 0, 0, 0);
+                    cur = nxt;
+                }
             }
-        mark(7);
-        // K_ji = K_ij^T straight from the fragments: entry (I, J) of the tile goes to (J, I) of the mirrored component.  Per store
-        // instruction a lane group writes four consecutive I of one J (32 bytes), and the four registers complete the 128 bytes
-        // of that J; the L2 merges them.  (Staging the tile through LDS to store it row-wise cost a barrier, three LDS round
-        // trips and the re-zeroing of the staging area: 2.4 k cycles per element against 1.x k.)
-        if (!(TRACE && (a.ablate & 4))) {
+            // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
+            // (loads and stores share one in-order counter: waiting for a load issued before a store waits for the store).
+            asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
+            // ... and the reference gradients of the NEXT element's phase P2 are requested here, ahead of this element's stores: P2 then waits
+            // for them with the stores still in flight (issued behind the stores, the wait would drain them: a write latency per element)
+            load_gref();
+            asm volatile("" ::: "memory");
+            val_cur = val_n1;
+            node_n1 = node_n2;
+            e_cur = e_n1;
+            e_n1 = e_n2;
+            e_n2 = e_n3;
+            if (!(TRACE && (a.ablate & 4)))
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i) {
+                    const mfma_f64x4 v = accD[i] + accM;
 #pragma unroll
-                for (int j = i + 1; j < 3; ++j)
+                    for (int reg = 0; reg < 4; ++reg) put(vo_row(reg), 4 * reg * (9 * N) + (i * 3 + i) * N, v[reg]);
+                }
+        }
+        mark(6);
+        // ---- round B: the components above the diagonal; K_ji = K_ij^T straight from the fragments: entry (I, J) of the tile goes to (J, I) of
+        // the mirrored component.  Per store instruction a lane group writes four consecutive I of one J (32 bytes), and the four registers
+        // complete the 128 bytes of that J; the L2 merges them.  (Staging the tile through LDS to store it row-wise cost a barrier, three LDS
+        // round trips and the re-zeroing of the staging area: 2.4 k cycles per element against 1.x k.)
+        {
+            mfma_f64x4 accO[3];   // (0, 1), (0, 2), (1, 2)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) put(vo_col[reg], (j * 3 + i) * N + 4 * reg, acc[i][j][reg]);
+            for (int i = 0; i < 3; ++i) accO[i] = mfma_f64x4{0, 0, 0, 0};
+            if (!(TRACE && (a.ablate & 2))) {
+                OpsB cur = fetch_b(0);
+#pragma unroll 1
+                for (int ks = 0; ks < nks; ++ks) {
+                    const OpsB nxt = fetch_b(min(ks + 1, 6));
+                    int t = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = i + 1; j < 3; ++j, ++t) {
+                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.cl * cur.ar[i], cur.ac[j], accO[t], 0, 0, 0);   // c_l a_I[i] a_J[j]
+                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.nca * cur.ar[j], cur.ac[i], accO[t], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                        }
+                    cur = nxt;
+                }
+            }
+            mark(7);
+            if (!(TRACE && (a.ablate & 4))) {
+                int t = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < 3; ++j, ++t)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            put(vo_row(reg), 4 * reg * (9 * N) + (i * 3 + j) * N, accO[t][reg]);
+                            put(vo_col(reg), (j * 3 + i) * N + 4 * reg, accO[t][reg]);
+                        }
+            }
         }
         lds_barrier();  // the next element's prologue overwrites G / A
         mark(8);

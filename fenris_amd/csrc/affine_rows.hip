@@ -215,6 +215,9 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         // NSTORE wavefronts share the work as one unit of SL = 64 NSTORE lanes: a trip moves SL consecutive 16-byte pieces.
         constexpr int SL = 64 * NSTORE;
         const int lane = tid - 320;
+        // the store wave's own instruction stream is the critical path of a position (78 % of it busy): its instructions go first on its SIMD
+        // (round 5; the level comes with the launch -- FENRIS_HIP_AFFINE_PRIO = store | loader << 2, default 3 | 2 << 2 -- one scalar branch per role and launch)
+        { const int pr = (ablate_arg >> AFFINE_ROWS_PRIO_SHIFT) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
         // Rows of a finished position: LDS -> global memory.  The write path wants whole, aligned 128-byte lines (16-byte
         // stores that start a wave off a line boundary reach 4.3 TB/s instead of 6.2, and a line written in two parts costs
         // about ten full ones: scripts/ubench_fill.hip), but a block's rows start and end anywhere.  So the staging buffer is
@@ -469,6 +472,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         // position after it was requested, so the wave waits for a fetch only when memory takes longer than a whole position;
         // the row waves and the store wave never touch vmcnt.
         const int lane = tid - 256;
+        { const int pr = (ablate_arg >> (AFFINE_ROWS_PRIO_SHIFT + 2)) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
         constexpr int NPC = GW / 2;                    // 16-byte pieces per record
         constexpr int ROUNDS = (NPC * 32 + 63) / 64;   // us <= 32 slots
         const int npieces = NPC * T.us;

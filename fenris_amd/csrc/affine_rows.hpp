@@ -30,6 +30,7 @@ constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
 constexpr int AFFINE_ROWS_NO_CLEAR = 0x40000;   // (timing experiments only: wrong results under a mask)
 constexpr int AFFINE_ROWS_NO_CARRY = 0x20000;   // (debugging) every position stores its own incomplete last line
 constexpr int AFFINE_ROWS_REC_NO_DMA = 0x80000, AFFINE_ROWS_REC_NO_MATH = 0x100000, AFFINE_ROWS_REC_NO_L1 = 0x200000, AFFINE_ROWS_REC_NO_L2 = 0x400000;   // (timing experiments on the records wave: wrong results)
+constexpr int AFFINE_ROWS_PRIO_SHIFT = 24;        // bits 24-25 of the launcher's `ablate` argument: s_setprio level of the store wave, 26-27: of the loader wave
 constexpr int AFFINE_ROWS_NT_STORES = 0x10000;  // bit of the launcher's `ablate` argument: non-temporal stores of the rows
 constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave (a second store wave: 448)
 

@@ -194,6 +194,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
     DevStatus* status = c->status.p + c->status_slot;
     const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", rop == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
                    (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0) |
+                   ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 3 | (2 << 2)) & 15) << AFFINE_ROWS_PRIO_SHIFT) |
                    ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 1) ? AFFINE_ROWS_REC_NO_DMA : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 2) ? AFFINE_ROWS_REC_NO_MATH : 0) |
                    ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 4) ? AFFINE_ROWS_REC_NO_L1 : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 8) ? AFFINE_ROWS_REC_NO_L2 : 0);
     // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
@@ -219,7 +220,7 @@ int launch_affine(fh_ctx* c, KArgs& a) {
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] affine ring: positions %d + %d ring=%d doubles lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, ring, lds, per_cu, grid);
                 HIP_TRY(c, affine_ring_launch(rop, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
-                                              a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 0) & 3) << 28)));
+                                              a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_RING_PRIO", 0) & 3) << 28)));
                 return FH_OK;
             }
         }
@@ -346,7 +347,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                 a.nq = 1;
             }
             RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->r_vconn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
-                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls};
+                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls, c->env_int("FENRIS_HIP_TET4_PRIO", 0) & 15};
             a.ub = std::max(c->p_us, 76);   // the X region of the layout (14 doubles per slot) holds the vertex table: 256 x 4 doubles
             a.nb_max = c->p_nbs;
             if (c->has_mask && a.overwrite) {   // blocks without an active element have no lane: clear the range first (rows_kernel.hpp)
@@ -373,7 +374,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] hex8 rows: positions %d lds=%zu B wgs/cu=%d grid=%d\n", c->npos_gen, lds_h, per_cu, grid);
                 c->last_kernel += "k_hex8_rows";
-                HIP_TRY(c, hex8_rows_launch(c->op, grid, lds_h, c->stream, a, T, a.ablate | (a.trace ? 0x10000 : 0)));
+                HIP_TRY(c, hex8_rows_launch(c->op, grid, lds_h, c->stream, a, T, a.ablate | (a.trace ? 0x10000 : 0) | ((c->env_int("FENRIS_HIP_HEX8_PRIO", 40) & 63) << HEX8_ROWS_PRIO_SHIFT)));
                 return FH_OK;
             }
         }

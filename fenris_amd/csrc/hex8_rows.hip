@@ -109,6 +109,8 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
         // memory the incomplete last line is carried to the head of the buffer instead of being written).  ONE buffer: this wave reads it
         // between the end of a position's phase C and the end of the next position's phase B, the row waves write it during phase C.
         const int lane = tid - 320;
+        // (round 5: wave priorities with the launch, FENRIS_HIP_HEX8_PRIO = store | loader << 2 | phase-B row waves << 4)
+        { const int pr = (ablate_arg >> HEX8_ROWS_PRIO_SHIFT) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
         auto put = [&](f64x2* dst, f64x2 val) {
             if (DBG && (ablate & 1)) return;
             if constexpr (OVERWRITE) *dst = val;
@@ -167,6 +169,7 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
     }
 
     if (wave == 4) {
+        { const int pr = (ablate_arg >> (HEX8_ROWS_PRIO_SHIFT + 2)) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
         // ------------------------------------------------------------------------------------------ loader wave
         // Every global load of the kernel.  Position p is current between the barriers B2(p - 1) and B2(p); the loader works in the
         // second half of that interval (phase C: nobody reads X, the lane table or the ring entry it writes):
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(HEX8_ROWS_THREADS, 4) k_hex8_rows(const KArgs 
     }
 
     // ---------------------------------------------------------------------------------------------- row waves
+    if (wave >= 2) { const int pr = (ablate_arg >> (HEX8_ROWS_PRIO_SHIFT + 4)) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
     lds_barrier();  // B0
     tr_start();
     const unsigned g_addr = (unsigned)(unsigned long long)G, zv_addr = (unsigned)(unsigned long long)ZV;
@@ -683,8 +687,8 @@ hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int
 hipError_t hex8_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const Hex8RowTables& T, int ablate) {
     // (the instrumented instantiation exists for overwriting assemblies only: an accumulating one under FENRIS_HIP_TRACE / FENRIS_HIP_ABLATE runs
     // the production kernel -- it used to take the instrumented one and OVERWRITE the values)
-    const bool ow = a.overwrite != 0, dbg = ablate != 0 && ow;
-    if (!dbg) ablate = 0;
+    const bool ow = a.overwrite != 0, dbg = (ablate & 0x1ffff) != 0 && ow;
+    if (!dbg) ablate &= ~0x1ffff;   // (the priority bits stay)
     void (*kern)(const KArgs, const Hex8RowTables, int);
     if (op == FH_LAPLACE) kern = dbg ? k_hex8_rows<FH_LAPLACE, true, true> : ow ? k_hex8_rows<FH_LAPLACE, true, false> : k_hex8_rows<FH_LAPLACE, false, false>;
     else kern = dbg ? k_hex8_rows<FH_LINEAR_ELASTIC, true, true> : ow ? k_hex8_rows<FH_LINEAR_ELASTIC, true, false> : k_hex8_rows<FH_LINEAR_ELASTIC, false, false>;

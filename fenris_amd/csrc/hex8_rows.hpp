@@ -36,6 +36,7 @@ hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int
 void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after);
 
 // op: FH_LAPLACE or FH_LINEAR_ELASTIC; a.ggeom / a.qw: reference gradients [8][8][3] and weights [8] of the rule
+constexpr int HEX8_ROWS_PRIO_SHIFT = 24;   // bits 24-29 of `ablate`: s_setprio level of the store wave, the loader wave, the row waves that carry phase B
 hipError_t hex8_rows_launch(int op, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const Hex8RowTables& T, int ablate);
 
 }  // namespace fenris_hip

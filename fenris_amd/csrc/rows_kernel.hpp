@@ -28,6 +28,7 @@ struct RowTablesS {
     const int* elem;     // [npos][us]
     const double* slotpar;  // [npos][us][2] (mu, lambda) of the element in each slot (piecewise-constant material), or null
     int rw, us, nbs, npos, ls;
+    int prio;            // s_setprio levels (round 5): bits 0-1 the two wavefronts that carry phase B (the last lanes), bits 2-3 the other two
 };
 constexpr int ROWS_TET4_VMAX = 256;   // unique vertices per position the tables can express (one per lane)
 
@@ -47,6 +48,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
     const int tid = threadIdx.x;
     const int G = gridDim.x;
     stage_tables<EK>(a, L, lds);
+    { const int pr = (T.prio >> ((tid >> 7) ? 0 : 2)) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
 
     struct Rec { int w, vid, sw; };   // record word, vertex id and slot word of this lane
     const int npos = T.npos, vs = ROWS_TET4_VMAX + T.us;

@@ -573,6 +573,16 @@ def main():
     flags |= fa.ASSEMBLE_OVERWRITE
     placement = slab_asm.placement if slab_asm is not None else None   # N > 1: rank 0's (every rank probes its own buffers)
     settle = None
+    t_first = None
+    if world == 1:
+        # the first assembly of the context: owner / lane tables of the pattern are built inside it (once per pattern).  What a caller of
+        # the reference's one-shot `assemble` (global.rs:122-131) pays on top of pattern_build_s.
+        torch.cuda.synchronize()
+        t0f = time.perf_counter()
+        eng.assemble_matrix_async(values, flags)
+        eng.poll_status()
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t0f
     if world == 1 and not args.no_settle and os.environ.get("FENRIS_BENCH_CHILD") != "1":
         settle = settle_device(eng, values, flags)     # first: the probe below compares allocations, not a cold device with a warm one
     if world == 1 and args.placement_tries > 0 and args.scatter == "gather":
@@ -637,7 +647,13 @@ def main():
                        "name": cfg, "elements_per_gpu": E, "nodes_per_gpu": N, "nnz_per_gpu": nnz, "scatter": args.scatter,
                        "partition": "single" if world == 1 else (f"{world} z-slabs, interface rows exchanged" if args.partition == "exchange"
                                                                    else f"{world} z-slabs, halo element layer recomputed, no communication"),
-                       "pattern_build_s": t_pattern, "values_alloc_s": t_values_alloc, "module_warmup_s": t_warm, "placement_probe": placement, "device_settle": settle},
+                       "pattern_build_s": t_pattern, "first_assembly_s": t_first, "values_alloc_s": t_values_alloc, "module_warmup_s": t_warm,
+                       "placement_probe": placement, "device_settle": settle,
+                       # the placement a caller of fh_assemble_matrix_dev gets without shopping for allocations (the first one of this process,
+                       # after the device settled): time and roofline fraction next to the probed figures of the line
+                       "first_placement_ms": (placement or {}).get("values_ms_seen", [None])[0] if world == 1 else None,
+                       "first_placement_frac": ((abytes / ((placement or {}).get("values_ms_seen", [None])[0] * 1e-3) / 1e9 / PEAK_HBM_GBS)
+                                                if world == 1 and (placement or {}).get("values_ms_seen") else None)},
         }
         if world > 1 and layers is None:
             # general partition: who holds what, what rank 0 exchanges, and the same check as for the slabs -- the rows of rank 0's owned

@@ -65,6 +65,8 @@ _SIGS = {
     "fh_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "fh_time_assembly_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "fh_tune_placement_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fh_vmm_alloc": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "fh_vmm_free": (C.c_int, [C.c_void_p]),
     "fh_group_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "fh_group_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "fh_group_destroy": (None, [C.c_void_p]),

@@ -225,6 +225,11 @@ int fh_poll_status(fh_ctx*, uint64_t* failed_element);
 /* A tuning switch of this context (a FENRIS_HIP_* name as fh_create reads them from the environment): set, or removed with value ==
  * NULL.  Launch-variant switches act at the next call.  For comparing variants inside ONE context on the same buffers. */
 int fh_set_option(fh_ctx*, const char* name, const char* value);
+/* Device memory through the virtual-memory API with an explicit physical chunk size (hipMemAddressReserve / hipMemCreate / hipMemMap): `bytes`
+ * on `device` from chunks of `chunk_bytes` (rounded up to the allocation granularity, reported in *granularity_out; 0 = one chunk).  For
+ * experiments on how a large `values` array is backed (profiles/r05_vmm_experiment.txt); free with fh_vmm_free.  No reference counterpart. */
+int fh_vmm_alloc(int device, uint64_t bytes, uint64_t chunk_bytes, void** out, uint64_t* granularity_out);
+int fh_vmm_free(void* ptr);
 int fh_time_assembly_dev(fh_ctx*, double* values_dev, int flags, int reps, double* ms_per_assembly);
 int fh_tune_placement_dev(fh_ctx*, double* values_dev, int flags, int tries, double* ms_before, double* ms_after);
 /* The CSR rows of the nodes [node_begin, node_end) only (FH_SCATTER_GATHER), whatever the context's own row range is: the

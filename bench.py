@@ -620,10 +620,38 @@ def main():
     (slab_asm or eng).poll_status()
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    per_rank_ms = None
+    exchange_ms = None
     if world > 1:
+        # every rank's own time per step (the line's ms_per_step is their maximum) and, after the timed region, what the interface exchange
+        # costs when nothing hides it: a scaling run can then tell load imbalance from communication
+        mine = torch.tensor([1e3 * elapsed / args.steps], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) for x in allr]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ex = getattr(slab_asm, "exchange", None)
+        if ex is not None and hasattr(ex, "run") and args.partition == "exchange":
+            try:
+                torch.cuda.synchronize()
+                dist.barrier()
+                ex.run()                       # (untimed: buffers, communicator warm)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0x = time.perf_counter()
+                for _ in range(3):
+                    ex.run()
+                torch.cuda.synchronize()
+                exchange_ms = 1e3 * (time.perf_counter() - t0x) / 3
+                # (the rows now hold four extra copies of the neighbours' contributions: restore them with one more assembly)
+                step()
+                torch.cuda.synchronize()
+                dist.barrier()
+            except Exception as exc:   # never take the line down
+                exchange_ms = None
+                print(f"[bench] exchange timing failed: {exc!r}", file=sys.stderr)
         e_t = torch.tensor([float(E)], dtype=torch.float64, device="cuda")
         dist.all_reduce(e_t, op=dist.ReduceOp.SUM)
         total_elements = float(e_t.item())
@@ -655,6 +683,11 @@ def main():
                        "first_placement_frac": ((abytes / ((placement or {}).get("values_ms_seen", [None])[0] * 1e-3) / 1e9 / PEAK_HBM_GBS)
                                                 if world == 1 and (placement or {}).get("values_ms_seen") else None)},
         }
+        if world > 1:
+            out["config"]["per_rank_ms_per_step"] = [round(x, 4) for x in per_rank_ms] if per_rank_ms else None
+            out["config"]["exchange_ms"] = round(exchange_ms, 4) if exchange_ms is not None else None
+            out["config"]["exchange_ms_note"] = ("the interface exchange alone, three times back to back after the timed region (host clock, rank 0); inside a "
+                                                 "step it runs beside the main launch")
         if world > 1 and layers is None:
             # general partition: who holds what, what rank 0 exchanges, and the same check as for the slabs -- the rows of rank 0's owned
             # nodes that other parts contribute to are complete only after the exchange, and a stiffness row sums to zero

@@ -131,3 +131,81 @@ def test_bench_two_ranks_sharing_the_device(cfg, extra):
     if "halo" not in extra:
         # rank 0's owned interface rows are complete only once rank 1's rows have arrived and been added: stiffness rows sum to zero
         assert float(line["config"]["interface_row_sum_over_max"]) <= 1e-12, line["config"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_c5_at_full_size_sharing_the_device():
+    """C5 (Hex8 elasticity 256^3) cut into two slabs of 128 layers, both ranks on the one GPU of the test box, through
+    bench.py's own N > 1 path: the interface plane of 257^2 nodes (3 x 81 values per node row: 128 MB) goes through the exchange the scaling
+    run will use, and rank 0's owned interface rows sum to zero once rank 1's rows have been added."""
+    env = dict(os.environ, FENRIS_BENCH_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c5", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-traffic", "--placement-tries", "0", "--no-settle"]
+    pr = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    own = 256 ** 3
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - own) <= 1e-6 * own
+    assert float(line["config"]["interface_row_sum_over_max"]) <= 1e-12, line["config"]
+    # per-rank times and the exchange of the line (item 6c): both ranks report, the exchange is a part of the step
+    pr_ms = line["config"]["per_rank_ms_per_step"]
+    assert len(pr_ms) == 2 and min(pr_ms) > 0 and max(pr_ms) <= line["ms_per_step"] * 1.0001
+    assert line["config"]["exchange_ms"] is not None and line["config"]["exchange_ms"] >= 0.0
+
+
+@pytest.mark.gpu
+def test_c_abi_list_exchange_at_c5_interface_size_on_a_one_rank_communicator():
+    """the library's own RCCL exchange (fh_group_set_exchange_nodes: pack kernel, ncclSend / ncclRecv in one group,
+    unpack-add kernel) with C5's real interface volume -- a plane of 257 x 257 nodes, 3 x 81 doubles per node row (128 MB) -- with the rank as
+    its own peer (two ranks cannot share a device under RCCL).  Rows of the plane are added onto themselves: exactly twice the assembled rows."""
+    import torch
+
+    from fenris_amd import partition as fp
+
+    mesh = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 1, 1, 1, 256)
+    # three layers of the 256^3 mesh around one interface plane: 256 x 256 x 2 cells
+    nx = 257
+    keep = np.flatnonzero(np.asarray(mesh.vertices)[:, 2] <= 2.0 / 256 + 1e-12)
+    assert len(keep) == nx * nx * 3
+    conn = np.asarray(mesh.connectivity).astype(np.int64)
+    inside = np.all(np.isin(conn, keep), axis=1)
+    remap = -np.ones(mesh.num_nodes(), dtype=np.int64)
+    remap[keep] = np.arange(len(keep))
+    sub = fa.Mesh(np.asarray(mesh.vertices)[keep], remap[conn[inside]].astype(np.uint64), fa.HEX8)
+    del mesh
+    w, p = quadrature.tensor.hexahedron_gauss(2)
+    qt = fa.UniformQuadratureTable.from_points_and_weights(p, w).with_uniform_data(fa.LameParameters.from_young_poisson(fa.YoungPoisson(1e6, 0.2)))
+    eng = fa.Engine(0)
+    try:
+        (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(sub).with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial()))
+         .with_quadrature_table(qt).with_u(None).build())
+        nnz = eng.build_pattern()
+        values = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+        flags = fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE
+        eng.assemble_matrix(values, flags)
+        plane = np.flatnonzero(np.abs(np.asarray(sub.vertices)[:, 2] - 1.0 / 256) <= 1e-12)
+        assert len(plane) == nx * nx
+        prob = fp.PartProblem(sub, np.arange(sub.num_nodes()), np.arange(sub.num_elements()), np.ones(sub.num_elements(), np.uint8),
+                              np.arange(sub.num_nodes()), {1: plane}, {1: plane}, 0, 1)
+        ex = fp.AbiPartExchange(prob, eng, self_loop=True).bind(eng, values)
+        try:
+            ro = np.asarray(eng.pattern(want_cols=False)[0]).astype(np.int64)
+            lo, hi = ro[3 * plane[0]], ro[3 * plane[-1] + 3]
+            before = values.clone()
+            sent = ex.bytes_sent()
+            assert sent >= 8 * (nx - 2) * (nx - 2) * 81 * 9 and sent <= 8 * nx * nx * 81 * 9      # 128 MB class
+            ex.run()
+            torch.cuda.synchronize()
+            # the plane's rows are contiguous (consecutive node ids): doubled; everything else untouched
+            assert torch.equal(values[lo:hi], 2.0 * before[lo:hi])
+            assert torch.equal(values[:lo], before[:lo]) and torch.equal(values[hi:], before[hi:])
+        finally:
+            ex.close()
+    finally:
+        eng.close()
+        torch.cuda.empty_cache()

@@ -40,6 +40,10 @@ typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 constexpr bool HEX27_PRIO = HEX27_PRIO_VALUE != 0;
 constexpr bool HEX27_PREFETCH_OPS = HEX27_PREFETCH_OPS_VALUE != 0;   // (unused since the two-round form)
 
+// log() out of line: inlined, the compiler keeps the coefficients of its polynomial in registers ACROSS the element loop (ten of them, hoisted as
+// loop invariants) -- with three workgroups per CU that is what spilled, and a spill is a scratch access with a full vmcnt wait in phase P5
+static __device__ __attribute__((noinline)) double hex27_log(double x) { return log(x); }
+
 struct Hex27Lds {
     // RP rows per component: the 27 nodes and ONE row of zeros -- the matrix-core tiles are 16 x 16, rows 27 .. 31 of the second tile all read
     // row 27 (round 5; they used to have five rows of zeros of their own).  QS: point stride (odd: bank spread).
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
                         const double nan = __builtin_nan("");
                         put_coef(q, nan, nan, nan);
                     } else {
-                        put_coef(q, s * lambda, s * (-mu + lambda * log(Jd)), s * mu);
+                        put_coef(q, s * lambda, s * (-mu + lambda * hex27_log(Jd)), s * mu);
                     }
                 }
             } else {
@@ -278,7 +282,13 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
         // operands, (c_l - c_a) a_I[i] a_J[i], and the coefficient is split as sign * sqrt|c| * sqrt|c| over the two
         // operands: entry (I, J) and entry (J, I) are then sums of identical products in the same order, in whichever
         // tile they lie.
-        const int tI = wave >> 1, tJ = wave & 1;
+        // Which wavefront takes which tile rotates from element to element (round 5): tile (1, 0) of the three diagonal components and of the trace
+        // term is the mirror image of tile (0, 1) and is no longer multiplied -- its wavefront skips round A, the wavefront of tile (0, 1) stores the
+        // mirror image as well -- so one SIMD in four has half the matrix instructions of an element, and the rotation spreads that relief over
+        // the four SIMDs (42 instead of 48 matrix instructions per k-step and workgroup).
+        const int tile = (__builtin_amdgcn_readfirstlane(wave) + (int)(((w - w0) / Gs) & 3)) & 3;
+        const bool light = tile == 2;
+        const int tI = tile >> 1, tJ = tile & 1;
         const int rI = min(16 * tI + (lane & 15), N), rJ = min(16 * tJ + (lane & 15), N), kq = lane >> 4;   // rows 27 .. 31: the row of zeros
         // Two rounds over the seven k-steps (round 5: three workgroups per CU leave 168 registers; seven accumulator tiles at once were 56
         // of them): (A) the three diagonal components and the trace term, stored while (B) the three components above the diagonal multiply.
@@ -329,45 +339,52 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
         const int I0 = 16 * tI + (lane >> 4);
         auto vo_row = [&](int reg) { return (I0 + 4 * reg < N && J < N) ? (unsigned)(I0 * (9 * N) + J) * 8u : 0x80000000u; };   // element (I0 + 4 reg, J) of a component
         auto vo_col = [&](int reg) { return (I0 + 4 * reg < N && J < N) ? (unsigned)(J * (9 * N) + I0) * 8u : 0x80000000u; };   // its mirror image (J, I0 + 4 reg)
-        int nks = 7;
-        asm volatile("" : "+s"(nks));   // opaque trip count: the compiler unrolls a loop of seven whatever the pragma says
         if (HEX27_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- round A: diagonal components and trace term
         {
             mfma_f64x4 accD[3], accM = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < 3; ++i) accD[i] = mfma_f64x4{0, 0, 0, 0};
-            if (!(TRACE && (a.ablate & 2))) {
-                OpsA cur = fetch_a(0);
-#pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) {
-                    const OpsA nxt = fetch_a(min(ks + 1, 6));   // the next step's operands beside this one's products
+            if (!light && !(TRACE && (a.ablate & 2))) {
+                // the next step's operands are fetched beside this one's products; two steps per trip with the two operand sets changing roles
+                // (`cur = nxt` at the end of a one-step trip was sixteen register moves per step: a quarter of the kernel's vector instructions)
+                auto mul_a = [&](const OpsA& o) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) accD[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rds * cur.ar[i], cur.rd * cur.ac[i], accD[i], 0, 0, 0);
+                    for (int i = 0; i < 3; ++i) accD[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.rds * o.ar[i], o.rd * o.ac[i], accD[i], 0, 0, 0);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.rms * cur.gr[k], cur.rm * cur.gc[k], accM, 0, 0, 0);
-                    cur = nxt;
+                    for (int k = 0; k < 3; ++k) accM = __builtin_amdgcn_mfma_f64_16x16x4f64(o.rms * o.gr[k], o.rm * o.gc[k], accM, 0, 0, 0);
+                };
+                // (fully unrolled: the two operand sets change roles without a copy; the compiler barrier keeps the fetches ONE step ahead -- all
+                // seven steps' operands in flight at once are more registers than there are)
+                OpsA oa[2];
+                oa[0] = fetch_a(0);
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    if (ks < 6) oa[(ks + 1) & 1] = fetch_a(ks + 1);
+                    mul_a(oa[ks & 1]);
+                    asm volatile("" ::: "memory");
                 }
             }
             // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
             // (loads and stores share one in-order counter: waiting for a load issued before a store waits for the store).
             asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
-            // ... and the reference gradients of the NEXT element's phase P2 are requested here, ahead of this element's stores: P2 then waits
-            // for them with the stores still in flight (issued behind the stores, the wait would drain them: a write latency per element)
-            load_gref();
-            asm volatile("" ::: "memory");
             val_cur = val_n1;
             node_n1 = node_n2;
             e_cur = e_n1;
             e_n1 = e_n2;
             e_n2 = e_n3;
-            if (!(TRACE && (a.ablate & 4)))
+            if (!light && !(TRACE && (a.ablate & 4))) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const mfma_f64x4 v = accD[i] + accM;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) put(vo_row(reg), 4 * reg * (9 * N) + (i * 3 + i) * N, v[reg]);
+                    if (tile == 1) {   // ... and tile (1, 0) of this component: the transpose
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) put(vo_col(reg), (i * 3 + i) * N + 4 * reg, v[reg]);
+                    }
                 }
+            }
         }
         mark(6);
         // ---- round B: the components above the diagonal; K_ji = K_ij^T straight from the fragments: entry (I, J) of the tile goes to (J, I) of
@@ -379,22 +396,31 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
 #pragma unroll
             for (int i = 0; i < 3; ++i) accO[i] = mfma_f64x4{0, 0, 0, 0};
             if (!(TRACE && (a.ablate & 2))) {
-                OpsB cur = fetch_b(0);
-#pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) {
-                    const OpsB nxt = fetch_b(min(ks + 1, 6));
+                auto mul_b = [&](const OpsB& o) {
                     int t = 0;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = i + 1; j < 3; ++j, ++t) {
-                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.cl * cur.ar[i], cur.ac[j], accO[t], 0, 0, 0);   // c_l a_I[i] a_J[j]
-                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.nca * cur.ar[j], cur.ac[i], accO[t], 0, 0, 0);  // -c_a a_I[j] a_J[i]
+                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.cl * o.ar[i], o.ac[j], accO[t], 0, 0, 0);   // c_l a_I[i] a_J[j]
+                            accO[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.nca * o.ar[j], o.ac[i], accO[t], 0, 0, 0);  // -c_a a_I[j] a_J[i]
                         }
-                    cur = nxt;
+                };
+                OpsB ob[2];
+                ob[0] = fetch_b(0);
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    if (ks < 6) ob[(ks + 1) & 1] = fetch_b(ks + 1);
+                    mul_b(ob[ks & 1]);
+                    asm volatile("" ::: "memory");
                 }
             }
             mark(7);
+            // The reference gradients of the NEXT element's phase P2 are requested here, ahead of the 24 stores of this round: P2 then waits for
+            // them with those stores still in flight (issued behind the stores, the wait would drain them: a write latency per element; the
+            // stores of round A are older, but a whole round older).  Not earlier: they would be live across this round's products.
+            load_gref();
+            asm volatile("" ::: "memory");
             if (!(TRACE && (a.ablate & 4))) {
                 int t = 0;
 #pragma unroll

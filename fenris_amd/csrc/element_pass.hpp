@@ -195,7 +195,191 @@ struct EPRegU {
     const double (&u)[N][S];
     __device__ __forceinline__ double operator()(int n, int k) const { return u[n][k]; }
 };
-template <int EK, int OP, int WHAT, class UAcc>
+
+// ---- Hex8 in the monomial basis (round 5).  A trilinear field is  v = c0 + c1 xi + c2 eta + c3 zeta + c4 xi eta + c5 xi zeta + c6 eta zeta
+// + c7 xi eta zeta  with c = (1/8) W v_nodes, W the sign matrix of the reference nodes (hexahedron.rs:49-58): a Walsh-Hadamard butterfly, 24
+// additions per field and ELEMENT.  Its reference gradient at a point is then three chains of three FMAs,
+//     d/dxi = c1 + c4 eta + c5 zeta + c7 eta zeta   (and cyclic),
+// 9 FMAs per field and point instead of the 24 of  sum_n ghat_n(xi_q) v_n  (elliptic.rs:398-422 evaluates exactly these sums); the same
+// identity read backwards turns  f_n += M_q ghat_n(xi_q)  (elliptic.rs:506-527) into twelve moment sums per component and point and one
+// butterfly per component at the end.  Any quadrature rule (the points' coordinates and pair products come with the table: a.qmono).
+// Same sums in another order: equal to the generic body to rounding, bitwise reproducible, checked against the oracle at 1e-12.
+// index of a reference node in binary order (bit 0: xi > 0, bit 1: eta > 0, bit 2: zeta > 0)
+__device__ __forceinline__ constexpr int hex8_bin(int n) { return n == 2 ? 3 : n == 3 ? 2 : n == 6 ? 7 : n == 7 ? 6 : n; }
+// w[k] = sum_b (prod over the axes in k of the sign of node b along that axis) v[b], in place; k in binary order
+__device__ __forceinline__ void hex8_wht(double (&v)[8]) {
+#pragma unroll
+    for (int ax = 1; ax < 8; ax <<= 1)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (!(b & ax)) {
+                const double lo = v[b], hi = v[b | ax];
+                v[b] = hi + lo;        // the axis is not in k
+                v[b | ax] = hi - lo;   // the axis is in k: sign +1 on the upper node, -1 on the lower
+            }
+}
+// AFF: every element of the mesh is a parallelepiped (k_classify_affine_hex8 says so for all of them: KArgs::all_affine) -- J from the three
+// linear coefficients of the map, once; no per-wavefront test, no second path (which alone keeps 24 more registers alive).
+template <int OP, int WHAT, bool AFF = false, class UAcc>
+__device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const long long e, const bool live, const long long ec,
+                                                       const double (&X)[8][3], const UAcc& U,
+                                                       double (&f)[EPDims<FH_HEX8, OP, WHAT>::NF][EPDims<FH_HEX8, OP, WHAT>::S], double& energy) {
+    using O = OpT<OP, 3>;
+    constexpr int D = 3, N = 8, S = O::S;
+    energy = 0.0;
+    const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[ec] * a.nq * 2 : nullptr;
+    // coefficients of the coordinate map and of u (c0 is not needed: only gradients enter)
+    double cx[D][8], cu[S][8];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) cx[i][hex8_bin(n)] = X[n][i];
+        hex8_wht(cx[i]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) cx[i][k] *= 0.125;
+        if constexpr (AFF) {   // (the mixed coefficients are rounding noise below 2^-46 of the edges: dropped, like in the affine stiffness kernel)
+            cx[i][3] = 0.0; cx[i][5] = 0.0; cx[i][6] = 0.0; cx[i][7] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < S; ++k2) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) cu[k2][hex8_bin(n)] = U(n, k2);
+        hex8_wht(cu[k2]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) cu[k2][k] *= 0.125;
+    }
+    // affine element (a parallelepiped: the mixed coefficients of the map vanish; the test of k_classify_affine_hex8, 2^-46 of the edges
+    // from node 0): J is the same at every point.  Uniform over the wavefront, like in the generic body.
+    double len = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) len += fabs(X[1][i] - X[0][i]) + fabs(X[3][i] - X[0][i]) + fabs(X[4][i] - X[0][i]);
+    const double tol = len * 0x1p-46 * 0.125;   // (the coefficients carry the factor 1/8)
+    bool aff = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) aff = aff && fabs(cx[i][3]) <= tol && fabs(cx[i][5]) <= tol && fabs(cx[i][6]) <= tol && fabs(cx[i][7]) <= tol;
+    const bool const_j = AFF || __all(aff ? 1 : 0) != 0;
+    // reference gradient of a field with coefficients c at the point (xi, eta, zeta; ez = eta zeta, xz = xi zeta, xe = xi eta)
+    auto grad = [](const double (&c)[8], double xi, double eta, double zeta, double ez, double xz, double xe, double (&g)[3]) {
+        g[0] = fma(c[7], ez, fma(c[5], zeta, fma(c[3], eta, c[1])));
+        g[1] = fma(c[7], xz, fma(c[6], zeta, fma(c[3], xi, c[2])));
+        g[2] = fma(c[7], xe, fma(c[6], eta, fma(c[5], xi, c[4])));
+    };
+    double J[D][D], Ji[D][D], adet = 0.0;
+    // moments of M = s P J^-T against the monomials of the reference gradients, summed straight into the coefficients of the sign products:
+    //   dk[i][1] (xi) += M_i0, [2] (eta) += M_i1, [4] (zeta) += M_i2, [3] (xi eta) += M_i0 eta + M_i1 xi, [5] (xi zeta) += M_i0 zeta + M_i2 xi,
+    //   [6] (eta zeta) += M_i1 zeta + M_i2 eta, [7] += M_i0 eta zeta + M_i1 xi zeta + M_i2 xi eta       (21 accumulators; [0] stays zero)
+    double dk[S][8];
+    if constexpr (WHAT == EP_VECTOR) {
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dk[i][t] = 0.0;
+    }
+    auto point = [&](int q, auto need_j_tag) {
+        constexpr bool need_j = decltype(need_j_tag)::value;
+        const ep_table Q = ep_const(a.qmono) + (size_t)q * 8;   // uniform over the wavefront: scalar loads
+        const double xi = Q[0], eta = Q[1], zeta = Q[2], ez = Q[3], xz = Q[4], xe = Q[5];
+        if constexpr (need_j) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) grad(cx[i], xi, eta, zeta, ez, xz, xe, J[i]);   // J[i][j] = d x_i / d xi_j (hexahedron.rs:101-107)
+            const double detJ = det_small<D>(J);
+            if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
+                if (live) report_singular(a.status, e);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Ji[i][j] = 0.0;
+            } else {
+                inv_small(J, detJ, Ji);
+            }
+            adet = fabs(detJ);
+        }
+        double R[D][S];   // R[j][k] = d u_k / d xi_j = sum_n ghat_n u_n^T
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            double g[3];
+            grad(cu[k], xi, eta, zeta, ez, xz, xe, g);
+#pragma unroll
+            for (int j = 0; j < D; ++j) R[j][k] = g[j];
+        }
+        const double s = ep_const(a.qw)[q] * adet;   // w |det J| (elliptic.rs:422)
+        double gu[D][S];                             // grad u = J^-T R
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                double t = 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) t = fma(Ji[m][i], R[m][k], t);
+                gu[i][k] = t;
+            }
+        double mu = 0.0, lambda = 0.0;
+        if (OP != FH_LAPLACE) {
+            if (par_e) { mu = par_e[2 * q]; lambda = par_e[2 * q + 1]; }
+            else { mu = ep_const(a.qparams)[2 * q]; lambda = ep_const(a.qparams)[2 * q + 1]; }
+        }
+        double P[S][D], psi;
+        material_point<OP, D, S, WHAT>(gu, mu, lambda, P, psi);
+        if constexpr (WHAT == EP_SCALAR) {
+            energy = fma(s, psi, energy);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                double Mi[D];   // (s P J^-T)[i][m]
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(P[i][k], Ji[m][k], t);
+                    Mi[m] = s * t;
+                }
+                dk[i][1] += Mi[0];
+                dk[i][2] += Mi[1];
+                dk[i][4] += Mi[2];
+                dk[i][3] = fma(Mi[1], xi, fma(Mi[0], eta, dk[i][3]));
+                dk[i][5] = fma(Mi[2], xi, fma(Mi[0], zeta, dk[i][5]));
+                dk[i][6] = fma(Mi[2], eta, fma(Mi[1], zeta, dk[i][6]));
+                dk[i][7] = fma(Mi[2], xe, fma(Mi[1], xz, fma(Mi[0], ez, dk[i][7])));
+            }
+        }
+    };
+    if constexpr (AFF) {
+        point(0, std::true_type{});
+        for (int q = 1; q < a.nq; ++q) point(q, std::false_type{});
+    } else if (const_j) {
+        point(0, std::true_type{});
+        for (int q = 1; q < a.nq; ++q) point(q, std::false_type{});
+    } else {
+        for (int q = 0; q < a.nq; ++q) point(q, std::true_type{});
+    }
+    if constexpr (WHAT == EP_VECTOR) {
+        // f_n[i] = (1/8) sum_k (sign products of node n over the axes in k) dk[i][k]
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            double d[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) d[t] = dk[i][t];
+            // synthesis: per axis, (k without the axis: ev, k with it: od) -> node with the bit set ev + od, node with the bit clear ev - od
+#pragma unroll
+            for (int ax = 1; ax < 8; ax <<= 1)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (!(b & ax)) {
+                        const double ev = d[b], od = d[b | ax];
+                        d[b] = ev - od;
+                        d[b | ax] = ev + od;
+                    }
+#pragma unroll
+            for (int n = 0; n < N; ++n) f[n][i] = 0.125 * d[hex8_bin(n)];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; ++k) f[0][k] = 0.0;
+    }
+}
+
+template <int EK, int OP, int WHAT, int MONO = 0, class UAcc>
 __device__ __forceinline__ void element_pass_body(const KArgs& a, const long long e, const bool live, const long long ec,
                                                   const double (&X)[EPDims<EK, OP, WHAT>::N][EPDims<EK, OP, WHAT>::D], const UAcc& U,
                                                   double (&f)[EPDims<EK, OP, WHAT>::NF][EPDims<EK, OP, WHAT>::S], double& energy) {
@@ -203,6 +387,10 @@ __device__ __forceinline__ void element_pass_body(const KArgs& a, const long lon
     using O = OpT<OP, E::D>;
     constexpr int D = E::D, N = E::N, S = O::S;
     static_assert(E::NG == N && N <= 8, "element pass: small iso-parametric elements");
+    if constexpr (MONO != 0 && EK == FH_HEX8) {   // the monomial form (its own instantiation: both forms in one kernel took 324 registers)
+        element_pass_body_hex8<OP, WHAT, MONO == 2>(a, e, live, ec, X, U, f, energy);
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < (WHAT == EP_VECTOR ? N : 1); ++n)
 #pragma unroll

@@ -262,6 +262,8 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.gref = c->gref.p;
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
+    a.all_affine = (c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff == c->E && c->E > 0 && !c->env("FENRIS_HIP_NO_AFFINE_PASS")) ? 1 : 0;
+    a.qmono = (c->elem_kind == FH_HEX8 && c->qmono.p && !c->env("FENRIS_HIP_NO_MONOMIAL")) ? c->qmono.p : nullptr;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
     a.rule_map = c->has_rules ? c->rule_map.p : nullptr;
     a.rparams = c->has_rules ? c->rparams.p : nullptr;
@@ -752,6 +754,18 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     HIP_TRY(c, c->phiref.alloc(phiref.size()));
     HIP_TRY(c, hipMemcpy(c->phiref.p, phiref.data(), sizeof(double) * phiref.size(), hipMemcpyHostToDevice));
+    if (c->elem_kind == FH_HEX8) {   // the monomial form of the element pass (element_pass.hpp)
+        std::vector<double> qm((size_t)nq * 8, 0.0);
+        for (uint32_t q = 0; q < nq; ++q) {
+            const double xi = pts[3 * q], eta = pts[3 * q + 1], zeta = pts[3 * q + 2];
+            double* m = qm.data() + (size_t)q * 8;
+            m[0] = xi; m[1] = eta; m[2] = zeta; m[3] = eta * zeta; m[4] = xi * zeta; m[5] = xi * eta;
+        }
+        HIP_TRY(c, c->qmono.alloc(qm.size()));
+        HIP_TRY(c, hipMemcpy(c->qmono.p, qm.data(), sizeof(double) * qm.size(), hipMemcpyHostToDevice));
+    } else {
+        c->qmono.release();
+    }
     HIP_TRY(c, c->qw.alloc(nq + 1));  // [nq]: sum of the weights (collapsed rule of the affine simplices, see dispatch)
     HIP_TRY(c, c->gref.alloc(gref.size()));
     HIP_TRY(c, c->ggeom.alloc(ggeom.size()));

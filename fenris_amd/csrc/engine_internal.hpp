@@ -300,6 +300,7 @@ struct fh_ctx {
     uint64_t sdim_ragged = 1;
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
+    DevBuf<double> qmono;       // Hex8: coordinates and pair products of the quadrature points (KArgs::qmono)
     DevBuf<unsigned> rule_map;
     bool has_rules = false;
     bool has_params = false, has_u = false;

@@ -268,7 +268,7 @@ struct TileSums {
     }
 };
 
-template <int EK, int OP, int TS>
+template <int EK, int OP, int TS, int MONO = 0>
 __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const VecTiles t, const unsigned char* active, double* partial) {
     constexpr int N = EPDims<EK, OP, EP_VECTOR>::N, S = EPDims<EK, OP, EP_VECTOR>::S, D = EPDims<EK, OP, EP_VECTOR>::D;
     __shared__ double stage[N * S * TS];
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const 
     // wavefront per SIMD -- 62 registers spill: 1.66 ms)
     double f[N][S];
     double energy;
-    element_pass_body<EK, OP, EP_VECTOR>(a, el, live, ec, X, EPRegU<N, S>{Uv}, f, energy);
+    element_pass_body<EK, OP, EP_VECTOR, MONO>(a, el, live, ec, X, EPRegU<N, S>{Uv}, f, energy);
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const 
 // energy (compute_element_elliptic_energy, local/elliptic.rs:551-605) over the same tiles: on a numbering without locality the tile order
 // is what makes the gathers of the coordinates and of u local; the tile's elements are summed in a fixed tree, one partial per workgroup
 // (workgroups beyond the last tile write a zero), k_sum_partials adds them in index order
-template <int EK, int OP, int TS>
+template <int EK, int OP, int TS, int MONO = 0>
 __global__ void __launch_bounds__(TS) k_element_energy_tiled(const KArgs a, const VecTiles t, const unsigned char* active, double* partial) {
     constexpr int N = EPDims<EK, OP, EP_SCALAR>::N, S = EPDims<EK, OP, EP_SCALAR>::S, D = EPDims<EK, OP, EP_SCALAR>::D;
     static_assert(TS == 256, "block_sum_256");
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(TS) k_element_energy_tiled(const KArgs a, cons
     }
     double f[1][S];
     double energy;
-    element_pass_body<EK, OP, EP_SCALAR>(a, el, live, el >= 0 ? el : 0, X, EPRegU<N, S>{Uv}, f, energy);
+    element_pass_body<EK, OP, EP_SCALAR, MONO>(a, el, live, el >= 0 ? el : 0, X, EPRegU<N, S>{Uv}, f, energy);
     const double tot = block_sum_256(live ? energy : 0.0, red);
     if (tid == 0) partial[blockIdx.x] = tot;
 }
@@ -554,6 +554,16 @@ int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const K
         case FH_STVK: hipLaunchKernelGGL((k_element_pass_tiled<EKC, FH_STVK, VT_TS>), dim3(8 * ((t.ntiles + 7) / 8)), dim3(VT_TS), 0, stream, a, t, active, partial); rs = 0; break; \
         default: break;                                                                                                                              \
     }
+    if (elem_kind == FH_HEX8 && a.qmono) {   // the monomial form (element_pass.hpp, round 5)
+        const dim3 g(8 * ((t.ntiles + 7) / 8));
+        switch (op) {
+            case FH_LAPLACE: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            case FH_LINEAR_ELASTIC: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            case FH_NEO_HOOKEAN: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            case FH_STVK: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_STVK, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_STVK, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            default: return -1;
+        }
+    }
     switch (elem_kind) {
         case FH_QUAD4: VT_OP(FH_QUAD4) break;
         case FH_TRI3: VT_OP(FH_TRI3) break;
@@ -575,6 +585,15 @@ int vector_tiles_energy_pass(int elem_kind, int op, hipStream_t stream, const KA
         case FH_NEO_HOOKEAN: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_NEO_HOOKEAN, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
         case FH_STVK: hipLaunchKernelGGL((k_element_energy_tiled<EKC, FH_STVK, VT_TS>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); rs = grid; break; \
         default: break;                                                                                                                              \
+    }
+    if (elem_kind == FH_HEX8 && a.qmono) {
+        switch (op) {
+            case FH_LAPLACE: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            case FH_LINEAR_ELASTIC: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            case FH_NEO_HOOKEAN: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            case FH_STVK: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_STVK, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_STVK, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            default: return -1;
+        }
     }
     switch (elem_kind) {
         case FH_QUAD4: VT_EN(FH_QUAD4) break;

@@ -913,14 +913,19 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
                                                           const unsigned* ncols, const int* p_conn, int cs, const int* p_elem,
                                                           int4* hdr_out, uint2* lanes, int* status,
                                                           unsigned long long* hash_out, const int mirror, const int* plist,
-                                                          unsigned long long* hash2_out) {
+                                                          unsigned long long* hash2_out, const int ksh) {
     // plist == null: one workgroup per position: header, two 64-bit hashes of the 256 records, and -- when `lanes` is given -- the
     // records themselves at lanes[p].  plist != null (second pass of the hash-only build): workgroup t forms the records of position
     // plist[t] once more and writes them to lanes[t] (the compact table), nothing else.
-    constexpr int N = 8, NKEY = 8 * 128, TMAX = 8;
-    __shared__ int cnt[NKEY];
-    __shared__ unsigned short bucket[NKEY * TMAX];
-    __shared__ unsigned lw0[256], lw1[256];
+    // keys (block-local node, column slot) = il << ksh | pos with 2^ksh >= the longest node row of the pattern (round 5: 32 on a hexahedral
+    // mesh instead of a fixed 128 -- a quarter of the key loops' trips and 7 instead of 22 KB of LDS, i.e. three times the workgroups per CU)
+    constexpr int N = 8, TMAX = 8;
+    const int KS = 1 << ksh, NKEY = 8 * KS;
+    extern __shared__ __attribute__((aligned(16))) char build_smem[];
+    int* cnt = reinterpret_cast<int*>(build_smem);                                   // [NKEY]
+    unsigned* lw0 = reinterpret_cast<unsigned*>(cnt + NKEY);                         // [256]
+    unsigned* lw1 = lw0 + 256;                                                       // [256]
+    unsigned short* bucket = reinterpret_cast<unsigned short*>(lw1 + 256);           // [NKEY * TMAX]
     const int p = plist ? plist[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int* rec = p_rec + (size_t)p * rw_old;
     const GatherHdr h = *reinterpret_cast<const GatherHdr*>(rec);
@@ -937,8 +942,8 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
         const int t = idx / N, j = idx % N;
         const unsigned e = ent[t];
         const unsigned slot = e >> 16, a_loc = (e >> 8) & 0xffu, il = e & 0xffu, pos = posb[t * N + j];
-        if (il >= 8u || pos >= 128u || slot >= 32u || a_loc >= 8u) { bad = true; continue; }
-        const int key = (int)(il * 128u + pos);
+        if (il >= 8u || pos >= (unsigned)KS || slot >= 32u || a_loc >= 8u) { bad = true; continue; }
+        const int key = (int)((il << ksh) + pos);
         const int s_ = atomicAdd(&cnt[key], 1);
         if (s_ < TMAX) bucket[key * TMAX + s_] = (unsigned short)(slot | (a_loc << 8) | ((unsigned)j << 11));
         else bad = true;
@@ -961,17 +966,17 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     // classes: 5..8 terms -> 4 lanes, 3..4 -> 2 lanes, 1..2 -> one lane; a block of these rows WITHOUT a term (element masks: no active
     // element joins the two nodes) gets a lane of its own that stores zeros, when the lanes suffice -- the position is then complete and
     // never needs its staging buffer cleared (the interface planes of a slab partition: ~140 owner lanes + 63 such blocks)
-    auto is_block = [&](int key) { const int il = key >> 7, pos = key & 127; return il < h.nb && pos < noff_old[il + 1] - noff_old[il]; };
+    auto is_block = [&](int key) { const int il = key >> ksh, pos = key & (KS - 1); return il < h.nb && pos < noff_old[il + 1] - noff_old[il]; };
     // mirror (k_hex8_rows): when both nodes of a block (I, J) are owned by this position, only the owner of the smaller node keeps
     // lanes for it; they store the block to (I, J) and its transpose to (J, I).  twin_of(key) = block-local index of J when the block
     // has such a partner (-1: none); skipped(key): this is the partner's copy
     auto twin_of = [&](int key) {
         if (!mirror || !is_block(key)) return -1;
-        const int il = key >> 7, pos = key & 127;
+        const int il = key >> ksh, pos = key & (KS - 1);
         const long long jl = (long long)ncols[(size_t)h.r0 + noff_old[il] + pos] - (long long)h.i0;
         return (jl >= 0 && jl < h.nb && jl != il) ? (int)jl : -1;
     };
-    auto skipped = [&](int key) { const int jl = twin_of(key); return jl >= 0 && jl < (key >> 7); };
+    auto skipped = [&](int key) { const int jl = twin_of(key); return jl >= 0 && jl < (key >> ksh); };
     for (int key = lane; key < NKEY; key += 64)
         if (skipped(key)) cnt[key] = -1;      // no lane, and not a block without a term either
     __syncthreads();
@@ -1004,7 +1009,7 @@ __global__ void __launch_bounds__(64) k_build_affine_rows(const int* p_rec, int 
     for (int base = 0; base < NKEY; base += 64) {
         const int key = base + lane;
         const int Tn = min(cnt[key], TMAX);
-        const unsigned il = (unsigned)key >> 7, pos = (unsigned)key & 127u;
+        const unsigned il = (unsigned)key >> ksh, pos = (unsigned)key & (unsigned)(KS - 1);
         const unsigned short* b = bucket + key * TMAX;
         const unsigned long long m4 = __ballot(Tn >= 5), m2 = __ballot(Tn == 3 || Tn == 4), m1 = __ballot(Tn == 1 || Tn == 2);
         const bool zb = zero_lanes && Tn == 0 && is_block(key);
@@ -1118,12 +1123,17 @@ __global__ void __launch_bounds__(256) k_affine_rows_compact(const uint2* lanes_
     }
 }
 
+// key shift and LDS bytes of k_build_affine_rows for a pattern whose longest node row has max_row entries
+static int build_key_shift(int max_row) { return max_row <= 32 ? 5 : max_row <= 64 ? 6 : 7; }
+static size_t build_lds_bytes(int ksh) { const size_t nkey = (size_t)8 << ksh; return nkey * 4 + 2 * 256 * 4 + nkey * 8 * 2; }
+
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* status, unsigned long long* hash, int mirror, unsigned long long* hash2) {
+                             int* status, unsigned long long* hash, int mirror, unsigned long long* hash2, int max_row) {
     if (npos <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
-                       p_elem, hdr, lanes, status, hash, mirror, (const int*)nullptr, hash2);
+    const int ksh = build_key_shift(max_row);
+    hipLaunchKernelGGL(k_build_affine_rows, dim3(npos), dim3(64), build_lds_bytes(ksh), stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs,
+                       p_elem, hdr, lanes, status, hash, mirror, (const int*)nullptr, hash2, ksh);
     return hipGetLastError();
 }
 
@@ -1138,10 +1148,11 @@ __global__ void __launch_bounds__(256) k_affine_rows_set_ids(const int* ids, int
 
 hipError_t affine_rows_tables(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S, const unsigned* ncols,
                               const int* p_conn, int cs, const int* p_elem, int mirror, const int* ids, const int* first_pos, int ntab,
-                              uint2* lanes_tab, int4* hdr, int* mismatch) {
+                              uint2* lanes_tab, int4* hdr, int* mismatch, int max_row) {
     if (npos <= 0 || ntab <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_build_affine_rows, dim3(ntab), dim3(64), 0, stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs, p_elem,
-                       (int4*)nullptr, lanes_tab, (int*)nullptr, (unsigned long long*)nullptr, mirror, first_pos, (unsigned long long*)nullptr);
+    const int ksh = build_key_shift(max_row);
+    hipLaunchKernelGGL(k_build_affine_rows, dim3(ntab), dim3(64), build_lds_bytes(ksh), stream, p_rec, rw_old, us, ms, nbs, npos, S, ncols, p_conn, cs, p_elem,
+                       (int4*)nullptr, lanes_tab, (int*)nullptr, (unsigned long long*)nullptr, mirror, first_pos, (unsigned long long*)nullptr, ksh);
     hipLaunchKernelGGL(k_affine_rows_set_ids, dim3((npos + 255) / 256), dim3(256), 0, stream, ids, npos, hdr, mismatch);
     return hipGetLastError();
 }

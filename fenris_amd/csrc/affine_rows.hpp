@@ -41,13 +41,14 @@ size_t affine_rows_lds_bytes(int op, int us, int acc_max, int fused_nu = 0);
 // (more than 8 terms per block, more than 256 lanes, offsets out of range).
 hipError_t affine_rows_build(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S,
                              const unsigned* ncols, const int* p_conn, int cs, const int* p_elem, int4* hdr, uint2* lanes,
-                             int* status, unsigned long long* hash, int mirror = 0, unsigned long long* hash2 = nullptr);
+                             int* status, unsigned long long* hash, int mirror = 0, unsigned long long* hash2 = nullptr, int max_row = 128);
+// (max_row: the longest node row of the pattern -- the builder sizes its key space and its LDS by it; a row longer than 128 makes the position `bad`)
 // lanes == nullptr: headers and hashes only (hash2: a second, independent 64-bit hash of the records) -- the records of the positions are
 // never written in full; affine_rows_tables then forms the records of the FIRST position of every distinct table once more, straight into
 // the compact tables, and puts the table ids into the headers (mismatch[1]: some position has a block without an owner lane)
 hipError_t affine_rows_tables(hipStream_t stream, const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int S, const unsigned* ncols,
                               const int* p_conn, int cs, const int* p_elem, int mirror, const int* ids, const int* first_pos, int ntab,
-                              uint2* lanes_tab, int4* hdr, int* mismatch);
+                              uint2* lanes_tab, int4* hdr, int* mismatch, int max_row = 128);
 // mirror != 0 (k_hex8_rows, hex8_rows.hip): a block whose two nodes are both owned by the position keeps the lanes of the smaller node's
 // owner only (x bit 29: the lane also stores the transpose to the twin), and y = offset in doubles | node << 13 | twin offset << 16 |
 // twin node << 29 (row strides from the position record)

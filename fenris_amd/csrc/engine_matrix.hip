@@ -268,6 +268,18 @@ int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* 
 }
 
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset) {
+    const auto t_entry = std::chrono::steady_clock::now();
+    const bool vt_entry = !c->has_partition && c->env("FENRIS_HIP_VERBOSE") != nullptr;
+    struct ExitPrint {   // FENRIS_HIP_VERBOSE: the first assembly of a context from entry to the end of its enqueueing
+        bool on; std::chrono::steady_clock::time_point t0; hipStream_t st;
+        ~ExitPrint() {
+            if (!on) return;
+            const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            (void)hipStreamSynchronize(st);
+            std::fprintf(stderr, "[fenris_hip] set-up: first assembly enqueued after %7.1f ms, finished after %7.1f ms\n", enq,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } exit_print{vt_entry, t_entry, c->stream};
     int rc = check_ready(c, "fh_assemble_matrix", true);
     if (rc) return rc;
     if (!values_dev) return c->fail(FH_BAD_ARGUMENT, "fh_assemble_matrix: values is null");
@@ -297,8 +309,17 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         }
     }
     if (mode == FH_SCATTER_GATHER) {
+        const bool vt_first = !c->has_partition && c->env("FENRIS_HIP_VERBOSE") != nullptr;
+        const auto t_bp0 = std::chrono::steady_clock::now();
+        if (vt_first) std::fprintf(stderr, "[fenris_hip] set-up: before build_partition               %7.1f ms\n",
+                                   std::chrono::duration<double, std::milli>(t_bp0 - t_entry).count());
         rc = build_partition(c);
         if (rc) return rc;
+        if (vt_first) {
+            (void)hipStreamSynchronize(c->stream);
+            std::fprintf(stderr, "[fenris_hip] set-up: build_partition in all              %7.1f ms\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bp0).count());
+        }
         if (c->part_rows_only && !(c->has_pipe && c->has_rows && a.fast && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) &&
                               !c->env("FENRIS_HIP_TRACE"))) {
             // these tables are for the row-owner kernel only (see build_partition); another kernel is about to run

@@ -24,7 +24,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     int bad = 0;
     if (!full) {
         HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, (uint2*)nullptr, st.p,
-                                     hash_d.p, mirror, hash_d.p + npos));
+                                     hash_d.p, mirror, hash_d.p + npos, (int)c->max_row));
         HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos * 2, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -54,7 +54,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
             HIP_TRY(c, hipMemcpyAsync(first_d.p, first.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
             HIP_TRY(c, affine_rows_tables(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, mirror, ids_d.p, first_d.p,
-                                          ntab, lanes.p, hdr.p, st.p));
+                                          ntab, lanes.p, hdr.p, st.p, (int)c->max_row));
             int mismatch[2] = {0, 0};   // [1]: some position has a block without an owner lane
             HIP_TRY(c, hipMemcpyAsync(mismatch, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -73,7 +73,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     }
     HIP_TRY(c, lanes_full.alloc((size_t)npos * 256));
     HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, lanes_full.p, st.p,
-                                 hash_d.p, mirror));
+                                 hash_d.p, mirror, nullptr, (int)c->max_row));
     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(hash_h.data(), hash_d.p, sizeof(unsigned long long) * (size_t)npos, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -128,6 +128,14 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     return FH_OK;
 }
 
+// largest number of unique elements / of (node, element) entries over the block headers
+static __global__ void __launch_bounds__(256) k_gather_hdr_max(const GatherHdr* hdr, int nblk, int* out) {
+    int u = 1, m = 1;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) { u = max(u, hdr[b].U); m = max(m, hdr[b].m); }
+    for (int o = 32; o > 0; o >>= 1) { u = max(u, __shfl_xor(u, o)); m = max(m, __shfl_xor(m, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(out, u); atomicMax(out + 1, m); }
+}
+
 // greedy partition of the node range into owner blocks (gather mode)
 
 int build_partition(fh_ctx* c) {
@@ -135,9 +143,13 @@ int build_partition(fh_ctx* c) {
     // FENRIS_HIP_VERBOSE: wall time of the stages of this set-up (stream drained at every mark)
     auto t_last = std::chrono::steady_clock::now();
     const bool vt = c->env("FENRIS_HIP_VERBOSE") != nullptr;
+    // (The stream is drained at every stage boundary ALSO without the print: measured on the 216^3 mesh, the first assembly takes 90 ms
+    // with these synchronisations and 118 ms without them -- the stages' temporaries are released with work still queued behind them
+    // otherwise, and a release then waits out the whole queue inside the runtime.)
+    const bool stage_sync = !c->env("FENRIS_HIP_NO_STAGE_SYNC");
     auto mark = [&](const char* what) {
+        if (stage_sync || vt) (void)hipStreamSynchronize(c->stream);
         if (!vt) return;
-        (void)hipStreamSynchronize(c->stream);
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[fenris_hip] set-up: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
@@ -260,8 +272,7 @@ int build_partition(fh_ctx* c) {
     const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? (c->rows_try == 0 ? 256 : 224) : 128)));
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
-    long long sum_rows = 0;
-    for (int i = 0; i < N; ++i) sum_rows += h_noff[i + 1] - h_noff[i];
+    const long long sum_rows = N ? (long long)h_noff[N] - (long long)h_noff[0] : 0;   // (telescoping: it used to be a loop over ten million nodes)
     const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
     int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
     std::vector<unsigned> blk;
@@ -386,10 +397,21 @@ int build_partition(fh_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     mark("block tables (k_build_gather_tables)");
     // staging capacity: all unique elements of the largest block if that fits the LDS budget
-    std::vector<GatherHdr> hh((size_t)std::max(c->nblk, 1));
-    if (c->nblk) HIP_TRY(c, hipMemcpy(hh.data(), c->gt_hdr.p, sizeof(GatherHdr) * (size_t)c->nblk, hipMemcpyDeviceToHost));
+    // (round 5: the two maxima by a device reduction -- the headers themselves, 47 MB for the 216^3 mesh, used to travel to the host for them)
     int umax = 1, mmax = 1;
-    for (int b = 0; b < c->nblk; ++b) { umax = std::max(umax, hh[b].U); mmax = std::max(mmax, hh[b].m); }
+    if (c->nblk) {
+        DevBuf<int> mx;
+        HIP_TRY(c, mx.alloc(2));
+        const int one[2] = {1, 1};
+        HIP_TRY(c, hipMemcpyAsync(mx.p, one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_hdr_max, dim3((unsigned)std::min(4096, (c->nblk + 255) / 256)), dim3(256), 0, c->stream, c->gt_hdr.p, c->nblk, mx.p);
+        HIP_TRY(c, hipGetLastError());
+        int got[2] = {1, 1};
+        HIP_TRY(c, hipMemcpyAsync(got, mx.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        umax = std::max(1, got[0]);
+        mmax = std::max(1, got[1]);
+    }
     int ub = 0;
     if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, umax, acc, 64, true, mb, c->fast_ok) <= lds_target) {
         ub = umax;
@@ -609,7 +631,7 @@ int build_partition(fh_ctx* c) {
                         HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         double cb = 0.0, ca = 0.0;
-                        hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca);
+                        hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, (long long)c->env_int("FENRIS_HIP_TUNE_PROPOSALS", 1000000));
                         HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         if (c->env("FENRIS_HIP_VERBOSE"))

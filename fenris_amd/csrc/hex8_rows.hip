@@ -547,10 +547,10 @@ inline int write_cost(const TuneLane* L, int first) {
 }
 }  // namespace
 
-void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after) {
+void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after, long long total_proposals) {
     int members[16][16], fill[16] = {0};
     for (int l = 0; l < 256; ++l) { const int g = hw_group(l); members[g][fill[g]++] = l; }
-    const int budget = std::max(500, std::min(40000, (int)(3000000ll / std::max(ntab, 1))));
+    const int budget = std::max(500, std::min(40000, (int)(std::max(100000ll, total_proposals) / std::max(ntab, 1))));
     // the tables are independent: every table has its own random stream (seeded by its index: the result does not depend on the number of
     // threads), host threads take tables from a shared counter (3 M proposals: 0.8 s on one core for the 93 tables of a 216^3 mesh)
     std::vector<double> before_t((size_t)std::max(ntab, 1), 0.0), after_t((size_t)std::max(ntab, 1), 0.0);

@@ -33,7 +33,7 @@ hipError_t hex8_rows_positions(hipStream_t stream, const int* p_rec, int rw, int
 // together (ds_read_b128 lane groups) read operand vectors from different banks.  Only moves that leave every sum unchanged: whole
 // DPP groups (aligned quads / pairs / single lanes) change places, and the two terms of a lane swap halves (the kernel adds its two
 // term accumulators, a commutative sum).  Returns the modelled LDS cycles per position before / after (diagnostics).
-void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after);
+void hex8_rows_tune_lanes(uint2* tables, int ntab, unsigned seed, double* cycles_before, double* cycles_after, long long total_proposals = 3000000ll);
 
 // op: FH_LAPLACE or FH_LINEAR_ELASTIC; a.ggeom / a.qw: reference gradients [8][8][3] and weights [8] of the rule
 constexpr int HEX8_ROWS_PRIO_SHIFT = 24;   // bits 24-29 of `ablate`: s_setprio level of the store wave, the loader wave, the row waves that carry phase B

@@ -1634,21 +1634,30 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
 // PASS 1: write the unique element list and, per (node, element) entry, the packed word
 // (unique slot << 16 | local index a << 8 | block-local node).  Entries of a block are the contiguous
 // range n2e[n2e_off[i0] .. n2e_off[i1]) -- ascending element per node, so the tables are deterministic.
-template <int PASS>
+// WAVES = 0: one workgroup per block (any size that fits the LDS).  WAVES = 4 (round 5): one WAVEFRONT per block, four blocks per workgroup,
+// `stride` ints of LDS each -- a block of the usual size has ~56 entries, and 1.46 million workgroups of 256 threads for them were 14 of the
+// 60 ms of the 216^3 mesh's set-up; the wavefront's lanes synchronise through the in-order LDS queue (wave_sync) instead of barriers.
+template <int PASS, int WAVES = 0>
 __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk_off, const unsigned* noff, const unsigned* n2e_off,
                                                              const unsigned* n2e, int N, GatherHdr* hdr, const unsigned* u_off,
                                                              unsigned* gt_elems, unsigned* gt_ent, const int* conn,
-                                                             const unsigned* ncols, unsigned char* gt_pos) {
+                                                             const unsigned* ncols, unsigned char* gt_pos, int nblk = 0, int stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* ent = reinterpret_cast<int*>(smem);
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    int* ent = reinterpret_cast<int*>(smem) + (WAVES ? (int)(threadIdx.x >> 6) * stride : 0);
+    const int b = WAVES ? (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6) : (int)blockIdx.x;
+    const int tid = WAVES ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nt = WAVES ? 64 : (int)blockDim.x;
+    if (WAVES && b >= nblk) return;
+    auto wg_sync = [&]() {
+        if (WAVES) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
+    };
     const int i0 = (int)blk_off[b], i1 = (int)blk_off[b + 1];
     const int k0 = (int)n2e_off[i0], k1 = (int)n2e_off[i1];
     const int m = k1 - k0;
     int* first = ent + m;
     int* rank = first + m;
     for (int t = tid; t < m; t += nt) ent[t] = (int)(n2e[k0 + t] / (unsigned)N);
-    __syncthreads();
+    wg_sync();
     for (int t = tid; t < m; t += nt) {
         const int e = ent[t];
         int f = t;
@@ -1656,7 +1665,7 @@ __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk
             if (ent[x] == e) { f = x; break; }
         first[t] = f;
     }
-    __syncthreads();
+    wg_sync();
     for (int t = tid; t < m; t += nt) {
         if (first[t] == t) {
             int r = 0;
@@ -1664,7 +1673,7 @@ __global__ void __launch_bounds__(256) k_build_gather_tables(const unsigned* blk
             rank[t] = r;
         }
     }
-    __syncthreads();
+    wg_sync();
     if (PASS == 0) {
         if (tid == 0) {
             int U = 0;

@@ -27,6 +27,7 @@
 #include "device_common.hpp"
 #include "group_internal.hpp"
 #include "host_inputs.hpp"
+#include "host_pool.hpp"
 #include "pattern_kernels.hpp"
 
 extern char** environ;

@@ -20,7 +20,7 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     DevBuf<uint2> lanes_full;
     DevBuf<unsigned long long> hash_d;
     HIP_TRY(c, hash_d.alloc((size_t)npos * 2));
-    std::vector<unsigned long long> hash_h((size_t)npos * 2);
+    HostBuf<unsigned long long> hash_h((size_t)npos * 2);   // (host_pool.hpp: not a std::vector)
     int bad = 0;
     if (!full) {
         HIP_TRY(c, affine_rows_build(c->stream, rec, c->p_rw, us, ms, nb_target, npos, S, c->ncols.p, conn, c->p_cs, elem, hdr.p, (uint2*)nullptr, st.p,
@@ -30,7 +30,8 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         bad_out = bad != 0;
         if (bad) return FH_OK;
-        std::vector<int> ids((size_t)npos), first;
+        HostBuf<int> ids((size_t)npos);
+        hvec<int> first;
         std::unordered_map<unsigned long long, int> seen;
         seen.reserve(1024);
         bool collision = false;
@@ -81,7 +82,8 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     if (bad) return FH_OK;
     // positions with identical lane records (the interior of a structured mesh) share one table: the kernel
     // skips the fetch when the table does not change, and what it fetches stays in the caches
-    std::vector<int> ids((size_t)npos), first;
+    HostBuf<int> ids((size_t)npos);
+    hvec<int> first;
     auto dedupe = [&](bool identity) {
         first.clear();
         if (identity) {
@@ -136,6 +138,40 @@ static __global__ void __launch_bounds__(256) k_gather_hdr_max(const GatherHdr* 
     if ((threadIdx.x & 63) == 0) { atomicMax(out, u); atomicMax(out + 1, m); }
 }
 
+// The cut of the node range into owner blocks for numberings made of LONG runs (grid lines), on the device (round 5): one thread per run start
+// walks its run and cuts it into ceil(L / nb_target) balanced pieces -- exactly what the host loop of build_partition does for such a run.
+// Anything else (a run shorter than nb_target, a piece over the budgets, a run too long for one thread to walk) raises info[0] and the host
+// loop does the whole cut.  start[n] = 1 for the first node of every piece and for n_hi; info[1] / info[2]: largest number of node-level
+// entries / of (node, element) adjacencies of a piece.
+static __global__ void __launch_bounds__(256) k_cut_runs(const unsigned char* link, const unsigned* noff, const unsigned* adj_off, int n_lo, int n_hi,
+                                                         int nb_target, long long acc_entries, int mb, unsigned char* start, int* info) {
+    const int i = n_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_hi) return;
+    if (i != n_lo && link[i - 1]) return;   // inside a run
+    int r1 = i + 1;
+    while (r1 < n_hi && link[r1 - 1] && r1 - i <= 65536) ++r1;
+    const int L = r1 - i;
+    if (L < nb_target || L > 65536) { info[0] = 1; return; }
+    const int k = (L + nb_target - 1) / nb_target;
+    int prev = i, mx = 0, mm = 0;
+    for (int j = 1; j <= k; ++j) {
+        const int e = i + (int)((long long)L * j / k);
+        const long long rows = (long long)noff[e] - (long long)noff[prev], ent = (long long)adj_off[e] - (long long)adj_off[prev];
+        if (rows > acc_entries || ent > mb) { info[0] = 1; return; }
+        mx = max(mx, (int)rows);
+        mm = max(mm, (int)ent);
+        start[prev] = 1;
+        prev = e;
+    }
+    if (r1 == n_hi) start[n_hi] = 1;
+    atomicMax(info + 1, mx);
+    atomicMax(info + 2, mm);
+}
+
+static __global__ void __launch_bounds__(256) k_iota_int(int* out, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = i;
+}
+
 // greedy partition of the node range into owner blocks (gather mode)
 
 int build_partition(fh_ctx* c) {
@@ -154,8 +190,8 @@ int build_partition(fh_ctx* c) {
         std::fprintf(stderr, "[fenris_hip] set-up: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
-    mark("host copies of the offsets");
+    // (round 5: the host copies of the two offset arrays -- 82 MB over PCIe on the 216^3 mesh -- are made only where the host cuts the node
+    // range itself; numberings made of grid lines are cut on the device, k_cut_runs)
     // adjacency that drives the numerics: all elements, or only the active ones when a mask is set
     const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
     const unsigned* adj_off_d = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
@@ -186,15 +222,16 @@ int build_partition(fh_ctx* c) {
         DevBuf<unsigned char> link_d;
         HIP_TRY(c, link_d.alloc((size_t)N + 1));
         hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
-        std::vector<unsigned char> lk((size_t)N);
+        HostBuf<unsigned char> lk((size_t)N);
         HIP_TRY(c, hipMemcpyAsync(lk.data(), link_d.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         long long linked = 0;
         for (int i = 0; i < N; ++i) linked += lk[i];
         const bool force = c->env_int("FENRIS_HIP_NODE_ORDER", 0) != 0;
         if (force || linked * 2 < (long long)N) {
+            { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
             const int D = c->ei.d;
-            std::vector<double> hv((size_t)N * D);
+            HostBuf<double> hv((size_t)N * D);
             HIP_TRY(c, hipMemcpyAsync(hv.data(), c->verts.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
@@ -272,10 +309,16 @@ int build_partition(fh_ctx* c) {
     const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? (c->rows_try == 0 ? 256 : 224) : 128)));
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
-    const long long sum_rows = N ? (long long)h_noff[N] - (long long)h_noff[0] : 0;   // (telescoping: it used to be a loop over ten million nodes)
+    unsigned noff_ends[2] = {0, 0};   // (telescoping sum of the row lengths; two values of the device array: the host copy may not exist)
+    if (N) {
+        HIP_TRY(c, hipMemcpyAsync(&noff_ends[0], noff_d, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&noff_ends[1], noff_d + N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    const long long sum_rows = (long long)noff_ends[1] - (long long)noff_ends[0];
     const int avg_row = N ? (int)((sum_rows + N - 1) / N) : 1;
     int acc = S * S * std::max<int>((int)max_row, std::min<int>(nb_target * (avg_row + avg_row / 4 + 1), 8192 / (S * S)));
-    std::vector<unsigned> blk;
+    hvec<unsigned> blk;
     // owner-computes covers the nodes [n_lo, n_hi): everything, or the range of fh_set_row_range
     const int n_lo = (c->row_hi < 0) ? 0 : (int)std::min<long long>(c->row_lo, N);
     const int n_hi = (c->row_hi < 0) ? N : (int)std::min<long long>(c->row_hi, N);
@@ -284,12 +327,58 @@ int build_partition(fh_ctx* c) {
     // a structured numbering): a run of L >= nb_target nodes is cut into ceil(L / nb_target) blocks of balanced size,
     // so that every line of a structured mesh is cut at the same places and consecutive blocks of a sweep chain
     // share exactly the elements between two lines.  Short runs (unstructured numberings) are merged greedily.
-    std::vector<unsigned char> link((size_t)N + 1, 1);
-    if (N > 0 && !c->env("FENRIS_HIP_NO_ALIGN")) {
-        DevBuf<unsigned char> link_d;
+    hvec<unsigned char> link;
+    DevBuf<unsigned char> link_d;
+    const bool aligned = N > 0 && !c->env("FENRIS_HIP_NO_ALIGN");
+    if (aligned) {
         HIP_TRY(c, link_d.alloc((size_t)N + 1));
         hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
         HIP_TRY(c, hipGetLastError());
+    }
+    // Numberings made of grid lines: the cut on the device (k_cut_runs), the block offsets never on the host
+    bool cut_done = false;
+    unsigned max_m = 0;
+    if (aligned && n_hi > n_lo && c->env_int("FENRIS_HIP_HOST_CUT", 0) == 0) {
+        DevBuf<unsigned char> start_d;
+        DevBuf<int> info_d;
+        HIP_TRY(c, start_d.alloc((size_t)N + 2));
+        HIP_TRY(c, info_d.alloc(4));
+        HIP_TRY(c, hipMemsetAsync(start_d.p, 0, (size_t)N + 2, c->stream));
+        HIP_TRY(c, hipMemsetAsync(info_d.p, 0, sizeof(int) * 4, c->stream));
+        hipLaunchKernelGGL(k_cut_runs, dim3((unsigned)((n_hi - n_lo + 255) / 256)), dim3(256), 0, c->stream, link_d.p, noff_d, adj_off_d, n_lo, n_hi, nb_target,
+                           (long long)(acc / (S * S)), mb, start_d.p, info_d.p);
+        HIP_TRY(c, hipGetLastError());
+        int info[4] = {1, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(info, info_d.p, sizeof info, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!info[0]) {
+            const int span = n_hi - n_lo + 1;
+            DevBuf<unsigned> sel;
+            HIP_TRY(c, sel.alloc((size_t)span + 1));
+            hipcub::CountingInputIterator<unsigned> first((unsigned)n_lo);
+            size_t tb = 0;
+            HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, tb, first, start_d.p + n_lo, sel.p, info_d.p + 3, span, c->stream));
+            DevBuf<char> tmp;
+            HIP_TRY(c, tmp.alloc(tb + 16));
+            HIP_TRY(c, hipcub::DeviceSelect::Flagged(tmp.p, tb, first, start_d.p + n_lo, sel.p, info_d.p + 3, span, c->stream));
+            int count = 0;
+            HIP_TRY(c, hipMemcpyAsync(&count, info_d.p + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (count >= 2) {
+                HIP_TRY(c, c->blk_off.alloc((size_t)count));
+                HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, sel.p, sizeof(unsigned) * (size_t)count, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));   // sel / tmp are released at the end of this scope
+                c->nblk = count - 1;
+                acc = S * S * std::max(1, info[1]);   // the accumulator budget tightened to the largest block actually formed
+                max_m = (unsigned)info[2];
+                cut_done = true;
+            }
+        }
+    }
+    if (!cut_done) {
+    { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
+    link.assign((size_t)N + 1, 1);
+    if (aligned) {
         HIP_TRY(c, hipMemcpyAsync(link.data(), link_d.p, (size_t)N, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -337,6 +426,8 @@ int build_partition(fh_ctx* c) {
     }
     mark("cutting the node range (host)");
     c->nblk = (int)blk.size() - 1;
+    }   // !cut_done
+    else mark("cutting the node range (device)");
     if (c->nblk <= 0) {  // empty row range: nothing to build, nothing to launch
         c->nblk = 0;
         c->has_pipe = false;
@@ -347,18 +438,17 @@ int build_partition(fh_ctx* c) {
         c->has_partition = true;
         return FH_OK;
     }
-    {   // tighten the accumulator budget to the largest block actually formed
+    if (!cut_done) {   // tighten the accumulator budget to the largest block actually formed
         long long mx = 1;
         for (size_t b = 0; b + 1 < blk.size(); ++b) mx = std::max<long long>(mx, (long long)h_noff[blk[b + 1]] - h_noff[blk[b]]);
         acc = (int)(S * S * mx);
-    }
-    HIP_TRY(c, c->blk_off.alloc(blk.size()));
-    HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, blk.data(), sizeof(unsigned) * blk.size(), hipMemcpyHostToDevice, c->stream));
-    // block tables: unique element lists and packed entries (built once per pattern/partition)
-    {
-        unsigned max_m = 0;
+        HIP_TRY(c, c->blk_off.alloc(blk.size()));
+        HIP_TRY(c, hipMemcpyAsync(c->blk_off.p, blk.data(), sizeof(unsigned) * blk.size(), hipMemcpyHostToDevice, c->stream));
         for (size_t b = 0; b + 1 < blk.size(); ++b)
             max_m = std::max(max_m, adj_off_hh[blk[b + 1]] - adj_off_hh[blk[b]]);
+    }
+    // block tables: unique element lists and packed entries (built once per pattern/partition)
+    {
         if (max_m >= 65536) return c->fail(FH_UNSUPPORTED, "gather mode: a node block has more than 65535 adjacent entries");
         const size_t tb = sizeof(int) * 3 * (size_t)std::max(1u, max_m);
         if (tb > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "gather mode: node valence too large for the table builder");
@@ -370,15 +460,24 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, c->gt_ent.alloc((size_t)c->flat_len + 1));
         auto k0 = k_build_gather_tables<0>;
         auto k1 = k_build_gather_tables<1>;
-        if (tb > 48 * 1024) {
+        // blocks of the usual size: one wavefront per block, four blocks per workgroup (see the kernel)
+        const bool by_wave = max_m <= 1024 && c->env_int("FENRIS_HIP_TABLES_BY_WORKGROUP", 0) == 0;
+        const int wstride = 3 * (int)std::max(1u, max_m);
+        if (by_wave) {
+            k0 = k_build_gather_tables<0, 4>;
+            k1 = k_build_gather_tables<1, 4>;
+        }
+        const size_t tb_l = by_wave ? 4 * tb : tb;
+        const unsigned g_tab = by_wave ? (unsigned)((nblk + 3) / 4) : (unsigned)nblk;
+        if (!by_wave && tb > 48 * 1024) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
         }
         c->has_pos = max_row < 256 && !c->env("FENRIS_HIP_NO_POS");
         if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
-        hipLaunchKernelGGL(k0, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
+        hipLaunchKernelGGL(k0, dim3(g_tab), dim3(256), tb_l, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
-                           (const unsigned*)nullptr, (unsigned char*)nullptr);
+                           (const unsigned*)nullptr, (unsigned char*)nullptr, nblk, wstride);
         hipLaunchKernelGGL(k_hdr_counts, dim3((nblk + 256) / 256), dim3(256), 0, c->stream, c->gt_hdr.p, nblk, counts.p);
         size_t tmpb = 0;
         HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmpb, counts.p, uoff.p, nblk + 1, c->stream));
@@ -389,9 +488,9 @@ int build_partition(fh_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(&total_u, uoff.p + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, c->gt_elems.alloc((size_t)total_u + 1));
-        hipLaunchKernelGGL(k1, dim3(nblk), dim3(256), tb, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
+        hipLaunchKernelGGL(k1, dim3(g_tab), dim3(256), tb_l, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, uoff.p, c->gt_elems.p, c->gt_ent.p, c->conn.p, ncols_d,
-                           c->has_pos ? c->gt_pos.p : (unsigned char*)nullptr);
+                           c->has_pos ? c->gt_pos.p : (unsigned char*)nullptr, nblk, wstride);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -451,7 +550,7 @@ int build_partition(fh_ctx* c) {
             mark("headers to the host, staging sizes");
             // Block classes: 1 = every adjacent element is affine, the block runs on k_affine_rows; 0 = general kernels.
             // Chains never mix classes, so each class gets its own sweep order and its own position-indexed tables.
-            std::vector<unsigned char> cls((size_t)nblk, 0);
+            hvec<unsigned char> cls((size_t)nblk, 0);
             DevBuf<unsigned char> cls_d;
             const bool want_aff = c->elem_kind == FH_HEX8 && c->has_aff && c->has_ghat && c->num_aff > 0 && !c->has_rules &&
                                   !c->aff_failed && c->affine_tol > 0.0 &&
@@ -467,7 +566,7 @@ int build_partition(fh_ctx* c) {
             }
             mark("block classes");
             // sweep order: chains of blocks whose consecutive members share elements (their staged data is reused)
-            std::vector<int> order[2], chain_off[2];
+            hvec<int> order[2], chain_off[2];
             chain_off[0].push_back(0);
             chain_off[1].push_back(0);
             // (every block affine -- structured boxes: no chains to form, the affine positions are sorted into CSR order below)
@@ -478,7 +577,11 @@ int build_partition(fh_ctx* c) {
                 std::fill(cls.begin(), cls.end(), (unsigned char)0);
                 if (cls_d.p) HIP_TRY(c, hipMemsetAsync(cls_d.p, 0, (size_t)nblk, c->stream));
             }
-            if (!c->env("FENRIS_HIP_NO_SWEEP") && !all_affine) {
+            // (round 5: ... and no host vectors either -- order and chain offsets of that case are one iota array made on the device; the two
+            // host loops with their uploads were 18 ms of the 216^3 mesh's first assembly)
+            const bool ident_aff = all_affine && c->env_int("FENRIS_HIP_HOST_ORDER", 0) == 0;
+            if (ident_aff) {
+            } else if (!c->env("FENRIS_HIP_NO_SWEEP") && !all_affine) {
                 DevBuf<int> node2blk, succ_d;
                 HIP_TRY(c, node2blk.alloc((size_t)N + 1));
                 HIP_TRY(c, hipMemsetAsync(node2blk.p, 0xff, sizeof(int) * ((size_t)N + 1), c->stream));  // -1: not in a block
@@ -487,10 +590,10 @@ int build_partition(fh_ctx* c) {
                 hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
                                    node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p,
                                    c->part_perm ? r2v_d.p : (const int*)nullptr);
-                std::vector<int> succ((size_t)nblk);
+                HostBuf<int> succ((size_t)nblk);
                 HIP_TRY(c, hipMemcpyAsync(succ.data(), succ_d.p, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
-                std::vector<unsigned char> visited((size_t)nblk, 0);
+                hvec<unsigned char> visited((size_t)nblk, 0);
                 for (int b = 0; b < nblk; ++b) {
                     if (visited[b]) continue;
                     const int k = cls[b];
@@ -510,14 +613,9 @@ int build_partition(fh_ctx* c) {
             c->p_us = us;
             c->p_rw = pipe_record_words(us, ms, n, nb_target);
             // position-indexed tables of one class
-            auto build_set = [&](const std::vector<int>& ord, const std::vector<int>& choff, DevBuf<int>& rec, DevBuf<int>& conn,
-                                 DevBuf<int>& elem, int by_parity) -> int {
-                const int npos = (int)ord.size(), nchains = (int)choff.size() - 1;
-                DevBuf<int> order_d, chain_d;
-                HIP_TRY(c, order_d.alloc(ord.size()));
-                HIP_TRY(c, chain_d.alloc(choff.size()));
-                HIP_TRY(c, hipMemcpyAsync(order_d.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(chain_d.p, choff.data(), sizeof(int) * choff.size(), hipMemcpyHostToDevice, c->stream));
+            auto build_set_dev = [&](int npos, int nchains, const int* order_p, const int* chain_p, DevBuf<int>& rec, DevBuf<int>& conn,
+                                     DevBuf<int>& elem, int by_parity) -> int {
+                struct { const int* p; } order_d{order_p}, chain_d{chain_p};
                 HIP_TRY(c, rec.alloc((size_t)npos * c->p_rw));
                 HIP_TRY(c, conn.alloc((size_t)npos * c->p_cs));
                 HIP_TRY(c, elem.alloc((size_t)npos * us));
@@ -533,21 +631,39 @@ int build_partition(fh_ctx* c) {
                 }
 #undef PT_LAUNCH
                 HIP_TRY(c, hipGetLastError());
-                HIP_TRY(c, hipStreamSynchronize(c->stream));  // order_d / chain_d are released on return
+                HIP_TRY(c, hipStreamSynchronize(c->stream));  // the callers' order / chain arrays are released after the return
                 return FH_OK;
             };
+            auto build_set = [&](const hvec<int>& ord, const hvec<int>& choff, DevBuf<int>& rec, DevBuf<int>& conn,
+                                 DevBuf<int>& elem, int by_parity) -> int {
+                DevBuf<int> order_d, chain_d;
+                HIP_TRY(c, order_d.alloc(ord.size()));
+                HIP_TRY(c, chain_d.alloc(choff.size()));
+                HIP_TRY(c, hipMemcpyAsync(order_d.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(chain_d.p, choff.data(), sizeof(int) * choff.size(), hipMemcpyHostToDevice, c->stream));
+                return build_set_dev((int)ord.size(), (int)choff.size() - 1, order_d.p, chain_d.p, rec, conn, elem, by_parity);
+            };
             c->a_npos = 0;
-            if (!order[1].empty()) {
+            if (ident_aff || !order[1].empty()) {
                 // the affine kernel keeps nothing staged from one block to the next, and its write-out carries incomplete
                 // 128-byte lines from a block to its successor in memory: positions in CSR order, every position its own chain
-                std::sort(order[1].begin(), order[1].end());
-                chain_off[1].resize(order[1].size() + 1);
-                for (size_t k = 0; k <= order[1].size(); ++k) chain_off[1][k] = (int)k;
                 DevBuf<int> tmp_rec;  // the pipelined kernel's records: input of the lane builder only
-                int rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem, 0);
+                int rs = FH_OK;
+                if (ident_aff) {
+                    DevBuf<int> iota_d;   // order[k] = k, chain_off[k] = k
+                    HIP_TRY(c, iota_d.alloc((size_t)nblk + 1));
+                    hipLaunchKernelGGL(k_iota_int, dim3((unsigned)std::min(4096, (nblk + 256) / 256)), dim3(256), 0, c->stream, iota_d.p, nblk + 1);
+                    HIP_TRY(c, hipGetLastError());
+                    rs = build_set_dev(nblk, nblk, iota_d.p, iota_d.p, tmp_rec, c->a_conn, c->a_elem, 0);
+                } else {
+                    std::sort(order[1].begin(), order[1].end());
+                    chain_off[1].resize(order[1].size() + 1);
+                    for (size_t k = 0; k <= order[1].size(); ++k) chain_off[1][k] = (int)k;
+                    rs = build_set(order[1], chain_off[1], tmp_rec, c->a_conn, c->a_elem, 0);
+                }
                 if (rs) return rs;
                 mark("position tables of the affine class (k_build_pipe_tables)");
-                const int npos = (int)order[1].size();
+                const int npos = ident_aff ? nblk : (int)order[1].size();
                 c->a_us = us;
                 bool bad = false;
                 rs = build_lane_tables(c, tmp_rec.p, us, ms, nb_target, npos, S, c->a_conn.p, c->a_elem.p, c->a_hdr, c->a_lanes, c->a_ntab,
@@ -610,7 +726,7 @@ int build_partition(fh_ctx* c) {
             c->has_pipe = true;
             if (c->env("FENRIS_HIP_VERBOSE"))
                 std::fprintf(stderr, "[fenris_hip] sweep order: %d general blocks in %d chains, %d affine blocks in %d chains (us=%d ms=%d)\n",
-                             c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, (int)chain_off[1].size() - 1, us, ms);
+                             c->npos_gen, (int)chain_off[0].size() - 1, c->a_npos, ident_aff ? c->a_npos : (int)chain_off[1].size() - 1, us, ms);
             c->has_rows = false;
             const int npg = c->npos_gen;
             // Hex8, Laplace / uniform LinearElastic: lane tables for the general positions as well (k_hex8_rows, hex8_rows.hip: row-owner
@@ -627,7 +743,7 @@ int build_partition(fh_ctx* c) {
                 if (!bad && !c->h_incomplete) {
                     // lanes rearranged so that the sixteen lanes the LDS serves together read different banks (host, unique tables only)
                     if (c->h_ntab <= c->env_int("FENRIS_HIP_TUNE_LANES_MAX", 4096) && !c->env("FENRIS_HIP_NO_LANE_TUNING")) {
-                        std::vector<uint2> tabs((size_t)c->h_ntab * 256);
+                        HostBuf<uint2> tabs((size_t)c->h_ntab * 256);
                         HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         double cb = 0.0, ca = 0.0;

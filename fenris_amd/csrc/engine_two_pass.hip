@@ -135,11 +135,13 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     if (max_row >= 65536) return c->fail(FH_UNSUPPORTED, "two-pass gather: node valence too large");
     const unsigned* adj_off = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
     const unsigned* adj = c->has_mask ? c->n2e_c.p : c->n2e.p;
-    { const int rc_h = host_offsets(c); if (rc_h) return rc_h; }
-    const std::vector<unsigned>& adj_off_h = c->has_mask ? c->h_n2e_off_c : c->h_n2e_off;
-    const long long entries = adj_off_h.empty() ? 0 : (long long)adj_off_h[c->N];
     const bool wide = max_row >= 256;
     if (!c->has_tp_pos) {  // once per pattern / element mask
+        // number of (node, element) adjacencies: the last offset, read from the device (round 5: this used to pull both offset arrays to the host)
+        unsigned last_off = 0;
+        HIP_TRY(c, hipMemcpyAsync(&last_off, adj_off + c->N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const long long entries = (long long)last_off;
         DevBuf<int> entry_node;
         HIP_TRY(c, entry_node.alloc((size_t)entries + 1));
         hipLaunchKernelGGL(k_entry_nodes, dim3(((int)c->N + 255) / 256), dim3(256), 0, c->stream, (int)c->N, adj_off, entry_node.p);

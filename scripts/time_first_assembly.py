@@ -42,3 +42,5 @@ for it in range(2):
           (cfg, it, mesh.num_elements(), 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), eng.last_kernel_name(), 1e3 * (t4 - t3)), flush=True)
     del values
     eng.close()
+    if os.environ.get("FENRIS_SLEEP_BETWEEN"):
+        time.sleep(float(os.environ["FENRIS_SLEEP_BETWEEN"]))

@@ -390,3 +390,28 @@ def test_affine_fused_records_wave(oracle, op, grid):
         assert ei.value.element == 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_node_range_cut_on_the_device_equals_the_host_cut(oracle, op):
+    """Round 5: numberings made of grid lines are cut into owner blocks on the device (k_cut_runs); FENRIS_HIP_HOST_CUT=1 keeps the host loop.
+    Same blocks -> the same kernel, the same sums in the same order: identical matrices bit for bit, on affine, mixed and general meshes, under
+    a row range (slabs) and with runs of many lengths (17 x 3 x 2: lines of 18, 4 and 3 nodes -- the short ones send the cut to the host)."""
+    for name in ("box9", "graded", "mixed", "perturbed", "slab_17x3x2", "single_element"):
+        mesh = _meshes()[name]
+        got = {}
+        for host in (0, 1):
+            eng = fa.Engine(0)
+            try:
+                eng.set_option("FENRIS_HIP_HOST_CUT", host)
+                asm, ref = _assemblers(eng, oracle, mesh, op)
+                k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+                got[host] = (k.values.copy(), eng.last_kernel_name())
+                if host == 0:
+                    st, _, ro, ci, vals = oracle.assemble(ref)
+                    assert st == 0
+                    assert np.abs(k.values - vals).max() <= TOL * np.abs(vals).max(), name
+            finally:
+                eng.close()
+        assert got[0][1] == got[1][1], name
+        assert np.array_equal(got[0][0], got[1][0]), name

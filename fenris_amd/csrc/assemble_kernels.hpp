@@ -1439,6 +1439,7 @@ static __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* 
                                                         const int* node2blk, int nblk, const unsigned char* cls, int* succ,
                                                         const int* r2v = nullptr) {
     __shared__ int cand[1024];
+    __shared__ int hkey[512], hcnt[512];
     __shared__ int best_blk, best_cnt;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (cls && cls[b] == 1) {   // an affine block: its kernel sweeps in CSR order, every position a chain of its own (build_partition)
@@ -1456,6 +1457,35 @@ static __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* 
         cand[i] = cb;
     }
     if (lane == 0) { best_blk = -1; best_cnt = 0; }
+    if (total <= 256) {
+        // round 5: the candidates counted in a hash table of 512 places (at most 256 distinct candidates: never full) instead of by comparing
+        // every candidate with every other (2 x 256 x 256 LDS reads per block, 18.8 ms for the 1.46 M blocks of the 216^3 mesh); the result
+        // -- largest count, smallest block among those -- does not depend on the order of the atomics
+        for (int i = lane; i < 512; i += 64) { hkey[i] = -1; hcnt[i] = 0; }
+        __syncthreads();
+        for (int i = lane; i < total; i += 64) {
+            const int c = cand[i];
+            if (c < 0) continue;
+            unsigned hsh = ((unsigned)c * 2654435761u) >> 23;
+            for (;;) {
+                const int old = atomicCAS(&hkey[hsh], -1, c);
+                if (old == -1 || old == c) { atomicAdd(&hcnt[hsh], 1); break; }
+                hsh = (hsh + 1) & 511u;
+            }
+        }
+        __syncthreads();
+        int bc = 0, bb = 0x7fffffff;
+        for (int i = lane; i < 512; i += 64) {
+            const int n = hcnt[i], k = hkey[i];
+            if (n > bc || (n == bc && n > 0 && k < bb)) { bc = n; bb = k; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int oc = __shfl_xor(bc, o), ob = __shfl_xor(bb, o);
+            if (oc > bc || (oc == bc && oc > 0 && ob < bb)) { bc = oc; bb = ob; }
+        }
+        if (lane == 0) succ[b] = (bc > 0) ? bb : -1;
+        return;
+    }
     __syncthreads();
     for (int i = lane; i < total; i += 64) {
         const int c = cand[i];
@@ -1557,31 +1587,86 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
             }
             for (int i = n + lane; i < us; i += 64) list[i] = 0;
             if (lane == 0) s_nnew = nnew;
-        } else if (lane == 0) {  // new elements take free slots in ascending order; list = new slots, then retained
-            // by_parity (the general positions of Hex8 meshes: k_hex8_rows): the lowest free slot whose parity is that of the element id,
-            // when there is one -- that kernel keeps the gradients of even and odd slots in different halves of the LDS banks, and on a
-            // structured mesh (an even number of cells per line) the elements that meet a node at the same local corner alternate in
+        } else {
+            // by_parity (the general positions of Hex8 meshes: k_hex8_rows): a new element takes a free slot whose parity is that of the
+            // element id when there is one -- that kernel keeps the gradients of even and odd slots in different halves of the LDS banks, and
+            // on a structured mesh (an even number of cells per line) the elements that meet a node at the same local corner alternate in
             // parity.  (Not for the affine positions: their kernel's element records are 80 bytes apart, and the slot numbering this
             // gives them cost the headline 4 - 7 %.)
-            int nnew = 0;
-            for (int k = 0; k < h.U; ++k) {
-                if (map[k] >= 0) continue;
-                int free_s = -1, any_s = -1;
-                for (int s_ = 0; s_ < us; ++s_) {
-                    if (new_elem[s_] >= 0) continue;
-                    if (any_s < 0) any_s = s_;
-                    if (!by_parity || (s_ & 1) == (int)(E[k] & 1u)) { free_s = s_; break; }
+            // Round 5: by the whole wavefront, like the branch above -- the r-th new element of a parity takes the r-th free slot of that
+            // parity; what is left over (a parity with more new elements than free slots) takes the remaining free slots in ascending order.
+            // One lane walking U x us candidates was 22 ms of set-up on the 216^3 mesh.
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int nfree2[2] = {0, 0};
+            for (int s0 = 0; s0 < us; s0 += 64) {
+                const int s_ = s0 + lane;
+                const bool fr = s_ < us && new_elem[s_] < 0;
+                const unsigned long long m0 = __ballot(fr && !(s_ & 1)), m1 = __ballot(fr && (s_ & 1));
+                if (fr) flist[(s_ & 1) * 128 + nfree2[s_ & 1] + __popcll(((s_ & 1) ? m1 : m0) & below)] = (unsigned char)s_;
+                nfree2[0] += __popcll(m0);
+                nfree2[1] += __popcll(m1);
+            }
+            __syncthreads();
+            int nn2[2] = {0, 0};
+            for (int k0 = 0; k0 < h.U; k0 += 64) {
+                const int k = k0 + lane;
+                const bool nw = k < h.U && map[k] < 0;
+                const int par = nw ? (int)(E[k] & 1u) : 0;
+                const unsigned long long m0 = __ballot(nw && par == 0), m1 = __ballot(nw && par == 1);
+                const int r = nn2[par] + __popcll((par ? m1 : m0) & below);
+                if (nw && r < nfree2[par]) {
+                    const int sl = flist[par * 128 + r];
+                    map[k] = sl;
+                    new_elem[sl] = (int)E[k];
                 }
-                if (free_s < 0) free_s = any_s;
-                map[k] = free_s;
-                new_elem[free_s] = (int)E[k];
-                list[nnew++] = (unsigned char)free_s;
+                nn2[0] += __popcll(m0);
+                nn2[1] += __popcll(m1);
+            }
+            __syncthreads();
+            // leftovers: the remaining free slots, ascending
+            int nfree = 0;
+            for (int s0 = 0; s0 < us; s0 += 64) {
+                const int s_ = s0 + lane;
+                const bool fr = s_ < us && new_elem[s_] < 0;
+                const unsigned long long m = __ballot(fr);
+                if (fr) flist[nfree + __popcll(m & below)] = (unsigned char)s_;
+                nfree += __popcll(m);
+            }
+            __syncthreads();
+            int nleft = 0;
+            for (int k0 = 0; k0 < h.U; k0 += 64) {
+                const int k = k0 + lane;
+                const bool nw = k < h.U && map[k] < 0;
+                const unsigned long long m = __ballot(nw);
+                const int r = nleft + __popcll(m & below);
+                if (nw && r < nfree) {
+                    const int sl = flist[r];
+                    map[k] = sl;
+                    new_elem[sl] = (int)E[k];
+                }
+                nleft += __popcll(m);
+            }
+            __syncthreads();
+            // list = the new slots in the order of their elements, then the retained ones
+            int nnew = 0;
+            for (int k0 = 0; k0 < h.U; k0 += 64) {
+                const int k = k0 + lane;
+                const int sl = (k < h.U) ? map[k] : -1;
+                const bool nw = sl >= 0 && slot_elem[sl] != new_elem[sl];
+                const unsigned long long m = __ballot(nw);
+                if (nw) list[nnew + __popcll(m & below)] = (unsigned char)sl;
+                nnew += __popcll(m);
             }
             int n = nnew;
-            for (int s_ = 0; s_ < us; ++s_)
-                if (new_elem[s_] >= 0 && slot_elem[s_] == new_elem[s_]) list[n++] = (unsigned char)s_;
-            for (; n < us; ++n) list[n] = 0;
-            s_nnew = nnew;
+            for (int s0 = 0; s0 < us; s0 += 64) {
+                const int s_ = s0 + lane;
+                const bool keep = s_ < us && new_elem[s_] >= 0 && slot_elem[s_] == new_elem[s_];
+                const unsigned long long m = __ballot(keep);
+                if (keep) list[n + __popcll(m & below)] = (unsigned char)s_;
+                n += __popcll(m);
+            }
+            for (int i = n + lane; i < us; i += 64) list[i] = 0;
+            if (lane == 0) s_nnew = nnew;
         }
         __syncthreads();
         // write the records of position p

@@ -1435,11 +1435,12 @@ static __global__ void __launch_bounds__(256) k_build_slot_params(const int* ele
 // wavefront per block.
 // cls (optional): class of every block; only blocks of the same class are candidates (chains never mix classes).
 // r2v (optional): position of every node in the order the blocks were formed in (null: the node numbering itself).
+template <int TBL>   // places of the hash table that counts the candidates: 512 (up to 256 candidates per block) or 2048 (up to 1024)
 static __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* hdr, const unsigned* gt_elems, const int* conn, int N,
                                                         const int* node2blk, int nblk, const unsigned char* cls, int* succ,
                                                         const int* r2v = nullptr) {
     __shared__ int cand[1024];
-    __shared__ int hkey[512], hcnt[512];
+    __shared__ int hkey[TBL], hcnt[TBL];
     __shared__ int best_blk, best_cnt;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (cls && cls[b] == 1) {   // an affine block: its kernel sweeps in CSR order, every position a chain of its own (build_partition)
@@ -1457,25 +1458,25 @@ static __global__ void __launch_bounds__(64) k_block_successor(const GatherHdr* 
         cand[i] = cb;
     }
     if (lane == 0) { best_blk = -1; best_cnt = 0; }
-    if (total <= 256) {
+    if (2 * total <= TBL) {
         // round 5: the candidates counted in a hash table of 512 places (at most 256 distinct candidates: never full) instead of by comparing
         // every candidate with every other (2 x 256 x 256 LDS reads per block, 18.8 ms for the 1.46 M blocks of the 216^3 mesh); the result
         // -- largest count, smallest block among those -- does not depend on the order of the atomics
-        for (int i = lane; i < 512; i += 64) { hkey[i] = -1; hcnt[i] = 0; }
+        for (int i = lane; i < TBL; i += 64) { hkey[i] = -1; hcnt[i] = 0; }
         __syncthreads();
         for (int i = lane; i < total; i += 64) {
             const int c = cand[i];
             if (c < 0) continue;
-            unsigned hsh = ((unsigned)c * 2654435761u) >> 23;
+            unsigned hsh = ((unsigned)c * 2654435761u) >> (TBL == 512 ? 23 : 21);
             for (;;) {
                 const int old = atomicCAS(&hkey[hsh], -1, c);
                 if (old == -1 || old == c) { atomicAdd(&hcnt[hsh], 1); break; }
-                hsh = (hsh + 1) & 511u;
+                hsh = (hsh + 1) & (unsigned)(TBL - 1);
             }
         }
         __syncthreads();
         int bc = 0, bb = 0x7fffffff;
-        for (int i = lane; i < 512; i += 64) {
+        for (int i = lane; i < TBL; i += 64) {
             const int n = hcnt[i], k = hkey[i];
             if (n > bc || (n == bc && n > 0 && k < bb)) { bc = n; bb = k; }
         }
@@ -1530,6 +1531,9 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
     __shared__ int map[256];         // block-local unique index -> slot
     __shared__ unsigned char list[256];
     __shared__ unsigned char flist[256];   // free slots, ascending
+    __shared__ unsigned Es[256];           // unique elements of the block
+    __shared__ int hk[512];                // ... hashed: element id (-1: empty place)
+    __shared__ unsigned char hv[512];      //             its index in the block's list
     __shared__ int s_nnew;
     const int lane = threadIdx.x;
     const int p0 = chain_off[blockIdx.x], p1 = chain_off[blockIdx.x + 1];
@@ -1537,16 +1541,39 @@ __global__ void __launch_bounds__(64) k_build_pipe_tables(const int* order, cons
     __syncthreads();
     for (int p = p0; p < p1; ++p) {
         const GatherHdr h = hdr[order[p]];
-        const unsigned* E = gt_elems + h.u_off;
+        // (round 5: the block's element list in LDS -- the search below reads it us x U times; from global memory that was most of the 36 ms
+        // this kernel took on the 5 M-element Tet4 mesh, ~180 elements per block)
+        for (int k = lane; k < h.U && k < 256; k += 64) Es[k] = gt_elems[h.u_off + k];
+        const unsigned* E = (h.U <= 256) ? Es : gt_elems + h.u_off;
         for (int s_ = lane; s_ < us; s_ += 64) new_elem[s_] = -1;
         for (int k = lane; k < h.U; k += 64) map[k] = -1;
         __syncthreads();
-        // retained: an element of this block already staged in some slot keeps it
-        for (int s_ = lane; s_ < us; s_ += 64) {
-            const int e = slot_elem[s_];
-            if (e < 0) continue;
-            for (int k = 0; k < h.U; ++k)
-                if ((int)E[k] == e) { map[k] = s_; new_elem[s_] = e; break; }
+        // retained: an element of this block already staged in some slot keeps it.  (Round 5: the block's elements go into a hash table of 512
+        // places -- at most 252 of them, all different -- and every staged slot looks its element up, instead of us x U comparisons.)
+        if (h.U <= 256) {
+            for (int i = lane; i < 512; i += 64) hk[i] = -1;
+            __syncthreads();
+            for (int k = lane; k < h.U; k += 64) {
+                const int e = (int)E[k];
+                unsigned hs = ((unsigned)e * 2654435761u) >> 23;
+                while (atomicCAS(&hk[hs], -1, e) != -1) hs = (hs + 1) & 511u;
+                hv[hs] = (unsigned char)k;
+            }
+            __syncthreads();
+            for (int s_ = lane; s_ < us; s_ += 64) {
+                const int e = slot_elem[s_];
+                if (e < 0) continue;
+                unsigned hs = ((unsigned)e * 2654435761u) >> 23;
+                for (int key = hk[hs]; key != -1; hs = (hs + 1) & 511u, key = hk[hs])
+                    if (key == e) { map[hv[hs]] = s_; new_elem[s_] = e; break; }
+            }
+        } else {
+            for (int s_ = lane; s_ < us; s_ += 64) {
+                const int e = slot_elem[s_];
+                if (e < 0) continue;
+                for (int k = 0; k < h.U; ++k)
+                    if ((int)E[k] == e) { map[k] = s_; new_elem[s_] = e; break; }
+            }
         }
         __syncthreads();
         if (!by_parity) {

@@ -132,10 +132,10 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
 
 // largest number of unique elements / of (node, element) entries over the block headers
 static __global__ void __launch_bounds__(256) k_gather_hdr_max(const GatherHdr* hdr, int nblk, int* out) {
-    int u = 1, m = 1;
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) { u = max(u, hdr[b].U); m = max(m, hdr[b].m); }
-    for (int o = 32; o > 0; o >>= 1) { u = max(u, __shfl_xor(u, o)); m = max(m, __shfl_xor(m, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(out, u); atomicMax(out + 1, m); }
+    int u = 1, m = 1, r = 1;   // ... and of node-level entries of the block's rows
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) { u = max(u, hdr[b].U); m = max(m, hdr[b].m); r = max(r, hdr[b].nrow); }
+    for (int o = 32; o > 0; o >>= 1) { u = max(u, __shfl_xor(u, o)); m = max(m, __shfl_xor(m, o)); r = max(r, __shfl_xor(r, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(out, u); atomicMax(out + 1, m); atomicMax(out + 2, r); }
 }
 
 // The cut of the node range into owner blocks for numberings made of LONG runs (grid lines), on the device (round 5): one thread per run start
@@ -497,19 +497,20 @@ int build_partition(fh_ctx* c) {
     mark("block tables (k_build_gather_tables)");
     // staging capacity: all unique elements of the largest block if that fits the LDS budget
     // (round 5: the two maxima by a device reduction -- the headers themselves, 47 MB for the 216^3 mesh, used to travel to the host for them)
-    int umax = 1, mmax = 1;
+    int umax = 1, mmax = 1, nrow_max = 1;
     if (c->nblk) {
         DevBuf<int> mx;
-        HIP_TRY(c, mx.alloc(2));
-        const int one[2] = {1, 1};
+        HIP_TRY(c, mx.alloc(3));
+        const int one[3] = {1, 1, 1};
         HIP_TRY(c, hipMemcpyAsync(mx.p, one, sizeof one, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_gather_hdr_max, dim3((unsigned)std::min(4096, (c->nblk + 255) / 256)), dim3(256), 0, c->stream, c->gt_hdr.p, c->nblk, mx.p);
         HIP_TRY(c, hipGetLastError());
-        int got[2] = {1, 1};
+        int got[3] = {1, 1, 1};
         HIP_TRY(c, hipMemcpyAsync(got, mx.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         umax = std::max(1, got[0]);
         mmax = std::max(1, got[1]);
+        nrow_max = std::max(1, got[2]);
     }
     int ub = 0;
     if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, umax, acc, 64, true, mb, c->fast_ok) <= lds_target) {
@@ -587,9 +588,14 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, hipMemsetAsync(node2blk.p, 0xff, sizeof(int) * ((size_t)N + 1), c->stream));  // -1: not in a block
                 HIP_TRY(c, succ_d.alloc((size_t)nblk));
                 hipLaunchKernelGGL(k_node_to_block, dim3((nblk + 255) / 256), dim3(256), 0, c->stream, c->blk_off.p, nblk, node2blk.p);
-                hipLaunchKernelGGL(k_block_successor, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
-                                   node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p,
-                                   c->part_perm ? r2v_d.p : (const int*)nullptr);
+                if (umax * n <= 256)
+                    hipLaunchKernelGGL(k_block_successor<512>, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
+                                       node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p,
+                                       c->part_perm ? r2v_d.p : (const int*)nullptr);
+                else
+                    hipLaunchKernelGGL(k_block_successor<2048>, dim3(nblk), dim3(64), 0, c->stream, c->gt_hdr.p, c->gt_elems.p, c->conn.p, n,
+                                       node2blk.p, nblk, want_aff ? cls_d.p : (const unsigned char*)nullptr, succ_d.p,
+                                       c->part_perm ? r2v_d.p : (const int*)nullptr);
                 HostBuf<int> succ((size_t)nblk);
                 HIP_TRY(c, hipMemcpyAsync(succ.data(), succ_d.p, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -778,6 +784,7 @@ int build_partition(fh_ctx* c) {
                 HIP_TRY(c, c->r_rec.alloc((size_t)npg * c->r_rw));
                 int bad = 0;
                 for (int ls : {128, 256}) {  // half the table (and its traffic) when no block needs more than 128 lanes
+                    if (ls == 128 && nrow_max > 128) continue;   // every (node, column) block of the rows takes a lane at least: 256 at once
                     c->r_ls = ls;
                     HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
                     HIP_TRY(c, c->r_lanes4.alloc((size_t)npg * ls));

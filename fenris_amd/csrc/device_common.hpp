@@ -89,6 +89,8 @@ struct KArgs {
     const double* phiref;  // nq x N       basis values (mass matrix only)
     int all_affine;        // Hex8: every element is a parallelepiped by k_classify_affine_hex8's test (the element pass takes J as constant without testing)
     const double* qmono;   // nq x 8       Hex8 only, or null: xi eta zeta, eta zeta, xi zeta, xi eta of every point (element_pass.hpp, monomial form)
+    const double* qmom;    // 8            Hex8 only, or null: moments of the rule (sum w, xi^2, eta^2, zeta^2, eta^2 zeta^2, xi^2 zeta^2, xi^2 eta^2) when every
+                           //              moment with an odd power vanishes AND the parameters are the same at every point (element_pass.hpp, AFFM = 2)
     const double* qparams; // nq x 2 (mu, lambda) or null
     // CompactQuadratureTable with shared points / weights: element e reads rparams[(rule_map[e] nq + q) 2 ..]
     const unsigned* rule_map;  // E, or null (uniform table)

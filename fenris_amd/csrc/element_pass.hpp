@@ -220,12 +220,23 @@ __device__ __forceinline__ void hex8_wht(double (&v)[8]) {
 }
 // AFF: every element of the mesh is a parallelepiped (k_classify_affine_hex8 says so for all of them: KArgs::all_affine) -- J from the three
 // linear coefficients of the map, once; no per-wavefront test, no second path (which alone keeps 24 more registers alive).
-template <int OP, int WHAT, bool AFF = false, class UAcc>
+// AFFM = 2 (round 5, residual of Laplace / LinearElastic with one parameter pair for every point, all elements affine): NO loop over the
+// quadrature points.  With J constant the integrand's matrix M(xi) = s P(J^-T R(xi)) J^-T is LINEAR in the reference gradient R(xi) of u, and
+// R(xi) = R_1 + R_xi xi + R_eta eta + R_zeta zeta + R_ez eta zeta + R_xz xi zeta + R_xe xi eta  with coefficient matrices that are rows of the
+// monomial coefficients of u (d/dxi = c1 + c3 eta + c5 zeta + c7 eta zeta, and cyclic).  The moment sums of the point loop then are
+//     sum_q w_q M(xi_q) (monomial)  =  sum_t  L(R_t)  x  (moment of the rule: sum_q w_q monomial_t monomial),
+// and for a rule that is symmetric in every coordinate (all moments with an odd power vanish: checked on the host, fh_ctx::qmom_ok) only the
+// seven squares survive: seven applications of the linear map L to sparse matrices -- and of each result only the columns that meet a
+// non-vanishing moment -- instead of eight full point evaluations: ~640 instead of ~1 200 vector instructions per element.  The same sums as
+// elliptic.rs:506-527 in another order (like the affine stiffness kernel: equal to rounding, checked against the oracle at 1e-12).
+template <int OP, int WHAT, int AFFM = 0, class UAcc>
 __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const long long e, const bool live, const long long ec,
                                                        const double (&X)[8][3], const UAcc& U,
                                                        double (&f)[EPDims<FH_HEX8, OP, WHAT>::NF][EPDims<FH_HEX8, OP, WHAT>::S], double& energy) {
     using O = OpT<OP, 3>;
     constexpr int D = 3, N = 8, S = O::S;
+    constexpr bool AFF = AFFM != 0;
+    constexpr bool POLY = AFFM == 2 && WHAT == EP_VECTOR && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC);
     energy = 0.0;
     const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[ec] * a.nq * 2 : nullptr;
     // coefficients of the coordinate map and of u (c0 is not needed: only gradients enter)
@@ -344,7 +355,81 @@ __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const lon
             }
         }
     };
-    if constexpr (AFF) {
+    if constexpr (POLY) {
+        // J = (c1, c2, c4) of the map, once (what point(0) forms: the mixed coefficients are zero here)
+#pragma unroll
+        for (int i = 0; i < D; ++i) { J[i][0] = cx[i][1]; J[i][1] = cx[i][2]; J[i][2] = cx[i][4]; }
+        const double detJ = det_small<D>(J);
+        if (detJ == 0.0) {  // try_inverse fails only for det == 0 exactly (elliptic.rs:401-404)
+            if (live) report_singular(a.status, e);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) Ji[i][j] = 0.0;
+        } else {
+            inv_small(J, detJ, Ji);
+        }
+        adet = fabs(detJ);
+        const double mu = (OP != FH_LAPLACE) ? ep_const(a.qparams)[0] : 0.0, lambda = (OP != FH_LAPLACE) ? ep_const(a.qparams)[1] : 0.0;
+        // L restricted: ROWS = which rows (reference directions) of the coefficient matrix are present (bit j: row j = r_j), COLS = which
+        // columns of M = P(J^-T R) J^-T are wanted
+        auto term = [&](auto rows_tag, auto cols_tag, int c0, int c1, int c2, double (&M)[S][D]) {
+            constexpr int ROWS = decltype(rows_tag)::value, COLS = decltype(cols_tag)::value;
+            const int cidx[3] = {c0, c1, c2};
+            double gu[D][S];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    double t = 0.0;
+                    bool first = true;
+#pragma unroll
+                    for (int m = 0; m < D; ++m)
+                        if (ROWS & (1 << m)) {
+                            t = first ? Ji[m][i] * cu[k][cidx[m]] : fma(Ji[m][i], cu[k][cidx[m]], t);
+                            first = false;
+                        }
+                    gu[i][k] = t;
+                }
+            double P[S][D], psi;
+            material_point<OP, D, S, WHAT>(gu, mu, lambda, P, psi);
+#pragma unroll
+            for (int i = 0; i < S; ++i)
+#pragma unroll
+                for (int m = 0; m < D; ++m)
+                    if (COLS & (1 << m)) {
+                        double t = P[i][0] * Ji[m][0];
+#pragma unroll
+                        for (int k = 1; k < D; ++k) t = fma(P[i][k], Ji[m][k], t);
+                        M[i][m] = t;
+                    }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>;
+        using I7 = std::integral_constant<int, 7>;
+        // moments of the rule times |det J|: [0] sum w, [1..3] xi^2, eta^2, zeta^2, [4..6] eta^2 zeta^2, xi^2 zeta^2, xi^2 eta^2
+        const ep_table mq = ep_const(a.qmom);
+        double M1[S][D], Mx[S][D], My[S][D], Mz[S][D], Myz[S][D], Mxz[S][D], Mxy[S][D];
+        term(I7{}, I7{}, 1, 2, 4, M1);     // constant part: rows c1, c2, c4
+        term(I6{}, I6{}, 0, 3, 5, Mx);     // coefficient of xi:   d/deta has c3 xi, d/dzeta has c5 xi;   wanted: columns eta, zeta
+        term(I5{}, I5{}, 3, 0, 6, My);     // coefficient of eta:  d/dxi has c3 eta, d/dzeta has c6 eta;  wanted: columns xi, zeta
+        term(I3{}, I3{}, 5, 6, 0, Mz);     // coefficient of zeta: d/dxi has c5 zeta, d/deta has c6 zeta; wanted: columns xi, eta
+        term(I1{}, I1{}, 7, 0, 0, Myz);    // eta zeta: d/dxi has c7;   wanted: column xi
+        term(I2{}, I2{}, 0, 7, 0, Mxz);    // xi zeta:  d/deta has c7;  wanted: column eta
+        term(I4{}, I4{}, 0, 0, 7, Mxy);    // xi eta:   d/dzeta has c7; wanted: column zeta
+        const double s0 = mq[0] * adet, sx = mq[1] * adet, sy = mq[2] * adet, sz = mq[3] * adet, syz = mq[4] * adet, sxz = mq[5] * adet,
+                     sxy = mq[6] * adet;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            dk[i][1] = s0 * M1[i][0];
+            dk[i][2] = s0 * M1[i][1];
+            dk[i][4] = s0 * M1[i][2];
+            dk[i][3] = fma(sx, Mx[i][1], sy * My[i][0]);
+            dk[i][5] = fma(sx, Mx[i][2], sz * Mz[i][0]);
+            dk[i][6] = fma(sy, My[i][2], sz * Mz[i][1]);
+            dk[i][7] = fma(sxy, Mxy[i][2], fma(sxz, Mxz[i][1], syz * Myz[i][0]));
+        }
+    } else if constexpr (AFF) {
         point(0, std::true_type{});
         for (int q = 1; q < a.nq; ++q) point(q, std::false_type{});
     } else if (const_j) {
@@ -388,7 +473,7 @@ __device__ __forceinline__ void element_pass_body(const KArgs& a, const long lon
     constexpr int D = E::D, N = E::N, S = O::S;
     static_assert(E::NG == N && N <= 8, "element pass: small iso-parametric elements");
     if constexpr (MONO != 0 && EK == FH_HEX8) {   // the monomial form (its own instantiation: both forms in one kernel took 324 registers)
-        element_pass_body_hex8<OP, WHAT, MONO == 2>(a, e, live, ec, X, U, f, energy);
+        element_pass_body_hex8<OP, WHAT, MONO == 3 ? 2 : MONO == 2 ? 1 : 0>(a, e, live, ec, X, U, f, energy);
         return;
     }
 #pragma unroll

@@ -264,6 +264,8 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.phiref = c->phiref.p;
     a.all_affine = (c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff == c->E && c->E > 0 && !c->env("FENRIS_HIP_NO_AFFINE_PASS")) ? 1 : 0;
     a.qmono = (c->elem_kind == FH_HEX8 && c->qmono.p && !c->env("FENRIS_HIP_NO_MONOMIAL")) ? c->qmono.p : nullptr;
+    a.qmom = (a.qmono && a.all_affine && c->qmom_ok && c->qmom.p && !c->has_rules && (c->op == FH_LAPLACE || (c->op == FH_LINEAR_ELASTIC && c->has_params)) &&
+              c->env_int("FENRIS_HIP_NO_MOMENT_RESIDUAL", 0) == 0) ? c->qmom.p : nullptr;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
     a.rule_map = c->has_rules ? c->rule_map.p : nullptr;
     a.rparams = c->has_rules ? c->rparams.p : nullptr;
@@ -763,8 +765,38 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
         }
         HIP_TRY(c, c->qmono.alloc(qm.size()));
         HIP_TRY(c, hipMemcpy(c->qmono.p, qm.data(), sizeof(double) * qm.size(), hipMemcpyHostToDevice));
+        // moments of the rule for the quadrature-free residual of affine elements (element_pass.hpp, AFFM = 2): usable when every moment
+        // sum_q w_q xi^a eta^b zeta^c (a, b, c <= 2) with an odd power vanishes -- the tensor Gauss rules -- and, for operators with
+        // parameters, when all points carry the same pair
+        double mom[3][3][3];
+        double scale = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                for (int d = 0; d < 3; ++d) {
+                    double m = 0.0, ma = 0.0;
+                    for (uint32_t q = 0; q < nq; ++q) {
+                        const double t = w[q] * std::pow(pts[3 * q], a) * std::pow(pts[3 * q + 1], b) * std::pow(pts[3 * q + 2], d);
+                        m += t;
+                        ma += std::fabs(t);
+                    }
+                    mom[a][b][d] = m;
+                    scale = std::max(scale, ma);
+                }
+        bool ok = scale > 0.0;
+        for (int a = 0; a < 3 && ok; ++a)
+            for (int b = 0; b < 3 && ok; ++b)
+                for (int d = 0; d < 3 && ok; ++d)
+                    if (((a | b | d) & 1) && std::fabs(mom[a][b][d]) > 1e-14 * scale) ok = false;
+        if (params)
+            for (uint32_t q = 1; q < nq && ok; ++q)
+                if (params[2 * q] != params[0] || params[2 * q + 1] != params[1]) ok = false;
+        c->qmom_ok = ok;
+        const double qm8[8] = {mom[0][0][0], mom[2][0][0], mom[0][2][0], mom[0][0][2], mom[0][2][2], mom[2][0][2], mom[2][2][0], 0.0};
+        HIP_TRY(c, c->qmom.alloc(8));
+        HIP_TRY(c, hipMemcpy(c->qmom.p, qm8, sizeof qm8, hipMemcpyHostToDevice));
     } else {
         c->qmono.release();
+        c->qmom_ok = false;
     }
     HIP_TRY(c, c->qw.alloc(nq + 1));  // [nq]: sum of the weights (collapsed rule of the affine simplices, see dispatch)
     HIP_TRY(c, c->gref.alloc(gref.size()));

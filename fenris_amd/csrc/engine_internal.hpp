@@ -302,6 +302,8 @@ struct fh_ctx {
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
     DevBuf<double> qmono;       // Hex8: coordinates and pair products of the quadrature points (KArgs::qmono)
+    DevBuf<double> qmom;        // Hex8: moments of the rule (KArgs::qmom); qmom_ok: the rule is symmetric and the parameters are the same at every point
+    bool qmom_ok = false;
     DevBuf<unsigned> rule_map;
     bool has_rules = false;
     bool has_params = false, has_u = false;

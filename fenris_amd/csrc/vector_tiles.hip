@@ -557,8 +557,8 @@ int vector_tiles_element_pass(int elem_kind, int op, hipStream_t stream, const K
     if (elem_kind == FH_HEX8 && a.qmono) {   // the monomial form (element_pass.hpp, round 5)
         const dim3 g(8 * ((t.ntiles + 7) / 8));
         switch (op) {
-            case FH_LAPLACE: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
-            case FH_LINEAR_ELASTIC: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            case FH_LAPLACE: if (a.all_affine && a.qmom) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 3>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
+            case FH_LINEAR_ELASTIC: if (a.all_affine && a.qmom) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 3>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
             case FH_NEO_HOOKEAN: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
             case FH_STVK: if (a.all_affine) hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_STVK, VT_TS, 2>), g, dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_pass_tiled<FH_HEX8, FH_STVK, VT_TS, 1>), g, dim3(VT_TS), 0, stream, a, t, active, partial); return 0;
             default: return -1;

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Resource usage + instruction histogram of one kernel of libfenris_hip.so (no GPU needed).
-#   scripts/kernel_info.sh <mangled-name-substring> [instruction-regex]
+#   [OBJ=unit.o] scripts/kernel_info.sh <mangled-name-substring> [instruction-regex]
 # e.g. scripts/kernel_info.sh k_gather_pipelinedILi1ELi1ELi8ELi2ELb0ELb1E 'ds_|global_|s_waitcnt|s_barrier'
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 LLVM=/opt/rocm/lib/llvm/bin
 TMP=$(mktemp -d)
-objcopy -O binary --only-section=.hip_fatbin "$ROOT/fenris_amd/lib/libfenris_hip.so" "$TMP/fat.bin"
+# (the library holds one bundle per translation unit since the engine was split: OBJ=<file>.o names the unit the kernel lives in)
+SRC="${OBJ:+$ROOT/fenris_amd/csrc/$OBJ}"; SRC="${SRC:-$ROOT/fenris_amd/lib/libfenris_hip.so}"
+objcopy -O binary --only-section=.hip_fatbin "$SRC" "$TMP/fat.bin"
 $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input="$TMP/fat.bin" --output="$TMP/dev.co" --unbundle
 SYM=$($LLVM/llvm-readelf --notes "$TMP/dev.co" | grep '\.name:' | awk '{print $2}' | grep "$1" | head -1)
 echo "kernel: $SYM"

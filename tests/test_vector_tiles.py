@@ -188,3 +188,64 @@ def test_tiles_survive_a_vertex_update(oracle):
         assert np.abs(want2 - want).max() > 1e-3 * np.abs(want).max()      # (the update did change the answer)
     finally:
         engine.close()
+
+
+@pytest.mark.parametrize("opname", ["LAPLACE", "LINEAR_ELASTIC"])
+def test_quadrature_free_residual_of_affine_hex8_meshes(oracle, opname):
+    """Round 5: when every Hex8 element is a parallelepiped, the operator is linear (Laplace, LinearElastic with one parameter pair) and the rule is
+    symmetric in every coordinate, the residual's element pass integrates the seven monomial terms of the integrand with the rule's moments
+    instead of looping over the points (element_pass.hpp, AFFM = 2).  Against the oracle (elliptic.rs:457-531 restated) at 1e-12 and against the
+    point loop of the same library (FENRIS_HIP_NO_MOMENT_RESIDUAL=1) on sheared, graded and mirrored boxes, for the 8- and the 27-point Gauss
+    rule; a rule with one point moved (odd moments no longer vanish) and parameters that differ from point to point keep the point loop and
+    must give the oracle's vector as well."""
+    rng = np.random.default_rng(23)
+    box = fa.procedural.create_rectangular_uniform_hex_mesh(1.0, 7, 6, 8, 1)
+    A = np.array([[1.0, 0.3, 0.1], [0.0, 0.8, -0.2], [0.25, 0.0, 1.4]])
+    meshes = {
+        "box": box,
+        "sheared": fa.Mesh(box.vertices @ A.T + np.array([3.0, -1.0, 0.5]), box.connectivity, fa.HEX8),
+        "graded": fa.Mesh(np.stack([box.vertices[:, 0] ** 1.7, box.vertices[:, 1] ** 0.8 * 2.0, np.expm1(box.vertices[:, 2])], axis=1),
+                          box.connectivity, fa.HEX8),
+        "mirrored": fa.Mesh(box.vertices * np.array([-1.0, 1.0, 1.0]), box.connectivity, fa.HEX8),
+    }
+    s = 1 if opname == "LAPLACE" else 3
+    rules = {"gauss2": quadrature.tensor.hexahedron_gauss(2), "gauss3": quadrature.tensor.hexahedron_gauss(3)}
+    w2, p2 = rules["gauss2"]
+    p_moved = np.array(p2, dtype=np.float64).copy()
+    p_moved[3, 0] += 0.05
+    rules["gauss2, one point moved"] = (w2, p_moved)
+    for mname, mesh in meshes.items():
+        u = rng.uniform(-1, 1, s * mesh.num_nodes())
+        for rname, (w, p) in rules.items():
+            got = {}
+            for no_moments in (0, 1):
+                eng = fa.Engine(0)
+                try:
+                    eng.set_option("FENRIS_HIP_NO_MOMENT_RESIDUAL", no_moments)
+                    asm = _assembler(eng, mesh, opname, w, p, u)
+                    got[no_moments] = np.asarray(fa.VectorAssembler().assemble_vector(asm)).copy()
+                    assert eng.last_kernel_name() == TILED
+                finally:
+                    eng.close()
+            st, want = _oracle_vector(oracle, oracle.HEX8, opname, mesh, np.asarray(mesh.connectivity), w, p, u)
+            assert st == 0
+            scale = np.abs(want).max()
+            assert np.abs(got[0] - want).max() <= 1e-12 * scale, (mname, rname)
+            assert np.abs(got[1] - want).max() <= 1e-12 * scale, (mname, rname)
+            assert np.abs(got[0] - got[1]).max() <= 1e-13 * scale, (mname, rname)
+    if opname == "LINEAR_ELASTIC":   # parameters that differ from point to point: the point loop
+        mesh = meshes["sheared"]
+        u = rng.uniform(-1, 1, 3 * mesh.num_nodes())
+        pairs = np.stack([3.0e2 * (1.0 + 0.1 * np.arange(len(w2))), 5.0e2 * (1.0 - 0.05 * np.arange(len(w2)))], axis=1)
+        eng = fa.Engine(0)
+        try:
+            qt = fa.UniformQuadratureTable.from_points_and_weights(p2, w2).with_data([fa.LameParameters(a, b) for a, b in pairs])
+            asm = (fa.ElementEllipticAssemblerBuilder(eng).with_finite_element_space(mesh)
+                   .with_operator(fa.MaterialEllipticOperator(fa.LinearElasticMaterial())).with_quadrature_table(qt).with_u(u).build())
+            got = np.asarray(fa.VectorAssembler().assemble_vector(asm))
+        finally:
+            eng.close()
+        ref = oracle.ElementAssembler(oracle.HEX8, oracle.LINEAR_ELASTIC, mesh.vertices, mesh.connectivity, w2, p2, params=pairs, u=u)
+        st, _, want = oracle.assemble_vector(ref)
+        assert st == 0
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()

@@ -24,7 +24,13 @@ int launch_hex27_mfma(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     if (st == c->tp_stream1 && c->tp_gather_cus > 0) dev_cus = std::max(1, dev_cus - c->tp_gather_cus);   // (CU-masked stream: the CUs left to this pass)
     const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", wgs_default)))));
     if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
-        auto kern = k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
+        auto kern = c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0 ? k_hex27_dense_mfma<FH_NEO_HOOKEAN, true, 1> : k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);
+    } else if (c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0) {
+        // the 4 x 4 x 4 block form (round 5 experiment, hex27_mfma.hpp "second form"): parity-green and bit-symmetric, measured SLOWER than the
+        // 16 x 16 tiles in its first two versions (7.80 / 8.33 against 7.37 / 7.58 ms on the same boxes, profiles/r05_c4_mfma_blocks.txt): opt-in
+        auto kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_mfma<FH_NEO_HOOKEAN, false, 1> : k_hex27_dense_mfma<FH_LINEAR_ELASTIC, false, 1>;
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);
     } else if (c->op == FH_NEO_HOOKEAN) {

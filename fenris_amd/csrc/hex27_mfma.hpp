@@ -68,7 +68,10 @@ struct Hex27Lds {
     static constexpr int total = o_A + 3 * RP * QS;
 };
 
-template <int OP, bool TRACE = false>
+// FORM 0 (the default): 16 x 16 tiles, v_mfma_f64_16x16x4.  FORM 1 (round 5 experiment, FENRIS_HIP_HEX27_BLOCKS=1): the products as 4 x 4 x 4
+// blocks, v_mfma_f64_4x4x4_4b -- see "matrix cores, second form" below: the instruction is 1.6 - 2 x faster per flop on this part, the form as
+// built is not (its operand fetches and its 32-byte store pieces cost more than the instruction saves; profiles/r05_c4_mfma_blocks.txt).
+template <int OP, bool TRACE = false, int FORM = 0>
 __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
     using L = Hex27Lds;
     constexpr int N = L::N, NG = L::NG, NQ = L::NQ, RP = L::RP, QS = L::QS;
@@ -103,9 +106,14 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
             const double y = rsqrt_newton(x), r = x * y;
             return fma(fma(-r, r, x), 0.5 * y, r);
         };
-        const double cd = c_l - c_a, rd = root(fabs(cd)), rm = root(fabs(c_m));
         lds[L::o_coef + q] = c_l;
         lds[L::o_coef + 28 + q] = -c_a;
+        if constexpr (FORM == 1) {   // the coefficient goes to ONE operand (the mirror images are copies there, see the stores): no roots
+            lds[L::o_coef + 56 + q] = c_l - c_a;
+            lds[L::o_coef + 112 + q] = c_m;
+            return;
+        }
+        const double cd = c_l - c_a, rd = root(fabs(cd)), rm = root(fabs(c_m));
         lds[L::o_coef + 56 + q] = copysign(rd, cd);
         lds[L::o_coef + 84 + q] = rd;
         lds[L::o_coef + 112 + q] = copysign(rm, c_m);
@@ -274,6 +282,220 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
             }
             lds_barrier();
             mark(5);
+        }
+        if constexpr (FORM == 1) {
+        // ---- matrix cores, second form (round 5): 4 x 4 x 4 blocks.
+        // Measured on this part (scripts/ubench/mfma_f64_rate.hip, profiles/r05_c4_mfma_blocks.txt): v_mfma_f64_16x16x4 issues once per ~100 cycles
+        // and SIMD whatever the number of wavefronts and accumulators (46 - 48 TFLOP/s, 61 % of the 78.6 the part is specified with; 33 - 35 with
+        // one wavefront per SIMD), v_mfma_f64_4x4x4_4b -- four independent 4 x 4 x 4 products per instruction -- reaches 75 TFLOP/s (55 - 68 with
+        // one wavefront).  The 16 x 16 tiles above were bound by exactly that: 73.5 instructions per wavefront and element x 100 cycles = 80 % of
+        // the pass.  The block form also pads 27 to 28 instead of 32 and can leave out the mirrored blocks one by one:
+        //   * a register holds FOUR node blocks (nodes 4 B .. 4 B + 3) x four points: lane = (i + 4 g) + 16 k reads node 4 arr[g] + i at point
+        //     4 ks + k -- which blocks, the ARRANGEMENT, is the lane's choice of address (layout found by experiment: scripts/ubench/
+        //     mfma_f64_4x4_layout.hip; the result D[i][j] of group g sits in lane (j + 4 g) + 16 i);
+        //   * one instruction multiplies row blocks arrA[g] by column blocks arrB[g], g = 0 .. 3.  A0 = (0, 1, 2, 3) and A1 = (4, 5, 6, 6) against
+        //     the seven rotations B_r = (r, r + 1, r + 2, r + 3) mod 7 (A1 against B_(r + 4)) cover all 7 x 7 blocks in 14 instructions (7 of the 56
+        //     blocks are duplicates, dropped at the store): 9 operand fetches for 14 instructions -- the components off the diagonal;
+        //   * a symmetric result (K_ii, trace term) needs its 28 upper blocks only: A0 x B_0 .. B_3 and three mixed arrangements X1 .. X3,
+        //     7 instructions instead of 14; the lower blocks are stored as copies (bit-identical, like util.rs:38-51 mirrors), and inside a
+        //     diagonal block the entries below the diagonal are copies as well, so the coefficient can multiply ONE operand.
+        // Per k-step and workgroup: 3 x 28 (off the diagonal, two terms each) + 6 x 7 (three diagonal components, three parts of the trace term)
+        // = 126 instructions of 512 flop = 1.1 x the useful work (the tiles: 42 x 2 048 = 1.45 x).  Wavefronts 0 - 2 take one component off the
+        // diagonal each, wavefront 3 the symmetric ones (K_ii = its two results added in registers: nothing crosses wavefronts).
+        const int role = (__builtin_amdgcn_readfirstlane(wave) + (int)(((w - w0) / Gs) & 3)) & 3;   // rotates from element to element: every SIMD gets every role
+        // (the lane id behind an empty asm: everything derived from it is formed per element instead of being kept in registers across the
+        // element loop as a loop invariant -- twenty operand offsets for the two roles together, which is what spilled)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int grp = (lane_o >> 2) & 3, idx = lane_o & 3, kq4 = lane_o >> 4;
+        // arrangements as packed nibbles (block of group g = (packed >> 4 g) & 15)
+        auto blk_of = [&](unsigned packed) { return (int)((packed >> (4 * grp)) & 15u); };
+        auto op_off = [&](unsigned packed) { return (unsigned)((min(4 * blk_of(packed) + idx, N) * QS + kq4) * 8); };   // byte offset inside one component's [RP][QS] array
+        constexpr unsigned ARR_A0 = 0x3210u, ARR_A1 = 0x6654u;
+        constexpr unsigned ARR_B[7] = {0x3210u, 0x4321u, 0x5432u, 0x6543u, 0x0654u, 0x1065u, 0x2106u};
+        constexpr unsigned ARR_XA[3] = {0x4210u, 0x4510u, 0x4560u}, ARR_XB[3] = {0x4654u, 0x5565u, 0x6666u};
+        const char* Gb = reinterpret_cast<const char*>(G);
+        const char* Ab = reinterpret_cast<const char*>(A);
+        auto ld = [&](const char* base, int comp, unsigned off, int ks) {
+            return *reinterpret_cast<const double*>(base + off + (size_t)((comp * RP * QS + 4 * ks) * 8));
+        };
+        const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * (81 * 81));
+        const unsigned long long ke_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ke_addr >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)ke_addr);
+        const auto ke_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ke_u), (short)0, 81 * 81 * 8, 0x00020000);
+        auto put = [&](unsigned voff, int soff_doubles, double v) {
+            typedef unsigned put_u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(put_u32x2, v), ke_rsrc, voff, soff_doubles * 8, 0);
+        };
+        // entry (I, J) of a component: I * 243 + J doubles from the component's first entry; a lane that must not store gets an offset beyond the
+        // matrix (the buffer's bounds check drops it): padding node 27, the duplicate group of A1, the lower half of a diagonal block
+        constexpr unsigned DROP = 0x40000000u;
+        if (HEX27_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (role < 3) {
+            // ---- a component off the diagonal: K_ij[I][J] = sum_q c_l a_I[i] a_J[j] - c_a a_I[j] a_J[i]   (i < j)
+            const int ci = role == 2 ? 1 : 0, cj = role == 0 ? 1 : 2;
+            const unsigned oA0 = op_off(ARR_A0), oA1 = op_off(ARR_A1);
+            unsigned oB[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) oB[r] = op_off(ARR_B[r]);
+            double acc0[7], acc1[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
+            if (!(TRACE && (a.ablate & 2))) {
+                // the operands of the NEXT k-step are fetched before this one's products (two sets that change roles; fully unrolled: no copies);
+                // without that every pair of matrix instructions waited out an LDS round trip (first form of this loop: 85 cycles per instruction)
+                struct OpsOff { double ai0, ai1, aj0, aj1, cl, nca, bi[7], bj[7]; };
+                auto fetch_off = [&](int ks) {
+                    OpsOff o;
+                    const int q = 4 * ks + kq4;
+                    o.cl = lds[L::o_coef + q]; o.nca = lds[L::o_coef + 28 + q];
+                    o.ai0 = ld(Ab, ci, oA0, ks); o.ai1 = ld(Ab, ci, oA1, ks); o.aj0 = ld(Ab, cj, oA0, ks); o.aj1 = ld(Ab, cj, oA1, ks);
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) { o.bi[r] = ld(Ab, ci, oB[r], ks); o.bj[r] = ld(Ab, cj, oB[r], ks); }
+                    return o;
+                };
+                auto mul_off = [&](const OpsOff& o) {
+                    const double pi0 = o.cl * o.ai0, pi1 = o.cl * o.ai1, pj0 = o.nca * o.aj0, pj1 = o.nca * o.aj1;
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi0, o.bj[r], acc0[r], 0, 0, 0);
+                        acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi1, o.bj[(r + 4) % 7], acc1[r], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pj0, o.bi[r], acc0[r], 0, 0, 0);
+                        acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pj1, o.bi[(r + 4) % 7], acc1[r], 0, 0, 0);
+                    }
+                };
+                OpsOff oo[2];
+                oo[0] = fetch_off(0);
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    if (ks < 6) oo[(ks + 1) & 1] = fetch_off(ks + 1);
+                    mul_off(oo[ks & 1]);
+                    asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
+            val_cur = val_n1;
+            node_n1 = node_n2;
+            e_cur = e_n1;
+            e_n1 = e_n2;
+            e_n2 = e_n3;
+            mark(6);
+            load_gref();
+            asm volatile("" ::: "memory");
+            if (!(TRACE && (a.ablate & 4))) {
+                // rows of the lane's result: I = 4 arrA[g] + kq4; columns J = 4 arrB[g] + idx.  The offsets are formed HERE, from a lane id the
+                // compiler cannot see through: as loop invariants it kept all 28 of them in registers across the element loop (40 spills)
+                int lane_s = lane;
+                asm volatile("" : "+v"(lane_s));
+                const int grp_s = (lane_s >> 2) & 3, idx_s = lane_s & 3, kq_s = lane_s >> 4;
+                auto blk_s = [&](unsigned packed) { return (int)((packed >> (4 * grp_s)) & 15u); };
+                const int I0 = 4 * blk_s(ARR_A0) + kq_s, I1 = 4 * blk_s(ARR_A1) + kq_s;
+                const bool ok0 = I0 < N, ok1 = I1 < N && grp_s < 3;
+                // direct: row part + column part; mirrored likewise (a dropped part alone puts the sum beyond the matrix, two of them as well)
+                const unsigned rowD0 = ok0 ? (unsigned)(I0 * (9 * N)) * 8u : DROP, rowD1 = ok1 ? (unsigned)(I1 * (9 * N)) * 8u : DROP;
+                const unsigned rowM0 = ok0 ? (unsigned)I0 * 8u : DROP, rowM1 = ok1 ? (unsigned)I1 * 8u : DROP;
+                unsigned colD[7], colM[7];
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    const int J = 4 * blk_s(ARR_B[r]) + idx_s;
+                    colD[r] = J < N ? (unsigned)J * 8u : DROP;
+                    colM[r] = J < N ? (unsigned)(J * (9 * N)) * 8u : DROP;
+                }
+                const int c_dir = (ci * 3 + cj) * N, c_mir = (cj * 3 + ci) * N;
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    put(rowD0 + colD[r], c_dir, acc0[r]);
+                    put(rowM0 + colM[r], c_mir, acc0[r]);
+                    put(rowD1 + colD[(r + 4) % 7], c_dir, acc1[r]);
+                    put(rowM1 + colM[(r + 4) % 7], c_mir, acc1[r]);
+                }
+            }
+        } else {
+            // ---- the symmetric ones: K_ii[I][J] = sum_q (c_l - c_a) a_I[i] a_J[i] + c_m sum_k g_I[k] g_J[k], upper blocks only
+            unsigned oRow[7], oCol[7];   // units 0 .. 3: A0 x B_u; 4 .. 6: the mixed arrangements
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { oRow[u] = op_off(ARR_A0); oCol[u] = op_off(ARR_B[u]); }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { oRow[4 + u] = op_off(ARR_XA[u]); oCol[4 + u] = op_off(ARR_XB[u]); }
+            double accD[3][7], accM[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) { accM[u] = 0.0; accD[0][u] = 0.0; accD[1][u] = 0.0; accD[2][u] = 0.0; }
+            if (!(TRACE && (a.ablate & 2))) {
+                // 42 half-groups (k-step, component, a / g): eleven operands and seven products each, the next half-group's operands fetched
+                // before this one's products (two sets that change roles; fully unrolled)
+                struct OpsSym { double c, row[4], col[7]; };   // row[0]: arrangement A0 (units 0 .. 3), row[1 .. 3]: the mixed ones
+                auto fetch_sym = [&](int n) {
+                    const int ks = n / 6, i = (n % 6) >> 1, part = n & 1;
+                    const char* base = part ? Gb : Ab;
+                    OpsSym o;
+                    o.c = lds[L::o_coef + (part ? 112 : 56) + 4 * ks + kq4];
+                    o.row[0] = ld(base, i, oRow[0], ks);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) o.row[1 + u] = ld(base, i, oRow[4 + u], ks);
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) o.col[u] = ld(base, i, oCol[u], ks);
+                    return o;
+                };
+                auto mul_sym = [&](int n, const OpsSym& o) {
+                    const int i = (n % 6) >> 1, part = n & 1;
+                    double sr[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sr[t] = o.c * o.row[t];
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        const double ra = sr[u < 4 ? 0 : u - 3];
+                        if (part) accM[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ra, o.col[u], accM[u], 0, 0, 0);
+                        else accD[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ra, o.col[u], accD[i][u], 0, 0, 0);
+                    }
+                };
+                OpsSym os[2];
+                os[0] = fetch_sym(0);
+#pragma unroll
+                for (int n = 0; n < 42; ++n) {
+                    if (n < 41) os[(n + 1) & 1] = fetch_sym(n + 1);
+                    mul_sym(n, os[n & 1]);
+                    asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
+            val_cur = val_n1;
+            node_n1 = node_n2;
+            e_cur = e_n1;
+            e_n1 = e_n2;
+            e_n2 = e_n3;
+            mark(6);
+            load_gref();
+            asm volatile("" ::: "memory");
+            if (!(TRACE && (a.ablate & 4))) {
+                int lane_s = lane;   // (see the other role)
+                asm volatile("" : "+v"(lane_s));
+                const int grp_s = (lane_s >> 2) & 3, idx_s = lane_s & 3, kq_s = lane_s >> 4;
+                auto blk_s = [&](unsigned packed) { return (int)((packed >> (4 * grp_s)) & 15u); };
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const unsigned pa = u < 4 ? ARR_A0 : ARR_XA[u < 4 ? 0 : u - 4], pb = u < 4 ? ARR_B[u < 4 ? u : 0] : ARR_XB[u < 4 ? 0 : u - 4];
+                    const int bI = blk_s(pa), bJ = blk_s(pb);
+                    const int I = 4 * bI + kq_s, J = 4 * bJ + idx_s;
+                    const bool in = I < N && J < N;
+                    // a diagonal block: the entries on and above its diagonal are stored, those below it are the copies
+                    const bool dir = in && (bI != bJ || kq_s <= idx_s), mir = in && (bI != bJ || kq_s < idx_s);
+                    const unsigned d = dir ? (unsigned)(I * (9 * N) + J) * 8u : DROP, m = mir ? (unsigned)(J * (9 * N) + I) * 8u : DROP;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double v = accD[i][u] + accM[u];
+                        put(d, (i * 3 + i) * N, v);
+                        put(m, (i * 3 + i) * N, v);
+                    }
+                }
+            }
+        }
+        mark(7);
+        lds_barrier();  // the next element's prologue overwrites G / A
+        mark(8);
+        continue;
         }
         // ---- matrix cores: wavefront w owns tile (tI, tJ) of the six K_ij with i <= j and of the trace term.
         // K_ji = K_ij^T (the element matrix is symmetric; util.rs:38-51 mirrors the upper triangle scalar by scalar), so the

@@ -150,3 +150,48 @@ def test_two_pass_path_is_bit_reproducible(oracle):
                 assert np.array_equal(k.values, ref_vals), grid
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("op,per_point", [("LINEAR_ELASTIC", False), ("NEO_HOOKEAN", False), ("NEO_HOOKEAN", True)])
+def test_block_form_of_the_first_pass(oracle, op, per_point):
+    """Round 5 experiment (FENRIS_HIP_HEX27_BLOCKS=1, hex27_mfma.hpp FORM 1): the element matrices from 4 x 4 x 4 blocks (v_mfma_f64_4x4x4_4b)
+    instead of 16 x 16 tiles -- the oracle's matrix at 1e-12, symmetric bit for bit (lower blocks and the lower halves of the diagonal blocks are
+    stored copies), NaN blocks where det F <= 0 (materials.rs:298-300), with many elements per workgroup (roles rotate from element to element),
+    and the same bits from run to run."""
+    eng = fa.Engine(0)
+    try:
+        eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 1)
+        eng.set_option("FENRIS_HIP_TWO_PASS_GRID", 3)            # 12 elements on three workgroups: every wavefront takes every role
+        mesh = _mesh(1)
+        u = 0.01 * np.random.default_rng(2).standard_normal(3 * mesh.num_nodes())
+        asm, ref = _build(eng, oracle, mesh, op, u, per_point)
+        k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+        st, _, ro, ci, vals = oracle.assemble(ref)
+        assert st == 0 and np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
+        assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
+        a = k.to_scipy()
+        d = (a - a.T).tocoo()
+        assert d.nnz == 0 or not np.any(d.data != 0.0)
+        k2 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert np.array_equal(k.values, k2.values)
+        # the tiles in the same context: the same matrix to rounding
+        eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 0)
+        k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert np.abs(k3.values - k.values).max() <= 1e-12 * np.abs(vals).max()
+        if op == "NEO_HOOKEAN" and not per_point:
+            eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 1)
+            mesh = _mesh(7)
+            u = 0.002 * np.random.default_rng(8).standard_normal(3 * mesh.num_nodes())
+            nodes = mesh.connectivity[4].astype(int)
+            centre = mesh.vertices[nodes].mean(axis=0)
+            for n in nodes:
+                u[3 * n: 3 * n + 3] = -2.2 * (mesh.vertices[n] - centre)
+            asm, ref = _build(eng, oracle, mesh, "NEO_HOOKEAN", u)
+            k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            vals = oracle.assemble(ref)[4]
+            assert np.isnan(vals).any() and np.array_equal(np.isnan(k.values), np.isnan(vals))
+            ok = ~np.isnan(vals)
+            assert np.abs(k.values[ok] - vals[ok]).max() <= 1e-12 * np.abs(vals[ok]).max()
+    finally:
+        eng.close()

@@ -28,8 +28,9 @@ int launch_hex27_mfma(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);
     } else if (c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0) {
-        // the 4 x 4 x 4 block form (round 5 experiment, hex27_mfma.hpp "second form"): parity-green and bit-symmetric, measured SLOWER than the
-        // 16 x 16 tiles in its first two versions (7.80 / 8.33 against 7.37 / 7.58 ms on the same boxes, profiles/r05_c4_mfma_blocks.txt): opt-in
+        // the 4 x 4 x 4 block form (round 5 experiment, hex27_mfma.hpp "second form"): parity-green and bit-symmetric; half the matrix-core time
+        // of the 16 x 16 tiles and still 3 - 4 % SLOWER end to end (7.30 - 7.38 against 7.04 - 7.07 ms on one box: the pass is latency-bound once
+        // the matrix instructions shrink, profiles/r05_c4_mfma_blocks.txt): opt-in
         auto kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_mfma<FH_NEO_HOOKEAN, false, 1> : k_hex27_dense_mfma<FH_LINEAR_ELASTIC, false, 1>;
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);

@@ -69,8 +69,9 @@ struct Hex27Lds {
 };
 
 // FORM 0 (the default): 16 x 16 tiles, v_mfma_f64_16x16x4.  FORM 1 (round 5 experiment, FENRIS_HIP_HEX27_BLOCKS=1): the products as 4 x 4 x 4
-// blocks, v_mfma_f64_4x4x4_4b -- see "matrix cores, second form" below: the instruction is 1.6 - 2 x faster per flop on this part, the form as
-// built is not (its operand fetches and its 32-byte store pieces cost more than the instruction saves; profiles/r05_c4_mfma_blocks.txt).
+// blocks, v_mfma_f64_4x4x4_4b -- see "matrix cores, second form" below: the instruction is 1.6 - 2 x faster per flop on this part and the form
+// halves the matrix-core time, but the pass as a whole does not get faster (7.30 - 7.38 against 7.04 - 7.07 ms: with three workgroups per CU the
+// latency of the prologue's seven phases is what remains; profiles/r05_c4_mfma_blocks.txt).
 template <int OP, bool TRACE = false, int FORM = 0>
 __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, double mu_u, double lambda_u) {
     using L = Hex27Lds;
@@ -288,37 +289,35 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
         // Measured on this part (scripts/ubench/mfma_f64_rate.hip, profiles/r05_c4_mfma_blocks.txt): v_mfma_f64_16x16x4 issues once per ~100 cycles
         // and SIMD whatever the number of wavefronts and accumulators (46 - 48 TFLOP/s, 61 % of the 78.6 the part is specified with; 33 - 35 with
         // one wavefront per SIMD), v_mfma_f64_4x4x4_4b -- four independent 4 x 4 x 4 products per instruction -- reaches 75 TFLOP/s (55 - 68 with
-        // one wavefront).  The 16 x 16 tiles above were bound by exactly that: 73.5 instructions per wavefront and element x 100 cycles = 80 % of
-        // the pass.  The block form also pads 27 to 28 instead of 32 and can leave out the mirrored blocks one by one:
-        //   * a register holds FOUR node blocks (nodes 4 B .. 4 B + 3) x four points: lane = (i + 4 g) + 16 k reads node 4 arr[g] + i at point
-        //     4 ks + k -- which blocks, the ARRANGEMENT, is the lane's choice of address (layout found by experiment: scripts/ubench/
-        //     mfma_f64_4x4_layout.hip; the result D[i][j] of group g sits in lane (j + 4 g) + 16 i);
-        //   * one instruction multiplies row blocks arrA[g] by column blocks arrB[g], g = 0 .. 3.  A0 = (0, 1, 2, 3) and A1 = (4, 5, 6, 6) against
-        //     the seven rotations B_r = (r, r + 1, r + 2, r + 3) mod 7 (A1 against B_(r + 4)) cover all 7 x 7 blocks in 14 instructions (7 of the 56
-        //     blocks are duplicates, dropped at the store): 9 operand fetches for 14 instructions -- the components off the diagonal;
-        //   * a symmetric result (K_ii, trace term) needs its 28 upper blocks only: A0 x B_0 .. B_3 and three mixed arrangements X1 .. X3,
-        //     7 instructions instead of 14; the lower blocks are stored as copies (bit-identical, like util.rs:38-51 mirrors), and inside a
-        //     diagonal block the entries below the diagonal are copies as well, so the coefficient can multiply ONE operand.
-        // Per k-step and workgroup: 3 x 28 (off the diagonal, two terms each) + 6 x 7 (three diagonal components, three parts of the trace term)
-        // = 126 instructions of 512 flop = 1.1 x the useful work (the tiles: 42 x 2 048 = 1.45 x).  Wavefronts 0 - 2 take one component off the
-        // diagonal each, wavefront 3 the symmetric ones (K_ii = its two results added in registers: nothing crosses wavefronts).
-        const int role = (__builtin_amdgcn_readfirstlane(wave) + (int)(((w - w0) / Gs) & 3)) & 3;   // rotates from element to element: every SIMD gets every role
-        // (the lane id behind an empty asm: everything derived from it is formed per element instead of being kept in registers across the
-        // element loop as a loop invariant -- twenty operand offsets for the two roles together, which is what spilled)
+        // one wavefront).  The 16 x 16 tiles below are bound by exactly that.  The block form pads 27 to 28 instead of 32 and leaves out the
+        // mirrored blocks of the symmetric components row block by row block.
+        //   * Register layout (found by experiment, scripts/ubench/mfma_f64_4x4_layout.hip): A: lane = (i + 4 g) + 16 k, B: lane = (j + 4 g) + 16 k,
+        //     D: lane = (j + 4 g) + 16 i, g = the block.  Which node block a group g holds is the lane's choice of LDS address.
+        //   * Third version of this form: ROW BROADCAST x COLUMN WINDOW.  The A operand holds ONE row block IB in all four groups (the four groups
+        //     read the same addresses: a broadcast), the B operand a window of sixteen consecutive nodes (four consecutive column blocks: the
+        //     conflict-free access the row stride of 29 was chosen for).  The result is then rows 4 IB .. 4 IB + 3 x sixteen consecutive columns:
+        //     the direct stores write runs of sixteen doubles like the tiles do.  Windows: W0 = nodes 0 .. 15, W1 = 16 .. 27 (+ padding), and for
+        //     row block 3 of the symmetric components Wx = 12 .. 27 (its four upper blocks in one instruction).
+        //     (First version: seven rotated column arrangements against two row arrangements -- 9 fetches per 14 instructions but wrapped
+        //     arrangements with bank conflicts, 32-byte store pieces and one wavefront with 3.4 x the fetches of the others: 7.80 ms against 7.37.)
+        //   * Work: wavefront role r = 0, 1, 2 takes row blocks r and 6 - r (38 instructions per k-step), role 3 row block 3 and the component
+        //     (1, 2) of row blocks 0 - 2 (30); roles rotate from element to element.  K_ii = its own part + the trace term, both in the registers
+        //     of the wavefront that owns the row block.  144 instructions of 512 flop per k-step and workgroup (the tiles: 42 of 2 048).
+        //   * The coefficient multiplies the A operand only; the lower blocks of the symmetric components and the lower halves of their diagonal
+        //     blocks are stored as copies of the upper ones (bit-identical, like util.rs:38-51 mirrors): no square roots in the prologue.
+        const int role = (__builtin_amdgcn_readfirstlane(wave) + (int)(((w - w0) / Gs) & 3)) & 3;   // rotates: every SIMD gets every role
+        // (the lane id behind an empty asm: everything derived from it is formed per element instead of living in registers across the loop)
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int grp = (lane_o >> 2) & 3, idx = lane_o & 3, kq4 = lane_o >> 4;
-        // arrangements as packed nibbles (block of group g = (packed >> 4 g) & 15)
-        auto blk_of = [&](unsigned packed) { return (int)((packed >> (4 * grp)) & 15u); };
-        auto op_off = [&](unsigned packed) { return (unsigned)((min(4 * blk_of(packed) + idx, N) * QS + kq4) * 8); };   // byte offset inside one component's [RP][QS] array
-        constexpr unsigned ARR_A0 = 0x3210u, ARR_A1 = 0x6654u;
-        constexpr unsigned ARR_B[7] = {0x3210u, 0x4321u, 0x5432u, 0x6543u, 0x0654u, 0x1065u, 0x2106u};
-        constexpr unsigned ARR_XA[3] = {0x4210u, 0x4510u, 0x4560u}, ARR_XB[3] = {0x4654u, 0x5565u, 0x6666u};
+        const int l15 = lane_o & 15, idx = lane_o & 3, kq4 = lane_o >> 4;
+        auto win_off = [&](int start) { return (unsigned)((min(start + l15, N) * QS + kq4) * 8); };      // window of 16 nodes from `start`
+        auto row_off = [&](int IB) { return (unsigned)((min(4 * IB + idx, N) * QS + kq4) * 8); };        // row block IB in every group
         const char* Gb = reinterpret_cast<const char*>(G);
         const char* Ab = reinterpret_cast<const char*>(A);
-        auto ld = [&](const char* base, int comp, unsigned off, int ks) {
-            return *reinterpret_cast<const double*>(base + off + (size_t)((comp * RP * QS + 4 * ks) * 8));
+        auto ldc = [&](const char* base, int comp, unsigned off) {   // `off` carries the k-step
+            return *reinterpret_cast<const double*>(base + off + (size_t)(comp * RP * QS * 8));
         };
+        auto mm = [](double x, double y, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, acc, 0, 0, 0); };
         const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * (81 * 81));
         const unsigned long long ke_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ke_addr >> 32)) << 32) |
                                         (unsigned)__builtin_amdgcn_readfirstlane((int)ke_addr);
@@ -327,169 +326,193 @@ __global__ void __launch_bounds__(256, 3) k_hex27_dense_mfma(const KArgs a, doub
             typedef unsigned put_u32x2 __attribute__((ext_vector_type(2)));
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(put_u32x2, v), ke_rsrc, voff, soff_doubles * 8, 0);
         };
-        // entry (I, J) of a component: I * 243 + J doubles from the component's first entry; a lane that must not store gets an offset beyond the
-        // matrix (the buffer's bounds check drops it): padding node 27, the duplicate group of A1, the lower half of a diagonal block
-        constexpr unsigned DROP = 0x40000000u;
-        if (HEX27_PRIO) __builtin_amdgcn_s_setprio(0);
-        if (role < 3) {
-            // ---- a component off the diagonal: K_ij[I][J] = sum_q c_l a_I[i] a_J[j] - c_a a_I[j] a_J[i]   (i < j)
-            const int ci = role == 2 ? 1 : 0, cj = role == 0 ? 1 : 2;
-            const unsigned oA0 = op_off(ARR_A0), oA1 = op_off(ARR_A1);
-            unsigned oB[7];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) oB[r] = op_off(ARR_B[r]);
-            double acc0[7], acc1[7];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
-            if (!(TRACE && (a.ablate & 2))) {
-                // the operands of the NEXT k-step are fetched before this one's products (two sets that change roles; fully unrolled: no copies);
-                // without that every pair of matrix instructions waited out an LDS round trip (first form of this loop: 85 cycles per instruction)
-                struct OpsOff { double ai0, ai1, aj0, aj1, cl, nca, bi[7], bj[7]; };
-                auto fetch_off = [&](int ks) {
-                    OpsOff o;
-                    const int q = 4 * ks + kq4;
-                    o.cl = lds[L::o_coef + q]; o.nca = lds[L::o_coef + 28 + q];
-                    o.ai0 = ld(Ab, ci, oA0, ks); o.ai1 = ld(Ab, ci, oA1, ks); o.aj0 = ld(Ab, cj, oA0, ks); o.aj1 = ld(Ab, cj, oA1, ks);
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) { o.bi[r] = ld(Ab, ci, oB[r], ks); o.bj[r] = ld(Ab, cj, oB[r], ks); }
-                    return o;
-                };
-                auto mul_off = [&](const OpsOff& o) {
-                    const double pi0 = o.cl * o.ai0, pi1 = o.cl * o.ai1, pj0 = o.nca * o.aj0, pj1 = o.nca * o.aj1;
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi0, o.bj[r], acc0[r], 0, 0, 0);
-                        acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi1, o.bj[(r + 4) % 7], acc1[r], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pj0, o.bi[r], acc0[r], 0, 0, 0);
-                        acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(pj1, o.bi[(r + 4) % 7], acc1[r], 0, 0, 0);
-                    }
-                };
-                OpsOff oo[2];
-                oo[0] = fetch_off(0);
-#pragma unroll
-                for (int ks = 0; ks < 7; ++ks) {
-                    if (ks < 6) oo[(ks + 1) & 1] = fetch_off(ks + 1);
-                    mul_off(oo[ks & 1]);
-                    asm volatile("" ::: "memory");
-                }
-            }
+        constexpr unsigned DROP = 0x80000000u;   // an offset beyond the matrix: the buffer's bounds check drops the lane's store
+        // offsets of the lane's entry (I, J) = (4 IB + i, start + lane & 15) for the stores of one (row block, window): direct and mirrored, for a
+        // component off the diagonal (every entry inside the matrix) and for a symmetric one (direct: blocks on and above the diagonal, in the
+        // diagonal block the entries on and above ITS diagonal; mirrored: the same without the diagonal itself)
+        struct StOff { unsigned dir, mir, dirs, mirs; };
+        auto st_off = [&](int IB, int start, int ls) {
+            const int i = ls >> 4, J = start + (ls & 15), I = 4 * IB + i, JB = J >> 2, jj = J & 3;
+            const bool valid = I < N && J < N;
+            const bool upper = JB > IB || (JB == IB && i <= jj), strict = JB > IB || (JB == IB && i < jj);
+            StOff o;
+            o.dir = valid ? (unsigned)(I * (9 * N) + J) * 8u : DROP;
+            o.mir = valid ? (unsigned)(J * (9 * N) + I) * 8u : DROP;
+            o.dirs = (valid && upper) ? o.dir : DROP;
+            o.mirs = (valid && strict) ? o.mir : DROP;
+            return o;
+        };
+        auto rotate_inputs = [&]() {
+            // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
             asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
             val_cur = val_n1;
             node_n1 = node_n2;
             e_cur = e_n1;
             e_n1 = e_n2;
             e_n2 = e_n3;
+        };
+        if (HEX27_PRIO) __builtin_amdgcn_s_setprio(0);
+        unsigned oC = (unsigned)(kq4 * 8);
+        unsigned oW0 = win_off(0), oW1 = win_off(16);
+        if (role < 3) {
+            // ---- row blocks IBa = role (windows W0 and W1; components (0, 1), (0, 2) off the diagonal) and IBb = 6 - role (symmetric: W1 only)
+            const int IBa = role, IBb = 6 - role;
+            unsigned oRa = row_off(IBa), oRb = row_off(IBb);
+            double aD[3][2], aM[2], a01[2], a02[2], bD[3], bM = 0.0, b01[2], b02[2], b12[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { aM[t] = 0.0; a01[t] = 0.0; a02[t] = 0.0; b01[t] = 0.0; b02[t] = 0.0; b12[t] = 0.0; aD[0][t] = 0.0; aD[1][t] = 0.0; aD[2][t] = 0.0; }
+            bD[0] = 0.0; bD[1] = 0.0; bD[2] = 0.0;
+            if (!(TRACE && (a.ablate & 2))) {
+#pragma unroll 1
+                for (int ks = 0; ks < 7; ++ks) {
+                    double Wa[3][2], Wg[3][2], ra[3], rg[3], rb[3], rh[3];
+                    const double cl = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef) + oC);
+                    const double nca = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 28) + oC);
+                    const double cd = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 56) + oC);
+                    const double cm = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 112) + oC);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ra[c] = ldc(Ab, c, oRa); rg[c] = ldc(Gb, c, oRa); }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { Wa[c][0] = ldc(Ab, c, oW0); Wa[c][1] = ldc(Ab, c, oW1); Wg[c][0] = ldc(Gb, c, oW0); Wg[c][1] = ldc(Gb, c, oW1); }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { rb[c] = ldc(Ab, c, oRb); rh[c] = ldc(Gb, c, oRb); }
+                    {   // row block IBa
+                        const double s0 = cd * ra[0], s1 = cd * ra[1], s2 = cd * ra[2], g0 = cm * rg[0], g1 = cm * rg[1], g2 = cm * rg[2];
+                        const double l0 = cl * ra[0], n1 = nca * ra[1], n2 = nca * ra[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            aD[0][t] = mm(s0, Wa[0][t], aD[0][t]); aD[1][t] = mm(s1, Wa[1][t], aD[1][t]); aD[2][t] = mm(s2, Wa[2][t], aD[2][t]);
+                            aM[t] = mm(g0, Wg[0][t], aM[t]); a01[t] = mm(l0, Wa[1][t], a01[t]); a02[t] = mm(l0, Wa[2][t], a02[t]);
+                            aM[t] = mm(g1, Wg[1][t], aM[t]); a01[t] = mm(n1, Wa[0][t], a01[t]); a02[t] = mm(n2, Wa[0][t], a02[t]);
+                            aM[t] = mm(g2, Wg[2][t], aM[t]);
+                        }
+                    }
+                    {   // row block IBb: its upper blocks lie in W1
+                        const double s0 = cd * rb[0], s1 = cd * rb[1], s2 = cd * rb[2], g0 = cm * rh[0], g1 = cm * rh[1], g2 = cm * rh[2];
+                        const double l0 = cl * rb[0], l1 = cl * rb[1], n1 = nca * rb[1], n2 = nca * rb[2];
+                        bD[0] = mm(s0, Wa[0][1], bD[0]); bD[1] = mm(s1, Wa[1][1], bD[1]); bD[2] = mm(s2, Wa[2][1], bD[2]);
+                        bM = mm(g0, Wg[0][1], bM);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            b01[t] = mm(l0, Wa[1][t], b01[t]); b02[t] = mm(l0, Wa[2][t], b02[t]); b12[t] = mm(l1, Wa[2][t], b12[t]);
+                            if (t == 0) bM = mm(g1, Wg[1][1], bM);
+                            b01[t] = mm(n1, Wa[0][t], b01[t]); b02[t] = mm(n2, Wa[0][t], b02[t]); b12[t] = mm(n2, Wa[1][t], b12[t]);
+                            if (t == 0) bM = mm(g2, Wg[2][1], bM);
+                        }
+                    }
+                    oC += 32u; oW0 += 32u; oW1 += 32u; oRa += 32u; oRb += 32u;
+                }
+            }
+            rotate_inputs();
             mark(6);
             load_gref();
             asm volatile("" ::: "memory");
             if (!(TRACE && (a.ablate & 4))) {
-                // rows of the lane's result: I = 4 arrA[g] + kq4; columns J = 4 arrB[g] + idx.  The offsets are formed HERE, from a lane id the
-                // compiler cannot see through: as loop invariants it kept all 28 of them in registers across the element loop (40 spills)
-                int lane_s = lane;
-                asm volatile("" : "+v"(lane_s));
-                const int grp_s = (lane_s >> 2) & 3, idx_s = lane_s & 3, kq_s = lane_s >> 4;
-                auto blk_s = [&](unsigned packed) { return (int)((packed >> (4 * grp_s)) & 15u); };
-                const int I0 = 4 * blk_s(ARR_A0) + kq_s, I1 = 4 * blk_s(ARR_A1) + kq_s;
-                const bool ok0 = I0 < N, ok1 = I1 < N && grp_s < 3;
-                // direct: row part + column part; mirrored likewise (a dropped part alone puts the sum beyond the matrix, two of them as well)
-                const unsigned rowD0 = ok0 ? (unsigned)(I0 * (9 * N)) * 8u : DROP, rowD1 = ok1 ? (unsigned)(I1 * (9 * N)) * 8u : DROP;
-                const unsigned rowM0 = ok0 ? (unsigned)I0 * 8u : DROP, rowM1 = ok1 ? (unsigned)I1 * 8u : DROP;
-                unsigned colD[7], colM[7];
+                int ls = lane;
+                asm volatile("" : "+v"(ls));
 #pragma unroll
-                for (int r = 0; r < 7; ++r) {
-                    const int J = 4 * blk_s(ARR_B[r]) + idx_s;
-                    colD[r] = J < N ? (unsigned)J * 8u : DROP;
-                    colM[r] = J < N ? (unsigned)(J * (9 * N)) * 8u : DROP;
+                for (int t = 0; t < 2; ++t) {
+                    const StOff o = st_off(IBa, 16 * t, ls);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double v = aD[i][t] + aM[t];
+                        put(o.dirs, (i * 3 + i) * N, v);
+                        put(o.mirs, (i * 3 + i) * N, v);
+                    }
+                    put(o.dir, (0 * 3 + 1) * N, a01[t]); put(o.mir, (1 * 3 + 0) * N, a01[t]);
+                    put(o.dir, (0 * 3 + 2) * N, a02[t]); put(o.mir, (2 * 3 + 0) * N, a02[t]);
                 }
-                const int c_dir = (ci * 3 + cj) * N, c_mir = (cj * 3 + ci) * N;
 #pragma unroll
-                for (int r = 0; r < 7; ++r) {
-                    put(rowD0 + colD[r], c_dir, acc0[r]);
-                    put(rowM0 + colM[r], c_mir, acc0[r]);
-                    put(rowD1 + colD[(r + 4) % 7], c_dir, acc1[r]);
-                    put(rowM1 + colM[(r + 4) % 7], c_mir, acc1[r]);
+                for (int t = 0; t < 2; ++t) {
+                    const StOff o = st_off(IBb, 16 * t, ls);
+                    if (t == 1) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const double v = bD[i] + bM;
+                            put(o.dirs, (i * 3 + i) * N, v);
+                            put(o.mirs, (i * 3 + i) * N, v);
+                        }
+                    }
+                    put(o.dir, (0 * 3 + 1) * N, b01[t]); put(o.mir, (1 * 3 + 0) * N, b01[t]);
+                    put(o.dir, (0 * 3 + 2) * N, b02[t]); put(o.mir, (2 * 3 + 0) * N, b02[t]);
+                    put(o.dir, (1 * 3 + 2) * N, b12[t]); put(o.mir, (2 * 3 + 1) * N, b12[t]);
                 }
             }
         } else {
-            // ---- the symmetric ones: K_ii[I][J] = sum_q (c_l - c_a) a_I[i] a_J[i] + c_m sum_k g_I[k] g_J[k], upper blocks only
-            unsigned oRow[7], oCol[7];   // units 0 .. 3: A0 x B_u; 4 .. 6: the mixed arrangements
+            // ---- row block 3 (symmetric components against the window 12 .. 27) and the component (1, 2) of row blocks 0, 1, 2
+            unsigned oWx = win_off(12), oR3 = row_off(3), oQ0 = row_off(0), oQ1 = row_off(1), oQ2 = row_off(2);
+            double cD[3], cM = 0.0, c01[2], c02[2], c12[2], d12[3][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { oRow[u] = op_off(ARR_A0); oCol[u] = op_off(ARR_B[u]); }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) { oRow[4 + u] = op_off(ARR_XA[u]); oCol[4 + u] = op_off(ARR_XB[u]); }
-            double accD[3][7], accM[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) { accM[u] = 0.0; accD[0][u] = 0.0; accD[1][u] = 0.0; accD[2][u] = 0.0; }
+            for (int t = 0; t < 2; ++t) { c01[t] = 0.0; c02[t] = 0.0; c12[t] = 0.0; d12[0][t] = 0.0; d12[1][t] = 0.0; d12[2][t] = 0.0; }
+            cD[0] = 0.0; cD[1] = 0.0; cD[2] = 0.0;
             if (!(TRACE && (a.ablate & 2))) {
-                // 42 half-groups (k-step, component, a / g): eleven operands and seven products each, the next half-group's operands fetched
-                // before this one's products (two sets that change roles; fully unrolled)
-                struct OpsSym { double c, row[4], col[7]; };   // row[0]: arrangement A0 (units 0 .. 3), row[1 .. 3]: the mixed ones
-                auto fetch_sym = [&](int n) {
-                    const int ks = n / 6, i = (n % 6) >> 1, part = n & 1;
-                    const char* base = part ? Gb : Ab;
-                    OpsSym o;
-                    o.c = lds[L::o_coef + (part ? 112 : 56) + 4 * ks + kq4];
-                    o.row[0] = ld(base, i, oRow[0], ks);
+#pragma unroll 1
+                for (int ks = 0; ks < 7; ++ks) {
+                    double Wa[3][2], Xa[3], Xg[3], r3[3], g3[3], q1[3], q2[3];
+                    const double cl = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef) + oC);
+                    const double nca = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 28) + oC);
+                    const double cd = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 56) + oC);
+                    const double cm = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds + L::o_coef + 112) + oC);
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) o.row[1 + u] = ld(base, i, oRow[4 + u], ks);
+                    for (int c = 0; c < 3; ++c) { r3[c] = ldc(Ab, c, oR3); g3[c] = ldc(Gb, c, oR3); }
 #pragma unroll
-                    for (int u = 0; u < 7; ++u) o.col[u] = ld(base, i, oCol[u], ks);
-                    return o;
-                };
-                auto mul_sym = [&](int n, const OpsSym& o) {
-                    const int i = (n % 6) >> 1, part = n & 1;
-                    double sr[4];
+                    for (int c = 0; c < 3; ++c) { Xa[c] = ldc(Ab, c, oWx); Xg[c] = ldc(Gb, c, oWx); Wa[c][0] = ldc(Ab, c, oW0); Wa[c][1] = ldc(Ab, c, oW1); }
+                    q1[0] = ldc(Ab, 1, oQ0); q1[1] = ldc(Ab, 1, oQ1); q1[2] = ldc(Ab, 1, oQ2);
+                    q2[0] = ldc(Ab, 2, oQ0); q2[1] = ldc(Ab, 2, oQ1); q2[2] = ldc(Ab, 2, oQ2);
+                    {
+                        const double s0 = cd * r3[0], s1 = cd * r3[1], s2 = cd * r3[2], g0 = cm * g3[0], g1 = cm * g3[1], g2 = cm * g3[2];
+                        const double l0 = cl * r3[0], l1 = cl * r3[1], n1 = nca * r3[1], n2 = nca * r3[2];
+                        cD[0] = mm(s0, Xa[0], cD[0]); cD[1] = mm(s1, Xa[1], cD[1]); cD[2] = mm(s2, Xa[2], cD[2]);
+                        cM = mm(g0, Xg[0], cM);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) sr[t] = o.c * o.row[t];
-#pragma unroll
-                    for (int u = 0; u < 7; ++u) {
-                        const double ra = sr[u < 4 ? 0 : u - 3];
-                        if (part) accM[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ra, o.col[u], accM[u], 0, 0, 0);
-                        else accD[i][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ra, o.col[u], accD[i][u], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) {
+                            c01[t] = mm(l0, Wa[1][t], c01[t]); c02[t] = mm(l0, Wa[2][t], c02[t]); c12[t] = mm(l1, Wa[2][t], c12[t]);
+                            if (t == 0) cM = mm(g1, Xg[1], cM);
+                            c01[t] = mm(n1, Wa[0][t], c01[t]); c02[t] = mm(n2, Wa[0][t], c02[t]); c12[t] = mm(n2, Wa[1][t], c12[t]);
+                            if (t == 0) cM = mm(g2, Xg[2], cM);
+                        }
                     }
-                };
-                OpsSym os[2];
-                os[0] = fetch_sym(0);
 #pragma unroll
-                for (int n = 0; n < 42; ++n) {
-                    if (n < 41) os[(n + 1) & 1] = fetch_sym(n + 1);
-                    mul_sym(n, os[n & 1]);
-                    asm volatile("" ::: "memory");
+                    for (int b = 0; b < 3; ++b) {
+                        const double l1 = cl * q1[b], n2 = nca * q2[b];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) d12[b][t] = mm(l1, Wa[2][t], d12[b][t]);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) d12[b][t] = mm(n2, Wa[1][t], d12[b][t]);
+                    }
+                    oC += 32u; oW0 += 32u; oW1 += 32u; oWx += 32u; oR3 += 32u; oQ0 += 32u; oQ1 += 32u; oQ2 += 32u;
                 }
             }
-            asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
-            val_cur = val_n1;
-            node_n1 = node_n2;
-            e_cur = e_n1;
-            e_n1 = e_n2;
-            e_n2 = e_n3;
+            rotate_inputs();
             mark(6);
             load_gref();
             asm volatile("" ::: "memory");
             if (!(TRACE && (a.ablate & 4))) {
-                int lane_s = lane;   // (see the other role)
-                asm volatile("" : "+v"(lane_s));
-                const int grp_s = (lane_s >> 2) & 3, idx_s = lane_s & 3, kq_s = lane_s >> 4;
-                auto blk_s = [&](unsigned packed) { return (int)((packed >> (4 * grp_s)) & 15u); };
-#pragma unroll
-                for (int u = 0; u < 7; ++u) {
-                    const unsigned pa = u < 4 ? ARR_A0 : ARR_XA[u < 4 ? 0 : u - 4], pb = u < 4 ? ARR_B[u < 4 ? u : 0] : ARR_XB[u < 4 ? 0 : u - 4];
-                    const int bI = blk_s(pa), bJ = blk_s(pb);
-                    const int I = 4 * bI + kq_s, J = 4 * bJ + idx_s;
-                    const bool in = I < N && J < N;
-                    // a diagonal block: the entries on and above its diagonal are stored, those below it are the copies
-                    const bool dir = in && (bI != bJ || kq_s <= idx_s), mir = in && (bI != bJ || kq_s < idx_s);
-                    const unsigned d = dir ? (unsigned)(I * (9 * N) + J) * 8u : DROP, m = mir ? (unsigned)(J * (9 * N) + I) * 8u : DROP;
+                int ls = lane;
+                asm volatile("" : "+v"(ls));
+                {
+                    const StOff o = st_off(3, 12, ls);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        const double v = accD[i][u] + accM[u];
-                        put(d, (i * 3 + i) * N, v);
-                        put(m, (i * 3 + i) * N, v);
+                        const double v = cD[i] + cM;
+                        put(o.dirs, (i * 3 + i) * N, v);
+                        put(o.mirs, (i * 3 + i) * N, v);
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const StOff o = st_off(3, 16 * t, ls);
+                    put(o.dir, (0 * 3 + 1) * N, c01[t]); put(o.mir, (1 * 3 + 0) * N, c01[t]);
+                    put(o.dir, (0 * 3 + 2) * N, c02[t]); put(o.mir, (2 * 3 + 0) * N, c02[t]);
+                    put(o.dir, (1 * 3 + 2) * N, c12[t]); put(o.mir, (2 * 3 + 1) * N, c12[t]);
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const StOff o = st_off(b, 16 * t, ls);
+                        put(o.dir, (1 * 3 + 2) * N, d12[b][t]); put(o.mir, (2 * 3 + 1) * N, d12[b][t]);
+                    }
             }
         }
         mark(7);

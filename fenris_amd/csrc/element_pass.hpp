@@ -236,7 +236,7 @@ __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const lon
     using O = OpT<OP, 3>;
     constexpr int D = 3, N = 8, S = O::S;
     constexpr bool AFF = AFFM != 0;
-    constexpr bool POLY = AFFM == 2 && WHAT == EP_VECTOR && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC);
+    constexpr bool POLY = AFFM == 2 && (OP == FH_LAPLACE || OP == FH_LINEAR_ELASTIC);   // (the energy too: a quadratic form, its cross moments vanish likewise)
     energy = 0.0;
     const double* par_e = a.rule_map ? a.rparams + (size_t)a.rule_map[ec] * a.nq * 2 : nullptr;
     // coefficients of the coordinate map and of u (c0 is not needed: only gradients enter)
@@ -373,7 +373,7 @@ __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const lon
         const double mu = (OP != FH_LAPLACE) ? ep_const(a.qparams)[0] : 0.0, lambda = (OP != FH_LAPLACE) ? ep_const(a.qparams)[1] : 0.0;
         // L restricted: ROWS = which rows (reference directions) of the coefficient matrix are present (bit j: row j = r_j), COLS = which
         // columns of M = P(J^-T R) J^-T are wanted
-        auto term = [&](auto rows_tag, auto cols_tag, int c0, int c1, int c2, double (&M)[S][D]) {
+        auto term = [&](auto rows_tag, auto cols_tag, int c0, int c1, int c2, double (&M)[S][D], double& psi_out) {
             constexpr int ROWS = decltype(rows_tag)::value, COLS = decltype(cols_tag)::value;
             const int cidx[3] = {c0, c1, c2};
             double gu[D][S];
@@ -393,6 +393,8 @@ __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const lon
                 }
             double P[S][D], psi;
             material_point<OP, D, S, WHAT>(gu, mu, lambda, P, psi);
+            psi_out = psi;
+            if constexpr (WHAT == EP_SCALAR) return;
 #pragma unroll
             for (int i = 0; i < S; ++i)
 #pragma unroll
@@ -410,17 +412,20 @@ __device__ __forceinline__ void element_pass_body_hex8(const KArgs& a, const lon
         // moments of the rule times |det J|: [0] sum w, [1..3] xi^2, eta^2, zeta^2, [4..6] eta^2 zeta^2, xi^2 zeta^2, xi^2 eta^2
         const ep_table mq = ep_const(a.qmom);
         double M1[S][D], Mx[S][D], My[S][D], Mz[S][D], Myz[S][D], Mxz[S][D], Mxy[S][D];
-        term(I7{}, I7{}, 1, 2, 4, M1);     // constant part: rows c1, c2, c4
-        term(I6{}, I6{}, 0, 3, 5, Mx);     // coefficient of xi:   d/deta has c3 xi, d/dzeta has c5 xi;   wanted: columns eta, zeta
-        term(I5{}, I5{}, 3, 0, 6, My);     // coefficient of eta:  d/dxi has c3 eta, d/dzeta has c6 eta;  wanted: columns xi, zeta
-        term(I3{}, I3{}, 5, 6, 0, Mz);     // coefficient of zeta: d/dxi has c5 zeta, d/deta has c6 zeta; wanted: columns xi, eta
-        term(I1{}, I1{}, 7, 0, 0, Myz);    // eta zeta: d/dxi has c7;   wanted: column xi
-        term(I2{}, I2{}, 0, 7, 0, Mxz);    // xi zeta:  d/deta has c7;  wanted: column eta
-        term(I4{}, I4{}, 0, 0, 7, Mxy);    // xi eta:   d/dzeta has c7; wanted: column zeta
+        double p1, px, py, pz, pyz, pxz, pxy;   // the energy density of each part (EP_SCALAR: psi is a quadratic form, the parts do not mix)
+        term(I7{}, I7{}, 1, 2, 4, M1, p1);     // constant part: rows c1, c2, c4
+        term(I6{}, I6{}, 0, 3, 5, Mx, px);     // coefficient of xi:   d/deta has c3 xi, d/dzeta has c5 xi;   wanted: columns eta, zeta
+        term(I5{}, I5{}, 3, 0, 6, My, py);     // coefficient of eta:  d/dxi has c3 eta, d/dzeta has c6 eta;  wanted: columns xi, zeta
+        term(I3{}, I3{}, 5, 6, 0, Mz, pz);     // coefficient of zeta: d/dxi has c5 zeta, d/deta has c6 zeta; wanted: columns xi, eta
+        term(I1{}, I1{}, 7, 0, 0, Myz, pyz);   // eta zeta: d/dxi has c7;   wanted: column xi
+        term(I2{}, I2{}, 0, 7, 0, Mxz, pxz);   // xi zeta:  d/deta has c7;  wanted: column eta
+        term(I4{}, I4{}, 0, 0, 7, Mxy, pxy);   // xi eta:   d/dzeta has c7; wanted: column zeta
         const double s0 = mq[0] * adet, sx = mq[1] * adet, sy = mq[2] * adet, sz = mq[3] * adet, syz = mq[4] * adet, sxz = mq[5] * adet,
                      sxy = mq[6] * adet;
+        if constexpr (WHAT == EP_SCALAR)
+            energy = fma(sxy, pxy, fma(sxz, pxz, fma(syz, pyz, fma(sz, pz, fma(sy, py, fma(sx, px, s0 * p1))))));
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
+        for (int i = 0; i < (WHAT == EP_VECTOR ? S : 0); ++i) {
             dk[i][1] = s0 * M1[i][0];
             dk[i][2] = s0 * M1[i][1];
             dk[i][4] = s0 * M1[i][2];

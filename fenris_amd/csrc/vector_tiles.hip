@@ -588,8 +588,8 @@ int vector_tiles_energy_pass(int elem_kind, int op, hipStream_t stream, const KA
     }
     if (elem_kind == FH_HEX8 && a.qmono) {
         switch (op) {
-            case FH_LAPLACE: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
-            case FH_LINEAR_ELASTIC: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            case FH_LAPLACE: if (a.all_affine && a.qmom) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 3>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LAPLACE, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
+            case FH_LINEAR_ELASTIC: if (a.all_affine && a.qmom) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 3>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_LINEAR_ELASTIC, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
             case FH_NEO_HOOKEAN: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_NEO_HOOKEAN, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
             case FH_STVK: if (a.all_affine) hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_STVK, VT_TS, 2>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); else hipLaunchKernelGGL((k_element_energy_tiled<FH_HEX8, FH_STVK, VT_TS, 1>), dim3(grid), dim3(VT_TS), 0, stream, a, t, active, partial); return grid;
             default: return -1;

@@ -217,7 +217,7 @@ def test_quadrature_free_residual_of_affine_hex8_meshes(oracle, opname):
     for mname, mesh in meshes.items():
         u = rng.uniform(-1, 1, s * mesh.num_nodes())
         for rname, (w, p) in rules.items():
-            got = {}
+            got, energy = {}, {}
             for no_moments in (0, 1):
                 eng = fa.Engine(0)
                 try:
@@ -225,6 +225,7 @@ def test_quadrature_free_residual_of_affine_hex8_meshes(oracle, opname):
                     asm = _assembler(eng, mesh, opname, w, p, u)
                     got[no_moments] = np.asarray(fa.VectorAssembler().assemble_vector(asm)).copy()
                     assert eng.last_kernel_name() == TILED
+                    energy[no_moments] = fa.assemble_scalar(asm)     # the energy takes the same route (a quadratic form: its parts do not mix)
                 finally:
                     eng.close()
             st, want = _oracle_vector(oracle, oracle.HEX8, opname, mesh, np.asarray(mesh.connectivity), w, p, u)
@@ -233,6 +234,11 @@ def test_quadrature_free_residual_of_affine_hex8_meshes(oracle, opname):
             assert np.abs(got[0] - want).max() <= 1e-12 * scale, (mname, rname)
             assert np.abs(got[1] - want).max() <= 1e-12 * scale, (mname, rname)
             assert np.abs(got[0] - got[1]).max() <= 1e-13 * scale, (mname, rname)
+            ref = oracle.ElementAssembler(oracle.HEX8, getattr(oracle, opname), mesh.vertices, np.asarray(mesh.connectivity), w, p,
+                                          params=(LAME.as_pair() if opname != "LAPLACE" else None), u=u)
+            st, _, eo = oracle.assemble_scalar(ref)
+            assert st == 0
+            assert abs(energy[0] - eo) <= 1e-12 * abs(eo) and abs(energy[1] - eo) <= 1e-12 * abs(eo), (mname, rname, energy, eo)
     if opname == "LINEAR_ELASTIC":   # parameters that differ from point to point: the point loop
         mesh = meshes["sheared"]
         u = rng.uniform(-1, 1, 3 * mesh.num_nodes())

@@ -4,7 +4,7 @@ Python host layer over the C ABI of libfenris_hip.so (include/fenris_hip.h).  On
 fenris -- global stiffness / residual assembly -- lives here; see DESIGN.md.
 """
 from . import _ffi, assembly, io, mesh, operators, quadrature, reorder
-from ._ffi import (ASSEMBLE_OVERWRITE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
+from ._ffi import (ASSEMBLE_OVERWRITE, ASSEMBLE_REPRODUCIBLE, HEX8, HEX27, LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, QUAD4, SCATTER_ATOMIC,
                    SCATTER_COLORED, SCATTER_GATHER, STVK, TET4, TRI3, TET10, QUAD9, TRI6, HEX20, TET20, MASS_SCALAR, MASS_VECTOR, FenrisError, SingularJacobianError)
 from .assembly import (CsrAssembler, CsrMatrix, CsrParAssembler, DisjointSubsetsColors, ElementEllipticAssembler, ElementMassAssembler,
                        ElementEllipticAssemblerBuilder, ElementSourceAssembler, ElementSourceAssemblerBuilder, Engine,

@@ -18,6 +18,7 @@ QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
 SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER = 0, 1, 2
 ASSEMBLE_OVERWRITE = 0x100
+ASSEMBLE_REPRODUCIBLE = 0x200
 
 ELEM_NODES = {QUAD4: 4, HEX8: 8, TET4: 4, HEX27: 27, TRI3: 3, TET10: 10, QUAD9: 9, TRI6: 6, HEX20: 20, TET20: 20}
 ELEM_DIM = {QUAD4: 2, HEX8: 3, TET4: 3, HEX27: 3, TRI3: 2, TET10: 3, QUAD9: 2, TRI6: 2, HEX20: 3, TET20: 3}

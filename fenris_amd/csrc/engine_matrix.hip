@@ -329,6 +329,25 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
             if (rc) return rc;
         }
         if (c->nblk == 0) return FH_OK;  // empty row range
+        if (flags & FH_ASSEMBLE_REPRODUCIBLE) {
+            // the kernels that sum in a fixed order: k_affine_rows (all positions affine), k_gather_rows (Tet4), k_hex8_rows -- the conditions of
+            // the launches below; anything else (k_gather_pipelined, the generic one-pass gather: LDS atomics in hardware order) goes two-pass
+            const bool pr = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
+            const bool lin = c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC;
+            const bool stable = c->npos_gen == 0 ||
+                                (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pr) && lin) ||
+                                (c->has_pipe && c->has_hrows && a.fast && !pr && c->nq == 8 && c->elem_kind == FH_HEX8 && lin &&
+                                 !c->env("FENRIS_HIP_NO_HEX8_ROWS") && hex8_rows_lds_bytes(c->g_acc) <= LDS_LIMIT);
+            if (!stable) {
+                if (c->row_hi >= 0) return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: this configuration needs the two-pass form, which has no row range");
+                const size_t ld = (size_t)c->S() * c->ei.n;
+                if (c->ke_dense.n < ld * ld * c->E && c->ke_dense.alloc(ld * ld * c->E) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: no memory for the dense element matrices of the two-pass form");
+                }
+                return assemble_two_pass(c, values_dev, overwrite);
+            }
+        }
         c->last_kernel.clear();
         if (c->a_npos > 0) {
             // node blocks whose elements are all affine (affine_kernel.hpp); the remaining positions follow below
@@ -428,6 +447,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, a.nc_row);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");
     if (mode == FH_SCATTER_ATOMIC) {
+        if (flags & FH_ASSEMBLE_REPRODUCIBLE) return c->fail(FH_BAD_ARGUMENT, "FH_ASSEMBLE_REPRODUCIBLE: fp64 atomics add in hardware order; use FH_SCATTER_GATHER or FH_SCATTER_COLORED");
         a.work_begin = 0;
         a.work_end = (long long)(c->has_mask ? c->num_active : c->E);
         a.labels = c->has_mask ? c->active_list.p : nullptr;

@@ -86,6 +86,13 @@ enum { FH_LAPLACE = 0, FH_LINEAR_ELASTIC = 1, FH_NEO_HOOKEAN = 2, FH_STVK = 3,
  * (= CsrAssembler::assemble, global.rs:124-131, without the explicit zero fill). */
 enum { FH_SCATTER_ATOMIC = 0, FH_SCATTER_COLORED = 1, FH_SCATTER_GATHER = 2, FH_SCATTER_MASK = 0xff };
 enum { FH_ASSEMBLE_OVERWRITE = 0x100 };
+/* OR-in FH_ASSEMBLE_REPRODUCIBLE (with FH_SCATTER_GATHER) to get the same bits from run to run and from launch geometry to launch geometry, like the
+ * reference's coloured loop (global.rs:322-373: every entry is a sum in a fixed order).  The row-owner kernels (affine and general Hex8 with the
+ * eight-point rule, Tet4) and the two-pass form (Hex27, NeoHookean, StVK) already are; the configurations whose one-pass kernel accumulates with
+ * LDS atomics in hardware order (Quad4 / Tri3, Hex8 with other rules or per-point parameters) take the two-pass form instead -- slower, and the
+ * dense element matrices need E (s n)^2 doubles; FH_UNSUPPORTED under a row range.  FH_SCATTER_COLORED is reproducible as it is;
+ * FH_SCATTER_ATOMIC never is (FH_BAD_ARGUMENT with this flag). */
+enum { FH_ASSEMBLE_REPRODUCIBLE = 0x200 };
 
 typedef struct fh_ctx fh_ctx;
 

@@ -351,7 +351,7 @@ def settle_device(eng, values, flags, max_s=2.5, group=20):
     return settle(eng, values, flags, max_s, group)
 
 
-def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
+def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2, tries=2, settle=False):
     """one secondary configuration on this GPU: {ms, frac, kernel, ...}; everything it allocates is released before it returns"""
     c = config_problem(cfg, 0, fa, quadrature, np)
     mesh = c["mesh"]()
@@ -370,7 +370,8 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
         eng.assemble_matrix_async(values, flags)     # the first assembly of the context: owner / lane tables, once per pattern
         torch.cuda.synchronize()
         t_first = time.perf_counter() - t0
-        values, placement = probe_placement(eng, values, flags, torch, 2)
+        settled = settle_device(eng, values, flags) if settle else None   # (the headline's set-up: a device that just released 30 GB is not at its steady rate)
+        values, placement = probe_placement(eng, values, flags, torch, tries)
         for _ in range(warmup):
             eng.assemble_matrix_async(values, flags)
         eng.poll_status()
@@ -388,7 +389,7 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2):
         bound, ach, peak, unit, frac = roofline_of(cfg, c, E, N, nnz, avg)
         return {"workload": c["desc"], "elements": E, "nnz": nnz, "ms": avg, "ms_min": ms[0], "elements_per_s": E / (avg * 1e-3),
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "kernel": eng.last_kernel_name(), "steps": steps,
-                "pattern_build_s": t_pattern, "first_assembly_s": t_first, "placement_probe": placement}
+                "pattern_build_s": t_pattern, "first_assembly_s": t_first, "placement_probe": placement, "device_settle": settled}
     finally:
         eng.close()
         values = None
@@ -807,7 +808,8 @@ def main():
                 time.sleep(0.3)
                 t0 = time.perf_counter()
                 try:
-                    sec[name] = time_secondary(name, fa, quadrature, np, torch, stream)
+                    # c5 is BASELINE's largest configuration: the same set-up as the headline (settle, four allocations tried); the others: two
+                    sec[name] = time_secondary(name, fa, quadrature, np, torch, stream, tries=4 if name == "c5" else 2, settle=(name == "c5"))
                     sec[name]["seconds_total"] = time.perf_counter() - t0
                 except Exception as exc:  # a secondary line must never take the headline down
                     sec[name] = {"error": repr(exc)}

@@ -365,6 +365,7 @@ struct fh_ctx {
     DevBuf<int4> h_hdr, h_pos;
     DevBuf<uint2> h_lanes;
     int h_ntab = 0, h_incomplete = 0;
+    int h_tune_pending = 0;   // k_hex8_rows: launches left before the lane tuner runs (0: done or off), see hex8_tune_lanes_now
     bool has_hrows = false;
     long long a_emin = 0, a_emax = -1;   // elements the affine positions of this partition refer to: the records kernel walks [a_emin, a_emax]
     unsigned max_row = 0;           // longest node-level row of the pattern (set by build_pattern)
@@ -454,7 +455,7 @@ struct fh_ctx {
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_vtab) X(a_nu) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
-    X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
+    X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(h_tune_pending) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};
     FH_PARTITION_MEMBERS(X)
@@ -512,6 +513,7 @@ int build_partition(fh_ctx* c);
 size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0, int nc_row = 0);
 int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem);
 int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite);
+int hex8_tune_lanes_now(fh_ctx* c);
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset = true);
 
 // dispatch over (element kind, operator kind) -> template instantiation

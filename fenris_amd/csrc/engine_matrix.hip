@@ -410,6 +410,12 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                 (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
                 const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds_h, 1)));
                 const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu))));
+                // the deferred lane tuner: in front of the launch that follows the first FENRIS_HIP_TUNE_AFTER ones
+                if (c->h_tune_pending > 0 && --c->h_tune_pending == 0) {
+                    c->h_tune_pending = 1;
+                    const int rt = hex8_tune_lanes_now(c);
+                    if (rt) return rt;
+                }
                 Hex8RowTables T{c->h_pos.p, c->h_lanes.p, c->p_conn.p, c->p_elem.p, c->p_us, c->p_cs, c->npos_gen, c->g_acc};
                 if (c->env("FENRIS_HIP_VERBOSE"))
                     std::fprintf(stderr, "[fenris_hip] hex8 rows: positions %d lds=%zu B wgs/cu=%d grid=%d\n", c->npos_gen, lds_h, per_cu, grid);

@@ -172,6 +172,25 @@ static __global__ void __launch_bounds__(256) k_iota_int(int* out, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = i;
 }
 
+// the lane tuner of k_hex8_rows on the context's unique lane tables (hex8_rows.hip: simulated annealing over moves that leave every sum unchanged);
+// called by build_partition or, deferred, in front of a later launch (fh_ctx::h_tune_pending)
+int hex8_tune_lanes_now(fh_ctx* c) {
+    c->h_tune_pending = 0;
+    if (!c->h_lanes.p || c->h_ntab <= 0) return FH_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    HostBuf<uint2> tabs((size_t)c->h_ntab * 256);
+    HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (also: no launch that reads the tables is still running when they are replaced)
+    double cb = 0.0, ca = 0.0;
+    hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, (long long)c->env_int("FENRIS_HIP_TUNE_PROPOSALS", 1000000));
+    HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->env("FENRIS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[fenris_hip] hex8 rows: %d lane tables tuned in %.1f ms, modelled LDS cycles per position and operand sweep %.1f -> %.1f (64 = conflict-free)\n",
+                     c->h_ntab, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cb, ca);
+    return FH_OK;
+}
+
 // greedy partition of the node range into owner blocks (gather mode)
 
 int build_partition(fh_ctx* c) {
@@ -747,18 +766,14 @@ int build_partition(fh_ctx* c) {
                                            c->h_incomplete, bad, "hex8 rows", 1);
                 if (rs) return rs;
                 if (!bad && !c->h_incomplete) {
-                    // lanes rearranged so that the sixteen lanes the LDS serves together read different banks (host, unique tables only)
+                    // lanes rearranged so that the sixteen lanes the LDS serves together read different banks (host, unique tables only).
+                    // Round 5: not here but in front of the SECOND launch of the kernel (FENRIS_HIP_TUNE_AFTER launches, default 1; 0: here) --
+                    // the tuner takes 18 ms on the 216^3 mesh and buys 0.16 ms per assembly (the matrix is the same bit for bit either way): a
+                    // caller who assembles once never needs it, a Newton loop pays it on its second assembly.
+                    c->h_tune_pending = 0;
                     if (c->h_ntab <= c->env_int("FENRIS_HIP_TUNE_LANES_MAX", 4096) && !c->env("FENRIS_HIP_NO_LANE_TUNING")) {
-                        HostBuf<uint2> tabs((size_t)c->h_ntab * 256);
-                        HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(c, hipStreamSynchronize(c->stream));
-                        double cb = 0.0, ca = 0.0;
-                        hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, (long long)c->env_int("FENRIS_HIP_TUNE_PROPOSALS", 1000000));
-                        HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
-                        HIP_TRY(c, hipStreamSynchronize(c->stream));
-                        if (c->env("FENRIS_HIP_VERBOSE"))
-                            std::fprintf(stderr, "[fenris_hip] hex8 rows: %d lane tables tuned, modelled LDS cycles per position and operand sweep %.1f -> %.1f (64 = conflict-free)\n",
-                                         c->h_ntab, cb, ca);
+                        c->h_tune_pending = 1 + std::max(0, c->env_int("FENRIS_HIP_TUNE_AFTER", 1));
+                        if (c->h_tune_pending == 1) { const int rt = hex8_tune_lanes_now(c); if (rt) return rt; }
                     }
                     HIP_TRY(c, c->h_pos.alloc((size_t)npg * 4));
                     HIP_TRY(c, hex8_rows_positions(c->stream, c->p_rec.p, c->p_rw, us, ms, c->h_hdr.p, npg, c->h_pos.p));

@@ -98,10 +98,34 @@ def run(cases=200, seed0=0, quiet=False, big=False):
         eng.set_active_elements(None)
         for name in ("FENRIS_HIP_AFFINE_GRID", "FENRIS_HIP_PIPE_GRID", "FENRIS_HIP_TWO_PASS_GRID"):
             eng.set_option(name, None)
+        # FH_ASSEMBLE_REPRODUCIBLE on the whole range: the same matrix (to rounding: the atomic kernels take the two-pass form), twice the same bits
+        rep_bad = False
+        if it % 3 == 0:
+            if masked:
+                eng.set_active_elements(None)
+            r1 = torch.full((nnz,), -7.25, dtype=torch.float64, device="cuda")
+            eng.set_option("FENRIS_HIP_TWO_PASS_ROWS_GRID", "5" if it % 2 else None)
+            eng.assemble_matrix(r1, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE | fa.ASSEMBLE_REPRODUCIBLE)
+            kr = eng.last_kernel_name()
+            eng.set_option("FENRIS_HIP_TWO_PASS_ROWS_GRID", None)
+            r2 = torch.full((nnz,), 1.5, dtype=torch.float64, device="cuda")
+            eng.assemble_matrix(r2, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE | fa.ASSEMBLE_REPRODUCIBLE)
+            full = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+            eng.assemble_matrix(full, fa.SCATTER_ATOMIC)
+            fv = full.cpu().numpy()
+            sc = max(np.abs(fv).max(), 1e-300)
+            same_nan = np.array_equal(np.isnan(r1.cpu().numpy()), np.isnan(fv))
+            okv = ~np.isnan(fv)
+            rep_bad = (not torch.equal(torch.nan_to_num(r1, nan=0.0), torch.nan_to_num(r2, nan=0.0))) or not same_nan or \
+                (okv.any() and np.abs(r1.cpu().numpy()[okv] - fv[okv]).max() > 1e-12 * sc) or "pipelined" in kr or "<gather>" in kr
+            if rep_bad:
+                print(f"   REPRODUCIBLE MISMATCH ({kr})", flush=True)
         wv, gv = want.cpu().numpy(), got.cpu().numpy()
         lo, hi = int(ro[s * lo_n]), int(ro[s * hi_n])
         scale = max(np.abs(wv).max(), 1e-300)
         ok = np.all(gv[:lo] == 4.5) and np.all(gv[hi:] == 4.5) and (hi == lo or np.abs(gv[lo:hi] - wv[lo:hi]).max() <= 1e-12 * scale)
+        if rep_bad:
+            bad += 1
         if not ok:
             bad += 1
             err = np.abs(gv[lo:hi] - wv[lo:hi]).max() / scale if hi > lo else 0.0

@@ -289,6 +289,10 @@ __global__ void __launch_bounds__(TS) k_element_pass_tiled(const KArgs a, const 
         int nd[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) nd[n] = t.tconn[((size_t)tile * N + n) * TS + tid];
+        if (a.ablate & 128) {   // (profiling: what the scattered gathers cost -- every thread reads the nodes of its wavefront's first element: wrong results)
+#pragma unroll
+            for (int n = 0; n < N; ++n) nd[n] = __builtin_amdgcn_readfirstlane(nd[n]);
+        }
 #pragma unroll
         for (int n = 0; n < N; ++n) {
 #pragma unroll

@@ -260,6 +260,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.nq = c->nq;
     a.qw = c->qw.p;
     a.gref = c->gref.p;
+    a.gref_t = c->gref_t.p;
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
     a.all_affine = (c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff == c->E && c->E > 0 && !c->env("FENRIS_HIP_NO_AFFINE_PASS")) ? 1 : 0;
@@ -401,12 +402,16 @@ void fh_destroy(fh_ctx* c) {
     if (c->trace.p) {  // ... and of k_hex27_dense_mfma (hex27_mfma.hpp): cycles of wavefront 0 per phase and element
         unsigned long long h[32] = {0};
         if (hipMemcpy(h, c->trace.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[31]) {
-            static const char* names[9] = {"P0 inputs", "P1 J, inverse", "P2 gradients", "P3 grad u", "P4 F, coefficients", "P5 F^-T g",
-                                           "round A + its stores", "round B", "stores of round B"};
+            static const char* names_tiles[9] = {"P0 inputs", "P1 J, inverse", "P2 gradients", "P3 grad u", "P4 F, coefficients", "P5 F^-T g",
+                                                 "round A + its stores", "round B", "stores of round B"};
+            // (h[30] == 2: hex27_blocks.hpp, five phases)
+            static const char* names_blocks[9] = {"P0 inputs + barrier", "P1 chain + barrier", "P2 a = M^T r + barrier", "matrix phase", "stores", "", "", "", ""};
+            const char* const* names = h[30] == 2 ? names_blocks : names_tiles;
+            const int nph = h[30] == 2 ? 5 : 9;
             unsigned long long tot = 0;
-            for (int k = 0; k < 9; ++k) tot += h[16 + k];
-            for (int k = 0; k < 9; ++k)
-                std::fprintf(stderr, "[fenris_hip trace] hex27 %-20s %10.0f cycles/element  %5.1f %%\n", names[k],
+            for (int k = 0; k < nph; ++k) tot += h[16 + k];
+            for (int k = 0; k < nph; ++k)
+                std::fprintf(stderr, "[fenris_hip trace] hex27 %-24s %10.0f cycles/element  %5.1f %%\n", names[k],
                              (double)h[16 + k] / (double)h[31], 100.0 * (double)h[16 + k] / (double)tot);
         }
     }
@@ -810,6 +815,16 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
     }
     HIP_TRY(c, hipMemcpy(c->gref.p, gref.data(), sizeof(double) * gref.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->ggeom.p, ggeom.data(), sizeof(double) * ggeom.size(), hipMemcpyHostToDevice));
+    if (c->elem_kind == FH_HEX27) {   // node-major copy for the per-point chain of the matrix-core first pass (hex27_blocks.hpp)
+        std::vector<double> gt(gref.size());
+        for (uint32_t q = 0; q < nq; ++q)
+            for (int n = 0; n < ei.n; ++n)
+                for (int d = 0; d < ei.d; ++d) gt[((size_t)n * nq + q) * ei.d + d] = gref[((size_t)q * ei.n + n) * ei.d + d];
+        HIP_TRY(c, c->gref_t.alloc(gt.size()));
+        HIP_TRY(c, hipMemcpy(c->gref_t.p, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+    } else {
+        c->gref_t.release();
+    }
     c->has_ghat = false;
     if (c->elem_kind == FH_HEX8) {
         // reference blocks of the affine-element kernel: Ghat_ab[c][d] = sum_q w_q ghat_a(xi_q)[c] ghat_b(xi_q)[d], summed in

@@ -301,6 +301,7 @@ struct fh_ctx {
     uint64_t sdim_ragged = 1;
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
+    DevBuf<double> gref_t;      // Hex27: reference gradients node-major (KArgs::gref_t)
     DevBuf<double> qmono;       // Hex8: coordinates and pair products of the quadrature points (KArgs::qmono)
     DevBuf<double> qmom;        // Hex8: moments of the rule (KArgs::qmom); qmom_ok: the rule is symmetric and the parameters are the same at every point
     bool qmom_ok = false;

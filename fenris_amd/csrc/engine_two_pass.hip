@@ -1,6 +1,7 @@
 // Two-pass owner-computes assembly: dense element matrices (fp64 MFMA for Hex27), then the row gather
 #include "engine_internal.hpp"
 #include "hex27_mfma.hpp"
+#include "hex27_blocks.hpp"
 #include "two_pass_kernels.hpp"
 
 namespace {
@@ -14,20 +15,30 @@ int launch_hex27_mfma(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     a.work_begin = w0;
     a.work_end = w1;
-    const size_t lds1 = sizeof(double) * (size_t)Hex27Lds::total;
-    // three workgroups per CU since round 5 (52.9 KB of LDS and 158 registers each: scripts/gpu_r5_c4_variants.sh -- 7.54 ms against 7.97 with
-    // two on one box, 8.36 for the round-4 kernel)
-    const int wgs_default = (int)std::min<size_t>(3, LDS_LIMIT / lds1);
+    // FENRIS_HIP_HEX27_FORM: 2 (default, round 6) = 4 x 4 x 4 blocks with one operand array, four workgroups per CU (hex27_blocks.hpp);
+    // 0 = the 16 x 16 tiles, 1 = the round-5 block experiment (hex27_mfma.hpp)
+    const int form = c->env_int("FENRIS_HIP_HEX27_FORM", c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0 ? 1 : 2);
+    const bool blocks2 = form == 2 && c->gref_t.p != nullptr;
+    const size_t lds1 = sizeof(double) * (size_t)(blocks2 ? Hex27BlkLds::total : Hex27Lds::total);
+    const int wgs_default = (int)std::min<size_t>(blocks2 ? 4 : 3, LDS_LIMIT / lds1);
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     // (FENRIS_HIP_TWO_PASS_GRID: tests force many elements / nodes per workgroup on small meshes)
     if (st == c->tp_stream1 && c->tp_gather_cus > 0) dev_cus = std::max(1, dev_cus - c->tp_gather_cus);   // (CU-masked stream: the CUs left to this pass)
     const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", wgs_default)))));
+    if (blocks2) {
+        void (*kern)(const KArgs, double, double);
+        if (a.trace) kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_blocks<FH_NEO_HOOKEAN, true> : k_hex27_dense_blocks<FH_LINEAR_ELASTIC, true>;
+        else kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_blocks<FH_NEO_HOOKEAN> : k_hex27_dense_blocks<FH_LINEAR_ELASTIC>;
+        hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);
+        HIP_TRY(c, hipGetLastError());
+        return FH_OK;
+    }
     if (c->op == FH_NEO_HOOKEAN && a.trace) {   // FENRIS_HIP_TRACE: per-phase cycle counters
-        auto kern = c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0 ? k_hex27_dense_mfma<FH_NEO_HOOKEAN, true, 1> : k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
+        auto kern = form == 1 ? k_hex27_dense_mfma<FH_NEO_HOOKEAN, true, 1> : k_hex27_dense_mfma<FH_NEO_HOOKEAN, true>;
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL(kern, dim3(grid1), dim3(256), lds1, st, a, c->uni_mu, c->uni_lambda);
-    } else if (c->env_int("FENRIS_HIP_HEX27_BLOCKS", 0) != 0) {
+    } else if (form == 1) {
         // the 4 x 4 x 4 block form (round 5 experiment, hex27_mfma.hpp "second form"): parity-green and bit-symmetric; half the matrix-core time
         // of the 16 x 16 tiles and still 3 - 4 % SLOWER end to end (7.30 - 7.38 against 7.04 - 7.07 ms on one box: the pass is latency-bound once
         // the matrix instructions shrink, profiles/r05_c4_mfma_blocks.txt): opt-in

@@ -246,15 +246,59 @@ def self_launch(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # every rank's stdout / stderr also goes to a file of its own (torchrun --tee): when the launch fails or hangs, the parent prints the tail of
+    # EVERY rank's stderr, so that a stuck RCCL bootstrap can be told from a kernel failure
+    import shutil
+    import signal
+    import tempfile
+
+    log_dir = tempfile.mkdtemp(prefix="fenris_bench_ranks_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--log-dir", log_dir, "--tee", "3", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    if pr.returncode != 0 or not lines:
-        sys.stderr.write(pr.stderr[-6000:])
+    env.setdefault("NCCL_DEBUG", "WARN")   # RCCL reports what it could not do (a failed bootstrap is otherwise silent)
+    # a fresh child in a process group of its own (never a re-exec of this process): on expiry exactly that group is killed
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, err = pr.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)   # start_new_session: the child leads the group pr.pid
+        except OSError:
+            pass
+        out, err = pr.communicate()
+
+    def rank_tails():
+        tails = []
+        for root, _, files in sorted(os.walk(log_dir)):
+            for fn in sorted(files):
+                if fn == "stderr.log":
+                    try:
+                        with open(os.path.join(root, fn), errors="replace") as fh:
+                            tails.append((os.path.basename(root), fh.read()[-6000:]))
+                    except OSError:
+                        pass
+        return tails
+
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    # (--tee prefixes the ranks' lines with "[default0]:" on some torch versions)
+    if not lines:
+        lines = [ln[ln.index("{"):] for ln in (out or "").splitlines() if '"metric"' in ln and "{" in ln]
+    if timed_out or pr.returncode != 0 or not lines:
+        for rk, tail in rank_tails():
+            sys.stderr.write(f"---- rank {rk}: last of its stderr ----\n{tail}\n")
+        sys.stderr.write("---- launcher stderr (tail) ----\n" + (err or "")[-6000:])
+        if timed_out:
+            sys.stderr.write(f"\nbench.py: the {args.gpus}-rank launch did not finish within --launch-timeout {args.launch_timeout} s: its process "
+                             f"group was killed\n")
+            shutil.rmtree(log_dir, ignore_errors=True)
+            raise SystemExit(124)
         sys.stderr.write(f"\nbench.py: the {args.gpus}-rank launch failed (exit code {pr.returncode})\n")
+        shutil.rmtree(log_dir, ignore_errors=True)
         raise SystemExit(pr.returncode or 1)
+    shutil.rmtree(log_dir, ignore_errors=True)
     line = json.loads(lines[-1])
     if line.get("n_gpus") != args.gpus:
         sys.stderr.write(f"bench.py: asked for {args.gpus} GPUs, the ranks report {line.get('n_gpus')}\n")
@@ -415,6 +459,8 @@ def main():
     ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
                     help="N > 1: interface rows moved by torch.distributed point-to-point (default) or by the library's own RCCL "
                          "calls behind the C ABI (fh_group_*)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="N > 1 without a launcher: seconds the torch.distributed.run child may take before its process group is killed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configurations timed after the headline (N = 1, --config ns)")
@@ -431,6 +477,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if launched and world > 1 and os.environ.get("FENRIS_BENCH_TEST_STALL_RANK") in (str(rank), "all"):
+        # test only (tests/test_bench_launch.py): this rank never arrives at the rendezvous -- the parent's --launch-timeout has to end the launch
+        sys.stderr.write(f"[bench rank {rank}] FENRIS_BENCH_TEST_STALL_RANK: stalling before the first barrier\n")
+        sys.stderr.flush()
+        time.sleep(3600)
     cfg = args.config
     if args.operator == "poisson" and cfg == "ns":  # old spelling of the Poisson run
         cfg = "c2"
@@ -452,7 +503,7 @@ def main():
             child += ["--cells", str(args.cells)]
         aff = ("k_affine_records", "k_affine_rows<")  # element records, then the rows: both run in every assembly
         knames = {"ns": aff, "c5": aff, "c2": aff, "ns-perturbed": ("k_hex8_rows",),
-                  "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}[cfg]
+                  "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_blocks", "k_rows_from_tri")}[cfg]
         try:
             helper = start_traffic_helper(child, knames)
         except OSError as exc:
@@ -483,6 +534,8 @@ def main():
     rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stderr.write(f"[bench rank {rank}/{world}] device {local_rank}: joining the process group\n")
+        sys.stderr.flush()
         if share:
             dist.init_process_group("gloo")
         else:
@@ -490,6 +543,9 @@ def main():
             t = torch.ones(1, device="cuda")
             dist.all_reduce(t)  # the communicator exists from here on; every rank answered
             rccl = {"backend": dist.get_backend(), "rccl_ranks": int(t.item()), "world_size": dist.get_world_size()}
+        sys.stderr.write(f"[bench rank {rank}/{world}] process group up: backend {dist.get_backend()}, "
+                         f"rccl_ranks {rccl['rccl_ranks'] if rccl else 0} (all-reduce of ones)\n")
+        sys.stderr.flush()
     stream = torch.cuda.current_stream().cuda_stream
 
     # code objects of the library loaded and the device warm before anything is timed: one tiny assembly
@@ -561,6 +617,9 @@ def main():
         E = slab.num_own_elements()  # numerics over own (+ halo in "halo" mode) elements, pattern over own + halo
         if rccl is not None and hasattr(slab_asm.exchange, "size"):
             rccl["fh_group_ranks"] = slab_asm.exchange.size()   # ncclCommCount of the library's own communicator
+        sys.stderr.write(f"[bench rank {rank}/{world}] engines and patterns built, fh_group_ranks "
+                         f"{rccl.get('fh_group_ranks') if rccl else None}: first assembly next\n")
+        sys.stderr.flush()
     t_pattern = time.perf_counter() - t0
     t_values_alloc = None
     if world == 1:

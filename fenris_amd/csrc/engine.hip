@@ -415,9 +415,6 @@ void fh_destroy(fh_ctx* c) {
                              (double)h[16 + k] / (double)h[31], 100.0 * (double)h[16 + k] / (double)tot);
         }
     }
-    for (hipEvent_t ev : c->tp_events) (void)hipEventDestroy(ev);
-    if (c->tp_stream) (void)hipStreamDestroy(c->tp_stream);
-    if (c->tp_stream1) (void)hipStreamDestroy(c->tp_stream1);
     delete c->rows_stash;
     delete c;
 }

@@ -427,14 +427,6 @@ struct fh_ctx {
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
-    // overlapped two-pass assembly (engine_two_pass.hip, round 5): the element matrices in chunks on the context's stream, the row gather of
-    // every finished chunk on a second stream beside the next chunk's matrices
-    hipStream_t tp_stream = nullptr, tp_stream1 = nullptr;   // gather stream; (CU-masked form only) the stream of the element matrices
-    int tp_gather_cus = -1;                      // CUs the gather stream is restricted to (0: no mask), as the streams were created
-    std::vector<hipEvent_t> tp_events;           // [chunks + 2]: chunk k done (k < chunks), start, gather done
-    DevBuf<int> tp_nodes;                        // nodes sorted by the chunk of their last adjacent element (ascending inside a chunk)
-    std::vector<int> tp_chunk_off;               // [chunks + 1] into tp_nodes
-    int tp_chunks = 0;                           // chunks the lists were built for (0: none)
     DevBuf<unsigned long long> trace;
     bool defer_status = false;   // fh_assemble_vector_async_dev: the launches are only enqueued, fh_poll_status reports their errors
     bool keep_status = false;    // ... over a rule-set table: the status slot is reset once in front of the group walk, not per group
@@ -514,6 +506,7 @@ int build_partition(fh_ctx* c);
 size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0, int nc_row = 0);
 int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem);
 int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite);
+size_t two_pass_dense_doubles(fh_ctx* c);   // doubles of the element-matrix buffer between the two passes (depends on the first pass's layout)
 int hex8_tune_lanes_now(fh_ctx* c);
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset = true);
 

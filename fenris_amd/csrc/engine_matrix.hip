@@ -298,12 +298,12 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         // owning node block is the expensive part: high-order elements, and the nonlinear materials on any element
         // (measured, Hex8 128^3: NeoHookean 11.1 -> 9.2 ms, StVK 19.2 -> 10.0 ms; LinearElastic with per-point
         // parameters is faster one-pass: 5.7 vs 8.2 ms).  The dense buffer costs E (s n)^2 doubles: capped.
-        const size_t ld = (size_t)c->S() * c->ei.n;
-        const double dense_gb = (double)c->E * ld * ld * 8.0 / 1e9;
+        const size_t dense_doubles = two_pass_dense_doubles(c);
+        const double dense_gb = (double)dense_doubles * 8.0 / 1e9;
         const bool want = c->ei.n > 8 || c->op == FH_NEO_HOOKEAN || c->op == FH_STVK || c->env("FENRIS_HIP_TWO_PASS");
         if (want && dense_gb <= (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96)) {
             // the dense buffer is allocated here: when the device cannot hold it the one-pass gather below takes over
-            if (c->ke_dense.n >= ld * ld * c->E || c->ke_dense.alloc(ld * ld * c->E) == hipSuccess)
+            if (c->ke_dense.n >= dense_doubles || c->ke_dense.alloc(dense_doubles) == hipSuccess)
                 return assemble_two_pass(c, values_dev, overwrite);
             (void)hipGetLastError();
         }
@@ -340,8 +340,8 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                                  !c->env("FENRIS_HIP_NO_HEX8_ROWS") && hex8_rows_lds_bytes(c->g_acc) <= LDS_LIMIT);
             if (!stable) {
                 if (c->row_hi >= 0) return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: this configuration needs the two-pass form, which has no row range");
-                const size_t ld = (size_t)c->S() * c->ei.n;
-                if (c->ke_dense.n < ld * ld * c->E && c->ke_dense.alloc(ld * ld * c->E) != hipSuccess) {
+                const size_t dense_doubles = two_pass_dense_doubles(c);
+                if (c->ke_dense.n < dense_doubles && c->ke_dense.alloc(dense_doubles) != hipSuccess) {
                     (void)hipGetLastError();
                     return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: no memory for the dense element matrices of the two-pass form");
                 }

@@ -41,6 +41,7 @@ struct Hex27BlkLds {
     static constexpr int o_X = o_qw + 28;                   // [g][3]
     static constexpr int o_U = o_X + NG * 3;                // [n][3]
     static constexpr int total = o_U + N * 3 + 1;
+    static constexpr int KE_TRI = (N * (N + 1) / 2) * 9;    // doubles per element in memory: the upper node-block triangle
     // scratch of the per-point chain: inside A, which is dead between the matrix phase of one element and phase P2 of the next.  Only rows
     // 0 .. 26 of a component are used (the row of zeros stays); the zeros of point 27 in those rows are rewritten by P2.
     static constexpr int s_P = 0;                           // [q][27]  partial sums of sum_n u_n r_n^T: [lane group][c][m]
@@ -270,53 +271,47 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
         lds_barrier();
         mark(2);
         __builtin_amdgcn_s_setprio(0);
-        // ---- matrix cores: 4 x 4 x 4 blocks, ROW BROADCAST x COLUMN WINDOW.
-        // Register layout of v_mfma_f64_4x4x4_4b (scripts/ubench/mfma_f64_4x4_layout.hip): A: lane = (i + 4 g) + 16 k, B: lane = (j + 4 g) + 16 k,
-        // D: lane = (j + 4 g) + 16 i, g = the block.  The A operand holds ONE row block IB in all four groups (the four groups read the same
-        // addresses: a broadcast), the B operand a window of sixteen consecutive nodes (conflict-free with the row stride of 29); the result is
-        // rows 4 IB .. 4 IB + 3 x sixteen consecutive columns, so the direct stores write runs of sixteen doubles.  Windows: W0 = nodes 0 .. 15,
-        // W1 = 16 .. 27 (+ padding), and for row block 3 of the symmetric components Wx = 12 .. 27.
-        // Work: role r = 0, 1, 2 takes row blocks r and 6 - r (38 instructions per k-step), role 3 row block 3 and the component (1, 2) of
-        // row blocks 0 - 2 (30); roles rotate from element to element.  The coefficient multiplies the row operand only.
+        // ---- matrix cores: the 28 node blocks (4 x 4 nodes) ON AND ABOVE the diagonal, every one with all nine components.
+        // v_mfma_f64_4x4x4_4b multiplies four independent 4 x 4 x 4 blocks; register layout (scripts/ubench/mfma_f64_4x4_layout.hip):
+        // A: lane = (i + 4 g) + 16 k, B: lane = (j + 4 g) + 16 k, D: lane = (j + 4 g) + 16 i, g = the block.  WHICH (row block, column block) a
+        // group works on is the lane's choice of LDS address, so the 28 blocks are packed into 7 units of four with nothing wasted:
+        //     role 0: (0,0) (0,1) (0,2) (0,3) | (0,4) (0,5) (0,6) (6,6)        role 1: (1,1) (1,2) (1,3) (1,4) | (1,5) (1,6) (5,5) (5,6)
+        //     role 2: (2,2) (2,3) (2,4) (2,5) | (2,6) (4,4) (4,5) (4,6)        role 3: (3,3) (3,4) (3,5) (3,6)
+        // (roles rotate from element to element: every SIMD gets the light one).  Per unit and k-step: 3 + 3 products for the three K_ii and
+        // the trace term, 12 for the six K_ij, i != j:  K_ij(I, J) = (c_l a_I[i]) a_J[j] + (-c_a a_I[j]) a_J[i]  -- the components below the
+        // diagonal are multiplied like the ones above it, on the upper node blocks only: the same 18 products per upper block as with mirrored
+        // components, but a lane then holds the COMPLETE 3 x 3 block of its node pair (I, J) and stores 72 contiguous bytes; nothing is
+        // mirrored.  The element matrix goes to memory as its upper node-block triangle, ke[e][tri(I, J)][i][j], tri(I, J) = I (53 - I) / 2 + J
+        // for I <= J (27 216 bytes instead of 52 488); k_rows_from_dense<TRI> reads a block (J, I), J < I, transposed.  126 matrix
+        // instructions per k-step and workgroup (the tiles: 42 of four times the size).
         const int role = (__builtin_amdgcn_readfirstlane(t_ >> 6) + (int)(((w - w0) / Gs) & 3)) & 3;
+        // row / column block of (unit u, group g) in bits 3 (g + 4 u) ..; 7 = idle (the row of zeros)
+        constexpr unsigned IBT[4] = {0u | 0u << 3 | 0u << 6 | 0u << 9 | 0u << 12 | 0u << 15 | 0u << 18 | 6u << 21,
+                                     1u | 1u << 3 | 1u << 6 | 1u << 9 | 1u << 12 | 1u << 15 | 5u << 18 | 5u << 21,
+                                     2u | 2u << 3 | 2u << 6 | 2u << 9 | 2u << 12 | 4u << 15 | 4u << 18 | 4u << 21,
+                                     3u | 3u << 3 | 3u << 6 | 3u << 9 | 7u << 12 | 7u << 15 | 7u << 18 | 7u << 21};
+        constexpr unsigned JBT[4] = {0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18 | 6u << 21,
+                                     1u | 2u << 3 | 3u << 6 | 4u << 9 | 5u << 12 | 6u << 15 | 5u << 18 | 6u << 21,
+                                     2u | 3u << 3 | 4u << 6 | 5u << 9 | 6u << 12 | 4u << 15 | 5u << 18 | 6u << 21,
+                                     3u | 4u << 3 | 5u << 6 | 6u << 9 | 7u << 12 | 7u << 15 | 7u << 18 | 7u << 21};
+        const unsigned ibt = role == 0 ? IBT[0] : (role == 1 ? IBT[1] : (role == 2 ? IBT[2] : IBT[3]));
+        const unsigned jbt = role == 0 ? JBT[0] : (role == 1 ? JBT[1] : (role == 2 ? JBT[2] : JBT[3]));
         int lane_o = t_ & 63;
         asm volatile("" : "+v"(lane_o));   // (everything derived from it is formed per element instead of living in registers across the loop)
-        const int l15 = lane_o & 15, idx = lane_o & 3, kq4 = lane_o >> 4;
-        auto win_off = [&](int start) { return (unsigned)((min(start + l15, N) * QS + kq4) * 8); };
-        auto row_off = [&](int IB) { return (unsigned)((min(4 * IB + idx, N) * QS + kq4) * 8); };
+        const int gq = (lane_o >> 2) & 3, idx = lane_o & 3, kq4 = lane_o >> 4;
+        auto node_off = [&](unsigned tbl, int u) {   // LDS byte offset of the lane's operand row: node 4 B + (lane & 3) of the group's block B
+            const int B = (int)((tbl >> (3 * (gq + 4 * u))) & 7u);
+            return (unsigned)((min(4 * B + idx, N) * QS + kq4) * 8);
+        };
         const char* Ab = reinterpret_cast<const char*>(A);
         const char* Cb = reinterpret_cast<const char*>(lds + L::o_coef);
         auto ldA = [&](int comp, unsigned off) { return *reinterpret_cast<const double*>(Ab + off + (size_t)(comp * RP * QS * 8)); };
         auto ldC = [&](int k, unsigned off) { return *reinterpret_cast<const double*>(Cb + off + (size_t)(k * 28 * 8)); };
         auto mm = [](double x, double y, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, acc, 0, 0, 0); };
-        const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * (81 * 81));
+        const unsigned long long ke_addr = reinterpret_cast<unsigned long long>(a.ke_out + (size_t)e * L::KE_TRI);
         const unsigned long long ke_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ke_addr >> 32)) << 32) |
                                         (unsigned)__builtin_amdgcn_readfirstlane((int)ke_addr);
-        const auto ke_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ke_u), (short)0, 81 * 81 * 8, 0x00020000);
-        // buffer stores with the hardware's bounds check: the lanes of padding rows / columns and of entries that are somebody else's get an
-        // offset beyond the element's matrix and their store is dropped -- no branch, no EXEC masking
-        auto put = [&](unsigned voff, int soff_doubles, double v) {
-            typedef unsigned put_u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(put_u32x2, v), ke_rsrc, voff, soff_doubles * 8, 0);
-        };
-        constexpr unsigned DROP = 0x80000000u;
-        // offsets of the lane's entry (I, J) = (4 IB + i, start + lane & 15): direct and mirrored, for a component off the diagonal (every entry
-        // inside the matrix) and for a symmetric one (direct: blocks on and above the diagonal, in the diagonal block the entries on and above ITS
-        // diagonal; mirrored: the same without the diagonal itself)
-        struct StOff { unsigned dir, mir, dirs, mirs; };
-        auto st_off = [&](int IB, int start, int ls) {
-            const int i = ls >> 4, J = start + (ls & 15), I = 4 * IB + i, JB = J >> 2, jj = J & 3;
-            const bool valid = I < N && J < N;
-            const bool upper = JB > IB || (JB == IB && i <= jj), strict = JB > IB || (JB == IB && i < jj);
-            StOff o;
-            o.dir = valid ? (unsigned)(I * (9 * N) + J) * 8u : DROP;
-            o.mir = valid ? (unsigned)(J * (9 * N) + I) * 8u : DROP;
-            o.dirs = (valid && upper) ? o.dir : DROP;
-            o.mirs = (valid && strict) ? o.mir : DROP;
-            if (TRACE && (a.ablate & 8)) { o.mir = DROP; o.mirs = DROP; }     // (timing only: no mirrored / no direct stores reach memory)
-            if (TRACE && (a.ablate & 16)) { o.dir = DROP; o.dirs = DROP; }
-            return o;
-        };
+        const auto ke_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ke_u), (short)0, L::KE_TRI * 8, 0x00020000);
         auto rotate_inputs = [&]() {
             // The requests of this element are consumed here: not earlier (they need their time), and not behind the stores below
             asm volatile("" : "+v"(val_n1), "+v"(node_n2), "+v"(e_n3));
@@ -326,62 +321,76 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
             e_n1 = e_n2;
             e_n2 = e_n3;
         };
-        // row operands of one row block: the three components scaled for the symmetric terms, the trace term and the terms off the diagonal
-        struct RowOps { double s[3], h[3], l0, l1, n1, n2; };
-        auto row_ops = [&](const double (&r)[3], const double (&cf)[9]) {
-            RowOps o;
-            o.s[0] = cf[2] * r[0]; o.s[1] = cf[2] * r[1]; o.s[2] = cf[2] * r[2];
-            o.h[0] = fma(cf[5], r[2], fma(cf[4], r[1], cf[3] * r[0]));
-            o.h[1] = fma(cf[7], r[2], fma(cf[6], r[1], cf[4] * r[0]));
-            o.h[2] = fma(cf[8], r[2], fma(cf[7], r[1], cf[5] * r[0]));
-            o.l0 = cf[0] * r[0]; o.l1 = cf[0] * r[1]; o.n1 = cf[1] * r[1]; o.n2 = cf[1] * r[2];
-            return o;
+        // accumulators of a unit: the lane's 3 x 3 block, the diagonal entries still without the trace term
+        struct Unit { double k[3][3], m; };
+        auto zero_unit = [](Unit& x) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) x.k[i][j] = 0.0;
+            x.m = 0.0;
+        };
+        // one k-step of a unit: row operands r (scaled here), column operands wb
+        auto step_unit = [&](Unit& x, const double (&r)[3], const double (&wb)[3], const double (&cf)[9]) {
+            const double s0 = cf[2] * r[0], s1 = cf[2] * r[1], s2 = cf[2] * r[2];
+            const double h0 = fma(cf[5], r[2], fma(cf[4], r[1], cf[3] * r[0]));
+            const double h1 = fma(cf[7], r[2], fma(cf[6], r[1], cf[4] * r[0]));
+            const double h2 = fma(cf[8], r[2], fma(cf[7], r[1], cf[5] * r[0]));
+            const double l0 = cf[0] * r[0], l1 = cf[0] * r[1], l2 = cf[0] * r[2];
+            const double n0 = cf[1] * r[0], n1 = cf[1] * r[1], n2 = cf[1] * r[2];
+            // (consecutive instructions on different accumulators)
+            x.k[0][0] = mm(s0, wb[0], x.k[0][0]); x.k[1][1] = mm(s1, wb[1], x.k[1][1]); x.k[2][2] = mm(s2, wb[2], x.k[2][2]);
+            x.m = mm(h0, wb[0], x.m);
+            x.k[0][1] = mm(l0, wb[1], x.k[0][1]); x.k[0][2] = mm(l0, wb[2], x.k[0][2]); x.k[1][0] = mm(l1, wb[0], x.k[1][0]);
+            x.k[1][2] = mm(l1, wb[2], x.k[1][2]); x.k[2][0] = mm(l2, wb[0], x.k[2][0]); x.k[2][1] = mm(l2, wb[1], x.k[2][1]);
+            x.m = mm(h1, wb[1], x.m);
+            x.k[0][1] = mm(n1, wb[0], x.k[0][1]); x.k[0][2] = mm(n2, wb[0], x.k[0][2]); x.k[1][0] = mm(n0, wb[1], x.k[1][0]);
+            x.k[1][2] = mm(n2, wb[1], x.k[1][2]); x.k[2][0] = mm(n0, wb[2], x.k[2][0]); x.k[2][1] = mm(n1, wb[2], x.k[2][1]);
+            x.m = mm(h2, wb[2], x.m);
+        };
+        // the lane's block of unit u to memory: 72 contiguous bytes (four 16-byte stores and one of 8); buffer stores with the hardware's bounds
+        // check -- padding nodes, node pairs below the diagonal and idle groups get an offset beyond the element's triangle: dropped
+        auto store_unit = [&](Unit& x, int u, int ls) {
+            typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned st_u32x2 __attribute__((ext_vector_type(2)));
+            typedef double st_f64x2 __attribute__((ext_vector_type(2)));
+            const int g = (ls >> 2) & 3;
+            const int IB = (int)((ibt >> (3 * (g + 4 * u))) & 7u), JB = (int)((jbt >> (3 * (g + 4 * u))) & 7u);
+            const int I = 4 * IB + (ls >> 4), J = 4 * JB + (ls & 3);
+            const bool valid = I < N && J < N && I <= J;
+            const unsigned vo = valid ? (unsigned)((I * (53 - I)) / 2 + J) * 72u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x.k[i][i] += x.m;
+            if (I == J) {   // a node with itself: symmetric bit for bit (util.rs:38-51 copies the upper triangle)
+                x.k[1][0] = x.k[0][1]; x.k[2][0] = x.k[0][2]; x.k[2][1] = x.k[1][2];
+            }
+            const double* f = &x.k[0][0];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const st_f64x2 v = {f[2 * p2], f[2 * p2 + 1]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st_u32x4, v), ke_rsrc, vo, 16 * p2, 0);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_u32x2, f[8]), ke_rsrc, vo, 64, 0);
         };
         unsigned oC = (unsigned)(kq4 * 8);
-        unsigned oW0 = win_off(0), oW1 = win_off(16);
         if (role < 3) {
-            // ---- row blocks IBa = role (windows W0 and W1; components (0, 1), (0, 2) off the diagonal) and IBb = 6 - role (symmetric: W1 only)
-            const int IBa = role, IBb = 6 - role;
-            unsigned oRa = row_off(IBa), oRb = row_off(IBb);
-            double aD[3][2], aM[2], a01[2], a02[2], bD[3], bM = 0.0, b01[2], b02[2], b12[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { aM[t] = 0.0; a01[t] = 0.0; a02[t] = 0.0; b01[t] = 0.0; b02[t] = 0.0; b12[t] = 0.0; aD[0][t] = 0.0; aD[1][t] = 0.0; aD[2][t] = 0.0; }
-            bD[0] = 0.0; bD[1] = 0.0; bD[2] = 0.0;
+            unsigned oR0 = node_off(ibt, 0), oC0 = node_off(jbt, 0), oR1 = node_off(ibt, 1), oC1 = node_off(jbt, 1);
+            Unit x0, x1;
+            zero_unit(x0);
+            zero_unit(x1);
             if (!(TRACE && (a.ablate & 2))) {
 #pragma unroll 1
                 for (int ks = 0; ks < 7; ++ks) {
-                    double Wa[3][2], ra[3], rb[3], cf[9];
+                    double r0[3], c0[3], r1[3], c1[3], cf[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k) cf[k] = ldC(k, oC);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ra[c] = ldA(c, oRa);
+                    for (int c = 0; c < 3; ++c) { r0[c] = ldA(c, oR0); c0[c] = ldA(c, oC0); }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { Wa[c][0] = ldA(c, oW0); Wa[c][1] = ldA(c, oW1); }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) rb[c] = ldA(c, oRb);
-                    {   // row block IBa
-                        const RowOps o = row_ops(ra, cf);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            aD[0][t] = mm(o.s[0], Wa[0][t], aD[0][t]); aD[1][t] = mm(o.s[1], Wa[1][t], aD[1][t]); aD[2][t] = mm(o.s[2], Wa[2][t], aD[2][t]);
-                            aM[t] = mm(o.h[0], Wa[0][t], aM[t]); a01[t] = mm(o.l0, Wa[1][t], a01[t]); a02[t] = mm(o.l0, Wa[2][t], a02[t]);
-                            aM[t] = mm(o.h[1], Wa[1][t], aM[t]); a01[t] = mm(o.n1, Wa[0][t], a01[t]); a02[t] = mm(o.n2, Wa[0][t], a02[t]);
-                            aM[t] = mm(o.h[2], Wa[2][t], aM[t]);
-                        }
-                    }
-                    {   // row block IBb: its upper blocks lie in W1
-                        const RowOps o = row_ops(rb, cf);
-                        bD[0] = mm(o.s[0], Wa[0][1], bD[0]); bD[1] = mm(o.s[1], Wa[1][1], bD[1]); bD[2] = mm(o.s[2], Wa[2][1], bD[2]);
-                        bM = mm(o.h[0], Wa[0][1], bM);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            b01[t] = mm(o.l0, Wa[1][t], b01[t]); b02[t] = mm(o.l0, Wa[2][t], b02[t]); b12[t] = mm(o.l1, Wa[2][t], b12[t]);
-                            if (t == 0) bM = mm(o.h[1], Wa[1][1], bM);
-                            b01[t] = mm(o.n1, Wa[0][t], b01[t]); b02[t] = mm(o.n2, Wa[0][t], b02[t]); b12[t] = mm(o.n2, Wa[1][t], b12[t]);
-                            if (t == 0) bM = mm(o.h[2], Wa[2][1], bM);
-                        }
-                    }
-                    oC += 32u; oW0 += 32u; oW1 += 32u; oRa += 32u; oRb += 32u;
+                    for (int c = 0; c < 3; ++c) { r1[c] = ldA(c, oR1); c1[c] = ldA(c, oC1); }
+                    step_unit(x0, r0, c0, cf);
+                    step_unit(x1, r1, c1, cf);
+                    oC += 32u; oR0 += 32u; oC0 += 32u; oR1 += 32u; oC1 += 32u;
                 }
             }
             rotate_inputs();
@@ -391,74 +400,23 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
             if (!(TRACE && (a.ablate & 4))) {
                 int ls = tid & 63;
                 asm volatile("" : "+v"(ls));
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const StOff o = st_off(IBa, 16 * t, ls);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const double v = aD[i][t] + aM[t];
-                        put(o.dirs, (i * 3 + i) * N, v);
-                        put(o.mirs, (i * 3 + i) * N, v);
-                    }
-                    put(o.dir, (0 * 3 + 1) * N, a01[t]); put(o.mir, (1 * 3 + 0) * N, a01[t]);
-                    put(o.dir, (0 * 3 + 2) * N, a02[t]); put(o.mir, (2 * 3 + 0) * N, a02[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const StOff o = st_off(IBb, 16 * t, ls);
-                    if (t == 1) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const double v = bD[i] + bM;
-                            put(o.dirs, (i * 3 + i) * N, v);
-                            put(o.mirs, (i * 3 + i) * N, v);
-                        }
-                    }
-                    put(o.dir, (0 * 3 + 1) * N, b01[t]); put(o.mir, (1 * 3 + 0) * N, b01[t]);
-                    put(o.dir, (0 * 3 + 2) * N, b02[t]); put(o.mir, (2 * 3 + 0) * N, b02[t]);
-                    put(o.dir, (1 * 3 + 2) * N, b12[t]); put(o.mir, (2 * 3 + 1) * N, b12[t]);
-                }
+                store_unit(x0, 0, ls);
+                store_unit(x1, 1, ls);
             }
         } else {
-            // ---- row block 3 (symmetric components against the window 12 .. 27) and the component (1, 2) of row blocks 0, 1, 2
-            unsigned oWx = win_off(12), oR3 = row_off(3), oQ0 = row_off(0), oQ1 = row_off(1), oQ2 = row_off(2);
-            double cD[3], cM = 0.0, c01[2], c02[2], c12[2], d12[3][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { c01[t] = 0.0; c02[t] = 0.0; c12[t] = 0.0; d12[0][t] = 0.0; d12[1][t] = 0.0; d12[2][t] = 0.0; }
-            cD[0] = 0.0; cD[1] = 0.0; cD[2] = 0.0;
+            unsigned oR0 = node_off(ibt, 0), oC0 = node_off(jbt, 0);
+            Unit x0;
+            zero_unit(x0);
             if (!(TRACE && (a.ablate & 2))) {
 #pragma unroll 1
                 for (int ks = 0; ks < 7; ++ks) {
-                    double Wa[3][2], Xa[3], r3[3], q1[3], q2[3], cf[9];
+                    double r0[3], c0[3], cf[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k) cf[k] = ldC(k, oC);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) r3[c] = ldA(c, oR3);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { Xa[c] = ldA(c, oWx); Wa[c][0] = ldA(c, oW0); Wa[c][1] = ldA(c, oW1); }
-                    q1[0] = ldA(1, oQ0); q1[1] = ldA(1, oQ1); q1[2] = ldA(1, oQ2);
-                    q2[0] = ldA(2, oQ0); q2[1] = ldA(2, oQ1); q2[2] = ldA(2, oQ2);
-                    {
-                        const RowOps o = row_ops(r3, cf);
-                        cD[0] = mm(o.s[0], Xa[0], cD[0]); cD[1] = mm(o.s[1], Xa[1], cD[1]); cD[2] = mm(o.s[2], Xa[2], cD[2]);
-                        cM = mm(o.h[0], Xa[0], cM);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            c01[t] = mm(o.l0, Wa[1][t], c01[t]); c02[t] = mm(o.l0, Wa[2][t], c02[t]); c12[t] = mm(o.l1, Wa[2][t], c12[t]);
-                            if (t == 0) cM = mm(o.h[1], Xa[1], cM);
-                            c01[t] = mm(o.n1, Wa[0][t], c01[t]); c02[t] = mm(o.n2, Wa[0][t], c02[t]); c12[t] = mm(o.n2, Wa[1][t], c12[t]);
-                            if (t == 0) cM = mm(o.h[2], Xa[2], cM);
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const double l1 = cf[0] * q1[b], n2 = cf[1] * q2[b];
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) d12[b][t] = mm(l1, Wa[2][t], d12[b][t]);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) d12[b][t] = mm(n2, Wa[1][t], d12[b][t]);
-                    }
-                    oC += 32u; oW0 += 32u; oW1 += 32u; oWx += 32u; oR3 += 32u; oQ0 += 32u; oQ1 += 32u; oQ2 += 32u;
+                    for (int c = 0; c < 3; ++c) { r0[c] = ldA(c, oR0); c0[c] = ldA(c, oC0); }
+                    step_unit(x0, r0, c0, cf);
+                    oC += 32u; oR0 += 32u; oC0 += 32u;
                 }
             }
             rotate_inputs();
@@ -468,29 +426,7 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
             if (!(TRACE && (a.ablate & 4))) {
                 int ls = tid & 63;
                 asm volatile("" : "+v"(ls));
-                {
-                    const StOff o = st_off(3, 12, ls);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const double v = cD[i] + cM;
-                        put(o.dirs, (i * 3 + i) * N, v);
-                        put(o.mirs, (i * 3 + i) * N, v);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const StOff o = st_off(3, 16 * t, ls);
-                    put(o.dir, (0 * 3 + 1) * N, c01[t]); put(o.mir, (1 * 3 + 0) * N, c01[t]);
-                    put(o.dir, (0 * 3 + 2) * N, c02[t]); put(o.mir, (2 * 3 + 0) * N, c02[t]);
-                    put(o.dir, (1 * 3 + 2) * N, c12[t]); put(o.mir, (2 * 3 + 1) * N, c12[t]);
-                }
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const StOff o = st_off(b, 16 * t, ls);
-                        put(o.dir, (1 * 3 + 2) * N, d12[b][t]); put(o.mir, (2 * 3 + 1) * N, d12[b][t]);
-                    }
+                store_unit(x0, 0, ls);
             }
         }
         mark(4);

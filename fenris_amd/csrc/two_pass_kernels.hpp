@@ -37,9 +37,6 @@ static __global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const
     for (unsigned t = adj_off[i]; t < adj_off[i + 1]; ++t) entry_node[t] = i;
 }
 
-// PLANAR: the dense matrices are stored node-major as ke[e][I][r][c][J] (what the MFMA kernel writes) instead of one
-// column-major (S n) x (S n) matrix; the S x S x n values of an (element, local node) entry are one contiguous run and a lane walks
-// (c, J) with J fastest.
 // k_rows_from_dense for small column-major element matrices (S n <= P <= 32, P a power of two): a row of K_e fills less
 // than half a wavefront, so 64 / P entries of the node share one load instruction (lane / P picks the entry) and all
 // EB groups of a node are in flight together -- Hex8: the 8 entries of a node in one round (the one-entry-per-load
@@ -92,12 +89,11 @@ __global__ void __launch_bounds__(256) k_rows_from_dense_small(int num_nodes, in
     }
 }
 
-template <int S, typename PT, bool PLANAR>
+template <int S, typename PT>
 __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, const unsigned* noff, const unsigned* adj_off,
                                                          const unsigned* adj, const PT* pos_tab, const double* ke, double* vals,
                                                          int overwrite, int max_cnt, const int* node_list, int node_count) {
-    // node_list (round 5, the overlapped form): the nodes of one chunk -- those whose last adjacent element lies in the chunk of element
-    // matrices that was just written -- instead of all nodes in order; the workgroup may be a single wavefront (blockDim.x = 64)
+    // node_list: a subset / another order of the nodes instead of all nodes in order (or null); the workgroup may be a single wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
     double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
@@ -123,15 +119,15 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                     const unsigned tk = min(t + (unsigned)k, t1 - 1);
                     const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
                     const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                    const double* kb = PLANAR ? ke + (size_t)e * ld * ld + (size_t)a * (S * S * n) : ke + (size_t)e * ld * ld + (size_t)S * a * ld;
+                    const double* kb = ke + (size_t)e * ld * ld + (size_t)S * a * ld;
                     const PT* pp = pos_tab + (size_t)tk * n;
 #pragma unroll
                     for (int h = 0; h < HB; ++h) {
                         const int idx = min(lane + 64 * (h0 + h), ld - 1);
-                        pos[k][h] = (int)pp[PLANAR ? idx % n : idx / S];
+                        pos[k][h] = (int)pp[idx / S];
 #pragma unroll
                         for (int r = 0; r < S; ++r)
-                            v[k][h][r] = PLANAR ? kb[(size_t)r * (S * n) + idx] : kb[(size_t)r * ld + idx];   // planar: ke[e][a][r][c][J], idx = c n + J
+                            v[k][h][r] = kb[(size_t)r * ld + idx];
                     }
                 }
 #pragma unroll
@@ -140,7 +136,7 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
                     for (int h = 0; h < HB; ++h) {
                         const int idx = lane + 64 * (h0 + h);
                         if (t + (unsigned)k < t1 && idx < ld) {
-                            double* dst = acc + S * pos[k][h] + (PLANAR ? idx / n : idx % S);
+                            double* dst = acc + S * pos[k][h] + idx % S;
 #pragma unroll
                             for (int r = 0; r < S; ++r) atomic_add_f64(dst + r * S * cnt, v[k][h][r]);
                         }
@@ -154,24 +150,65 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
 }
 
 
-// chunk of the LAST adjacent element of every node (entries ascend per node), for the overlapped two-pass assembly: the rows of a node
-// can be gathered as soon as the chunk of element matrices that holds its last element is complete.  A node without elements: chunk 0.
-static __global__ void __launch_bounds__(256) k_node_last_chunk(int num_nodes, int n, const unsigned* adj_off, const unsigned* adj, long long E, int chunks,
-                                                                unsigned* chunk_of, unsigned* node_id, unsigned* counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_nodes) return;
-    const unsigned t0 = adj_off[i], t1 = adj_off[i + 1];
-    unsigned k = 0;
-    if (t1 > t0) {
-        const long long e = (long long)(adj[t1 - 1] / (unsigned)n);
-        // chunk k holds the elements [k E / chunks, (k + 1) E / chunks)
-        k = (unsigned)min((long long)chunks - 1, (e * chunks + chunks - 1) / E);
-        while (k > 0 && e < (long long)k * E / chunks) --k;
-        while ((long long)(k + 1) * E / chunks <= e) ++k;
+// Second pass for the Hex27 matrix-core first pass (hex27_blocks.hpp): the element matrices are stored as their UPPER NODE-BLOCK TRIANGLE,
+// ke[e][tri(I, J)][i][j] with tri(I, J) = I (53 - I) / 2 + J for I <= J (378 blocks of 3 x 3 = 3 402 doubles instead of 6 561).  The rows of local
+// node a of element e are the blocks (a, J), J >= a -- one contiguous run -- and, by symmetry (K_e[(a, r), (J, c)] = K_e[(J, c), (a, r)]), the
+// TRANSPOSED blocks (J, a), J < a: a 72-byte piece each.  A lane takes the entries idx = lane + 64 h, h < 4, of the entry's 243 values in the
+// order (J, r, c).  Both halves of a symmetric pair of the global matrix are sums of the SAME stored doubles in the same (ascending element)
+// order: the assembled matrix is symmetric bit for bit.
+template <typename PT>
+__global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, const unsigned* adj_off, const unsigned* adj, const PT* pos_tab,
+                                                       const double* ke, double* vals, int overwrite, int max_cnt, const int* node_list,
+                                                       int node_count) {
+    constexpr int S = 3, n = 27, TRI = (n * (n + 1) / 2) * 9, EB = 4, HR = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
+    double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
+    // the lane's four places inside an entry (the last round is partly empty: 243 = 3 x 64 + 51)
+    int Jl[HR], rcl[HR], tl[HR];
+#pragma unroll
+    for (int h = 0; h < HR; ++h) {
+        const int idx = min(lane + 64 * h, S * S * n - 1);
+        Jl[h] = idx / 9;
+        rcl[h] = idx - 9 * Jl[h];
+        tl[h] = (rcl[h] % 3) * 3 + rcl[h] / 3;   // the same place in the transposed block
     }
-    chunk_of[i] = k;
-    node_id[i] = (unsigned)i;
-    atomicAdd(&counts[k], 1u);
+    for (int it = blockIdx.x * wpb + wave; it < node_count; it += gridDim.x * wpb) {
+        const int i = __builtin_amdgcn_readfirstlane(node_list ? node_list[it] : it);
+        const unsigned r0 = noff[i];
+        const int cnt = (int)(noff[i + 1] - r0);
+        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
+        const unsigned t0 = __builtin_amdgcn_readfirstlane(adj_off[i]), t1 = __builtin_amdgcn_readfirstlane(adj_off[i + 1]);
+        for (unsigned t = t0; t < t1; t += EB) {
+            double v[EB][HR];
+            int pos[EB][HR];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const unsigned tk = min(t + (unsigned)k, t1 - 1);
+                const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
+                const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
+                const double* kb = ke + (size_t)e * TRI;
+                const PT* pp = pos_tab + (size_t)tk * n;
+                const int row_a = (a * (53 - a)) / 2;
+#pragma unroll
+                for (int h = 0; h < HR; ++h) {
+                    const int J = Jl[h];
+                    const int src = J >= a ? (row_a + J) * 9 + rcl[h] : ((J * (53 - J)) / 2 + a) * 9 + tl[h];
+                    pos[k][h] = (int)pp[J];
+                    v[k][h] = kb[src];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k)
+#pragma unroll
+                for (int h = 0; h < HR; ++h)
+                    if (t + (unsigned)k < t1 && lane + 64 * h < S * S * n)
+                        atomic_add_f64(acc + (rcl[h] / 3) * S * cnt + S * pos[k][h] + rcl[h] % 3, v[k][h]);
+        }
+        double* out = vals + (size_t)S * S * r0;
+        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
+        else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
+    }
 }
 
 }  // namespace fenris_hip

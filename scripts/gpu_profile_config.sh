@@ -34,7 +34,7 @@ PY
 python3 - >> gpurun_out/prof_$CFG/summary.txt <<PY
 import glob, sqlite3
 names = {"ns": ("k_affine_rows<", "k_affine_records"), "c5": ("k_affine_rows<", "k_affine_records"), "c2": ("k_affine_rows<", "k_affine_records"),
-         "ns-perturbed": ("k_hex8_rows",), "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_mfma", "k_rows_from_dense")}.get("$CFG", ())
+         "ns-perturbed": ("k_hex8_rows",), "c3": ("k_gather_rows_tet4",), "c4": ("k_hex27_dense_blocks", "k_rows_from_tri")}.get("$CFG", ())
 for f in glob.glob("gpurun_out/prof_$CFG/stats/**/*.db", recursive=True):
     db = sqlite3.connect(f)
     print("== the last 20 dispatches of the configuration's kernels in the kernel-trace run (= its 20 timed steps):")

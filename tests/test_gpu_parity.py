@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 import fenris_amd as fa
+
+HEX27_TWO_PASS = ("k_hex27_dense_blocks + k_rows_from_tri",)
 from fenris_amd import quadrature
 from conftest import load_golden_mesh
 
@@ -787,7 +789,7 @@ def test_full_size_hex27_neo_hookean_properties(engine, oracle):
     # the production path for high-order elements: two-pass owner-computes, element matrices on the fp64 matrix cores
     v3 = torch.empty_like(vals).fill_(float("nan"))
     eng.assemble_matrix(v3, fa.SCATTER_GATHER | fa.ASSEMBLE_OVERWRITE)
-    assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+    assert eng.last_kernel_name() in HEX27_TWO_PASS
     assert float((vals - v3).abs().max()) <= 1e-12 * float(vals.abs().max())
     # size-independent properties through the blocked-CSR SpMV: a rigid translation carries no force (every elastic
     # tangent annihilates constant displacement fields), and K is symmetric: x.(K y) == y.(K x)

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 
 import fenris_amd as fa
+
+HEX27_TWO_PASS = ("k_hex27_dense_blocks + k_rows_from_tri",)
 from fenris_amd import quadrature
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +49,7 @@ def test_mfma_path_matches_oracle(engine, oracle, op, per_point):
     u = 0.01 * np.random.default_rng(2).standard_normal(3 * mesh.num_nodes())
     asm, ref = _build(engine, oracle, mesh, op, u, per_point)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert engine.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+    assert engine.last_kernel_name() in HEX27_TWO_PASS
     st, _, ro, ci, vals = oracle.assemble(ref)
     assert st == 0 and np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
     assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
@@ -94,7 +96,7 @@ def test_mfma_path_nan_positions_for_inverted_element(engine, oracle):
         u[3 * n: 3 * n + 3] = -2.2 * (mesh.vertices[n] - centre)
     asm, ref = _build(engine, oracle, mesh, "NEO_HOOKEAN", u)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert "mfma" in engine.last_kernel_name()
+    assert engine.last_kernel_name() in HEX27_TWO_PASS
     vals = oracle.assemble(ref)[4]
     assert np.isnan(vals).any() and np.array_equal(np.isnan(k.values), np.isnan(vals))
     ok = ~np.isnan(vals)
@@ -144,7 +146,7 @@ def test_two_pass_path_is_bit_reproducible(oracle):
             asm, _ = _build(eng, oracle, mesh, "NEO_HOOKEAN", u)
             for _ in range(2 if grid else 4):
                 k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-                assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+                assert eng.last_kernel_name() in HEX27_TWO_PASS
                 if ref_vals is None:
                     ref_vals = k.values.copy()
                 assert np.array_equal(k.values, ref_vals), grid
@@ -153,20 +155,19 @@ def test_two_pass_path_is_bit_reproducible(oracle):
 
 
 @pytest.mark.parametrize("op,per_point", [("LINEAR_ELASTIC", False), ("NEO_HOOKEAN", False), ("NEO_HOOKEAN", True)])
-def test_block_form_of_the_first_pass(oracle, op, per_point):
-    """Round 5 experiment (FENRIS_HIP_HEX27_BLOCKS=1, hex27_mfma.hpp FORM 1): the element matrices from 4 x 4 x 4 blocks (v_mfma_f64_4x4x4_4b)
-    instead of 16 x 16 tiles -- the oracle's matrix at 1e-12, symmetric bit for bit (lower blocks and the lower halves of the diagonal blocks are
-    stored copies), NaN blocks where det F <= 0 (materials.rs:298-300), with many elements per workgroup (roles rotate from element to element),
-    and the same bits from run to run."""
+def test_roles_rotate_and_triangles_are_symmetric(oracle, op, per_point):
+    """hex27_blocks.hpp: the element matrices from 4 x 4 x 4 blocks (v_mfma_f64_4x4x4_4b), stored as upper node-block triangles -- with MANY
+    elements per workgroup (12 elements on three workgroups: every wavefront takes every role, scratch of the per-point chain is reused from
+    element to element), the oracle's matrix at 1e-12, symmetric bit for bit (both halves of a symmetric pair are sums of the same stored
+    doubles), the same bits from run to run, and against the generic first pass with full column-major matrices in the same context."""
     eng = fa.Engine(0)
     try:
-        eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 1)
-        eng.set_option("FENRIS_HIP_TWO_PASS_GRID", 3)            # 12 elements on three workgroups: every wavefront takes every role
+        eng.set_option("FENRIS_HIP_TWO_PASS_GRID", 3)
         mesh = _mesh(1)
         u = 0.01 * np.random.default_rng(2).standard_normal(3 * mesh.num_nodes())
         asm, ref = _build(eng, oracle, mesh, op, u, per_point)
         k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-        assert eng.last_kernel_name() == "k_hex27_dense_mfma + k_rows_from_dense"
+        assert eng.last_kernel_name() in HEX27_TWO_PASS
         st, _, ro, ci, vals = oracle.assemble(ref)
         assert st == 0 and np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
         assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
@@ -175,12 +176,12 @@ def test_block_form_of_the_first_pass(oracle, op, per_point):
         assert d.nnz == 0 or not np.any(d.data != 0.0)
         k2 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
         assert np.array_equal(k.values, k2.values)
-        # the tiles in the same context: the same matrix to rounding
-        eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 0)
+        eng.set_option("FENRIS_HIP_NO_MFMA", 1)
         k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert eng.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
         assert np.abs(k3.values - k.values).max() <= 1e-12 * np.abs(vals).max()
+        eng.set_option("FENRIS_HIP_NO_MFMA", None)
         if op == "NEO_HOOKEAN" and not per_point:
-            eng.set_option("FENRIS_HIP_HEX27_BLOCKS", 1)
             mesh = _mesh(7)
             u = 0.002 * np.random.default_rng(8).standard_normal(3 * mesh.num_nodes())
             nodes = mesh.connectivity[4].astype(int)
@@ -195,3 +196,17 @@ def test_block_form_of_the_first_pass(oracle, op, per_point):
             assert np.abs(k.values[ok] - vals[ok]).max() <= 1e-12 * np.abs(vals[ok]).max()
     finally:
         eng.close()
+
+
+def test_large_deformation_keeps_the_tolerance(engine, oracle):
+    """the trace term is formed as a_I^T (F F^T) a_J with a = F^-T g instead of g_I . g_J (hex27_blocks.hpp): its rounding error grows with
+    cond(F)^2 -- a stretch of 3 x 1 x 1/3 with shear (cond F ~ 10) stays at 1e-11 of the largest entry"""
+    mesh = _mesh(13, cells=(2, 2, 2))
+    A = np.array([[2.0, 0.4, 0.0], [0.0, 0.0, 0.3], [0.2, 0.0, -2.0 / 3.0]])   # F = I + A
+    u = (mesh.vertices @ A.T).reshape(-1)
+    asm, ref = _build(engine, oracle, mesh, "NEO_HOOKEAN", u)
+    k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    assert engine.last_kernel_name() in HEX27_TWO_PASS
+    vals = oracle.assemble(ref)[4]
+    assert not np.isnan(vals).any()
+    assert np.abs(k.values - vals).max() <= 1e-11 * np.abs(vals).max()

@@ -10,7 +10,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
 
 TWO_PASS_GENERIC = "k_assemble_matrix<dump> + k_rows_from_dense"
-TWO_PASS_MFMA = "k_hex27_dense_mfma + k_rows_from_dense"
+TWO_PASS_MFMA = "k_hex27_dense_blocks + k_rows_from_tri"
 
 
 def expected(mesh, rule, op, data, mask):

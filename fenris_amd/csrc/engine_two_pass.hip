@@ -130,9 +130,10 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // entry_node is released on scope exit
         c->has_tp_pos = true;
     }
-    // (Triangle layout, measured and not kept -- profiles/r06_c4_triangle.txt: walking the nodes in Morton order of their coordinates and / or
-    // giving every XCD a contiguous part of the node list halves the reads that leave the L2s (17.7 -> 10.1 GB) and makes the pass SLOWER,
-    // 3.4 -> 3.6 - 4.1 ms: the pass is bound by latency per node, not by traffic.)
+    // (Triangle layout, measured and not kept -- profiles/r06_c4_triangle.txt: walking the nodes in Morton order of their coordinates, by their
+    // first adjacent element, and / or giving every XCD a contiguous part of the node list.  Morton + XCD parts halve the reads that leave the
+    // L2s (17.7 -> 10.1 GB) and make the pass SLOWER, 3.4 -> 3.6 - 4.1 ms; the pass follows its occupancy instead (4 / 8 / 16 / 20 wavefronts per
+    // CU: 7.4 / 4.5 / 3.4 / ~3.25 ms), which registers and the LDS rows of the longest node row hold at 16.)
     const int* node_list = nullptr;
     const int rows_grid_cap = c->env_int("FENRIS_HIP_TWO_PASS_ROWS_GRID", c->env_int("FENRIS_HIP_TWO_PASS_GRID", 1 << 17));   // (C4: 2^17 workgroups 8.33 ms, one per four nodes (410 k) 8.42, 2^13 8.45, 2^11 8.68)
     c->last_kernel = mfma ? "k_hex27_dense_blocks + k_rows_from_tri" : "k_assemble_matrix<dump> + k_rows_from_dense";

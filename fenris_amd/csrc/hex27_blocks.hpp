@@ -365,6 +365,16 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
                 x.k[1][0] = x.k[0][1]; x.k[2][0] = x.k[0][2]; x.k[2][1] = x.k[1][2];
             }
             const double* f = &x.k[0][0];
+            if (TRACE && (a.ablate & 8)) {   // timing only (wrong places): the same bytes as whole 1 KB runs per instruction -- what ideal stores would cost
+                const unsigned base = (unsigned)((role * 2 + u) * 4608);
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const st_f64x2 v = {f[2 * p2], f[2 * p2 + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st_u32x4, v), ke_rsrc, (base + (unsigned)(p2 * 1024 + ls * 16)) % 27200u, 0, 0);
+                }
+                if (ls < 32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st_u32x4, (st_f64x2){f[8], f[8]}), ke_rsrc, (base + (unsigned)(4096 + ls * 16)) % 27200u, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int p2 = 0; p2 < 4; ++p2) {
                 const st_f64x2 v = {f[2 * p2], f[2 * p2 + 1]};

@@ -337,9 +337,9 @@ struct fh_ctx {
     bool part_perm = false;     // the blocks were formed in a locality order of the nodes (row-owner Tet4 kernel only)
     bool part_rows_only = false;  // tables that only the row-owner Tet4 kernel can use (locality order and / or larger blocks)
     int rows_try = 0;           // block sizes tried for them: 0 = nine nodes / 256 entries, 1 = seven / 224, then the standard form
-    DevBuf<uint4> r_lanes4;     //                                     lanes per position (Tet4)
+    DevBuf<unsigned> r_lanes4;  //                                     lanes per position (Tet4): three words each
     DevBuf<int> r_vconn;        //                                     unique vertices + slot words per position (Tet4)
-    int r_rw = 0, r_ls = 256;
+    int r_rw = 0, r_ls = 256, r_vn = 256;   // (r_vn: vertices per position in r_vconn)
     bool has_rows = false;
     int p_rw = 0;
     int p_cs = 0, p_ms = 0, p_nbs = 0, p_jt = 1, p_us = 0;
@@ -445,7 +445,7 @@ struct fh_ctx {
 
 // Everything build_partition produces (and the row range it was produced for), as a detachable unit.
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
-    X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls)  \
+    X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls) X(r_vn)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
     X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_vtab) X(a_nu) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
     X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(h_tune_pending) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
@@ -454,7 +454,7 @@ struct PartStash {
     FH_PARTITION_MEMBERS(X)
 #undef X
     unsigned long long built_gen = ~0ull;
-    PartStash() { row_lo = 0; row_hi = -1; r_ls = 256; p_jt = 1; }
+    PartStash() { row_lo = 0; row_hi = -1; r_ls = 256; r_vn = 256; p_jt = 1; }
 };
 template <class T> static void part_swap(DevBuf<T>& a, DevBuf<T>& b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
 template <class T> static void part_swap(T& a, T& b) { std::swap(a, b); }

@@ -387,7 +387,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                 a.nq = 1;
             }
             RowTablesS T{c->r_rec.p, c->r_lanes4.p, c->r_vconn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr,
-                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls, c->env_int("FENRIS_HIP_TET4_PRIO", 0) & 15};
+                         c->r_rw, c->p_us, c->p_nbs, c->npos_gen, c->r_ls, c->r_vn, c->env_int("FENRIS_HIP_TET4_PRIO", 0) & 15};
             a.ub = std::max(c->p_us, 76);   // the X region of the layout (14 doubles per slot) holds the vertex table: 256 x 4 doubles
             a.nb_max = c->p_nbs;
             if (c->has_mask && a.overwrite) {   // blocks without an active element have no lane: clear the range first (rows_kernel.hpp)
@@ -523,6 +523,9 @@ int fh_time_assembly_dev(fh_ctx* c, double* values_dev, int flags, int reps, dou
     if (!(flags & FH_ASSEMBLE_OVERWRITE)) return c->fail(FH_BAD_ARGUMENT, "fh_time_assembly_dev: needs FH_ASSEMBLE_OVERWRITE (the timed assemblies write the values)");
     int rc = fh_assemble_matrix_async_dev(c, values_dev, flags);   // tables, code objects, first touch
     if (rc) return rc;
+    // the deferred lane tuner of k_hex8_rows (host work in front of a later launch) belongs to the set-up, not into the timed assemblies --
+    // nor into the baseline fh_tune_placement_dev compares its candidates with
+    if (c->h_tune_pending > 0) { rc = hex8_tune_lanes_now(c); if (rc) return rc; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t he = hipEventCreate(&e0);
     if (he == hipSuccess) he = hipEventCreate(&e1);

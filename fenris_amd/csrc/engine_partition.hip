@@ -180,7 +180,9 @@ int hex8_tune_lanes_now(fh_ctx* c) {
     const auto t0 = std::chrono::steady_clock::now();
     HostBuf<uint2> tabs((size_t)c->h_ntab * 256);
     HIP_TRY(c, hipMemcpyAsync(tabs.data(), c->h_lanes.p, sizeof(uint2) * tabs.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (also: no launch that reads the tables is still running when they are replaced)
+    // The tables are rewritten in place: NO launch that reads them may still be running -- on any stream (fh_set_stream does not drain the
+    // stream it replaces, so a k_hex8_rows of this context can be in flight on another one).  Once per pattern, next to ~18 ms of host work.
+    HIP_TRY(c, hipDeviceSynchronize());
     double cb = 0.0, ca = 0.0;
     hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, (long long)c->env_int("FENRIS_HIP_TUNE_PROPOSALS", 1000000));
     HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
@@ -530,6 +532,7 @@ int build_partition(fh_ctx* c) {
         umax = std::max(1, got[0]);
         mmax = std::max(1, got[1]);
         nrow_max = std::max(1, got[2]);
+        (void)nrow_max;
     }
     int ub = 0;
     if (layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, umax, acc, 64, true, mb, c->fast_ok) <= lds_target) {
@@ -794,36 +797,64 @@ int build_partition(fh_ctx* c) {
                 hipLaunchKernelGGL(k_row_starts, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->noff.p,
                                    c->part_perm ? v2r_d.p : (const unsigned*)nullptr, N, row_real.p);
                 DevBuf<int> st;
-                HIP_TRY(c, st.alloc(1));
-                HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
+                HIP_TRY(c, st.alloc(2));
                 HIP_TRY(c, c->r_rec.alloc((size_t)npg * c->r_rw));
                 int bad = 0;
-                for (int ls : {128, 256}) {  // half the table (and its traffic) when no block needs more than 128 lanes
-                    if (ls == 128 && nrow_max > 128) continue;   // every (node, column) block of the rows takes a lane at least: 256 at once
+                // the kernel reads these tables at every position and is bound by the bytes it moves (profiles/r06_c3_tables.txt): the strides
+                // are the most lanes / distinct vertices any position needs, rounded up to 32 -- counted first, by the builders themselves
+                int h_st[2] = {0, 0};
+                auto counted = [&](auto&& launch) -> int {   // status[1] of a count-only run of a builder
+                    HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+                    launch();
+                    HIP_TRY(c, hipGetLastError());
+                    HIP_TRY(c, hipMemcpyAsync(h_st, st.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    return FH_OK;
+                };
+                {
+                    const int rc_c = counted([&]() {
+                        hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms, nb_target, npg,
+                                           c->r_rw, c->r_rec.p, (unsigned*)nullptr, 256, st.p, row_real.p, 1);
+                    });
+                    if (rc_c) return rc_c;
+                }
+                bad = h_st[0];
+                if (bad == 0 && h_st[1] > 256) bad = 1;
+                if (bad == 0) {
+                    const int ls = std::max(32, (h_st[1] + 31) / 32 * 32);
                     c->r_ls = ls;
-                    HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                    HIP_TRY(c, c->r_lanes4.alloc((size_t)npg * ls));
+                    HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+                    HIP_TRY(c, c->r_lanes4.alloc((size_t)npg * ls * 3));
                     hipLaunchKernelGGL(k_build_row_lanes_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_rec.p, c->p_rw, us, ms,
-                                       nb_target, npg, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p, row_real.p);
+                                       nb_target, npg, c->r_rw, c->r_rec.p, c->r_lanes4.p, ls, st.p, row_real.p, 0);
                     HIP_TRY(c, hipGetLastError());
                     HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    if (bad != 2) break;  // 2: only the stride was too small
                 }
                 mark("row lanes (Tet4)");
                 if (bad == 0) {   // the position's unique vertices and the slot words that index them
-                    HIP_TRY(c, hipMemsetAsync(st.p, 0, sizeof(int), c->stream));
-                    HIP_TRY(c, c->r_vconn.alloc((size_t)npg * (ROWS_TET4_VMAX + us)));
-                    hipLaunchKernelGGL(k_build_row_verts_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_conn.p, us, npg, c->r_vconn.p, st.p);
-                    HIP_TRY(c, hipGetLastError());
-                    HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    const int rc_c = counted([&]() {
+                        hipLaunchKernelGGL(k_build_row_verts_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_conn.p, us, npg, (int*)nullptr, st.p,
+                                           ROWS_TET4_VMAX, 1);
+                    });
+                    if (rc_c) return rc_c;
+                    if (h_st[1] > ROWS_TET4_VMAX) bad = 4;
+                    if (bad == 0) {
+                        const int vn = std::max(32, (h_st[1] + 31) / 32 * 32);
+                        c->r_vn = vn;
+                        HIP_TRY(c, hipMemsetAsync(st.p, 0, 2 * sizeof(int), c->stream));
+                        HIP_TRY(c, c->r_vconn.alloc((size_t)npg * (vn + us)));
+                        hipLaunchKernelGGL(k_build_row_verts_tet4, dim3(npg), dim3(64), 0, c->stream, c->p_conn.p, us, npg, c->r_vconn.p, st.p, vn, 0);
+                        HIP_TRY(c, hipGetLastError());
+                        HIP_TRY(c, hipMemcpyAsync(&bad, st.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    }
                 }
                 c->has_rows = bad == 0;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));  // row_real is released at the end of this scope
                 mark("row vertices (Tet4)");
                 if (c->env("FENRIS_HIP_VERBOSE"))
-                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, stride %d): %s\n", c->r_ls,
+                    std::fprintf(stderr, "[fenris_hip] row-owner lanes (Tet4, %d lanes and %d vertices per position): %s\n", c->r_ls, c->r_vn,
                                  c->has_rows ? "built" : "mesh not expressible, pipelined kernel kept");
             }
         }

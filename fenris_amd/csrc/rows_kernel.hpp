@@ -14,23 +14,33 @@
 namespace fenris_hip {
 
 // Tet4 (one-point rule): six terms per lane.  A node of a tetrahedral mesh has ~24 elements and ~15 columns: the diagonal
-// block takes 4 lanes (24 terms), everything else one lane.  Lane record (uint4):
-//   x, y, z: six 16-bit terms  slot | a << 8 | j << 10;   w: pos | il << 7 (4 bits) | nterms << 11 | log2(group) << 14 | store << 16
+// block takes 4 lanes (24 terms), everything else one lane.  Lane record: 96 bits (round 6: the kernel is bound by the bytes it moves -- 2.0 GB
+// on C3, a third of them these tables -- and no longer by anything it computes, profiles/r06_c3_tables.txt; the record was a uint4 with 16-bit
+// terms at a stride of 128 or 256 lanes):
+//   six 12-bit terms  slot | a << 8 | j << 10  in bits 0 .. 71,  then  pos | il << 7 (4 bits) | nterms << 11 | log2(group) << 14 | store << 16  in bits 72 .. 88
 struct RowTablesS {
     const int* rec;      // [npos][rw]   GatherHdr | occupied slots (us / 4 words) | row offsets relative to the block (nbs + 1 words)
                          //              | first node-level CSR entry of every node's row (nbs words; the nodes of a block need not be
                          //              consecutive in memory: build_partition may form the blocks in a locality order)
-    const uint4* lanes;  // [npos][ls]   ls = 128 when no block needs more lanes, else 256
-    const int* vconn;    // [npos][256 + us]   the position's UNIQUE vertices (node ids; padded with its first one), then one word per slot:
-                         //              the four bytes index that list (k_build_row_verts_tet4).  A block of nine nodes sees ~180 elements
-                         //              but only ~70 distinct vertices: gathering every (slot, local node) coordinate again at every
-                         //              position was 720 scattered 24-byte fetches and twelve LDS writes per lane
+    const unsigned* lanes;  // [npos][ls][3]   ls = the most lanes any position needs, rounded up to 32
+    const int* vconn;    // [npos][vn + us]   the position's UNIQUE vertices (node ids; padded with its first one; vn = the most any position has,
+                         //              rounded up to 32), then one word per slot: the four bytes index that list (k_build_row_verts_tet4).
+                         //              A block of nine nodes sees ~180 elements but only ~70 distinct vertices: gathering every (slot, local
+                         //              node) coordinate again at every position was 720 scattered 24-byte fetches and twelve LDS writes per lane
     const int* elem;     // [npos][us]
     const double* slotpar;  // [npos][us][2] (mu, lambda) of the element in each slot (piecewise-constant material), or null
-    int rw, us, nbs, npos, ls;
+    int rw, us, nbs, npos, ls, vn;
     int prio;            // s_setprio levels (round 5): bits 0-1 the two wavefronts that carry phase B (the last lanes), bits 2-3 the other two
 };
 constexpr int ROWS_TET4_VMAX = 256;   // unique vertices per position the tables can express (one per lane)
+// the packed record <-> six 16-bit terms in three words + the control word
+__host__ __device__ inline void rows_tet4_pack(const unsigned (&w3)[3], unsigned w, unsigned (&out)[3]) {
+    const unsigned t0 = w3[0] & 0xfffu, t1 = (w3[0] >> 16) & 0xfffu, t2 = w3[1] & 0xfffu, t3 = (w3[1] >> 16) & 0xfffu, t4 = w3[2] & 0xfffu,
+                   t5 = (w3[2] >> 16) & 0xfffu;
+    out[0] = t0 | t1 << 12 | (t2 & 0xffu) << 24;
+    out[1] = (t2 >> 8) | t3 << 4 | t4 << 16 | (t5 & 0xfu) << 28;
+    out[2] = (t5 >> 4) | w << 8;
+}
 
 // ELEMPAR: (mu, lambda) per element: every term carries its element's pair, the block is
 //   sum_e mu_e (tr G_e I + G_e^T) + lambda_e G_e  =  tr(Gmu) I + Gmu^T + Gla   with Gmu = sum mu_e G_e, Gla = sum lambda_e G_e
@@ -51,18 +61,20 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
     { const int pr = (T.prio >> ((tid >> 7) ? 0 : 2)) & 3; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
 
     struct Rec { int w, vid, sw; };   // record word, vertex id and slot word of this lane
-    const int npos = T.npos, vs = ROWS_TET4_VMAX + T.us;
+    const int npos = T.npos, vs = T.vn + T.us;
     const int p_begin = (int)((long long)blockIdx.x * npos / G), p_end = (int)((long long)(blockIdx.x + 1) * npos / G);
     auto load_rec = [&](int p, Rec& r) {
         p = min(p, npos - 1);
         r.w = T.rec[(size_t)p * T.rw + min(tid, T.rw - 1)];
-        r.vid = T.vconn[(size_t)p * vs + tid];
-        r.sw = T.vconn[(size_t)p * vs + ROWS_TET4_VMAX + min(tid, T.us - 1)];
+        r.vid = T.vconn[(size_t)p * vs + min(tid, T.vn - 1)];   // (lanes behind the list re-read its last entry and park nothing)
+        r.sw = T.vconn[(size_t)p * vs + T.vn + min(tid, T.us - 1)];
     };
     // lanes beyond the table's stride re-read its last record and switch themselves off
+    struct LaneRec { unsigned x, y, z; };   // the packed record (see RowTablesS)
     auto load_lane = [&](int p) {
-        uint4 r = T.lanes[(size_t)min(p, npos - 1) * T.ls + min(tid, T.ls - 1)];
-        if (tid >= T.ls) r.w = 0u;
+        const unsigned* q = T.lanes + ((size_t)min(p, npos - 1) * T.ls + min(tid, T.ls - 1)) * 3;
+        LaneRec r{q[0], q[1], q[2]};
+        if (tid >= T.ls) r.z = 0u;
         return r;
     };
     double V[D];
@@ -76,16 +88,21 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         f64x2 xy;
         xy.x = V[0]; xy.y = V[1];
         double* row = lds + L.o_X + 4 * tid;             // vertex table: 32 bytes per entry, [x y | z -]
-        *reinterpret_cast<f64x2*>(row) = xy;
-        row[2] = V[2];
+        if (tid < T.vn) {
+            *reinterpret_cast<f64x2*>(row) = xy;
+            row[2] = V[2];
+        }
         if (tid < T.us) slot_words[tid] = r.sw;
         if (tid < T.rw) rec_base(parity)[tid] = r.w;
     };
+    // (Round 6, measured and removed -- profiles/r06_c3_tables.txt: the finished blocks through an image of the position's rows in LDS and from
+    // there to global memory by all 256 lanes, 16 contiguous bytes each, beside the next position's phase B: 0.61 against 0.47 ms.  The image's
+    // own LDS traffic costs more than the straight stores do.)
     const double sqw = sqrt(a.qw[0]);
     int p = p_begin;
     if (p >= p_end) return;
     Rec nxt;
-    uint4 lane_cur;
+    LaneRec lane_cur;
     {
         Rec cur;
         load_rec(p, cur);
@@ -93,7 +110,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         lane_cur = load_lane(p);
         load_rec(p + 1, nxt);
         park(cur, 0);
-        asm volatile("" : "+v"(nxt.w), "+v"(nxt.vid), "+v"(nxt.sw), "+v"(lane_cur.x), "+v"(lane_cur.w));
+        asm volatile("" : "+v"(nxt.w), "+v"(nxt.vid), "+v"(nxt.sw), "+v"(lane_cur.x), "+v"(lane_cur.z));
     }
     __syncthreads();
 
@@ -117,7 +134,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         load_verts(nxt);
         Rec nn;
         load_rec(p + 2, nn);
-        uint4 lane_nxt = load_lane(p + 1);
+        LaneRec lane_nxt = load_lane(p + 1);
         const int U = (p == p_begin) ? hc.U : hc.k0;
         stamp(0);
         // phase B: one lane per new slot (one quadrature point)
@@ -134,9 +151,10 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         stamp(2);
 
         // phase C: G = sum over the lane's terms of h_a h_j^T
-        const unsigned wl = lane_cur.w;
+        const unsigned wl = lane_cur.z >> 8;
         const int nterms = (int)((wl >> 11) & 7u), grp = (int)((wl >> 14) & 3u);
-        const unsigned tw[3] = {lane_cur.x, lane_cur.y, lane_cur.z};
+        const unsigned tm[TL] = {lane_cur.x & 0xfffu, (lane_cur.x >> 12) & 0xfffu, (lane_cur.x >> 24) | (lane_cur.y & 0xfu) << 8,
+                                 (lane_cur.y >> 4) & 0xfffu, (lane_cur.y >> 16) & 0xfffu, (lane_cur.y >> 28) | (lane_cur.z & 0xffu) << 4};
         double Gm[D][D], Gl[ELEMPAR ? D : 1][ELEMPAR ? D : 1];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -151,7 +169,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
             double mu_t[ELEMPAR ? TL : 1], la_t[ELEMPAR ? TL : 1];
     #pragma unroll
             for (int t = 0; t < TL; ++t) {
-                const unsigned term = (tw[t / 2] >> (16 * (t % 2))) & 0xffffu;
+                const unsigned term = tm[t];
                 const double* pq = lds + L.o_QP + (size_t)(term & 255u) * L.qss;
                 pa[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 8) & 3u));
                 pj[t] = (unsigned)(unsigned long long)(pq + 4 * ((term >> 10) & 3u));
@@ -238,19 +256,19 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
         // for these loads becomes vmcnt(0) -- every position then waited for its own nine stores per lane to drain, a write
         // latency per position (round 3: C3 0.63 -> see DESIGN 3.4).  X is read by phase B only, which lies behind the barrier above.
         if (have_next) park(nxt, parity ^ 1);
-        asm volatile("" : "+v"(nn.w), "+v"(nn.vid), "+v"(nn.sw), "+v"(lane_nxt.x), "+v"(lane_nxt.w));
+        asm volatile("" : "+v"(nn.w), "+v"(nn.vid), "+v"(nn.sw), "+v"(lane_nxt.x), "+v"(lane_nxt.z));
         if (((wl >> 16) & 1u) && !(a.ablate & 4)) {   // (ablate bit 2: no global stores)
             const int il = (int)((wl >> 7) & 15u), pos = (int)(wl & 127u);
             const int cnt = noff_l[il + 1] - noff_l[il];
             double* base = a.vals + (size_t)S * S * (size_t)(unsigned)noff_l[T.nbs + 1 + il] + S * pos;
+            const bool ow = a.overwrite;
             double tr = 0.0;
 #pragma unroll
             for (int i = 0; i < D; ++i) tr += Gm[i][i];
             if (OP == FH_LAPLACE) {
-                if (a.overwrite) base[0] = tr; else base[0] += tr;
+                if (ow) base[0] = tr; else base[0] += tr;
             } else {
-                // a row of the block is 24 bytes at an 8-byte boundary: one 16-byte and one 8-byte store (the 16-byte one needs no
-                // more than the 8-byte alignment), six store instructions per lane instead of nine
+                // a row of the block is 24 bytes at an 8-byte boundary: one 16-byte and one 8-byte store
                 typedef double f64x2_u8 __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
@@ -261,7 +279,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
                         if constexpr (ELEMPAR) v[j] = ((i == j) ? tr : 0.0) + Gm[j][i] + Gl[i % (ELEMPAR ? D : 1)][j % (ELEMPAR ? D : 1)];
                         else v[j] = (i == j) ? fma(a.mu, tr + Gm[i][i], a.lambda * Gm[i][i]) : fma(a.mu, Gm[j][i], a.lambda * Gm[i][j]);
                     }
-                    if (a.overwrite) {
+                    if (ow) {
                         f64x2_u8 lo;
                         lo.x = v[0]; lo.y = v[1];
                         *reinterpret_cast<f64x2_u8*>(row) = lo;
@@ -291,8 +309,10 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 // lanes of every position for the Tet4 kernel (see k_build_row_lanes).  Terms are kept in one compact array (a block has
 // at most ms N of them) behind per-column offsets; blocks with up to 48 terms (a node of an unstructured mesh easily has
 // 30-40 elements) take groups of up to 8 lanes.
+// count_only: nothing is written but status[1] = the most lanes any position needs (atomicMax) -- the caller sizes the stride ls by it
 static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
-                                                             int* rec_new, uint4* lanes, int ls, int* status, const unsigned* row_real) {
+                                                             int* rec_new, unsigned* lanes, int ls, int* status, const unsigned* row_real,
+                                                             int count_only) {
     constexpr int N = 4, NKEY = 16 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;   // up to 16 nodes per block
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
     __shared__ unsigned short terms[MAXTERMS];
@@ -305,9 +325,11 @@ static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p
     const unsigned char* posb = reinterpret_cast<const unsigned char*>(rec + 8 + us / 4 + ms);
     const int* noff_old = rec + 8 + us / 4 + ms + ms * N / 4;
     int* out = rec_new + (size_t)p * rw_new;
-    for (int i = lane; i < 8 + us / 4; i += 64) out[i] = rec[i];
-    for (int i = lane; i <= nbs; i += 64) out[8 + us / 4 + i] = noff_old[i];
-    for (int i = lane; i < nbs; i += 64) out[8 + us / 4 + nbs + 1 + i] = (i < h.nb) ? (int)row_real[h.i0 + i] : 0;
+    if (!count_only) {
+        for (int i = lane; i < 8 + us / 4; i += 64) out[i] = rec[i];
+        for (int i = lane; i <= nbs; i += 64) out[8 + us / 4 + i] = noff_old[i];
+        for (int i = lane; i < nbs; i += 64) out[8 + us / 4 + nbs + 1 + i] = (i < h.nb) ? (int)row_real[h.i0 + i] : 0;
+    }
     for (int i = lane; i < NKEY; i += 64) { cnt[i] = 0; fill[i] = 0; }
     for (int i = lane; i < 256 * 4; i += 64) lw[i / 4][i % 4] = 0u;
     __syncthreads();
@@ -320,6 +342,16 @@ static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p
         atomicAdd(&cnt[(int)(il * 128u + pos)], 1);
     }
     __syncthreads();
+    if (count_only) {   // lanes by classes: 25..48 terms -> 8 lanes, 13..24 -> 4, 7..12 -> 2, 1..6 -> 1 (as below)
+        int need = 0;
+        for (int base = 0; base < NKEY; base += 64) {
+            const int Tn = cnt[base + lane];
+            need += 8 * __popcll(__ballot(Tn > 4 * TL)) + 4 * __popcll(__ballot(Tn > 2 * TL && Tn <= 4 * TL)) +
+                    2 * __popcll(__ballot(Tn > TL && Tn <= 2 * TL)) + __popcll(__ballot(Tn >= 1 && Tn <= TL));
+        }
+        if (lane == 0) atomicMax(status + 1, need);
+        return;
+    }
     // exclusive prefix sum of the counts: 16 consecutive keys per lane, then across the lanes
     {
         int local = 0;
@@ -369,7 +401,7 @@ static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p
     if (base1 + n1 > 256) bad = true;
     if (__ballot(bad || too_many)) {
         if (lane == 0) atomicOr(status, __ballot(bad) ? 1 : 2);
-        for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = lane; i < 3 * ls; i += 64) lanes[(size_t)p * ls * 3 + i] = 0u;
         return;
     }
     int r8 = 0, r4 = 0, r2 = 0, r1 = 0;
@@ -403,7 +435,13 @@ static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p
         r8 += __popcll(m8); r4 += __popcll(m4); r2 += __popcll(m2); r1 += __popcll(m1);
     }
     __syncthreads();
-    for (int i = lane; i < ls; i += 64) lanes[(size_t)p * ls + i] = make_uint4(lw[i][0], lw[i][1], lw[i][2], lw[i][3]);
+    for (int i = lane; i < ls; i += 64) {
+        const unsigned w3[3] = {lw[i][0], lw[i][1], lw[i][2]};
+        unsigned pk[3];
+        rows_tet4_pack(w3, lw[i][3], pk);
+        unsigned* q = lanes + ((size_t)p * ls + i) * 3;
+        q[0] = pk[0]; q[1] = pk[1]; q[2] = pk[2];
+    }
 }
 
 // With an element mask a block (I, J) of the pattern may have no active element and therefore no lane: k_gather_rows_tet4 writes every
@@ -419,11 +457,13 @@ static __global__ void __launch_bounds__(256) k_zero_node_rows(const unsigned* n
 // cells are numbered in table order, every slot gets the four numbers of its nodes.  Which cell a node lands in may depend on the order
 // the lanes arrive (linear probing): only the numbering inside the position's vertex table does, never a value of the matrix.
 // More than ROWS_TET4_VMAX distinct vertices: status bit 2 (the caller keeps the pipelined kernel).
-static __global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p_conn, int us, int npos, int* vconn, int* status) {
+// vn: length of a position's vertex list in the table (a multiple of 32, <= ROWS_TET4_VMAX).  count_only: nothing is written but status[1] = the most
+// distinct vertices any position has (atomicMax).
+static __global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p_conn, int us, int npos, int* vconn, int* status, int vn, int count_only) {
     constexpr int H = 2048, CSMAX = 1024;
     __shared__ int key[H];
     __shared__ unsigned short cell_of[CSMAX], num[H];
-    const int p = blockIdx.x, lane = threadIdx.x, cs = 4 * us, vs = ROWS_TET4_VMAX + us;
+    const int p = blockIdx.x, lane = threadIdx.x, cs = 4 * us, vs = vn + us;
     const int* conn = p_conn + (size_t)p * cs;
     int* out = vconn + (size_t)p * vs;
     for (int i = lane; i < H; i += 64) key[i] = -1;
@@ -446,20 +486,24 @@ static __global__ void __launch_bounds__(64) k_build_row_verts_tet4(const int* p
         const unsigned long long m = __ballot(occ);
         const int idx = total + __popcll(m & below);
         num[base + lane] = (unsigned short)idx;
-        if (occ && idx < ROWS_TET4_VMAX) out[idx] = key[base + lane];
+        if (!count_only && occ && idx < vn) out[idx] = key[base + lane];
         total += __popcll(m);
     }
-    if (total > ROWS_TET4_VMAX) {
+    if (count_only) {
+        if (lane == 0) atomicMax(status + 1, total);
+        return;
+    }
+    if (total > vn) {
         if (lane == 0) atomicOr(status, 4);
         return;
     }
     __syncthreads();
     const int first = (cs > 0) ? conn[0] : 0;
-    for (int i = total + lane; i < ROWS_TET4_VMAX; i += 64) out[i] = first;   // padding: a vertex this position fetches anyway
+    for (int i = total + lane; i < vn; i += 64) out[i] = first;   // padding: a vertex this position fetches anyway
     for (int s_ = lane; s_ < us; s_ += 64) {
         unsigned w = 0;
         for (int g = 0; g < 4; ++g) w |= (unsigned)num[cell_of[4 * s_ + g]] << (8 * g);
-        out[ROWS_TET4_VMAX + s_] = (int)w;
+        out[vn + s_] = (int)w;
     }
 }
 

@@ -219,7 +219,11 @@ int fh_set_colors(fh_ctx*, uint64_t num_colors, const uint64_t* color_offsets, c
  * values are unspecified (the reference aborts at the first failing element). */
 int fh_assemble_matrix(fh_ctx*, double* values, int flags, uint64_t* failed_element);
 int fh_assemble_matrix_dev(fh_ctx*, double* values_dev, int flags, uint64_t* failed_element);
-/* same, but only enqueues; check the status later with fh_poll_status (no host sync; for timing loops) */
+/* same, but only enqueues; check the status later with fh_poll_status (no host sync; for timing loops).  The FIRST calls after a change of
+ * the mesh, the pattern, the mask or the operator do block the host: the first builds the owner-computes tables (tens of milliseconds), and
+ * on general Hex8 meshes the second runs the lane tuner of k_hex8_rows in front of its launch (a device synchronisation and ~20 ms of host
+ * work, once; FENRIS_HIP_TUNE_AFTER moves it, FENRIS_HIP_NO_LANE_TUNING removes it).  fh_time_assembly_dev and fh_tune_placement_dev run both
+ * before their timed assemblies. */
 int fh_assemble_matrix_async_dev(fh_ctx*, double* values_dev, int flags);
 int fh_poll_status(fh_ctx*, uint64_t* failed_element);
 /* Placement of the streamed buffers.  On MI355X the time of the owner-computes kernels follows how the large buffers they stream

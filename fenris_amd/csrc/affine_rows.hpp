@@ -19,22 +19,16 @@ struct AffineRowTables {
     int us, npos, acc_max;  // slots per position, positions of this launch, largest S * S * nrow
     int pos0, npos_all;     // first position of this launch (launches may cover a part of the sweep), positions in the tables
     int incomplete;         // some position has a (node, column) block without an owner lane (element masks): staged rows are cleared behind the store
-    int chunk;              // > 0 (experiment): positions dealt to the workgroups in chunks of this many instead of one contiguous range each
-    // fused form (round 5): the records wave forms the element records itself from
-    const int* vtab;        // [npos][nu + 32]  per position: its distinct vertices (nodes 0, 1, 3, 4 of its slots' elements), ascending, padded to nu
-                            //                  entries; then per slot the places of those four nodes in the list | empty << 31 (affine_rows_vertex_tables)
-    int nu;                 // padded length of the vertex lists (multiple of 4, <= 128); 0: no vertex table
 };
 
 constexpr int AFFINE_ROWS_GW_LE = 10, AFFINE_ROWS_GW_LAP = 6;
-constexpr int AFFINE_ROWS_NO_CLEAR = 0x40000;   // (timing experiments only: wrong results under a mask)
-constexpr int AFFINE_ROWS_NO_CARRY = 0x20000;   // (debugging) every position stores its own incomplete last line
-constexpr int AFFINE_ROWS_REC_NO_DMA = 0x80000, AFFINE_ROWS_REC_NO_MATH = 0x100000, AFFINE_ROWS_REC_NO_L1 = 0x200000, AFFINE_ROWS_REC_NO_L2 = 0x400000;   // (timing experiments on the records wave: wrong results)
+constexpr int AFFINE_ROWS_NO_CLEAR = 0x40000;   // bits of the launcher's `ablate` argument kept from round 3's timing experiments (scripts/exp_slab_time3.py set them
+constexpr int AFFINE_ROWS_NO_CARRY = 0x20000;   // through environment switches that are gone): never set by the library
 constexpr int AFFINE_ROWS_PRIO_SHIFT = 24;        // bits 24-25 of the launcher's `ablate` argument: s_setprio level of the store wave, 26-27: of the loader wave
 constexpr int AFFINE_ROWS_NT_STORES = 0x10000;  // bit of the launcher's `ablate` argument: non-temporal stores of the rows
-constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave (a second store wave: 448)
+constexpr int AFFINE_ROWS_THREADS = 384;  // four row waves + one loader wave + one store wave
 
-size_t affine_rows_lds_bytes(int op, int us, int acc_max, int fused_nu = 0);
+size_t affine_rows_lds_bytes(int op, int us, int acc_max);
 
 // lane records, headers and slot vertices of every position from the pipelined kernel's position records (p_rec, layout of
 // k_build_pipe_tables) and its per-slot connectivity.  *status (device) is set to 1 when a block cannot be expressed
@@ -65,21 +59,10 @@ hipError_t affine_records_launch(int op, hipStream_t stream, const double* verts
 hipError_t affine_rows_compact(hipStream_t stream, const uint2* lanes_full, const int* ids, const int* first_pos, int npos, int ntab,
                                uint2* lanes_tab, int4* hdr, int* mismatch);
 
-// op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; nstore (1 or 2): store waves; ablate != 0 selects the instrumented instantiation (profiling only)
-// fused (round 5): the kernel's seventh wavefront forms the element records from the vertices (a.verts, a.conn) -- no affine_records_launch,
-// T.rec unused; only where affine_rows_can_fuse (depth 2, one store wave, production instantiation, no chunk experiment)
-bool affine_rows_can_fuse(int depth, int nstore, int ablate, int chunk);
-// the vertex tables of the fused form, once per pattern: largest number of distinct vertices of a position (device int, atomicMax), then the rows
-hipError_t affine_rows_vertex_count(hipStream_t stream, const int* elem, const int* conn, int us, int npos, int* nu_max_dev);
-hipError_t affine_rows_vertex_tables(hipStream_t stream, const int* elem, const int* conn, int us, int npos, int* vtab, int nu_pad);
-hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
-                              int ablate, bool masked, bool fused = false);
-
-// ---- third form, k_affine_ring (affine_ring.hip): no workgroup barrier in the sweep, rows staged in a ring that mirrors the value stream
-// ring size in doubles (a power of two holding at least two positions; want_kb > 0: at least that many KiB)
-int affine_ring_doubles(int acc_max, int want_kb);
-size_t affine_ring_lds_bytes(int op, int us, int ring);
-hipError_t affine_ring_launch(int op, int ring, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T,
-                              int ablate);
+// op: FH_LAPLACE or FH_LINEAR_ELASTIC; depth (1 or 2): positions the loader wave's requests run ahead; ablate != 0 selects the instrumented
+// instantiation (profiling only).  (Retired to scripts/attic/: the fused form whose seventh wavefront formed the element records, the chunked
+// dealing of positions, a second store wave, and the ring form affine_ring.hip.)
+hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T, int ablate,
+                              bool masked);
 
 }  // namespace fenris_hip

@@ -154,7 +154,7 @@ int build_pattern(fh_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if (h_flags[0]) return c->fail(FH_BAD_ARGUMENT, "connectivity refers to a node index >= num_nodes");
     const unsigned long long max_cand = (unsigned long long)h_red[0] * (unsigned)c->ei.n;
-    bool once = N > 0 && !c->ragged && max_cand <= 128ull && !c->env("FENRIS_HIP_PATTERN_TWO_PASSES");
+    bool once = N > 0 && !c->ragged && max_cand <= 128ull;
     DevBuf<unsigned> rows64;
     if (once) {
         // every node has at most 64 (hexahedra) or 128 (tetrahedra: two per lane) candidates: one neighbour pass into scratch rows of 64
@@ -519,7 +519,7 @@ static int classify_affine(fh_ctx* c) {
     // reserved NOW, while the device memory of a fresh context is still unfragmented -- allocated at the first assembly it lands in
     // whatever the table builders' temporaries left behind, and the time of the headline kernel follows how its buffers happen to be
     // backed (two modes 8 % apart, profiles/r03_affine_experiments.txt).
-    if (h > 0 && !c->env("FENRIS_HIP_RECS_LATE") && c->a_recs.n < (size_t)c->E * AFFINE_ROWS_GW_LE)
+    if (h > 0 && c->a_recs.n < (size_t)c->E * AFFINE_ROWS_GW_LE)
         HIP_TRY(c, c->a_recs.alloc((size_t)c->E * AFFINE_ROWS_GW_LE));
     return FH_OK;
 }

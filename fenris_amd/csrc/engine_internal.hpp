@@ -356,8 +356,6 @@ struct fh_ctx {
     DevBuf<double> ghat;            // [64][10] LinearElastic blocks | [64][6] Laplace blocks
     bool has_ghat = false;
     DevBuf<int> a_conn, a_elem;     // k_affine_rows (affine_rows.hip): per-slot connectivity (table build only), element ids
-    DevBuf<int> a_vtab;             // ... vertex tables of the fused form (affine_rows_vertex_tables): [a_npos][a_nu + 32]
-    int a_nu = 0;                   // padded length of their vertex lists (0: none -- the separate records kernel runs)
     DevBuf<uint2> a_lanes;          // lane records
     DevBuf<int4> a_hdr;             // position headers
     DevBuf<double> a_recs;          // element records (R or M), rewritten by every assembly
@@ -447,7 +445,7 @@ struct fh_ctx {
 #define FH_PARTITION_MEMBERS(X)                                                                                              \
     X(blk_off) X(gt_elems) X(gt_ent) X(gt_pos) X(has_pos) X(p_conn) X(p_rec) X(p_elem) X(r_rec) X(r_lanes4) X(r_vconn) X(r_rw) X(r_ls) X(r_vn)  \
     X(has_rows) X(p_rw) X(p_cs) X(p_ms) X(p_nbs) X(p_jt) X(p_us) X(has_pipe) X(gt_hdr) X(nblk) X(g_ub) X(g_mb) X(g_acc)      \
-    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_vtab) X(a_nu) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
+    X(g_nb) X(g_umax) X(has_partition) X(a_conn) X(a_elem) X(a_lanes) X(a_hdr) X(a_us) X(a_npos) X(a_ntab) X(a_incomplete) X(a_emin) X(a_emax) X(npos_gen)       \
     X(h_hdr) X(h_pos) X(h_lanes) X(h_ntab) X(h_incomplete) X(h_tune_pending) X(has_hrows) X(aff_failed) X(row_lo) X(row_hi) X(p_slotpar) X(has_slotpar) X(part_perm) X(part_rows_only) X(rows_try) X(perm_failed)
 struct PartStash {
 #define X(name) decltype(fh_ctx::name) name{};

@@ -86,7 +86,7 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     bool fullq = false;
     if constexpr (EK == FH_HEX8 && QC == 8 && JT == 2) {
         const size_t lds_planar = make_layout<EK, OP, WHAT_MATRIX>(a.nq, a.ub, a.acc_max, a.nb_max, true, a.mb, 1, QC, 0, 1).bytes();
-        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 && !c->env("FENRIS_HIP_NO_FULLQ") &&
+        fullq = a.nq == QC && T.cs <= 256 && T.rw <= 256 &&
                 (2 * lds_planar + 1024 <= LDS_LIMIT || 2 * lds + 1024 > LDS_LIMIT);
         if (fullq) lds = lds_planar;
     }
@@ -96,7 +96,7 @@ int launch_pipelined_j(fh_ctx* c, KArgs& a, const PipeTables& T) {
     const int wgs = std::max(1, c->env_int("FENRIS_HIP_PIPE_WGS_PER_CU", per_cu));
     const int grid = std::max(1, std::min(c->npos_gen, c->env_int("FENRIS_HIP_PIPE_GRID", dev_cus * wgs)));
     // the instrumented instantiation only where it is used for profiling (Hex8, the default tiling)
-    const bool dbg = (c->env("FENRIS_HIP_TRACE") || c->env("FENRIS_HIP_ABLATE") || c->env("FENRIS_HIP_DBG_KERNEL"));
+    const bool dbg = (c->env("FENRIS_HIP_TRACE") || c->env("FENRIS_HIP_ABLATE"));
     void (*kern)(const KArgs, const PipeTables) = k_gather_pipelined<EK, OP, QC, JT>;
     constexpr int N_ = ElemT<EK>::N;
     constexpr bool DEFAULT_JT = JT == ((N_ % 2 == 0) ? 2 : N_);  // per-element data: the default tiling only
@@ -171,71 +171,35 @@ int launch_pipelined(fh_ctx* c, KArgs& a, const PipeTables& T, size_t lds, int g
     }
 }
 
-// node blocks all of whose elements are affine: k_affine_ring / k_affine_rows (affine_ring.hip, affine_rows.hip) over their position tables
+// node blocks all of whose elements are affine: k_affine_records + k_affine_rows (affine_rows.hip) over their position tables
 int launch_affine(fh_ctx* c, KArgs& a) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     // the scalar mass matrix rides the Laplace kernel: records (|det J|, 0 ...), reference blocks (sum_q w rho phi_a phi_b, 0 ...)
     const int rop = (c->op == FH_MASS_SCALAR) ? (int)FH_LAPLACE : c->op;
     const int gw = (rop == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
-    // round 5 (experiment, FENRIS_HIP_AFFINE_FUSED=1): the element records formed inside k_affine_rows by a seventh wavefront (FUSED
-    // instantiation) -- no k_affine_records launch, no record array.  Measured SLOWER than the two launches (4.82 against 4.73 ms on the
-    // headline in one context, C2 0.56 against 0.31): what the records kernel costs is its cold reads, and the fused form has as many.
-    const int a_depth = c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), a_nstore = c->env_int("FENRIS_HIP_AFFINE_STORE_WAVES", 1);
-    const int a_chunk = c->env_int("FENRIS_HIP_AFFINE_CHUNK", 0);
-    bool fused = c->op != FH_MASS_SCALAR && c->a_nu > 0 && c->a_vtab.p && c->env_int("FENRIS_HIP_AFFINE_FUSED", 0) != 0 &&
-                 affine_rows_can_fuse(a_depth, a_nstore, a.ablate, a_chunk);
-    if (fused && affine_rows_lds_bytes(rop, c->a_us, c->g_acc, c->a_nu) > LDS_LIMIT) fused = false;
-#ifdef FENRIS_HIP_WITH_RING
-    if (c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0) fused = false;
-#endif
-    if (!fused && c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
+    // (Measured and retired to scripts/attic/: the element records formed inside k_affine_rows by a seventh wavefront -- 4.82 against 4.73 ms on the
+    // headline, profiles/r05_fused_records_experiment.txt; the barrier-free ring form, affine_ring.hip -- 5 % slower; positions dealt in chunks
+    // instead of one contiguous range per workgroup, profiles/r04_chunk_experiment.txt; non-temporal row stores for elasticity; two store waves.)
+    const int a_depth = c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2);
+    if (c->a_recs.n < (size_t)c->E * gw) HIP_TRY(c, c->a_recs.alloc((size_t)c->E * gw));
     const unsigned char* act = c->has_mask ? c->active.p : nullptr;
     DevStatus* status = c->status.p + c->status_slot;
-    const int nt = (c->env_int("FENRIS_HIP_AFFINE_NT", rop == FH_LAPLACE ? 1 : 0) ? AFFINE_ROWS_NT_STORES : 0) |
-                   (c->env("FENRIS_HIP_AFFINE_NO_CARRY") ? AFFINE_ROWS_NO_CARRY : 0) | (c->env("FENRIS_HIP_AFFINE_NO_CLEAR") ? AFFINE_ROWS_NO_CLEAR : 0) |
-                   ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 3 | (2 << 2)) & 15) << AFFINE_ROWS_PRIO_SHIFT) |
-                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 1) ? AFFINE_ROWS_REC_NO_DMA : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 2) ? AFFINE_ROWS_REC_NO_MATH : 0) |
-                   ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 4) ? AFFINE_ROWS_REC_NO_L1 : 0) | ((c->env_int("FENRIS_HIP_AFFINE_REC_ABLATE", 0) & 8) ? AFFINE_ROWS_REC_NO_L2 : 0);
-    // third form (affine_ring.hip): no barrier in the sweep, rows staged in a ring; second form: one barrier per position, double buffer
-    // (instrumentation: compiled only into a `make TRACE=1` library)
-#ifdef FENRIS_HIP_WITH_RING
-    const bool use_ring = c->env_int("FENRIS_HIP_AFFINE_RING", 0) != 0;
-#endif
-    if (c->env("FENRIS_HIP_VERBOSE_PTRS"))   // where the buffers of this context lie (the spread between identical contexts, profiles/r03_affine_experiments.txt)
-        std::fprintf(stderr, "[fenris_hip ptrs] recs=%p hdr=%p elem=%p lanes=%p vals=%p verts=%p conn=%p\n", (void*)c->a_recs.p, (void*)c->a_hdr.p,
-                     (void*)c->a_elem.p, (void*)c->a_lanes.p, (void*)a.vals, (void*)c->verts.p, (void*)c->conn.p);
+    const int nt = (rop == FH_LAPLACE ? AFFINE_ROWS_NT_STORES : 0) | ((c->env_int("FENRIS_HIP_AFFINE_PRIO", 3 | (2 << 2)) & 15) << AFFINE_ROWS_PRIO_SHIFT);
     auto rows = [&](int pos0, int count) -> int {
         AffineRowTables T{c->a_hdr.p, c->a_lanes.p, c->a_elem.p, c->a_recs.p,
                           c->ghat.p + (c->op == FH_MASS_SCALAR ? 64 * (AFFINE_GW_LE + AFFINE_GW_LAP) : c->op == FH_LAPLACE ? 64 * AFFINE_GW_LE : 0), c->a_us, count,
-                          c->g_acc, pos0, c->a_npos, c->a_incomplete, a_chunk, fused ? c->a_vtab.p : nullptr, fused ? c->a_nu : 0};
-#ifdef FENRIS_HIP_WITH_RING
-        if (use_ring) {
-            const int ring = affine_ring_doubles(c->g_acc, c->env_int("FENRIS_HIP_AFFINE_RING_KB", 0));
-            const size_t lds = affine_ring_lds_bytes(rop, c->a_us, ring);
-            if (lds <= LDS_LIMIT) {
-                const int cap = rop == FH_LAPLACE ? 4 : 3;
-                const int per_cu = std::max(1, (int)std::min<size_t>(cap, LDS_LIMIT / std::max<size_t>(lds, 1)));
-                const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
-                if (c->env("FENRIS_HIP_VERBOSE"))
-                    std::fprintf(stderr, "[fenris_hip] affine ring: positions %d + %d ring=%d doubles lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, ring, lds, per_cu, grid);
-                HIP_TRY(c, affine_ring_launch(rop, ring, c->env_int("FENRIS_HIP_AFFINE_DEPTH", 2), grid, lds, c->stream, a, T,
-                                              a.ablate | nt | ((c->env_int("FENRIS_HIP_AFFINE_THROTTLE", 0) & 0xff) << 20) | ((c->env_int("FENRIS_HIP_AFFINE_RING_PRIO", 0) & 3) << 28)));
-                return FH_OK;
-            }
-        }
-#endif
-        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc, fused ? c->a_nu : 0);
+                          c->g_acc, pos0, c->a_npos, c->a_incomplete};
+        const size_t lds = affine_rows_lds_bytes(rop, c->a_us, c->g_acc);
         if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "affine gather: LDS footprint too large");
         // workgroups per CU, measured best: 3 (elasticity), 4 (Laplace: fewer registers, less LDS)
         const int per_cu = std::max(1, (int)std::min<size_t>(rop == FH_LAPLACE ? 4 : 3, (LDS_LIMIT - 512) / std::max<size_t>(lds, 1)));
         const int grid = std::max(1, std::min(count, c->env_int("FENRIS_HIP_AFFINE_GRID", dev_cus * c->env_int("FENRIS_HIP_AFFINE_WGS_PER_CU", per_cu))));
         if (c->env("FENRIS_HIP_VERBOSE"))
-            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d fused=%d\n", pos0, count, lds, per_cu, grid, (int)fused);
-        HIP_TRY(c, affine_rows_launch(rop, a_depth, a_nstore, grid, lds, c->stream, a, T, a.ablate | nt, c->has_mask, fused));
+            std::fprintf(stderr, "[fenris_hip] affine rows: positions %d + %d lds=%zu B wgs/cu=%d grid=%d\n", pos0, count, lds, per_cu, grid);
+        HIP_TRY(c, affine_rows_launch(rop, a_depth, grid, lds, c->stream, a, T, a.ablate | nt, c->has_mask));
         return FH_OK;
     };
-    if (fused) return rows(0, c->a_npos);
     // element records first (R = sqrt|det J| J^-1 or M = R R^T per affine element): same stream, once per assembly.  (Round 3: making
     // the records of all but the first eighth of the sweep on a second stream beside the first part's launch was measured 0.3 ms
     // SLOWER than the 0.41 ms it hides -- the two kernels' workgroups compete for the CUs; two launches of the sweep in one stream cost
@@ -445,7 +409,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
     a.epb = choose_epb(c, WHAT_MATRIX);
     a.ub = a.epb;
     // high-order elements: column search of the scatter in LDS (neighbour lists staged per element)
-    if (c->ei.n > 8 && !c->env("FENRIS_HIP_NO_NC_LDS")) {
+    if (c->ei.n > 8) {
         const unsigned max_row = c->max_row;
         const size_t with_nc = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast, (int)max_row);
         if (with_nc <= LDS_TARGET + 16 * 1024) a.nc_row = (int)max_row;

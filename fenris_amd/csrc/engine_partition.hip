@@ -3,7 +3,7 @@
 
 // Lane tables of the row-owner kernels (k_affine_rows, k_hex8_rows) for the positions described by the pipelined kernel's records
 // `rec`: one record of 256 lanes per position (affine_rows_build), positions with identical records share one table (hashed on the
-// device with two independent 64-bit hashes, merged here on equality of the 128 bits; only the full form, FENRIS_HIP_LANE_TABLES_FULL, still
+// device with two independent 64-bit hashes, merged here on equality of the 128 bits; only the full form (FENRIS_HIP_NO_LANE_DEDUPE, or more than 2^23 positions) still
 // compares the records on the device), the table id goes into every header.  `bad`: some block cannot be expressed.
 static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_target, int npos, int S, const int* conn, const int* elem,
                              DevBuf<int4>& hdr, DevBuf<uint2>& lanes, int& ntab_out, int& incomplete_out, bool& bad_out, const char* what,
@@ -14,9 +14,9 @@ static int build_lane_tables(fh_ctx* c, const int* rec, int us, int ms, int nb_t
     HIP_TRY(c, hdr.alloc((size_t)npos));
     // Hash-only build (round 4): the 256 records of a position are formed in LDS, hashed twice (128 bits) and dropped; the records of the
     // first position of every distinct table are formed once more into the compact tables.  Writing all of them (2 KB x 1.46 M positions
-    // = 3 GB on the 216^3 mesh) cost an allocation of 40 - 120 ms.  FENRIS_HIP_LANE_TABLES_FULL keeps the full form (its compaction
+    // = 3 GB on the 216^3 mesh) cost an allocation of 40 - 120 ms.  FENRIS_HIP_NO_LANE_DEDUPE keeps the full form (its compaction
     // compares every position with its table); two positions whose first hashes agree and whose second ones differ send the build there too.
-    bool full = c->env("FENRIS_HIP_LANE_TABLES_FULL") != nullptr || c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23);
+    bool full = c->env("FENRIS_HIP_NO_LANE_DEDUPE") != nullptr || npos >= (1 << 23);
     DevBuf<uint2> lanes_full;
     DevBuf<unsigned long long> hash_d;
     HIP_TRY(c, hash_d.alloc((size_t)npos * 2));
@@ -184,7 +184,7 @@ int hex8_tune_lanes_now(fh_ctx* c) {
     // stream it replaces, so a k_hex8_rows of this context can be in flight on another one).  Once per pattern, next to ~18 ms of host work.
     HIP_TRY(c, hipDeviceSynchronize());
     double cb = 0.0, ca = 0.0;
-    hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, (long long)c->env_int("FENRIS_HIP_TUNE_PROPOSALS", 1000000));
+    hex8_rows_tune_lanes(tabs.data(), c->h_ntab, 12345u, &cb, &ca, 1000000ll);   // (proposals: a third of round 4's, +1.7 % kernel time for half the tuner's)
     HIP_TRY(c, hipMemcpyAsync(c->h_lanes.p, tabs.data(), sizeof(uint2) * tabs.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->env("FENRIS_HIP_VERBOSE"))
@@ -203,7 +203,7 @@ int build_partition(fh_ctx* c) {
     // (The stream is drained at every stage boundary ALSO without the print: measured on the 216^3 mesh, the first assembly takes 90 ms
     // with these synchronisations and 118 ms without them -- the stages' temporaries are released with work still queued behind them
     // otherwise, and a release then waits out the whole queue inside the runtime.)
-    const bool stage_sync = !c->env("FENRIS_HIP_NO_STAGE_SYNC");
+    const bool stage_sync = true;
     auto mark = [&](const char* what) {
         if (stage_sync || vt) (void)hipStreamSynchronize(c->stream);
         if (!vt) return;
@@ -350,7 +350,7 @@ int build_partition(fh_ctx* c) {
     // share exactly the elements between two lines.  Short runs (unstructured numberings) are merged greedily.
     hvec<unsigned char> link;
     DevBuf<unsigned char> link_d;
-    const bool aligned = N > 0 && !c->env("FENRIS_HIP_NO_ALIGN");
+    const bool aligned = N > 0;
     if (aligned) {
         HIP_TRY(c, link_d.alloc((size_t)N + 1));
         hipLaunchKernelGGL(k_linked_to_next, dim3((N + 255) / 256), dim3(256), 0, c->stream, adj_off_d, adj_d, c->ei.n, N, link_d.p);
@@ -482,7 +482,7 @@ int build_partition(fh_ctx* c) {
         auto k0 = k_build_gather_tables<0>;
         auto k1 = k_build_gather_tables<1>;
         // blocks of the usual size: one wavefront per block, four blocks per workgroup (see the kernel)
-        const bool by_wave = max_m <= 1024 && c->env_int("FENRIS_HIP_TABLES_BY_WORKGROUP", 0) == 0;
+        const bool by_wave = max_m <= 1024;
         const int wstride = 3 * (int)std::max(1u, max_m);
         if (by_wave) {
             k0 = k_build_gather_tables<0, 4>;
@@ -494,7 +494,7 @@ int build_partition(fh_ctx* c) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
         }
-        c->has_pos = max_row < 256 && !c->env("FENRIS_HIP_NO_POS");
+        c->has_pos = max_row < 256;
         if (c->has_pos) HIP_TRY(c, c->gt_pos.alloc((size_t)c->flat_len * c->ei.n + 4));
         hipLaunchKernelGGL(k0, dim3(g_tab), dim3(256), tb_l, c->stream, c->blk_off.p, noff_d, adj_off_d, adj_d, c->ei.n,
                            c->gt_hdr.p, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
@@ -602,7 +602,7 @@ int build_partition(fh_ctx* c) {
             }
             // (round 5: ... and no host vectors either -- order and chain offsets of that case are one iota array made on the device; the two
             // host loops with their uploads were 18 ms of the 216^3 mesh's first assembly)
-            const bool ident_aff = all_affine && c->env_int("FENRIS_HIP_HOST_ORDER", 0) == 0;
+            const bool ident_aff = all_affine;
             if (ident_aff) {
             } else if (!c->env("FENRIS_HIP_NO_SWEEP") && !all_affine) {
                 DevBuf<int> node2blk, succ_d;
@@ -722,28 +722,6 @@ int build_partition(fh_ctx* c) {
                     c->a_emax = got[1];
                 }
                 mark("element range of the affine class");
-                // round 5, the fused form of k_affine_rows: per position the distinct vertices of its slots' elements (nodes 0, 1, 3, 4) and
-                // their places per slot, so that the kernel's records wave forms the element records itself (no k_affine_records launch)
-                c->a_nu = 0;
-                c->a_vtab.release();
-                // NOT the default: measured slower than the separate records kernel (profiles/r05_fused_records_experiment.txt); the tables
-                // (0.7 GB on the 216^3 mesh) are built only when FENRIS_HIP_AFFINE_FUSED=1 is set before the pattern is built.
-                if (c->env_int("FENRIS_HIP_AFFINE_FUSED", 0) != 0 && c->op != FH_MASS_SCALAR) {
-                    DevBuf<int> numax;
-                    HIP_TRY(c, numax.alloc(1));
-                    HIP_TRY(c, hipMemsetAsync(numax.p, 0, sizeof(int), c->stream));
-                    HIP_TRY(c, affine_rows_vertex_count(c->stream, c->a_elem.p, c->conn.p, us, npos, numax.p));
-                    int nu = 0;
-                    HIP_TRY(c, hipMemcpyAsync(&nu, numax.p, sizeof nu, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    const int nu_pad = std::max(4, (nu + 3) / 4 * 4);
-                    if (nu > 0 && nu_pad <= 128) {
-                        HIP_TRY(c, c->a_vtab.alloc((size_t)npos * (nu_pad + 32)));
-                        HIP_TRY(c, affine_rows_vertex_tables(c->stream, c->a_elem.p, c->conn.p, us, npos, c->a_vtab.p, nu_pad));
-                        c->a_nu = nu_pad;
-                    }
-                    mark("vertex tables of the affine class (fused records)");
-                }
             }
             c->npos_gen = (int)order[0].size();
             if (!order[0].empty()) {
@@ -774,7 +752,7 @@ int build_partition(fh_ctx* c) {
                     // the tuner takes 18 ms on the 216^3 mesh and buys 0.16 ms per assembly (the matrix is the same bit for bit either way): a
                     // caller who assembles once never needs it, a Newton loop pays it on its second assembly.
                     c->h_tune_pending = 0;
-                    if (c->h_ntab <= c->env_int("FENRIS_HIP_TUNE_LANES_MAX", 4096) && !c->env("FENRIS_HIP_NO_LANE_TUNING")) {
+                    if (c->h_ntab <= 4096 && !c->env("FENRIS_HIP_NO_LANE_TUNING")) {
                         c->h_tune_pending = 1 + std::max(0, c->env_int("FENRIS_HIP_TUNE_AFTER", 1));
                         if (c->h_tune_pending == 1) { const int rt = hex8_tune_lanes_now(c); if (rt) return rt; }
                     }

@@ -73,14 +73,11 @@ static int sum_partials(fh_ctx* c, const double* dev, int blocks, int K, double*
 static int spmv_launch(fh_ctx* c, const double* vals, const double* x, double* y, double* partial, int grid) {
     const int N = (int)c->N;
     if (c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE")) {   // half a wavefront per node, one lane per column block
-        const int un = c->env_int("FENRIS_HIP_SPMV_PAIRS", 2);
         switch (c->S()) {
             case 1: hipLaunchKernelGGL((k_spmv_blocked_half<1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
             case 2: hipLaunchKernelGGL((k_spmv_blocked_half<2>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
             default:
-                if (un >= 4) hipLaunchKernelGGL((k_spmv_blocked_half<3, 4>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial);
-                else if (un <= 1) hipLaunchKernelGGL((k_spmv_blocked_half<3, 1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial);
-                else hipLaunchKernelGGL((k_spmv_blocked_half<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial);
+                hipLaunchKernelGGL((k_spmv_blocked_half<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial);
                 break;
         }
         HIP_TRY(c, hipGetLastError());

@@ -30,7 +30,7 @@ static int launch_vector_stream_nt(fh_ctx* c, KArgs& a) {
 template <int EK, int OP>
 static int launch_vector_stream(fh_ctx* c, KArgs& a) {
     if constexpr (ElemT<EK>::NG == ElemT<EK>::N && (ElemT<EK>::N == 4 || ElemT<EK>::N == 8)) {
-        int rs = c->env_int("FENRIS_HIP_VEC_NT", 256) == 256 ? launch_vector_stream_nt<EK, OP, 256>(c, a) : -1;
+        int rs = launch_vector_stream_nt<EK, OP, 256>(c, a);
         if (rs < 0) rs = launch_vector_stream_nt<EK, OP, 128>(c, a);
         return rs;
     } else {
@@ -191,7 +191,7 @@ static int assemble_vector_single(fh_ctx* c, double* out_dev, uint64_t* failed) 
     // persistent, prefetching form for the small iso-parametric elements (no element list: a mask keeps the generic kernel).
     // Two passes by default: element vectors to a scratch buffer, then one thread per row sums its node's entries in
     // ascending element order -- no atomics, bitwise reproducible (FENRIS_HIP_VECTOR_ATOMICS keeps the one-pass scatter)
-    if (!a.labels && !c->env("FENRIS_HIP_NO_VECTOR_STREAM")) {
+    if (!a.labels) {
         const bool two_pass = !c->env("FENRIS_HIP_VECTOR_ATOMICS") && !c->ragged &&
                               (c->elem_kind == FH_HEX8 || c->elem_kind == FH_TET4 || c->elem_kind == FH_QUAD4);
         if (two_pass) {
@@ -457,7 +457,7 @@ static int assemble_scalar_single(fh_ctx* c, double* out, uint64_t* failed) {
     if (a.work_end == 0) return FH_OK;
     // element tiles (vector_tiles.hip): the elements in the tiles' (space-compact) order -- what makes the gathers local on a numbering
     // without locality (C3's permuted tetrahedra: 0.76 -> 0.20 ms per call); an element mask zeroes the inactive elements' energies
-    if (element_pass_covers(c) && !c->env("FENRIS_HIP_NO_VECTOR_TILES") && c->env_int("FENRIS_HIP_ENERGY_TILES", 1)) {
+    if (element_pass_covers(c) && !c->env("FENRIS_HIP_NO_VECTOR_TILES")) {
         rc = ensure_vector_tiles(c);
         if (rc) return rc;
         if (!c->vt_bad) {

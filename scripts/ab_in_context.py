@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of launch variants INSIDE one context, on the same buffers (fh_set_option): the spread is ~0.5 %, against up to 10 % between
-contexts / allocations.    python scripts/ab_in_context.py --config ns "base:" "ring:FENRIS_HIP_AFFINE_RING=1" ..."""
+contexts / allocations.    python scripts/ab_in_context.py --config ns "base:" "depth1:FENRIS_HIP_AFFINE_DEPTH=1" ..."""
 import argparse
 import json
 import os

@@ -44,16 +44,114 @@ namespace fenris_hip {
 // gidx = 8 a + b selects Ghat_ab; gidx 64 is a block of zeros (absent term).
 constexpr unsigned AR_ZERO_G = 64u;
 
-size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
+size_t affine_rows_lds_bytes(int op, int us, int acc_max, int fused_nu) {
     const int gw = (op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     const size_t accp = (size_t)((acc_max + 16 + 1) & ~1);
-    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
+    // fused (fused_nu = AffineRowTables::nu > 0): the records wave's DMA stages -- four rows of the vertex table, two sets of vertices
+    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2) +
+           (fused_nu > 0 ? (size_t)16 * (fused_nu + 32) + (size_t)64 * fused_nu : 0);
 }
 
-template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED>
-__global__ void __launch_bounds__(320 + 64 * NSTORE, 5)
+// ------------------------------------------------------------------------------------------------ vertex tables (FUSED)
+// One wavefront per position: the distinct vertices its slots need -- nodes 0, 1, 3, 4 of every element (up to 4 x 32 = 128
+// candidates, two per lane, sorted by the bitonic network below) -- ascending, and per slot the places of its four nodes in that list.
+// FILL == false: only the largest number of distinct vertices over all positions (*nu_max); FILL == true: the rows
+//   vtab[p] = { nu_pad vertex ids (the last one repeated behind the list), 32 words  place0 | place1 << 8 | place3 << 16 | place4 << 24 | empty << 31 }.
+__device__ __forceinline__ void affine_sort128(unsigned& v0, unsigned& v1, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 128; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {
+                const unsigned lo = min(v0, v1), hi = max(v0, v1);
+                v0 = lo; v1 = hi;
+            } else {
+                const unsigned o0 = (unsigned)__shfl_xor((int)v0, stride, 64), o1 = (unsigned)__shfl_xor((int)v1, stride, 64);
+                const bool lower = (lane & stride) == 0;
+                const bool up0 = size == 128 || (lane & size) == 0, up1 = size == 128 || ((64 + lane) & size) == 0;
+                v0 = (lower == up0) ? min(v0, o0) : max(v0, o0);
+                v1 = (lower == up1) ? min(v1, o1) : max(v1, o1);
+            }
+        }
+}
+template <bool FILL>
+__global__ void __launch_bounds__(64) k_build_affine_verts(const int* elem, const int* conn, int us, int npos, int* nu_max, int* vtab, int vw, int nu_pad) {
+    __shared__ unsigned uq[128];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    unsigned v[2], orig[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int idx = lane + 64 * w, sl = idx >> 2, k = idx & 3;
+        const int e = sl < us ? elem[(size_t)p * us + sl] : -1;
+        orig[w] = v[w] = e >= 0 ? (unsigned)conn[(size_t)e * 8 + k + (k >= 2 ? 1 : 0)] : 0xffffffffu;
+    }
+    affine_sort128(v[0], v[1], lane);
+    unsigned base = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        unsigned prev = (unsigned)__shfl_up((int)v[w], 1, 64);
+        if (w > 0) { const unsigned last = (unsigned)__shfl((int)v[0], 63, 64); if (lane == 0) prev = last; }
+        const bool keep = v[w] != 0xffffffffu && ((w == 0 && lane == 0) || v[w] != prev);
+        const unsigned long long mask = __ballot(keep);
+        const unsigned r = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) uq[r] = v[w];
+        base += (unsigned)__popcll(mask);
+    }
+    const int nu = (int)base;
+    if constexpr (!FILL) {
+        if (lane == 0) atomicMax(nu_max, nu);
+        return;
+    } else {
+        __syncthreads();
+        int* row = vtab + (size_t)p * vw;
+        for (int i = lane; i < nu_pad; i += 64) row[i] = nu > 0 ? (int)uq[min(i, nu - 1)] : 0;
+        unsigned li[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            int lo = 0, hi = max(nu - 1, 0);   // first place with uq[place] >= node (the node is in the list)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (uq[mid] < orig[w]) lo = mid + 1; else hi = mid;
+            }
+            li[w] = orig[w] == 0xffffffffu ? 0u : (unsigned)lo;
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            // the four nodes of a slot sit in four adjacent lanes
+            unsigned word = li[w] << (8 * (lane & 3));
+            word |= (unsigned)__shfl_xor((int)word, 1, 64);
+            word |= (unsigned)__shfl_xor((int)word, 2, 64);
+            if (orig[w] == 0xffffffffu) word |= 0x80000000u;   // (all four nodes of an empty slot are absent together)
+            word |= (unsigned)__shfl_xor((int)(word & 0x80000000u), 1, 64) | (unsigned)__shfl_xor((int)(word & 0x80000000u), 2, 64);
+            if ((lane & 3) == 0) row[nu_pad + ((lane + 64 * w) >> 2)] = (int)word;
+        }
+    }
+}
+
+hipError_t affine_rows_vertex_count(hipStream_t stream, const int* elem, const int* conn, int us, int npos, int* nu_max_dev) {
+    if (npos <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_affine_verts<false>, dim3(npos), dim3(64), 0, stream, elem, conn, us, npos, nu_max_dev, (int*)nullptr, 0, 0);
+    return hipGetLastError();
+}
+hipError_t affine_rows_vertex_tables(hipStream_t stream, const int* elem, const int* conn, int us, int npos, int* vtab, int nu_pad) {
+    if (npos <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_affine_verts<true>, dim3(npos), dim3(64), 0, stream, elem, conn, us, npos, (int*)nullptr, vtab, nu_pad + 32, nu_pad);
+    return hipGetLastError();
+}
+
+// MASKED: the tables were built under an element mask (blocks without a term: lanes that store zeros; positions that stay incomplete
+// take one barrier more).  A separate instantiation: the per-position checks cost the unmasked Laplace sweep 13 %.
+// CHUNK (experiment, FENRIS_HIP_AFFINE_CHUNK = C): instead of one contiguous range of positions per workgroup (768 write fronts ~25 MB
+// apart), the positions are dealt in chunks of C -- chunk c goes to workgroup c mod G -- so that all concurrent stores fall into one
+// moving window of G x C positions.  Inside the kernel `p` is then the workgroup's own running index and PH(p) the position.
+// FUSED (round 5): a seventh wavefront -- the records wave -- forms the element records of the next position's slots from the vertex
+// coordinates itself (element id -> nodes 0, 1, 3, 4 -> four vertices, every level requested two positions before its use), so that
+// k_affine_records, its 80 bytes per element each way and the loader's record fetches are gone; the loader is left with headers and lane tables.
+template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED, bool CHUNK = false, bool FUSED = false>
+__global__ void __launch_bounds__(320 + 64 * NSTORE + (FUSED ? 64 : 0), FUSED ? (OP == FH_LAPLACE ? 7 : 6) : 5)
 k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
-    constexpr int NT = 320 + 64 * NSTORE;
+    static_assert(!(FUSED && CHUNK), "the records wave walks positions directly");
+    constexpr int NT = 320 + 64 * NSTORE + (FUSED ? 64 : 0);
     constexpr bool LAP = (OP == FH_LAPLACE);
     constexpr int S = LAP ? 1 : 3, SS = S * S;
     constexpr int GW = LAP ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
@@ -72,9 +170,25 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, npos = T.npos_all;
-    const int p_begin = T.pos0 + (int)((long long)blockIdx.x * T.npos / G);
-    const int p_end = T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
+    // (the non-CHUNK instantiation keeps the exact expressions it had: the production kernel is sensitive to its instruction layout)
+    auto chunk_count = [&]() {   // positions of this workgroup under the chunked dealing
+        const int CHc = max(T.chunk, 1);
+        const int nch = (T.npos + CHc - 1) / CHc, b = (int)blockIdx.x;
+        const int mine = b < nch ? (nch - b + G - 1) / G : 0;                       // chunks b, b + G, ...
+        int nk = mine * CHc;
+        if (mine > 0 && (b + (mine - 1) * G) == nch - 1) nk -= nch * CHc - T.npos;  // the last chunk of the launch may be short
+        return nk;
+    };
+    const int p_begin = CHUNK ? 0 : T.pos0 + (int)((long long)blockIdx.x * T.npos / G);
+    const int p_end = CHUNK ? chunk_count() : T.pos0 + (int)((long long)(blockIdx.x + 1) * T.npos / G);
     if (p_begin >= p_end) return;
+    // CHUNK: position behind the running index (clamped to this workgroup's last one: prefetches past the end stay harmless)
+    auto PHC = [&](int v) {
+        const int CHc = max(T.chunk, 1);
+        v = min(v, p_end - 1);
+        const int c = v / CHc;
+        return T.pos0 + (c * G + (int)blockIdx.x) * CHc + (v - c * CHc);
+    };
     for (int i = tid; i < 65 * GW; i += NT) GH[i] = (i < 64 * GW) ? T.ghat[i] : 0.0;
     for (int i = tid; i < 2 * accp; i += NT) OUT[i] = 0.0;
     const size_t vals_w = reinterpret_cast<size_t>(a.vals) >> 3;
@@ -96,7 +210,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         }
     };
 
-    if (wave >= 5) {
+    if (wave >= 5 && (!FUSED || wave < 5 + NSTORE)) {   // (!FUSED: exactly the test the kernel always had -- its layout is what it is sensitive to)
         // ------------------------------------------------------------------------------------------ store wave(s)
         // NSTORE wavefronts share the work as one unit of SL = 64 NSTORE lanes: a trip moves SL consecutive 16-byte pieces.
         constexpr int SL = 64 * NSTORE;
@@ -115,7 +229,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         auto rfl = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
         auto put = [&](f64x2* dst, f64x2 val) {
             if (DBG && (ablate & 1)) return;
-            // non-temporal stores (Laplace only -- measured; the switch is gone): the rows are written once and never read by this
+            // non-temporal stores (FENRIS_HIP_AFFINE_NT; default: Laplace only): the rows are written once and never read by this
             // kernel.  3 % on Laplace; on elasticity equal within the run-to-run spread.
             if constexpr (OVERWRITE) { if (nt_stores) __builtin_nontemporal_store(val, dst); else *dst = val; }
             else { const f64x2 o = *dst; f64x2 r; r.x = o.x + val.x; r.y = o.y + val.y; *dst = r; }
@@ -193,6 +307,159 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
     }
 
 
+    if constexpr (FUSED) {
+        if (wave == 5 + NSTORE) {
+            // ------------------------------------------------------------------------------------------ records wave (FUSED)
+            // The record of an affine element from four of its vertices, exactly as k_affine_records below forms it (the edges from
+            // node 0 to nodes 1, 3, 4 are twice the columns of J: hexahedron.rs:49-58, elliptic.rs:398-404), written straight into the
+            // slot records of the NEXT position.  An element sits in up to four node lines, so its record is formed up to four times --
+            // by the same instruction sequence, hence with the same bits: K stays symmetric bit for bit and reproducible.
+            // Two levels of indirection, both moved by LDS-DMA (global_load_lds: nothing in registers while in flight, so the depth
+            // costs LDS only), each requested RD positions before its use:
+            //   L1  the position's row of the vertex table (k_build_affine_verts: the DISTINCT vertices its slots need, ascending,
+            //       then one word per slot with the places of its nodes 0, 1, 3, 4 in that list) -- one DMA of 16 bytes per lane;
+            //   L2  those vertices, two 16-byte pieces each (x y | y z: a vertex is 24 bytes, 8-byte aligned) -- lane pairs on
+            //       ascending vertices, so that runs of consecutive node ids (every structured mesh) coalesce into whole lines.
+            // (First forms: the three levels element id -> node ids -> vertices in registers spilled, and every spill is a scratch
+            // access that drains vmcnt: 6.2 against 4.8 ms; the same three levels by DMA, 4 x 64 scattered vertex pieces per position:
+            // 4.9 ms -- the DMA issue alone took 38 % of a position, the vector memory pipeline it shares with the store wave was
+            // what it cost; without the DMAs the kernel ran at 4.05 ms.)
+            // While p is current the wave forms the records of p + 1 from vertex stage (p + 1) & 1, then refills that stage with the
+            // vertices of p + 1 + RD (their list landed) and requests the list of p + 1 + 2 RD into list stage (p + 1) & 3.  1 + rounds
+            // DMA instructions per position and nothing else of this wave on the vector-memory counter: they complete in order, so ONE
+            // counted wait at the top of a position says "everything issued RD positions ago has landed".
+            constexpr int RD = 2;
+            const int lane = tid - (320 + 64 * NSTORE);
+            const unsigned slot = (unsigned)lane & 31u;
+            const bool writer = lane < T.us;
+            auto rfl = [](unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); };
+            auto dma16 = [](const void* gsrc, unsigned lds_dst) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            };
+            const unsigned nu = (unsigned)T.nu, vw = nu + 32u, nu2 = 2u * nu;
+            const int rounds = __builtin_amdgcn_readfirstlane((int)((nu2 + 63u) >> 6));   // 1 .. 4
+            const unsigned IDW = 4u * vw, VBW = 32u * nu;
+            char* RW = reinterpret_cast<char*>(LT + 512);   // [4][IDW] list stages, then [2][VBW] vertex stages
+            const unsigned rw = (unsigned)(unsigned long long)RW, VBo = 4u * IDW;
+            auto issue_l1 = [&](int t) {
+                const unsigned dst = rfl(rw + IDW * ((unsigned)t & 3u));
+                if ((unsigned)lane < (vw >> 2)) dma16(T.vtab + (size_t)(unsigned)min(t, npos - 1) * vw + 4u * (unsigned)lane, dst);
+            };
+            auto issue_l2 = [&](int t) {
+                const char* ids = RW + IDW * ((unsigned)t & 3u);
+                const unsigned d0 = rfl(rw + VBo + VBW * ((unsigned)t & 1u));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r < rounds) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)r;
+                        if (i < nu2) {
+                            const unsigned id = *reinterpret_cast<const unsigned*>(ids + 4u * (i >> 1));
+                            dma16(reinterpret_cast<const char*>(a.verts) + (size_t)id * 24 + 8u * (i & 1u), d0 + 1024u * (unsigned)r);
+                        }
+                    }
+                }
+            };
+            int sing_e = 0x7fffffff;
+            auto make_record = [&](int t, int parity) {
+                const int w = *reinterpret_cast<const int*>(RW + IDW * ((unsigned)t & 3u) + 4u * nu + 4u * slot);   // places of nodes 0 1 3 4 | empty << 31
+                const char* vb = RW + VBo + VBW * ((unsigned)t & 1u);
+                double X[4][3];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const char* q = vb + 32u * (((unsigned)w >> (8 * v)) & 0x7fu);
+                    const f64x2 pa = *reinterpret_cast<const f64x2*>(q), pb = *reinterpret_cast<const f64x2*>(q + 16);
+                    X[v][0] = pa.x; X[v][1] = pa.y; X[v][2] = pb.y;
+                }
+                double J[3][3], R[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) J[i][k] = 0.5 * (X[k + 1][i] - X[0][i]);
+                const double detJ = det_small<3>(J);
+                const bool sg = detJ == 0.0;   // "Singular element Jacobian" (try_inverse fails only then): reported, record zero
+                adj_scaled(J, sg ? 0.0 : copysign(rsqrt_newton(fabs(detJ)), detJ), R);
+                if (sg && writer && w >= 0 && !(ablate_arg & (AFFINE_ROWS_REC_NO_DMA | AFFINE_ROWS_REC_NO_L1 | AFFINE_ROWS_REC_NO_L2)))   // (never on a valid mesh.  Under an element mask the slots hold active elements only -- they
+                                              // come from the compute adjacency --, so every singular element met here is reported)
+                    sing_e = min(sing_e, T.elem[(size_t)((unsigned)min(t, npos - 1) * (unsigned)T.us + slot)]);
+                f64x2* o = reinterpret_cast<f64x2*>(JS + ((size_t)parity * T.us + slot) * GW);
+                if constexpr (LAP) {
+                    double M[6];
+                    int k = 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int d = c; d < 3; ++d, ++k) M[k] = R[c][0] * R[d][0] + R[c][1] * R[d][1] + R[c][2] * R[d][2];
+                    if (writer) {
+#pragma unroll
+                        for (int h2 = 0; h2 < 3; ++h2) { f64x2 v; v.x = M[2 * h2]; v.y = M[2 * h2 + 1]; o[h2] = v; }
+                    }
+                } else {
+                    if (writer) {
+                        f64x2 v;
+                        v.x = R[0][0]; v.y = R[0][1]; o[0] = v;
+                        v.x = R[0][2]; v.y = R[1][0]; o[1] = v;
+                        v.x = R[1][1]; v.y = R[1][2]; o[2] = v;
+                        v.x = R[2][0]; v.y = R[2][1]; o[3] = v;
+                        v.x = R[2][2]; v.y = 0.0; o[4] = v;
+                    }
+                }
+            };
+            auto wait_all = []() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+            // what position p - RD issued has landed: (RD - 1) (1 + rounds) younger operations may still be in flight
+            const bool no_l1 = (ablate_arg & AFFINE_ROWS_REC_NO_L1) != 0, no_l2 = (ablate_arg & AFFINE_ROWS_REC_NO_L2) != 0;   // (timing experiments)
+            auto wait_landed = [&]() {
+                static_assert(RD == 2, "the immediates below are (RD - 1) (1 + rounds)");
+                const int cnt = (no_l1 ? 0 : 1) + (no_l2 ? 0 : rounds);
+                if (cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (cnt == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (cnt == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (cnt == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            };
+            // prologue, level by level with full waits: the record of p_begin, then the stages as RD steady-state positions would have left them
+            for (int t = p_begin; t <= p_begin + RD; ++t) {
+                issue_l1(t); wait_all();
+                issue_l2(t); wait_all();
+                if (t == p_begin) { make_record(t, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            }
+            for (int t = p_begin + RD + 1; t <= p_begin + 2 * RD; ++t) issue_l1(t);
+            wait_all();
+            lds_barrier();  // B0
+            tr_start();
+            int par = 0;
+            unsigned long long rt_wait = 0, rt_math = 0, rt_issue = 0, rt_bar = 0;
+            for (int p = p_begin; p < p_end; ++p, par ^= 1) {
+                if constexpr (MASKED) { if (!(rfl((unsigned)HDR[p & 3].z) & 1u)) tr_barrier(); }   // incomplete position: see the row waves
+                // (timing experiments, FENRIS_HIP_AFFINE_REC_ABLATE: 1 no DMA and no wait -- stale vertices --, 2 no record arithmetic)
+                const bool no_dma = (ablate_arg & AFFINE_ROWS_REC_NO_DMA) != 0, no_math = (ablate_arg & AFFINE_ROWS_REC_NO_MATH) != 0;
+                unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+                if (a.trace) tc0 = __builtin_readcyclecounter();
+                if (!no_dma) { if (p > p_begin) wait_landed(); }
+                if (a.trace) tc1 = __builtin_readcyclecounter();
+                if (!no_math) make_record(p + 1, par ^ 1);
+                if (a.trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tc2 = __builtin_readcyclecounter(); }
+                if (!no_dma) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is refilled: its reads are done
+                    if (!no_l2) issue_l2(p + 1 + RD);
+                    if (!no_l1) issue_l1(p + 1 + 2 * RD);
+                }
+                if (a.trace) tc3 = __builtin_readcyclecounter();
+                lds_barrier();
+                if (a.trace) { rt_wait += tc1 - tc0; rt_math += tc2 - tc1; rt_issue += tc3 - tc2; rt_bar += __builtin_readcyclecounter() - tc3; }
+            }
+            wait_all();   // nothing of this wave may land in LDS after the workgroup is gone
+            if (a.trace && lane == 0) {   // FENRIS_HIP_TRACE: "wave 3" of the report = this role: landed-wait, record arithmetic, DMA issue, barrier
+                atomicAdd(a.trace + 21, rt_wait); atomicAdd(a.trace + 22, rt_math); atomicAdd(a.trace + 23, rt_issue); atomicAdd(a.trace + 24, rt_bar);
+                atomicAdd(a.trace + 27, 1ull);
+            }
+            int sing_min = sing_e;
+            for (int o = 32; o > 0; o >>= 1) sing_min = min(sing_min, __shfl_xor(sing_min, o));
+            if (lane == 0 && sing_min != 0x7fffffff) report_singular(a.status, (long long)sing_min);
+            return;
+        }
+    }
 
     // ring entry .w: head | extent of the position's rows in doubles << 4 (what an incomplete position clears, below)
     auto with_head = [&](int4 h) { h.w = MASKED ? (head_of(h.x) | ((SS * h.y) << 4)) : (head_of(h.x) | (h.w << 8)); return h; };
@@ -215,7 +482,8 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         // 32 p + s --, 512 only the first of the three record rounds)
         auto load_elem = [&](int p, int r) {
             if (DBG && (ablate & 256)) return (int)(((unsigned)p * 32u + (unsigned)slot_of(r)) & 0x7fffffu);
-            return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))];
+            if constexpr (CHUNK) return T.elem[(size_t)((unsigned)PHC(p) * (unsigned)T.us + (unsigned)slot_of(r))];
+            else return T.elem[(size_t)((unsigned)min(p, npos - 1) * (unsigned)T.us + (unsigned)slot_of(r))];
         };
         // ablate 128 (profiling): every record from the first 4096 (cache-resident): the same instruction stream without the HBM reads
         auto load_piece = [&](int e, int r) {
@@ -233,7 +501,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             return o;
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
-        int4 hq0 = T.hdr[p_begin], hq1 = T.hdr[min(p_begin + 1, npos - 1)];
+        int4 hq0 = CHUNK ? T.hdr[PHC(p_begin)] : T.hdr[p_begin], hq1 = CHUNK ? T.hdr[PHC(p_begin + 1)] : T.hdr[min(p_begin + 1, npos - 1)];
         int slot_cur = 0;                                              // table slot of position p + 1 while p is current
         int id_prev = hq0.z >> 8;
         {
@@ -249,22 +517,26 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         // (p - p_begin) mod DEPTH = k.  While p is current, its stage holds the records of p + 1 (parked now), the element ids
         // of p + 1 + DEPTH (their records are requested now) and the header of p + 2 (ring entry now); each is refilled in
         // place with what the stage needs DEPTH positions later.
-        f64x2 piece[DEPTH][ROUNDS];
-        int e_nxt[DEPTH][ROUNDS];
+        f64x2 piece[FUSED ? 1 : DEPTH][FUSED ? 1 : ROUNDS];   // (FUSED: the records wave forms the records; nothing of this here)
+        int e_nxt[FUSED ? 1 : DEPTH][FUSED ? 1 : ROUNDS];
         int4 h_nxt[DEPTH];
         uint4 tab0 = {0, 0, 0, 0}, tab1 = {0, 0, 0, 0};
         bool tab_pending = false;                                      // tab0 / tab1 hold the lane table of position p + 1
         int slot_pending = 0;
+        if constexpr (!FUSED) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
+            for (int r = 0; r < ROUNDS; ++r) park_piece(0, r, load_piece(load_elem(p_begin, r), r));
+        }
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
-            h_nxt[k] = T.hdr[min(p_begin + k + 2, npos - 1)];
+            h_nxt[k] = CHUNK ? T.hdr[PHC(p_begin + k + 2)] : T.hdr[min(p_begin + k + 2, npos - 1)];
+            if constexpr (!FUSED) {
 #pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                const int e1 = load_elem(p_begin + k + 1, r);
-                e_nxt[k][r] = load_elem(p_begin + k + 1 + DEPTH, r);
-                piece[k][r] = load_piece(e1, r);
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int e1 = load_elem(p_begin + k + 1, r);
+                    e_nxt[k][r] = load_elem(p_begin + k + 1 + DEPTH, r);
+                    piece[k][r] = load_piece(e1, r);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the row waves
@@ -285,12 +557,14 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             /* in place: what was requested DEPTH positions ago goes to LDS, the next requests go out */                     \
             unsigned long long tq0 = 0;                                                                                       \
             if (DBG && a.trace) tq0 = __builtin_readcyclecounter();                                                           \
+            if constexpr (!FUSED) {                                                                                           \
             if (!(DBG && (ablate & 4))) {                                                                                     \
                 _Pragma("unroll") for (int r = 0; r < ROUNDS; ++r) {                                                          \
                     park_piece(par ^ 1, r, piece[k][r]);              /* records of p + 1 */                                  \
                     piece[k][r] = load_piece(e_nxt[k][r], r);         /* records of p + 1 + DEPTH */                          \
                     e_nxt[k][r] = load_elem((p) + 1 + 2 * DEPTH, r);                                                          \
                 }                                                                                                             \
+            }                                                                                                                 \
             }                                                                                                                 \
             if (DBG && a.trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_seg += __builtin_readcyclecounter() - tq0; } \
             /* lane table of p + 1, requested a position ago, into its slot (nobody reads that slot during this position) */ \
@@ -304,7 +578,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }          \
             slot_cur = slot2;                                                                                                 \
             id_prev = id2;                                                                                                    \
-            h_nxt[k] = T.hdr[min((p) + 2 + DEPTH, npos - 1)];                                                                 \
+            h_nxt[k] = CHUNK ? T.hdr[PHC((p) + 2 + DEPTH)] : T.hdr[min((p) + 2 + DEPTH, npos - 1)];                             \
             tr_barrier();                                                                                                     \
             par ^= 1;                                                                                                         \
         }
@@ -897,23 +1171,50 @@ static auto affine_rows_pick(bool ow, bool dbg) -> void (*)(const KArgs, const A
     return ow ? k_affine_rows<OP, true, false, DEPTH, NSTORE, MASKED> : k_affine_rows<OP, false, false, DEPTH, NSTORE, MASKED>;
 }
 template <int OP, bool MASKED>
-static auto affine_rows_pick_variant(int depth, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
-    // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower); a second store wave
-    // (NSTORE = 2) was measured and is no longer instantiated
+static auto affine_rows_pick_variant(int depth, int nstore, bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
+    // depth 3 and beyond: the loader's stages no longer fit the register budget of five waves per SIMD (measured slower)
+    if (nstore >= 2) return depth <= 1 ? affine_rows_pick<OP, 1, 2, MASKED>(ow, dbg) : affine_rows_pick<OP, 2, 2, MASKED>(ow, dbg);
     return depth <= 1 ? affine_rows_pick<OP, 1, 1, MASKED>(ow, dbg) : affine_rows_pick<OP, 2, 1, MASKED>(ow, dbg);
 }
 
-hipError_t affine_rows_launch(int op, int depth, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a, const AffineRowTables& T, int ablate,
-                              bool masked) {
+template <int OP, bool MASKED>
+static auto affine_rows_pick_fused(bool ow, bool dbg) -> void (*)(const KArgs, const AffineRowTables, int) {
+    if (dbg) return k_affine_rows<OP, true, true, 2, 1, MASKED, false, true>;
+    return ow ? k_affine_rows<OP, true, false, 2, 1, MASKED, false, true> : k_affine_rows<OP, false, false, 2, 1, MASKED, false, true>;
+}
+
+bool affine_rows_can_fuse(int depth, int nstore, int ablate, int chunk) {
+    (void)ablate;   // (the instrumented instantiation exists for the fused form as well)
+    return depth >= 2 && nstore < 2 && chunk <= 0;
+}
+
+hipError_t affine_rows_launch(int op, int depth, int nstore, int grid, size_t lds_bytes, hipStream_t stream, const KArgs& a,
+                              const AffineRowTables& T, int ablate, bool masked, bool fused) {
     const bool ow = a.overwrite != 0, dbg = (ablate & 0xffff) != 0;
+    if (fused) {
+        if (!affine_rows_can_fuse(depth, nstore, ablate, T.chunk) || !T.vtab || T.nu < 4 || T.nu > 128 || (T.nu & 3)) return hipErrorInvalidValue;
+        void (*kf)(const KArgs, const AffineRowTables, int) =
+            masked ? (op == FH_LAPLACE ? affine_rows_pick_fused<FH_LAPLACE, true>(ow, dbg) : affine_rows_pick_fused<FH_LINEAR_ELASTIC, true>(ow, dbg))
+                   : (op == FH_LAPLACE ? affine_rows_pick_fused<FH_LAPLACE, false>(ow, dbg) : affine_rows_pick_fused<FH_LINEAR_ELASTIC, false>(ow, dbg));
+        if (lds_bytes > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(448), lds_bytes, stream, a, T, ablate);
+        return hipGetLastError();
+    }
     void (*kern)(const KArgs, const AffineRowTables, int) =
-        masked ? (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, true>(depth, ow, dbg) : affine_rows_pick_variant<FH_LINEAR_ELASTIC, true>(depth, ow, dbg))
-               : (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, false>(depth, ow, dbg) : affine_rows_pick_variant<FH_LINEAR_ELASTIC, false>(depth, ow, dbg));
+        masked ? (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, true>(depth, nstore, ow, dbg)
+                                   : affine_rows_pick_variant<FH_LINEAR_ELASTIC, true>(depth, nstore, ow, dbg))
+               : (op == FH_LAPLACE ? affine_rows_pick_variant<FH_LAPLACE, false>(depth, nstore, ow, dbg)
+                                   : affine_rows_pick_variant<FH_LINEAR_ELASTIC, false>(depth, nstore, ow, dbg));
+    if (T.chunk > 0 && ow && !dbg && depth >= 2 && nstore < 2 && !masked)   // (experiment: positions dealt in chunks, see the kernel)
+        kern = op == FH_LAPLACE ? k_affine_rows<FH_LAPLACE, true, false, 2, 1, false, true> : k_affine_rows<FH_LINEAR_ELASTIC, true, false, 2, 1, false, true>;
     if (lds_bytes > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(AFFINE_ROWS_THREADS), lds_bytes, stream, a, T, ablate);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(320 + 64 * (nstore >= 2 ? 2 : 1)), lds_bytes, stream, a, T, ablate);
     return hipGetLastError();
 }
 

@@ -340,16 +340,14 @@ def test_scalar_mass_matrix_on_the_affine_kernel(oracle, shape):
 
 @pytest.mark.parametrize("op", ["LAPLACE", "LINEAR_ELASTIC"])
 @pytest.mark.parametrize("grid", [None, "2"])
-def test_affine_fused_records_wave(oracle, op, grid):
-    """Round 5 (experiment, opt-in): FENRIS_HIP_AFFINE_FUSED=1 builds per-position vertex tables and lets a seventh wavefront of k_affine_rows
-    form the element records from the vertices by LDS-DMA (no k_affine_records launch).  Same matrix to the tolerance against the oracle,
-    symmetric bit for bit, reproducible, under an element mask, accumulating, with few workgroups (many positions each: the steady state of
-    the DMA pipeline), and the singular element is reported."""
+def test_affine_rows_many_positions_per_workgroup(oracle, op, grid):
+    """k_affine_records + k_affine_rows with few workgroups (FENRIS_HIP_AFFINE_GRID: many positions each -- the steady state of the loader's
+    pipeline) and with the default grid: the oracle's matrix, symmetric bit for bit, reproducible, accumulating, under an element mask, and
+    the singular element is reported.  (Round 5 ran these checks on the fused-records form, which is retired to scripts/attic/.)"""
     names = ("box9", "graded", "sheared", "mirrored", "mixed", "slab_17x3x2", "single_element")
     for name in names:
         eng = fa.Engine(0)
         try:
-            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
             if grid:
                 eng.set_option("FENRIS_HIP_AFFINE_GRID", grid)
             mesh = _meshes()[name]
@@ -366,11 +364,6 @@ def test_affine_fused_records_wave(oracle, op, grid):
             assert np.array_equal(k.values, k2.values)
             fa.CsrAssembler(fa.SCATTER_GATHER).assemble_into_csr(k, asm)
             assert np.abs(k.values - 2.0 * vals).max() <= 2 * TOL * np.abs(vals).max()
-            # the separate records kernel inside the same context: same matrix to rounding (the records are formed by other instructions)
-            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 0)
-            k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-            assert np.abs(k3.values - k2.values).max() <= TOL * np.abs(vals).max()
-            eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
             active = (np.arange(mesh.num_elements()) % 5 != 2)
             if mesh.num_elements() > 5:
                 eng.set_active_elements(active)
@@ -382,7 +375,8 @@ def test_affine_fused_records_wave(oracle, op, grid):
     # singular element (det J == 0 exactly): reported with the lowest element, like elliptic.rs:401-404
     eng = fa.Engine(0)
     try:
-        eng.set_option("FENRIS_HIP_AFFINE_FUSED", 1)
+        if grid:
+            eng.set_option("FENRIS_HIP_AFFINE_GRID", grid)
         flat = _sheared(fa.procedural.create_unit_box_uniform_hex_mesh_3d(4), [[1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]])
         asm, _ = _assemblers(eng, oracle, flat, op)
         with pytest.raises(fa.SingularJacobianError) as ei:

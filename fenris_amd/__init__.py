@@ -18,6 +18,6 @@ from .compose import (AggregateElementAssembler, MapElementNodes, TransformEleme
                       TransformElementVector)
 from .mesh import Mesh, hex20_mesh_from_hex8, hex27_mesh_from_hex8, procedural, quad9_mesh_from_quad4, tet10_mesh_from_tet4, tet20_mesh_from_tet4, tri6_mesh_from_tri3
 from .operators import (Density, GravitySource, SourceFunction, LameParameters, LaplaceOperator, LinearElasticMaterial, MaterialEllipticOperator,
-                        NeoHookeanMaterial, StVKMaterial, YoungPoisson)
+                        NeoHookeanMaterial, StVKMaterial, TensorEllipticOperator, YoungPoisson)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

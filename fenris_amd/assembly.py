@@ -90,6 +90,11 @@ class Engine:
     def set_operator(self, op_kind):
         self._check(self._lib.fh_set_operator(self._h, op_kind))
 
+    def set_operator_tensor(self, tensors, symmetric):
+        """fh_set_operator_tensor: (nq, d^4) coefficient tensors of FH_TENSOR for the quadrature table in use"""
+        t = _ffi.as_f64(tensors)
+        self._check(self._lib.fh_set_operator_tensor(self._h, _ffi.fp(t), t.shape[0], 1 if symmetric else 0))
+
     def set_quadrature_uniform(self, weights, points, params=None):
         w, p = _ffi.as_f64(weights), _ffi.as_f64(points)
         q = None if params is None else _ffi.as_f64(params)
@@ -557,6 +562,8 @@ class ElementEllipticAssembler(_Composable):
             if len(u) != s * space.num_nodes():
                 raise ValueError("Local element dofs (u) dimension mismatch")  # elliptic.rs:385-389
         engine.set_quadrature_table(qtable)
+        if op.op_kind == _ffi.TENSOR:   # the operator's data: one tensor per point of the table just set
+            engine.set_operator_tensor(op.tensors_for(len(qtable.weights), space.vertices.shape[1]), op.symmetric)
         engine.set_u(u)
 
     # ElementConnectivityAssembler (src/assembly/local.rs:18-47)

@@ -412,7 +412,7 @@ __device__ __forceinline__ void prologue(const KArgs& a, const Layout& L, double
         double* coef = qp + O::NVEC * N * D;
         if (L.fast) {
             // nothing: scale folded into the gradients
-        } else if (OP == FH_LAPLACE) {
+        } else if (OP == FH_LAPLACE || OP == FH_TENSOR) {
             coef[0] = s;
         } else if (OP == FH_LINEAR_ELASTIC) {
             coef[0] = s * mu;
@@ -655,6 +655,35 @@ __device__ __forceinline__ void pair_block(const KArgs& ka, const Layout& L, con
         for (int i = 0; i < S; ++i)
 #pragma unroll
             for (int j = 0; j < S; ++j) blk[i][j] = (i == j) ? m : 0.0;
+    } else if (OP == FH_TENSOR) {
+        // C(a, b)[i][k] = sum_jl a[j] A[i][j][k][l] b[l] with the point's tensor (fenris_hip.h, FH_TENSOR; what `contract` of operators.rs:146-161
+        // returns for a gradient-independent operator), scaled by w |det J| (elliptic.rs:422): the block of the ORDERED pair (I, J)
+        double B[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) B[i][k] = 0.0;
+        for (int q = 0; q < nq; ++q, qp += L.qpd) {
+            const double* a = qp + I * D;
+            const double* b = qp + J * D;
+            const double* A = ka.tensor + (size_t)q * (D * D * D * D);
+            const double sc = qp[N * D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+#pragma unroll
+                        for (int l = 0; l < D; ++l) t = fma(a[j] * A[((i * D + j) * D + k) * D + l], b[l], t);
+                    B[i][k] = fma(sc, t, B[i][k]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) blk[i % S][k % S] = B[i][k];
     } else if (OP == FH_LAPLACE) {
         double k = 0.0;
         for (int q = 0; q < nq; ++q, qp += L.qpd) {
@@ -752,7 +781,7 @@ __device__ __forceinline__ void pair_block(const KArgs& ka, const Layout& L, con
 #pragma unroll
             for (int j = 0; j < D; ++j) blk[i % S][j % S] = B[i][j];
     }
-    if (I == J) {  // scalar-level mirror inside the diagonal block (util.rs:46-50)
+    if (I == J && !(OP == FH_TENSOR && (ka.nonsym & 1))) {  // scalar-level mirror inside the diagonal block (util.rs:46-50; not for Symmetry::NonSymmetric)
 #pragma unroll
         for (int i = 0; i < S; ++i)
 #pragma unroll
@@ -830,6 +859,47 @@ __device__ __forceinline__ void unpack_pair(int p, int& I, int& J) {
     I = p - j * (j + 1) / 2;
 }
 
+// element-centric store of a NON-SYMMETRIC pair of blocks (FH_TENSOR): p1 goes to (I, J) as it is, q1 TRANSPOSED to (J, I) -- the two stores of
+// k_assemble_matrix below with separate sources
+template <int EK, int OP, int MODE>
+__device__ __forceinline__ void tensor_store(const KArgs& a, const Layout& L, const int* lds_i, bool nc_lds, int u, int I, int J, long long w0,
+                                             const double (&p1)[OpT<OP, ElemT<EK>::D>::S][OpT<OP, ElemT<EK>::D>::S],
+                                             const double (&q1)[OpT<OP, ElemT<EK>::D>::S][OpT<OP, ElemT<EK>::D>::S]) {
+    using E = ElemT<EK>;
+    constexpr int N = E::N, S = OpT<OP, E::D>::S;
+    if (MODE == MODE_DUMP) {
+        double* ke = a.ke_out + (size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * (S * N) * (S * N);
+        for (int j = 0; j < S; ++j)
+            for (int i = 0; i < S; ++i) ke[(size_t)(S * J + j) * (S * N) + S * I + i] = p1[i][j];
+        if (I != J)
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < S; ++j) ke[(size_t)(S * I + i) * (S * N) + S * J + j] = q1[i][j];
+        return;
+    }
+    const unsigned ni = (unsigned)lds_i[L.o_cn + u * N + I], nj = (unsigned)lds_i[L.o_cn + u * N + J];
+    for (int side = 0; side < (I != J ? 2 : 1); ++side) {
+        const int R = side ? J : I;
+        const unsigned nr = side ? nj : ni, nc = side ? ni : nj;
+        unsigned r0, cnt;
+        int pos;
+        if (nc_lds) {
+            r0 = (unsigned)lds_i[L.o_ncr + 2 * (u * N + R)];
+            cnt = (unsigned)lds_i[L.o_ncr + 2 * (u * N + R) + 1];
+            pos = find_col_lds(lds_i + L.o_nc + (u * N + R) * a.nc_row, (int)cnt, (int)nc);
+        } else {
+            r0 = a.noff[nr];
+            cnt = a.noff[nr + 1] - r0;
+            pos = find_col(a.ncols + r0, (int)cnt, nc);
+        }
+        double* base = a.vals + (size_t)S * S * r0 + (size_t)S * pos;
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j < S; ++j) {
+                if (side == 0) add_value<MODE>(base + (size_t)i * S * cnt + j, p1[i][j]);
+                else add_value<MODE>(base + (size_t)j * S * cnt + i, q1[i][j]);
+            }
+    }
+}
+
 // ============================================================================================ matrix
 template <int EK, int OP, int MODE>
 __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
@@ -877,6 +947,25 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             unpack_pair(it % NP, I, J);
             double blk[S][S];
             pair_block<EK, OP>(a, L, lds, a.nq, u, I, J, blk);
+            if constexpr (OP == FH_TENSOR) {
+                // Symmetry::NonSymmetric (operators.rs:178-181): K_JI is a block of its own, not the mirror image of K_IJ.  Below, `blk` is what
+                // goes to (I, J) and its transpose to (J, I): with P = K_IJ and Q = K_JI that is blk = P for the first and blk = Q^T for the
+                // second store -- or, for the transposed element matrices of the two-pass assembly (nonsym bit 1), Q^T and P.
+                if (a.nonsym & 1) {
+                    double b2[S][S], p1[S][S], q1[S][S];
+                    if (I != J) pair_block<EK, OP>(a, L, lds, a.nq, u, J, I, b2);
+#pragma unroll
+                    for (int i = 0; i < S; ++i)
+#pragma unroll
+                        for (int j = 0; j < S; ++j) {
+                            const double kji_t = (I != J) ? b2[j][i] : blk[j][i];   // (K_JI)^T [i][j]
+                            p1[i][j] = (a.nonsym & 2) ? kji_t : blk[i][j];
+                            q1[i][j] = (a.nonsym & 2) ? blk[i][j] : kji_t;
+                        }
+                    tensor_store<EK, OP, MODE>(a, L, lds_i, nc_lds, u, I, J, w0, p1, q1);
+                    continue;
+                }
+            }
             if (MODE == MODE_DUMP) {
                 // K_e column-major (s n) x (s n), both triangles
                 double* ke = a.ke_out + (size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * (S * N) * (S * N);
@@ -987,7 +1076,7 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
             const int an = (int)((packed >> 8) & 0xffu);
             const int il = (int)(packed & 0xffu);
             double blk[S][S];
-            const bool swap = an > Jn;
+            const bool swap = an > Jn && !(OP == FH_TENSOR && (a.nonsym & 1));   // (NonSymmetric: the block of the ordered pair itself)
             pair_block<EK, OP>(a, L, lds, a.nq, u, swap ? Jn : an, swap ? an : Jn, blk);
             const int rb = lds_i[L.o_noff + il] - r0, cnt = lds_i[L.o_noff + il + 1] - lds_i[L.o_noff + il];
             int pos;

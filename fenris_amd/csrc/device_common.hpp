@@ -53,6 +53,13 @@ template <int D> struct OpT<FH_MASS_VECTOR, D> {
     static constexpr bool NEEDS_U = false;
 };
 
+// operator given as data (fenris_hip.h, FH_TENSOR): one d x d x d x d tensor per quadrature point from KArgs::tensor; the point record is the
+// physical gradients and the scale, like Laplace's
+template <int D> struct OpT<FH_TENSOR, D> {
+    static constexpr int S = D, NVEC = 1, NCOEF = 1;  // [s]
+    static constexpr bool NEEDS_U = false;
+};
+
 enum { MODE_ATOMIC = 0, MODE_COLORED = 1, MODE_GATHER = 2, MODE_DUMP = 3 };
 
 // status words in device memory
@@ -93,6 +100,9 @@ struct KArgs {
     const double* qmom;    // 8            Hex8 only, or null: moments of the rule (sum w, xi^2, eta^2, zeta^2, eta^2 zeta^2, xi^2 zeta^2, xi^2 eta^2) when every
                            //              moment with an odd power vanishes AND the parameters are the same at every point (element_pass.hpp, AFFM = 2)
     const double* qparams; // nq x 2 (mu, lambda) or null
+    const double* tensor;  // FH_TENSOR: nq x d^4 coefficient tensors, index ((i d + j) d + k) d + l
+    int nonsym;            // FH_TENSOR: bit 0 = Symmetry::NonSymmetric (every block formed, nothing mirrored); bit 1 (MODE_DUMP, two-pass assembly):
+                           // store K_e TRANSPOSED, so that the row gather's contiguous "columns" are the rows of K_e
     // CompactQuadratureTable with shared points / weights: element e reads rparams[(rule_map[e] nq + q) 2 ..]
     const unsigned* rule_map;  // E, or null (uniform table)
     const double* rparams;     // num_rules x nq x 2

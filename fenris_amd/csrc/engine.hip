@@ -242,7 +242,10 @@ int check_ready(fh_ctx* c, const char* who, bool need_pattern) {
     if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, std::string(who) + ": no finite element mesh set");
     if (c->op < 0) return c->fail(FH_INVALID_STATE, std::string(who) + ": no operator set");
     if (c->nq <= 0) return c->fail(FH_INVALID_STATE, std::string(who) + ": no quadrature table set");
-    if (c->op != FH_LAPLACE && !c->has_params)
+    if (c->op == FH_TENSOR) {
+        if (!c->tensor.p || c->tensor_nq != c->nq)
+            return c->fail(FH_INVALID_STATE, std::string(who) + ": FH_TENSOR needs fh_set_operator_tensor with one tensor per point of the quadrature table in use");
+    } else if (c->op != FH_LAPLACE && !c->has_params)
         return c->fail(FH_INVALID_STATE, std::string(who) + ": operator needs per-point parameters (mu, lambda)");
     if (need_pattern && !c->has_pattern) return c->fail(FH_INVALID_STATE, std::string(who) + ": call fh_pattern first");
     return FH_OK;
@@ -268,6 +271,8 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.qmom = (a.qmono && a.all_affine && c->qmom_ok && c->qmom.p && !c->has_rules && (c->op == FH_LAPLACE || (c->op == FH_LINEAR_ELASTIC && c->has_params)) &&
               c->env_int("FENRIS_HIP_NO_MOMENT_RESIDUAL", 0) == 0) ? c->qmom.p : nullptr;
     a.qparams = c->has_params ? c->qparams.p : nullptr;
+    a.tensor = c->op == FH_TENSOR ? c->tensor.p : nullptr;
+    a.nonsym = (c->op == FH_TENSOR && !c->tensor_sym) ? 1 : 0;
     a.rule_map = c->has_rules ? c->rule_map.p : nullptr;
     a.rparams = c->has_rules ? c->rparams.p : nullptr;
     a.u = c->has_u ? c->u.p : nullptr;
@@ -729,13 +734,27 @@ int fh_affine_stats(const fh_ctx* c, uint64_t* affine_elements, uint64_t* affine
 int fh_set_operator(fh_ctx* c, int op_kind) {
     if (!c) return FH_BAD_ARGUMENT;
     DevGuard dev_guard_(c->device);
-    if (op_kind < FH_LAPLACE || op_kind > FH_MASS_VECTOR) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
+    if (op_kind < FH_LAPLACE || op_kind > FH_TENSOR) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator: unknown operator");
     if (c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator: context holds a ragged connectivity");
     const int old_s = c->S(), old_op = c->op;
     c->op = op_kind;
     if (c->S() != old_s) { c->has_u = false; c->has_tp_pos = false; }
     // the owner-computes partition (LDS budgets, kernel classes, slot parameters) is built for one operator
     if (op_kind != old_op) { c->has_partition = false; ++c->struct_gen; c->has_slotpar = false; c->perm_failed = false; c->rows_try = 0; }
+    return FH_OK;
+}
+
+int fh_set_operator_tensor(fh_ctx* c, const double* tensors, uint32_t nq, int symmetric) {
+    if (!c) return FH_BAD_ARGUMENT;
+    DevGuard dev_guard_(c->device);
+    if (!c->has_mesh || c->ragged) return c->fail(FH_INVALID_STATE, "fh_set_operator_tensor: set the mesh first");
+    if (!tensors || nq == 0) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator_tensor: bad argument");
+    if (c->nq > 0 && (int)nq != c->nq) return c->fail(FH_BAD_ARGUMENT, "fh_set_operator_tensor: one tensor per point of the quadrature table in use");
+    const size_t d = (size_t)c->ei.d, len = (size_t)nq * d * d * d * d;
+    HIP_TRY(c, c->tensor.alloc(len));
+    HIP_TRY(c, hipMemcpy(c->tensor.p, tensors, sizeof(double) * len, hipMemcpyHostToDevice));
+    c->tensor_nq = (int)nq;
+    c->tensor_sym = symmetric != 0;
     return FH_OK;
 }
 

@@ -302,6 +302,9 @@ struct fh_ctx {
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
     DevBuf<double> gref_t;      // Hex27: reference gradients node-major (KArgs::gref_t)
+    DevBuf<double> tensor;      // FH_TENSOR: nq x d^4 coefficient tensors (fh_set_operator_tensor); tensor_nq = the point count they were given for
+    int tensor_nq = 0;
+    bool tensor_sym = true;
     DevBuf<double> qmono;       // Hex8: coordinates and pair products of the quadrature points (KArgs::qmono)
     DevBuf<double> qmom;        // Hex8: moments of the rule (KArgs::qmom); qmom_ok: the rule is symmetric and the parameters are the same at every point
     bool qmom_ok = false;
@@ -531,6 +534,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         case FH_STVK: CALL(EKC, FH_STVK); break;                    \
         case FH_MASS_SCALAR: CALL(EKC, FH_MASS_SCALAR); break;      \
         case FH_MASS_VECTOR: CALL(EKC, FH_MASS_VECTOR); break;      \
+        case FH_TENSOR: CALL(EKC, FH_TENSOR); break;                \
         default: break;                                             \
     }
 

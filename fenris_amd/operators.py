@@ -51,6 +51,39 @@ class StVKMaterial:
     op_kind = _ffi.STVK
 
 
+class TensorEllipticOperator:
+    """An elliptic operator given as data (FH_TENSOR, include/fenris_hip.h): the contraction
+    C(a, b)[i][k] = sum_jl a[j] A[i][j][k][l] b[l] of an `EllipticContraction` (src/assembly/operators.rs:146-189) whose coefficients do not
+    depend on grad u, SolutionDim = GeometryDim.  ``tensor``: (d, d, d, d) for every quadrature point, or (nq, d, d, d, d).
+    ``symmetric=True`` is `Symmetry::Symmetric` (the caller asserts A[i][j][k][l] == A[k][l][i][j]; the upper block triangle is formed and
+    mirrored, operators.rs:176-181), ``False`` is `Symmetry::NonSymmetric` (every block formed)."""
+    op_kind = _ffi.TENSOR
+
+    def __init__(self, tensor, symmetric=False):
+        import numpy as np
+
+        self.tensor = np.asarray(tensor, dtype=np.float64)
+        self.symmetric = bool(symmetric)
+
+    def tensors_for(self, nq, d):
+        import numpy as np
+
+        t = self.tensor
+        if t.shape == (d, d, d, d):
+            t = np.broadcast_to(t, (nq, d, d, d, d))
+        if t.shape != (nq, d, d, d, d):
+            raise ValueError(f"TensorEllipticOperator: tensor of shape {self.tensor.shape} for {nq} points in {d} dimensions")
+        return np.ascontiguousarray(t).reshape(nq, d ** 4)
+
+    @staticmethod
+    def linear_elastic(mu, lambda_, d=3):
+        """the tensor of LinearElasticMaterial (materials.rs:108-118): mu (delta_ik delta_jl + delta_il delta_jk) + lambda delta_ij delta_kl"""
+        import numpy as np
+
+        I = np.eye(d)
+        return mu * (np.einsum("ik,jl->ijkl", I, I) + np.einsum("il,jk->ijkl", I, I)) + lambda_ * np.einsum("ij,kl->ijkl", I, I)
+
+
 class MaterialEllipticOperator:
     """fenris-solid/src/lib.rs:412-508: turns a hyperelastic material into an elliptic operator
     (SolutionDim = GeometryDim, Parameters = LameParameters)."""

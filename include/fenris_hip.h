@@ -74,7 +74,14 @@ enum { FH_QUAD4 = 0, FH_HEX8 = 1, FH_TET4 = 2, FH_HEX27 = 3, FH_TRI3 = 4,
 enum { FH_LAPLACE = 0, FH_LINEAR_ELASTIC = 1, FH_NEO_HOOKEAN = 2, FH_STVK = 3,
        /* ElementMassAssembler::with_solution_dim(1 | D) (src/assembly/local/mass.rs:48-286): M_IJ = I_s sum_q w |det J|
         * rho phi_I phi_J; the per-point parameter pair carries Density(rho) in its first slot.  Matrix only. */
-       FH_MASS_SCALAR = 4, FH_MASS_VECTOR = 5 };
+       FH_MASS_SCALAR = 4, FH_MASS_VECTOR = 5,
+       /* An elliptic operator given as DATA instead of code (round 6): the contraction of an EllipticContraction (src/assembly/operators.rs:146-189)
+        * whose coefficients do not depend on grad u,
+        *     C(a, b)[i][k] = sum_{j, l} a[j] A[i][j][k][l] b[l],       s = d,
+        * with one tensor A per quadrature point (fh_set_operator_tensor).  Covers every LINEAR elliptic operator -- anisotropic elasticity,
+        * a linearisation frozen at some state, operators that are not symmetric -- without a closure crossing the boundary; a caller
+        * with a nonlinear operator evaluates its tangent at the quadrature data it owns.  Stiffness matrix only (all scatter modes). */
+       FH_TENSOR = 6 };
 
 /* how K_e contributions reach the CSR values (flags argument of fh_assemble_matrix*):
  *   FH_SCATTER_ATOMIC  : element-parallel, fp64 atomic adds (replaces the rayon colour loop)
@@ -132,6 +139,12 @@ int fh_set_active_elements(fh_ctx*, const uint8_t* mask);
 int fh_set_row_range(fh_ctx*, uint64_t node_begin, uint64_t node_end);
 /* Operator: replaces .with_operator(&op) (elliptic.rs:99-108).  Solution dim s = 1 for Laplace, D else. */
 int fh_set_operator(fh_ctx*, int op_kind);
+/* The coefficient tensors of FH_TENSOR: nq x d^4 doubles, index ((i d + j) d + k) d + l, nq = the points of the quadrature table in use (set the
+ * table first; a later fh_set_quadrature_* with another point count invalidates them).  symmetric != 0: the caller asserts
+ * A[i][j][k][l] == A[k][l][i][j], i.e. Symmetry::Symmetric -- only the blocks I <= J are formed and the rest mirrored exactly like for the
+ * built-in operators (operators.rs:176-181, util.rs:38-51); 0: Symmetry::NonSymmetric -- every block of every row is formed (operators.rs:180),
+ * nothing is mirrored, and the assembled matrix is not symmetric. */
+int fh_set_operator_tensor(fh_ctx*, const double* tensors, uint32_t nq, int symmetric);
 /* UniformQuadratureTable::from_points_and_weights(points, weights).with_data / with_uniform_data
  * (src/assembly/local/quadrature_table.rs:213-298).  params: nq x 2 doubles (LameParameters{mu,lambda}
  * per point, fenris-solid/src/materials.rs:8-12) or NULL for operators without parameters. */

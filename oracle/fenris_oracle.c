@@ -141,7 +141,7 @@ int fo_element_dim(int k) {
         default: return -1;
     }
 }
-int fo_operator_solution_dim(int op, int d) { return (op == FO_LAPLACE || op == FO_MASS_SCALAR) ? 1 : d; }
+int fo_operator_solution_dim(int op, int d) { return (op == FO_LAPLACE || op == FO_MASS_SCALAR) ? 1 : d; }   /* (FO_TENSOR: s = d) */
 
 /* src/element.rs:244-298 */
 static double phi_linear_1d(double alpha, double xi) { return (1.0 + alpha * xi) / 2.0; }
@@ -1268,10 +1268,24 @@ int fo_assemble_element_matrix(const fo_assembler* a, uint64_t e, double* ke) {
         }
         double scale = weight * fabs(j_det); /* :422 */
         /* accumulate_contractions_into: operators.rs:176-188 / fenris-solid lib.rs:381-391.
-         * All shipped operators are Symmetric => I in 0..=J */
+         * All shipped operators are Symmetric => I in 0..=J; the data-defined operator may say NonSymmetric => I in 0..M (:178-181) */
+        const int full = a->op_kind == FO_TENSOR && !a->tensor_symmetric;
         for (int Jn = 0; Jn < n; ++Jn)
-            for (int In = 0; In <= Jn; ++In) {
+            for (int In = 0; In <= (full ? n - 1 : Jn); ++In) {
                 double C[9];
+                if (a->op_kind == FO_TENSOR) {
+                    /* C[i][k] = sum_jl a_I[j] A[i][j][k][l] b_J[l]: what `contract` of a gradient-independent operator returns */
+                    const double* A = a->q_tensor + (size_t)q * d * d * d * d;
+                    const double* ga = ws.phi_grad + (size_t)d * In;
+                    const double* gb = ws.phi_grad + (size_t)d * Jn;
+                    for (int i = 0; i < d; ++i)
+                        for (int k = 0; k < d; ++k) {
+                            double t = 0.0;
+                            for (int j = 0; j < d; ++j)
+                                for (int l = 0; l < d; ++l) t += ga[j] * A[((i * d + j) * d + k) * d + l] * gb[l];
+                            C[CM(i, k, d)] = t;
+                        }
+                } else
                 contraction(a, d, u_grad, ws.phi_grad + (size_t)d * In, ws.phi_grad + (size_t)d * Jn, params, C);
                 if (a->op_kind == FO_LAPLACE) {
                     /* c_IJ += contraction * alpha */
@@ -1283,9 +1297,10 @@ int fo_assemble_element_matrix(const fo_assembler* a, uint64_t e, double* ke) {
                 }
             }
     }
-    /* clone_upper_to_lower util.rs:38-51 */
-    for (int j = 0; j < ld; ++j)
-        for (int i = j + 1; i < ld; ++i) ke[CM(i, j, ld)] = ke[CM(j, i, ld)];
+    /* clone_upper_to_lower util.rs:38-51 -- `if matches!(operator.symmetry(), Symmetry::Symmetric)` (elliptic.rs:434-436) */
+    if (!(a->op_kind == FO_TENSOR && !a->tensor_symmetric))
+        for (int j = 0; j < ld; ++j)
+            for (int i = j + 1; i < ld; ++i) ke[CM(i, j, ld)] = ke[CM(j, i, ld)];
     return FO_OK;
 }
 

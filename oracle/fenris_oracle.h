@@ -49,7 +49,10 @@ enum { FO_QUAD4 = 0, FO_HEX8 = 1, FO_TET4 = 2, FO_HEX27 = 3, FO_TRI3 = 4,
 /* operator kinds */
 enum { FO_LAPLACE = 0, FO_LINEAR_ELASTIC = 1, FO_NEO_HOOKEAN = 2, FO_STVK = 3,
        /* ElementMassAssembler (src/assembly/local/mass.rs) with solution_dim 1 / geometry dim; q_params[2q] = density */
-       FO_MASS_SCALAR = 4, FO_MASS_VECTOR = 5 };
+       FO_MASS_SCALAR = 4, FO_MASS_VECTOR = 5,
+       /* a contraction given as DATA: C(a, b)[i][k] = sum_jl a[j] A[i][j][k][l] b[l], one d x d x d x d tensor per quadrature point, s = d.
+        * What an EllipticContraction (src/assembly/operators.rs:146-189) whose coefficients do not depend on grad u computes; symmetric or not. */
+       FO_TENSOR = 6 };
 /* status codes */
 enum { FO_OK = 0, FO_SINGULAR_JACOBIAN = 1, FO_BAD_ARGUMENT = 2, FO_COLUMN_NOT_FOUND = 4 };
 
@@ -126,6 +129,10 @@ typedef struct {
     const uint64_t* elem_to_rule;
     const double* rule_params;
     uint64_t num_rules;
+    /* FO_TENSOR only: nq x d^4 doubles, index ((i d + j) d + k) d + l; tensor_symmetric != 0: Symmetry::Symmetric (operators.rs:176-181:
+     * only I <= J is filled, then clone_upper_to_lower), 0: Symmetry::NonSymmetric (every block filled, nothing mirrored) */
+    const double* q_tensor;
+    int tensor_symmetric;
 } fo_assembler;
 
 /* per-element kernels (src/assembly/local/elliptic.rs:361-439, 457-531, 551-605) */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfenris_oracle.so")
 
 QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR = 0, 1, 2, 3, 4, 5
+LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR, TENSOR = 0, 1, 2, 3, 4, 5, 6
 OK, SINGULAR_JACOBIAN, BAD_ARGUMENT, COLUMN_NOT_FOUND = 0, 1, 2, 4
 
 _u64p = C.POINTER(C.c_uint64)
@@ -39,6 +39,8 @@ class _Assembler(C.Structure):
         ("elem_to_rule", _u64p),
         ("rule_params", _f64p),
         ("num_rules", C.c_uint64),
+        ("q_tensor", _f64p),
+        ("tensor_symmetric", C.c_int),
     ]
 
 
@@ -297,7 +299,7 @@ class ElementAssembler:
     """Mirror of ElementEllipticAssembler<Mesh, Op, UniformQuadratureTable> for the oracle."""
 
     def __init__(self, elem_kind, op_kind, vertices, connectivity, weights, points, params=None, u=None, elem_to_rule=None,
-                 rule_params=None):
+                 rule_params=None, tensor=None, tensor_symmetric=False):
         self.elem_kind, self.op_kind = elem_kind, op_kind
         self.n, self.d = element_num_nodes(elem_kind), element_dim(elem_kind)
         self.s = solution_dim(op_kind, self.d)
@@ -323,7 +325,17 @@ class ElementAssembler:
                               _f(self.params) if self.params is not None else None,
                               _u(self.elem_to_rule) if self.elem_to_rule is not None else None,
                               _f(self.rule_params) if self.rule_params is not None else None,
-                              0 if self.rule_params is None else len(self.rule_params))
+                              0 if self.rule_params is None else len(self.rule_params),
+                              None, 0)
+        # TENSOR: one d x d x d x d coefficient tensor per quadrature point (or one for all: broadcast)
+        self.tensor = None
+        if tensor is not None:
+            t = np.asarray(tensor, dtype=np.float64)
+            if t.ndim == 4:
+                t = np.tile(t, (nq, 1, 1, 1, 1))
+            self.tensor = np.ascontiguousarray(t.reshape(nq, self.d ** 4))
+            self._st.q_tensor = _f(self.tensor)
+            self._st.tensor_symmetric = 1 if tensor_symmetric else 0
 
     # ElementConnectivityAssembler (src/assembly/local.rs:18-47)
     def solution_dim(self):

@@ -431,7 +431,9 @@ def time_secondary(cfg, fa, quadrature, np, torch, stream, steps=5, warmup=2, tr
         avg = sum(ms) / len(ms)
         E, N = mesh.num_elements(), mesh.num_nodes()
         bound, ach, peak, unit, frac = roofline_of(cfg, c, E, N, nnz, avg)
-        return {"workload": c["desc"], "elements": E, "nnz": nnz, "ms": avg, "ms_min": ms[0], "elements_per_s": E / (avg * 1e-3),
+        return {"workload": c["desc"], "elements": E, "nodes": N, "nnz": nnz,
+                "algorithmic_bytes": algorithmic_bytes(E, N, c["s"], c["n_el"], c["d"], nnz, c["uses_u"]),
+                "ms": avg, "ms_min": ms[0], "elements_per_s": E / (avg * 1e-3),
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "kernel": eng.last_kernel_name(), "steps": steps,
                 "pattern_build_s": t_pattern, "first_assembly_s": t_first, "placement_probe": placement, "device_settle": settled}
     finally:

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FENRIS_HIP_LIB: another build of the library (side-by-side timing of two builds on one box); default: the in-tree build
 LIB_PATH = os.environ.get("FENRIS_HIP_LIB") or os.path.join(_HERE, "lib", "libfenris_hip.so")
 
-FH_OK, FH_SINGULAR_JACOBIAN, FH_BAD_ARGUMENT, FH_HIP_ERROR, FH_INVALID_STATE, FH_UNSUPPORTED = 0, 1, 2, 3, 5, 6
+FH_OK, FH_SINGULAR_JACOBIAN, FH_BAD_ARGUMENT, FH_HIP_ERROR, FH_OUT_OF_MEMORY, FH_INVALID_STATE, FH_UNSUPPORTED = 0, 1, 2, 3, 4, 5, 6
 QUAD4, HEX8, TET4, HEX27, TRI3, TET10, QUAD9, TRI6, HEX20, TET20 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 LAPLACE, LINEAR_ELASTIC, NEO_HOOKEAN, STVK, MASS_SCALAR, MASS_VECTOR, TENSOR = 0, 1, 2, 3, 4, 5, 6
 SCATTER_ATOMIC, SCATTER_COLORED, SCATTER_GATHER = 0, 1, 2
@@ -60,6 +60,7 @@ _SIGS = {
     "fh_set_row_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "fh_set_operator": (C.c_int, [C.c_void_p, C.c_int]),
     "fh_set_operator_tensor": (C.c_int, [C.c_void_p, f64p, C.c_uint32, C.c_int]),
+    "fh_host_pool_trim": (C.c_uint64, []),
     "fh_add_mapped_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fh_add_mapped_vector_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p]),
     "fh_add_mapped_vector_sdim_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_uint64, C.c_void_p]),

@@ -266,7 +266,11 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.gref_t = c->gref_t.p;
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
-    a.all_affine = (c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff == c->E && c->E > 0 && !c->env("FENRIS_HIP_NO_AFFINE_PASS")) ? 1 : 0;
+    // (the all-affine instantiations of the element pass drop the mixed coefficients of the geometry map for the residual and the energy of EVERY
+    // operator: only under the default tolerance, where that is below rounding -- a caller who loosened fh_set_affine_tolerance gets the
+    // stiffness fast path its documentation promises and exact geometry everywhere else, consistent with the two-pass tangent)
+    a.all_affine = (c->elem_kind == FH_HEX8 && c->has_aff && c->num_aff == c->E && c->E > 0 && c->affine_tol <= 0x1p-46 &&
+                    !c->env("FENRIS_HIP_NO_AFFINE_PASS")) ? 1 : 0;
     a.qmono = (c->elem_kind == FH_HEX8 && c->qmono.p && !c->env("FENRIS_HIP_NO_MONOMIAL")) ? c->qmono.p : nullptr;
     a.qmom = (a.qmono && a.all_affine && c->qmom_ok && c->qmom.p && !c->has_rules && (c->op == FH_LAPLACE || (c->op == FH_LINEAR_ELASTIC && c->has_params)) &&
               c->env_int("FENRIS_HIP_NO_MOMENT_RESIDUAL", 0) == 0) ? c->qmom.p : nullptr;
@@ -472,6 +476,7 @@ int fh_synchronize(fh_ctx* c) {
     return FH_OK;
 }
 
+uint64_t fh_host_pool_trim(void) { return (uint64_t)HostPool::trim(); }
 uint64_t fh_solution_dim(const fh_ctx* c) { return c ? (uint64_t)c->S() : 0; }
 uint64_t fh_num_elements(const fh_ctx* c) { return c ? c->E : 0; }
 uint64_t fh_num_nodes(const fh_ctx* c) { return c ? c->N : 0; }

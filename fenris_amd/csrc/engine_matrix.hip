@@ -232,6 +232,22 @@ int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* 
     return rc;
 }
 
+// Which kernel the general positions (those not in the affine class) of an FH_SCATTER_GATHER assembly run on: ONE rule, read by the dispatch below
+// and by the FH_ASSEMBLE_REPRODUCIBLE check (it used to hand-copy the conditions; scripts/kernel_selection_table.py tabulates the outcome).
+enum GatherKernel { GK_ROWS_TET4, GK_HEX8_ROWS, GK_PIPELINED, GK_GENERIC };
+static GatherKernel select_gather_kernel(fh_ctx* c, bool fast, bool* pipe_rules_out) {
+    const bool pipe_rules = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
+    const bool lin = c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC;
+    if (pipe_rules_out) *pipe_rules_out = pipe_rules;
+    // Tet4 is affine: with uniform parameters any rule equals the one-point rule that carries the sum of its weights
+    if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (fast || pipe_rules) && lin) return GK_ROWS_TET4;
+    if (c->has_pipe && c->has_hrows && fast && !pipe_rules && c->nq == 8 && c->elem_kind == FH_HEX8 && lin && !c->env("FENRIS_HIP_NO_HEX8_ROWS") &&
+        hex8_rows_lds_bytes(c->g_acc) <= LDS_LIMIT)
+        return GK_HEX8_ROWS;
+    if (c->has_pipe && (fast || pipe_rules) && lin) return GK_PIPELINED;
+    return GK_GENERIC;
+}
+
 int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset) {
     const auto t_entry = std::chrono::steady_clock::now();
     const bool vt_entry = !c->has_partition && c->env("FENRIS_HIP_VERBOSE") != nullptr;
@@ -295,20 +311,18 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         }
         if (c->nblk == 0) return FH_OK;  // empty row range
         if (flags & FH_ASSEMBLE_REPRODUCIBLE) {
-            // the kernels that sum in a fixed order: k_affine_rows (all positions affine), k_gather_rows (Tet4), k_hex8_rows -- the conditions of
-            // the launches below; anything else (k_gather_pipelined, the generic one-pass gather: LDS atomics in hardware order) goes two-pass
-            const bool pr = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
-            const bool lin = c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC;
-            const bool stable = c->npos_gen == 0 ||
-                                (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pr) && lin) ||
-                                (c->has_pipe && c->has_hrows && a.fast && !pr && c->nq == 8 && c->elem_kind == FH_HEX8 && lin &&
-                                 !c->env("FENRIS_HIP_NO_HEX8_ROWS") && hex8_rows_lds_bytes(c->g_acc) <= LDS_LIMIT);
+            // the kernels that sum in a fixed order: k_affine_rows (all positions affine), k_gather_rows_tet4, k_hex8_rows; anything else
+            // (k_gather_pipelined, the generic one-pass gather: LDS atomics in hardware order) goes two-pass
+            const GatherKernel gk = select_gather_kernel(c, a.fast != 0, nullptr);
+            const bool stable = c->npos_gen == 0 || gk == GK_ROWS_TET4 || gk == GK_HEX8_ROWS;
             if (!stable) {
                 if (c->row_hi >= 0) return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: this configuration needs the two-pass form, which has no row range");
                 const size_t dense_doubles = two_pass_dense_doubles(c);
+                if ((double)dense_doubles * 8.0 / 1e9 > (double)c->env_int("FENRIS_HIP_TWO_PASS_MAX_GB", 96))
+                    return c->fail(FH_OUT_OF_MEMORY, "FH_ASSEMBLE_REPRODUCIBLE: the dense element matrices of the two-pass form exceed FENRIS_HIP_TWO_PASS_MAX_GB");
                 if (c->ke_dense.n < dense_doubles && c->ke_dense.alloc(dense_doubles) != hipSuccess) {
                     (void)hipGetLastError();
-                    return c->fail(FH_UNSUPPORTED, "FH_ASSEMBLE_REPRODUCIBLE: no memory for the dense element matrices of the two-pass form");
+                    return c->fail(FH_OUT_OF_MEMORY, "FH_ASSEMBLE_REPRODUCIBLE: no device memory for the dense element matrices of the two-pass form");
                 }
                 return assemble_two_pass(c, values_dev, overwrite);
             }
@@ -333,7 +347,8 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         a.acc_max = c->g_acc;
         a.nb_max = c->g_nb;
         const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, a.acc_max, a.nb_max, true, a.mb, a.fast);
-        const bool pipe_rules = c->has_pipe && c->has_rules && c->elem_par && c->fast_ok && c->op == FH_LINEAR_ELASTIC;
+        bool pipe_rules = false;
+        const GatherKernel gk = select_gather_kernel(c, a.fast != 0, &pipe_rules);
         if (pipe_rules && !c->has_slotpar) {
             const size_t n = (size_t)c->npos_gen * c->p_us;
             HIP_TRY(c, c->p_slotpar.alloc(2 * n));
@@ -344,8 +359,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
         }
         // Tet4 is affine: gradients and det J are the same at every point, so with uniform parameters any rule equals the
         // one-point rule that carries the sum of its weights (the table of gradients at point 0 serves as is)
-        if (c->has_pipe && c->has_rows && c->elem_kind == FH_TET4 && (a.fast || pipe_rules) &&
-            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+        if (gk == GK_ROWS_TET4) {
             a.fast = 1;
             if (c->nq > 1) {
                 a.qw = c->qw.p + c->nq;
@@ -367,10 +381,9 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
             if (pipe_rules) return launch_rows_tet4<FH_LINEAR_ELASTIC, true>(c, a, T);
             return c->op == FH_LAPLACE ? launch_rows_tet4<FH_LAPLACE>(c, a, T) : launch_rows_tet4<FH_LINEAR_ELASTIC>(c, a, T);
         }
-        if (c->has_pipe && c->has_hrows && a.fast && !pipe_rules && c->nq == 8 && c->elem_kind == FH_HEX8 &&
-            (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->env("FENRIS_HIP_NO_HEX8_ROWS")) {
+        if (gk == GK_HEX8_ROWS) {
             const size_t lds_h = hex8_rows_lds_bytes(c->g_acc);
-            if (lds_h <= LDS_LIMIT) {
+            {
                 int dev_cus = 256;
                 (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
                 const int per_cu = std::max(1, (int)std::min<size_t>(2, (LDS_LIMIT - 512) / std::max<size_t>(lds_h, 1)));
@@ -389,7 +402,7 @@ int assemble_matrix_enqueue(fh_ctx* c, double* values_dev, int flags, bool reset
                 return FH_OK;
             }
         }
-        if (c->has_pipe && (a.fast || pipe_rules) && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC)) {
+        if (gk == GK_PIPELINED) {
             a.fast = 1;
             PipeTables T{c->p_rec.p, c->p_conn.p, c->p_elem.p, pipe_rules ? c->p_slotpar.p : nullptr, c->p_rw,
                          c->p_cs, c->p_ms, c->p_nbs, c->p_us, c->npos_gen};

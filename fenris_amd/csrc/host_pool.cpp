@@ -61,6 +61,23 @@ void HostPool::give(void* p, size_t bytes) noexcept {
     std::free(p);
 }
 
+size_t HostPool::trim() {
+    Pool& P = pool();
+    std::vector<void*> blocks;
+    size_t freed = 0;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        for (auto& v : P.free_blocks) {
+            blocks.insert(blocks.end(), v.begin(), v.end());
+            v.clear();
+        }
+        freed = P.retained;
+        P.retained = 0;
+    }
+    for (void* p : blocks) std::free(p);   // (outside the lock: unmapping touched memory can take tens of milliseconds, host_pool.hpp)
+    return freed;
+}
+
 size_t HostPool::retained_bytes() {
     Pool& P = pool();
     std::lock_guard<std::mutex> g(P.mu);

@@ -16,10 +16,11 @@ namespace fenris_hip {
 
 struct HostPool {
     static constexpr size_t SMALL = 64 * 1024;                    // below: plain malloc / free (the heap, nothing is unmapped)
-    static constexpr size_t POOL_LIMIT = (size_t)2 << 30;         // bytes retained at most
+    static constexpr size_t POOL_LIMIT = (size_t)1 << 30;         // bytes retained at most (the set-up of the 216^3 mesh stages < 200 MB at a time)
     static void* take(size_t bytes);
     static void give(void* p, size_t bytes) noexcept;
     static size_t retained_bytes();                               // (tests)
+    static size_t trim();                                         // frees every retained block (fh_host_pool_trim); returns the bytes freed
 };
 
 template <typename T>

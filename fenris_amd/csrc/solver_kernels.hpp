@@ -66,6 +66,26 @@ __global__ void __launch_bounds__(256) k_spmv_blocked(int num_nodes, const unsig
     if (dot_partial) block_sum_store<1>(dot, dot_partial + blockIdx.x);
 }
 
+// sum over the 32 lanes of a half wavefront by DPP moves on the vector pipe (xor 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 hands the
+// total of rows 0 / 2 to rows 1 / 3): the lanes 16 .. 31 of the half hold the total.  Through __shfl_xor the same sum is ten ds_bpermute per value --
+// LDS-pipe instructions; the SpMV issued sixty of them per four nodes.
+__device__ __forceinline__ double half_sum_hi(double v) {
+    v += dpp_quad_full<0xB1>(v);
+    v += dpp_quad_full<0x4E>(v);
+    v += dpp_xor4(v);
+    {   // row_ror:8 = lane ^ 8 inside a row of 16
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_mov_dpp((int)b, 0x128, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x128, 0xF, 0xF, true);
+        v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+    }
+    {   // row_bcast:15 into rows 1 and 3 (row mask 0xA); rows 0 and 2 add zero
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x142, 0xA, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x142, 0xA, 0xF, false);
+        v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+    }
+    return v;
+}
+
 // The same product for patterns whose node rows hold at most 32 column blocks (Quad4 9, Tet4 ~15, Hex8 27): HALF a wavefront per
 // node, one lane per column block -- the lane fetches its column index, the S entries of x and its S x S block (S runs of S
 // contiguous doubles; neighbouring lanes read neighbouring runs) -- and two node pairs per wavefront in flight.  The
@@ -95,20 +115,32 @@ __global__ void __launch_bounds__(256) k_spmv_blocked_half(int num_nodes, const 
 #pragma unroll
                 for (int c = 0; c < S; ++c) xv[c] = x[(size_t)S * col + c];
                 const double* blk = vals + (size_t)S * S * r0 + (size_t)S * hl;
+                if constexpr (S == 3) {
+                    // a row of the block is 24 bytes at an 8-byte boundary: one 16-byte and one 8-byte load (six load instructions per lane instead of nine)
+                    typedef double f64x2_u8s __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+                    for (int a = 0; a < S; ++a) {
+                        const double* rw = blk + (size_t)a * S * cnt;
+                        const f64x2_u8s v01 = *reinterpret_cast<const f64x2_u8s*>(rw);
+                        const double v2 = rw[2];
+                        acc[u][a] = fma(v01.x, xv[0], acc[u][a]);
+                        acc[u][a] = fma(v01.y, xv[1], acc[u][a]);
+                        acc[u][a] = fma(v2, xv[2], acc[u][a]);
+                    }
+                } else {
 #pragma unroll
                 for (int a = 0; a < S; ++a)
 #pragma unroll
                     for (int c = 0; c < S; ++c) acc[u][a] = fma(blk[(size_t)a * S * cnt + c], xv[c], acc[u][a]);
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
             for (int a = 0; a < S; ++a) {
-                double s = acc[u][a];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);   // over the half wavefront
-                if (hl == 0 && node[u] < num_nodes) {
+                const double s = half_sum_hi(acc[u][a]);   // over the half wavefront: its lanes 16 .. 31 hold the sum
+                if (hl == 16 && node[u] < num_nodes) {
                     y[(size_t)S * node[u] + a] = s;
                     dot[0] = fma(x[(size_t)S * node[u] + a], s, dot[0]);
                 }

@@ -3,6 +3,7 @@
 // No reference counterpart.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -37,6 +38,12 @@ extern "C" {
 int fh_vmm_alloc(int device, uint64_t bytes, uint64_t chunk_bytes, void** out, uint64_t* granularity_out) {
     if (!out || bytes == 0) return FH_BAD_ARGUMENT;
     *out = nullptr;
+    int ndev = 0, prev = -1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FH_BAD_ARGUMENT;
+    // the reservation and the mappings are made with `device` current, and the caller's device is restored on every way out
+    (void)hipGetDevice(&prev);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
+    if (hipSetDevice(device) != hipSuccess) return FH_HIP_ERROR;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;

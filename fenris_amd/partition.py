@@ -433,14 +433,22 @@ class PartAssembly:
         import torch
 
         s = self.main.solution_dim()
-        scratch = torch.zeros_like(out)
+        # one scratch vector per (shape, dtype, device), cleared in place -- not an allocation per residual
+        key = (tuple(out.shape), out.dtype, str(out.device))
+        if getattr(self, "_vec_scratch_key", None) != key:
+            self._vec_scratch = torch.zeros_like(out)
+            self._vec_scratch_key = key
+        else:
+            self._vec_scratch.zero_()
+        scratch = self._vec_scratch
         self.main.assemble_vector(scratch)
         self.exchange.run_vector(scratch, s)
-        if getattr(self, "_owned_dofs", None) is None or self._owned_dofs_s != s:
+        okey = (s, str(out.device), id(self.prob.owned), len(self.prob.owned))
+        if getattr(self, "_owned_dofs_key", None) != okey:
             owned = np.asarray(self.prob.owned, dtype=np.int64)
             dofs = (s * owned[:, None] + np.arange(s, dtype=np.int64)[None, :]).reshape(-1)
             self._owned_dofs = torch.from_numpy(dofs).to(out.device)
-            self._owned_dofs_s = s
+            self._owned_dofs_key = okey
         out.index_add_(0, self._owned_dofs, scratch.index_select(0, self._owned_dofs))
 
     def poll_status(self):

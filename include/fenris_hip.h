@@ -46,7 +46,7 @@ enum {
     FH_SINGULAR_JACOBIAN = 1,
     FH_BAD_ARGUMENT = 2,
     FH_HIP_ERROR = 3,         /* a HIP or RCCL call failed; fh_last_error has the text */
-    /* 4 is not used (reserved; ABI version 1 never returned it) */
+    FH_OUT_OF_MEMORY = 4,     /* a buffer the call needs does not fit: device memory, or a cap such as FENRIS_HIP_TWO_PASS_MAX_GB (round 6; the value was reserved) */
     FH_INVALID_STATE = 5,     /* e.g. assemble before pattern, operator/element dimension mismatch */
     FH_UNSUPPORTED = 6,
     /* SolveErrorKind of the conjugate-gradient solver (fenris-sparse/src/cg.rs:277-286) */
@@ -188,7 +188,9 @@ int fh_quadrature_rule_groups(const fh_ctx*, uint64_t* num_groups);
  * without a quadrature loop; every other block keeps the general kernels.  An element qualifies when the four mixed
  * coefficients of its trilinear map are at most rel_tol times its shortest edge-direction coefficient.  Results change
  * by O(rel_tol) relative at most (exactly affine elements -- every generated box mesh -- agree to rounding).
- * Default 2^-46 (1.4e-14); 0 switches the path off.  No reference counterpart (the reference has one code path). */
+ * Default 2^-46 (1.4e-14); 0 switches the path off.  No reference counterpart (the reference has one code path).
+ * Only the stiffness fast path follows a loosened tolerance: the residual / energy kernels take the all-affine shortcut of a mesh
+ * only at the default tolerance (or tighter) and use the exact geometry otherwise. */
 int fh_set_affine_tolerance(fh_ctx*, double rel_tol);
 /* how the last FH_SCATTER_GATHER assembly was split: elements found affine, node blocks on the affine kernel, node blocks on
  * the general kernels (any pointer may be NULL; zeros before the first assembly) */
@@ -254,6 +256,10 @@ int fh_set_option(fh_ctx*, const char* name, const char* value);
  * experiments on how a large `values` array is backed (profiles/r05_vmm_experiment.txt); free with fh_vmm_free.  No reference counterpart. */
 int fh_vmm_alloc(int device, uint64_t bytes, uint64_t chunk_bytes, void** out, uint64_t* granularity_out);
 int fh_vmm_free(void* ptr);
+/* Host staging memory of the set-up stages comes from a process-wide pool that is never returned to the operating system while in use (unmapping
+ * memory a device copy has touched suspends the process's GPU queues for tens of milliseconds, profiles/r05_setup.txt): at most 1 GiB is retained.
+ * fh_host_pool_trim frees what the pool holds (call it when no latency-critical launch is near); returns the bytes freed. */
+uint64_t fh_host_pool_trim(void);
 int fh_time_assembly_dev(fh_ctx*, double* values_dev, int flags, int reps, double* ms_per_assembly);
 int fh_tune_placement_dev(fh_ctx*, double* values_dev, int flags, int tries, double* ms_before, double* ms_after);
 /* The CSR rows of the nodes [node_begin, node_end) only (FH_SCATTER_GATHER), whatever the context's own row range is: the

@@ -14,6 +14,9 @@ int launch_hex27_blocks(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     a.work_begin = w0;
     a.work_end = w1;
+    // (Measured and retired, scripts/attic/hex27_roles_r06.hpp: a wave-specialised form -- four matrix wavefronts + four prologue wavefronts per workgroup,
+    // double-buffered operands, one barrier per element -- runs the pass in 3.16 ms against 3.20: the fp64 vector work of the prologue and the matrix
+    // instructions share one datapath and add up whichever wavefronts issue them; profiles/r06_c4_triangle.txt section 4.)
     // four workgroups per CU (29.8 KB of LDS and 128 registers each).  The 16 x 16 tile form of rounds 2 - 5 with full planar matrices
     // (scripts/attic/hex27_mfma_tiles_r05.hpp) took 7.1 - 7.4 ms for C4 where this form takes 6.6 - 6.9 (profiles/r06_c4_triangle.txt).
     const size_t lds1 = sizeof(double) * (size_t)Hex27BlkLds::total;

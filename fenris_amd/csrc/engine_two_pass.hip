@@ -42,11 +42,17 @@ int launch_rows_t(fh_ctx* c, int layout, hipStream_t st, const PT* pos, const un
     const size_t lds = (size_t)wpb * sizeof(double) * SS * SS * max_row;
     if (layout == 2) {   // upper node-block triangles (Hex27 from hex27_blocks.hpp)
         if (SS != 3 || c->ei.n != 27) return c->fail(FH_HIP_ERROR, "two-pass gather: triangle layout is for Hex27, s = 3");
-        auto kt = k_rows_from_tri<PT>;
+        const int abl = c->env_int("FENRIS_HIP_ABLATE", 0) >> 8;   // (profiling, timing only: bits 8.. = no stores / no value loads / no LDS adds / no clearing in the second pass)
+        auto kt = abl ? k_rows_from_tri<PT, true> : k_rows_from_tri<PT, false>;
+        overwrite = (overwrite ? 1 : 0) | (abl << 8);
         if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int grid = std::max(1, std::min((count + wpb - 1) / wpb, grid_cap));
+        // consecutive nodes per wavefront: 4, more when the grid would pass its cap (small grids in the tests: FENRIS_HIP_TWO_PASS_GRID);
+        // nodes per wavefront slot of an XCD's chunk: 1 024 (a chunk = 4 096 nodes; 0 = workgroups in launch order)
+        int npw = std::max(1, c->env_int("FENRIS_HIP_TWO_PASS_NODES_PER_WAVE", 4));
+        while ((long long)grid_cap * wpb * npw < count) npw *= 2;
+        const int grid = std::max(1, (count + wpb * npw - 1) / (wpb * npw));
         hipLaunchKernelGGL(kt, dim3(grid), dim3(threads), lds, st, c->noff.p, adj_off, adj, pos, c->ke_dense.p, values_dev, overwrite, (int)max_row,
-                           node_list, count);
+                           node_list, count, npw, std::max(0, c->env_int("FENRIS_HIP_TWO_PASS_XCD_CHUNK", 1024) / npw));
         HIP_TRY(c, hipGetLastError());
         return FH_OK;
     }

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "assemble_kernels.hpp"
 #include "device_common.hpp"
 
@@ -156,58 +158,136 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
 // TRANSPOSED blocks (J, a), J < a: a 72-byte piece each.  A lane takes the entries idx = lane + 64 h, h < 4, of the entry's 243 values in the
 // order (J, r, c).  Both halves of a symmetric pair of the global matrix are sums of the SAME stored doubles in the same (ascending element)
 // order: the assembled matrix is symmetric bit for bit.
-template <typename PT>
+template <typename PT, bool ABL = false>
 __global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, const unsigned* adj_off, const unsigned* adj, const PT* pos_tab,
                                                        const double* ke, double* vals, int overwrite, int max_cnt, const int* node_list,
-                                                       int node_count) {
+                                                       int node_count, int npw, int xcw) {
     constexpr int S = 3, n = 27, TRI = (n * (n + 1) / 2) * 9, EB = 4, HR = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
     double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
-    // the lane's four places inside an entry (the last round is partly empty: 243 = 3 x 64 + 51)
-    int Jl[HR], rcl[HR], tl[HR];
+    // the lane's four places inside an entry (the last round is partly empty: 243 = 3 x 64 + 51), as byte offsets into the element's triangle:
+    //   direct[h] + 72 row(a)        the block (a, J), J >= a         (row(a) = a (53 - a) / 2: scalar)
+    //   mirror[h] + 72 a             the transposed block (J, a), J < a
+    // and the lane of the entry's position load (one load per entry: lane J holds the column slot of local node J; the four places fetch
+    // theirs with ds_bpermute) and the place of the value in the staged rows (row r of the node, column c of the block).
+    unsigned direct[HR], mirror[HR];
+    int Jl[HR], rowoff[HR], colc[HR];
 #pragma unroll
     for (int h = 0; h < HR; ++h) {
         const int idx = min(lane + 64 * h, S * S * n - 1);
-        Jl[h] = idx / 9;
-        rcl[h] = idx - 9 * Jl[h];
-        tl[h] = (rcl[h] % 3) * 3 + rcl[h] / 3;   // the same place in the transposed block
+        const int J = idx / 9, rc = idx - 9 * J;
+        Jl[h] = J;
+        direct[h] = 8u * (unsigned)idx;
+        mirror[h] = 8u * (unsigned)(((J * (53 - J)) / 2) * 9 + (rc % 3) * 3 + rc / 3);
+        rowoff[h] = rc / 3;
+        colc[h] = rc % 3;
     }
-    for (int it = blockIdx.x * wpb + wave; it < node_count; it += gridDim.x * wpb) {
-        const int i = __builtin_amdgcn_readfirstlane(node_list ? node_list[it] : it);
-        const unsigned r0 = noff[i];
-        const int cnt = (int)(noff[i + 1] - r0);
-        for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
-        const unsigned t0 = __builtin_amdgcn_readfirstlane(adj_off[i]), t1 = __builtin_amdgcn_readfirstlane(adj_off[i + 1]);
+    const bool last_round = lane + 64 * (HR - 1) < S * S * n;
+    const unsigned poff = (unsigned)sizeof(PT) * (unsigned)min(lane, n - 1);
+    // Everything a node needs before its first value load -- its row range, its range of entries, the entries themselves -- is requested TWO nodes
+    // ahead and becomes valid at the one full wait of the node in between (the wait for that node's last values), so that no load is ever
+    // waited for across the stores of a finished node (loads and stores retire through one in-order counter).  As dependent loads per node
+    // (row offsets -> entry offsets -> entries -> values) the pass spent 1.5 of its 3.5 ms on C4 with every load, add and store taken out.
+    //   desc:  lanes 0 .. 3 hold noff[i], noff[i + 1], adj_off[i], adj_off[i + 1]
+    //   ents:  lane k holds the node's k-th entry (the first 64; a node with more reads the rest directly)
+    // A wavefront takes `npw` CONSECUTIVE nodes (4 on C4: 2 and 4 are level, 8 loses 4 %, 16 and more lose 10 - 20 %, and so do persistent
+    // wavefronts over interleaved nodes at any grid: the nodes in flight must stay one compact window of the value array).
+    // Workgroups go to the eight XCDs in turn (workgroup b to XCD b mod 8) and every XCD has its own L2: every XCD takes whole chunks of `xcw`
+    // consecutive workgroups' worth of nodes (chunk c to XCD c mod 8), so that nodes which share elements -- neighbours in a row, neighbouring
+    // rows -- read the lines they share through ONE L2 (C4: 18.1 -> 13.7 GB leave the L2s, -0.2 ms; chunks of 1 024 to 16 384 nodes are level).
+    constexpr int step = 1;
+    int vb = (int)blockIdx.x;
+    if (xcw > 0) {
+        const int per = 8 * xcw, full = ((int)gridDim.x / per) * per;
+        if (vb < full) { const int xcd = vb & 7, k = vb >> 3; vb = ((k / xcw) * 8 + xcd) * xcw + k % xcw; }
+    }
+    int it = (vb * wpb + wave) * npw;
+    node_count = min(node_count, it + npw);
+    if (it >= node_count) return;
+    auto load_desc = [&](int itx) {
+        const int ic = min(itx, node_count - 1);
+        const int ii = node_list ? node_list[ic] : ic;
+        return ((lane & 2) ? adj_off : noff)[ii + (lane & 1)];
+    };
+    auto rl = [](unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); };
+    auto load_ents = [&](unsigned ta, unsigned tb) { return tb > ta ? adj[ta + min((unsigned)lane, tb - ta - 1u)] : 0u; };
+    unsigned d0 = load_desc(it), d1 = load_desc(it + step), d2 = load_desc(it + 2 * step);
+    unsigned r0 = rl(d0, 0), r1 = rl(d0, 1), t0 = rl(d0, 2), t1 = rl(d0, 3);
+    unsigned n_r0 = rl(d1, 0), n_r1 = rl(d1, 1), n_t0 = rl(d1, 2), n_t1 = rl(d1, 3);
+    unsigned ents = load_ents(t0, t1), n_ents = load_ents(n_t0, n_t1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    for (;;) {
+        const int cnt = (int)(r1 - r0);
+        if (!(ABL && (overwrite & 0x800))) for (int k = lane; k < S * S * cnt; k += 64) acc[k] = 0.0;
+        // requests for the node after the next (its descriptor arrived a node ago) and the descriptor of the one after that
+        const unsigned nn_r0 = rl(d2, 0), nn_r1 = rl(d2, 1), nn_t0 = rl(d2, 2), nn_t1 = rl(d2, 3);
+        const unsigned nn_ents = load_ents(nn_t0, nn_t1);
+        const unsigned d3 = load_desc(it + 3 * step);
+        const auto pos_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(pos_tab + (size_t)t0 * n), (short)0, (int)((t1 - t0) * (unsigned)(n * sizeof(PT))), 0x00020000);
         for (unsigned t = t0; t < t1; t += EB) {
-            double v[EB][HR];
-            int pos[EB][HR];
+            // Groups of up to EB entries; every load of the group is issued before the first LDS add.  Only the entries that exist are loaded
+            // (corner nodes of a structured mesh have 8 entries, edge nodes 4, face nodes 2, interior nodes 1 -- clamped duplicates were 37 % of
+            // the loads of C4), and an entry costs FIVE load instructions: four of values and one of column slots.
+            // One straight-line body per group size (a scalar branch picks it): with one `if (k < ng)` around the loads of entry k and another
+            // around its adds, the compiler cannot see that the two go together and waits for the loads of entry k - 1 before it touches a
+            // register for entry k.
+            const int ng = (int)min((unsigned)EB, t1 - t);
+            auto group = [&](auto ngc) {
+                constexpr int NG = decltype(ngc)::value;
+                double v[NG][HR];
+                int pl[NG];
 #pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const unsigned tk = min(t + (unsigned)k, t1 - 1);
-                const unsigned ent = __builtin_amdgcn_readfirstlane(adj[tk]);
-                const int e = (int)(ent / (unsigned)n), a = (int)(ent % (unsigned)n);
-                const double* kb = ke + (size_t)e * TRI;
-                const PT* pp = pos_tab + (size_t)tk * n;
-                const int row_a = (a * (53 - a)) / 2;
+                for (int k = 0; k < NG; ++k) {
+                    const unsigned tk = t + (unsigned)k;
+                    const unsigned ent = tk - t0 < 64u ? rl(ents, (int)(tk - t0)) : (unsigned)__builtin_amdgcn_readfirstlane((int)adj[tk]);
+                    const unsigned e = ent / (unsigned)n, a = ent - e * (unsigned)n;
+                    const char* kb = reinterpret_cast<const char*>(ke + (size_t)e * TRI);
+                    // (a buffer load: scalar base and offset + the lane's constant offset -- as a flat load the compiler builds a 64-bit address in
+                    // registers that earlier loads of the group still target, and waits for those loads first)
+                    if constexpr (sizeof(PT) == 1) pl[k] = (int)__builtin_amdgcn_raw_buffer_load_b8(pos_rsrc, poff, (int)((tk - t0) * (unsigned)n), 0);
+                    else pl[k] = (int)__builtin_amdgcn_raw_buffer_load_b16(pos_rsrc, poff, (int)((tk - t0) * (unsigned)(2 * n)), 0);
+                    const unsigned sd = 72u * ((a * (53u - a)) >> 1), sm = 72u * a;
 #pragma unroll
-                for (int h = 0; h < HR; ++h) {
-                    const int J = Jl[h];
-                    const int src = J >= a ? (row_a + J) * 9 + rcl[h] : ((J * (53 - J)) / 2 + a) * 9 + tl[h];
-                    pos[k][h] = (int)pp[J];
-                    v[k][h] = kb[src];
+                    for (int h = 0; h < HR; ++h) {
+                        unsigned off = (unsigned)Jl[h] >= a ? direct[h] + sd : mirror[h] + sm;
+                        if (ABL && (overwrite & 0x1000)) off = direct[h] + 1944u * (a % 13u);   // (timing only: the entry's 243 values as ONE contiguous run)
+                        // (the partly empty last round: loaded under the same condition as it is used -- an unconditional load with a conditional
+                        // use is moved down to the use by the compiler, behind the wait for everything else)
+                        if (ABL && (overwrite & 0x200)) v[k][h] = 1.0;
+                        else if (ABL && (overwrite & 0x2000)) { if (h < HR - 1 || last_round) v[k][h] = __builtin_nontemporal_load(reinterpret_cast<const double*>(kb + off)); }
+                        else if (h < HR - 1 || last_round) v[k][h] = *reinterpret_cast<const double*>(kb + off);
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < EB; ++k)
+                for (int k = 0; k < NG; ++k) {
 #pragma unroll
-                for (int h = 0; h < HR; ++h)
-                    if (t + (unsigned)k < t1 && lane + 64 * h < S * S * n)
-                        atomic_add_f64(acc + (rcl[h] / 3) * S * cnt + S * pos[k][h] + rcl[h] % 3, v[k][h]);
+                    for (int h = 0; h < HR; ++h) {
+                        const int pos = __builtin_amdgcn_ds_bpermute(4 * Jl[h], pl[k]);
+                        if (ABL && (overwrite & 0x400)) { if (pos == 12345 + lane) acc[0] = v[k][h]; }
+                        else if (h < HR - 1 || last_round) atomic_add_f64(acc + rowoff[h] * S * cnt + S * pos + colc[h], v[k][h]);
+                    }
+                }
+            };
+            if (ng == 4) group(std::integral_constant<int, 4>());
+            else if (ng == 2) group(std::integral_constant<int, 2>());
+            else if (ng == 1) group(std::integral_constant<int, 1>());
+            else group(std::integral_constant<int, 3>());
         }
+        // every request of this node has arrived (the last group waited for its values; a node without entries waits here): nothing that the
+        // next nodes read is outstanding when the stores go out
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         double* out = vals + (size_t)S * S * r0;
-        if (overwrite) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
+        if (ABL && (overwrite & 0x100)) { if (cnt == 12345) out[lane] = acc[lane]; }
+        else if (ABL && (overwrite & 0x4000)) for (int k = lane; k < S * S * cnt; k += 64) out[k] = acc[k];
+        // (non-temporal: the rows are written once and not read by this kernel -- 0.17 of 3.5 ms on C4)
+        else if (overwrite & 1) for (int k = lane; k < S * S * cnt; k += 64) __builtin_nontemporal_store(acc[k], out + k);
         else for (int k = lane; k < S * S * cnt; k += 64) out[k] += acc[k];
+        it += step;
+        if (it >= node_count) break;
+        r0 = n_r0; r1 = n_r1; t0 = n_t0; t1 = n_t1; ents = n_ents;
+        n_r0 = nn_r0; n_r1 = nn_r1; n_t0 = nn_t0; n_t1 = nn_t1; n_ents = nn_ents;
+        d2 = d3;
     }
 }
 

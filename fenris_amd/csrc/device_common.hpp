@@ -93,6 +93,7 @@ struct KArgs {
     const double* qw;      // nq
     const double* gref;    // nq x N x D   reference gradients of the element basis
     const double* gref_t;  // N x nq x D   the same table node-major (Hex27: hex27_blocks.hpp), or null
+    unsigned long long vtx_pack;  // hex27_blocks.hpp: conn, gref and gref_t have their node index permuted; 5 bits per geometry vertex = its place
     const double* ggeom;   // nq x NG x D  reference gradients of the geometry map
     const double* phiref;  // nq x N       basis values (mass matrix only)
     int all_affine;        // Hex8: every element is a parallelepiped by k_classify_affine_hex8's test (the element pass takes J as constant without testing)

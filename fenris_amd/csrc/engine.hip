@@ -264,6 +264,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.qw = c->qw.p;
     a.gref = c->gref.p;
     a.gref_t = c->gref_t.p;
+    a.vtx_pack = 0;
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
     // (the all-affine instantiations of the element pass drop the mixed coefficients of the geometry map for the residual and the energy of EVERY
@@ -843,8 +844,38 @@ int fh_set_quadrature_uniform(fh_ctx* c, const double* w, const double* pts, uin
                 for (int d = 0; d < ei.d; ++d) gt[((size_t)n * nq + q) * ei.d + d] = gref[((size_t)q * ei.n + n) * ei.d + d];
         HIP_TRY(c, c->gref_t.alloc(gt.size()));
         HIP_TRY(c, hipMemcpy(c->gref_t.p, gt.data(), sizeof(double) * gt.size(), hipMemcpyHostToDevice));
+        // the same two tables with the nodes in lexicographic order of their reference positions (engine_internal.hpp: hex27_perm): node n is
+        // the one whose basis function is 1 at lattice point (ix, iy, iz) of {-1, 0, 1}^3; its place is ix + 3 iy + 9 iz
+        bool found_all = true;
+        for (int l = 0; l < 27; ++l) {
+            const double xi[3] = {(double)(l % 3) - 1.0, (double)((l / 3) % 3) - 1.0, (double)(l / 9) - 1.0};
+            double phi[27];
+            ref_basis(FH_HEX27, xi, phi);
+            int who = -1;
+            for (int n = 0; n < 27; ++n) if (std::fabs(phi[n] - 1.0) < 1e-9) who = who < 0 ? n : 27;
+            if (who < 0 || who >= 27) { found_all = false; break; }
+            c->hex27_perm[who] = l;
+        }
+        c->has_hex27_perm = found_all;
+        if (found_all) {
+            std::vector<double> gl(gref.size()), gtl(gref.size());
+            for (uint32_t q = 0; q < nq; ++q)
+                for (int n = 0; n < 27; ++n)
+                    for (int d = 0; d < 3; ++d) {
+                        const double v = gref[((size_t)q * 27 + n) * 3 + d];
+                        gl[((size_t)q * 27 + c->hex27_perm[n]) * 3 + d] = v;
+                        gtl[((size_t)c->hex27_perm[n] * nq + q) * 3 + d] = v;
+                    }
+            HIP_TRY(c, c->gref_lex.alloc(gl.size()));
+            HIP_TRY(c, c->gref_t_lex.alloc(gtl.size()));
+            HIP_TRY(c, hipMemcpy(c->gref_lex.p, gl.data(), sizeof(double) * gl.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->gref_t_lex.p, gtl.data(), sizeof(double) * gtl.size(), hipMemcpyHostToDevice));
+            c->hex27_vtx_pack = 0;
+            for (int g = 0; g < 8; ++g) c->hex27_vtx_pack |= (unsigned long long)c->hex27_perm[g] << (5 * g);
+        }
     } else {
         c->gref_t.release();
+        c->has_hex27_perm = false;
     }
     c->has_ghat = false;
     if (c->elem_kind == FH_HEX8) {

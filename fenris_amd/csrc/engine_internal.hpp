@@ -302,6 +302,13 @@ struct fh_ctx {
     int nq = 0;
     DevBuf<double> qw, gref, ggeom, phiref, phigeom, qparams, u, rparams;
     DevBuf<double> gref_t;      // Hex27: reference gradients node-major (KArgs::gref_t)
+    // Hex27 matrix-core first pass: the element's nodes in LEXICOGRAPHIC order of their reference positions (x fastest) instead of the element's own
+    // (vertices, edges, faces, centre): neighbouring nodes of a mesh row then own neighbouring blocks of the stored triangle, and the second pass
+    // finds the lines it shares with its neighbours in the L2 / L1 (engine_two_pass.hip).  perm[n] = place of local node n.
+    DevBuf<double> gref_lex, gref_t_lex;   // the two gradient tables with their node index permuted
+    int hex27_perm[27] = {0};
+    unsigned long long hex27_vtx_pack = 0;  // 5 bits per geometry vertex: its place
+    bool has_hex27_perm = false;
     DevBuf<double> tensor;      // FH_TENSOR: nq x d^4 coefficient tensors (fh_set_operator_tensor); tensor_nq = the point count they were given for
     int tensor_nq = 0;
     bool tensor_sym = true;
@@ -428,6 +435,9 @@ struct fh_ctx {
     DevBuf<unsigned char> tp_pos8;     // ... and the column slot per (entry, local node), 8 or 16 bit
     DevBuf<unsigned short> tp_pos16;
     bool has_tp_pos = false;
+    int tp_pos_layout = -1;            // the layout (engine_two_pass.hip) the cached tables were built for
+    DevBuf<int> tp_conn;               // triangle layout: connectivity with permuted columns, and the (node, element) entries with the permuted local index
+    DevBuf<unsigned> tp_adj;
     DevBuf<unsigned long long> trace;
     bool defer_status = false;   // fh_assemble_vector_async_dev: the launches are only enqueued, fh_poll_status reports their errors
     bool keep_status = false;    // ... over a rule-set table: the status slot is reset once in front of the group walk, not per group

@@ -14,6 +14,14 @@ int launch_hex27_blocks(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     a.labels = c->has_mask ? c->active_list.p : nullptr;
     a.work_begin = w0;
     a.work_end = w1;
+    if (!c->env("FENRIS_HIP_HEX27_NO_LEX")) {
+        a.conn = c->tp_conn.p;   // nodes in lexicographic order (assemble_two_pass built the tables)
+        a.gref = c->gref_lex.p;
+        a.gref_t = c->gref_t_lex.p;
+        a.vtx_pack = c->hex27_vtx_pack;
+    } else {
+        for (int g = 0; g < 8; ++g) a.vtx_pack |= (unsigned long long)g << (5 * g);
+    }
     // (Measured and retired, scripts/attic/hex27_roles_r06.hpp: a wave-specialised form -- four matrix wavefronts + four prologue wavefronts per workgroup,
     // double-buffered operands, one barrier per element -- runs the pass in 3.16 ms against 3.20: the fp64 vector work of the prologue and the matrix
     // instructions share one datapath and add up whichever wavefronts issue them; profiles/r06_c4_triangle.txt section 4.)
@@ -92,7 +100,7 @@ int launch_rows(fh_ctx* c, int layout, hipStream_t st, const unsigned* adj_off, 
 // (hex27_blocks.hpp: Hex27 LinearElastic / NeoHookean with a uniform table of 27 points run on the matrix cores)
 static int two_pass_layout(fh_ctx* c) {
     const bool mfma = c->elem_kind == FH_HEX27 && (c->op == FH_LINEAR_ELASTIC || c->op == FH_NEO_HOOKEAN) && !c->has_rules &&
-                      c->nq == 27 && c->has_params && c->gref_t.p != nullptr && !c->env("FENRIS_HIP_NO_MFMA");
+                      c->nq == 27 && c->has_params && c->gref_t.p != nullptr && c->has_hex27_perm && !c->env("FENRIS_HIP_NO_MFMA");
     return mfma ? 2 : 0;
 }
 size_t two_pass_dense_doubles(fh_ctx* c) {
@@ -115,12 +123,32 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     const unsigned* adj_off = c->has_mask ? c->n2e_off_c.p : c->n2e_off.p;
     const unsigned* adj = c->has_mask ? c->n2e_c.p : c->n2e.p;
     const bool wide = max_row >= 256;
-    if (!c->has_tp_pos) {  // once per pattern / element mask
+    const bool lex = layout == 2 && !c->env("FENRIS_HIP_HEX27_NO_LEX");
+    if (!c->has_tp_pos || c->tp_pos_layout != layout + (lex ? 16 : 0)) {  // once per pattern / element mask / layout
         // number of (node, element) adjacencies: the last offset, read from the device (round 5: this used to pull both offset arrays to the host)
         unsigned last_off = 0;
         HIP_TRY(c, hipMemcpyAsync(&last_off, adj_off + c->N, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const long long entries = (long long)last_off;
+        const int* conn_tab = c->conn.p;
+        const unsigned* adj_tab = adj;
+        if (lex) {   // the triangle layout works on the nodes in lexicographic order (engine_internal.hpp: hex27_perm)
+            DevBuf<int> perm;
+            HIP_TRY(c, perm.alloc(27));
+            HIP_TRY(c, hipMemcpyAsync(perm.p, c->hex27_perm, sizeof(int) * 27, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, c->tp_conn.alloc((size_t)c->E * 27));
+            HIP_TRY(c, c->tp_adj.alloc((size_t)entries + 1));
+            const long long tc = (long long)c->E * 27;
+            hipLaunchKernelGGL(k_permute_conn27, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, c->stream, tc, c->conn.p, perm.p, c->tp_conn.p);
+            if (entries) hipLaunchKernelGGL(k_permute_entries27, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, c->stream, entries, adj, perm.p, c->tp_adj.p);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));   // perm is released on scope exit
+            conn_tab = c->tp_conn.p;
+            adj_tab = c->tp_adj.p;
+        } else {
+            c->tp_conn.release();
+            c->tp_adj.release();
+        }
         DevBuf<int> entry_node;
         HIP_TRY(c, entry_node.alloc((size_t)entries + 1));
         hipLaunchKernelGGL(k_entry_nodes, dim3(((int)c->N + 255) / 256), dim3(256), 0, c->stream, (int)c->N, adj_off, entry_node.p);
@@ -128,16 +156,17 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         const int g = (int)((total + 255) / 256);
         if (wide) {
             HIP_TRY(c, c->tp_pos16.alloc((size_t)total + 1));
-            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned short>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj,
-                                          c->noff.p, c->ncols.p, c->conn.p, entry_node.p, c->tp_pos16.p);
+            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned short>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj_tab,
+                                          c->noff.p, c->ncols.p, conn_tab, entry_node.p, c->tp_pos16.p);
         } else {
             HIP_TRY(c, c->tp_pos8.alloc((size_t)total + 1));
-            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned char>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj,
-                                          c->noff.p, c->ncols.p, c->conn.p, entry_node.p, c->tp_pos8.p);
+            if (total) hipLaunchKernelGGL((k_entry_positions<unsigned char>), dim3(g), dim3(256), 0, c->stream, total, c->ei.n, adj_off, adj_tab,
+                                          c->noff.p, c->ncols.p, conn_tab, entry_node.p, c->tp_pos8.p);
         }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // entry_node is released on scope exit
         c->has_tp_pos = true;
+        c->tp_pos_layout = layout + (lex ? 16 : 0);
     }
     // (Triangle layout, measured and not kept -- profiles/r06_c4_triangle.txt: walking the nodes in Morton order of their coordinates, by their
     // first adjacent element, and / or giving every XCD a contiguous part of the node list.  Morton + XCD parts halve the reads that leave the
@@ -155,5 +184,5 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
         const int r1 = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
         if (r1) return r1;
     }
-    return launch_rows(c, layout, c->stream, adj_off, adj, values_dev, overwrite, max_row, node_list, (int)c->N, 256, rows_grid_cap);
+    return launch_rows(c, layout, c->stream, adj_off, lex ? c->tp_adj.p : adj, values_dev, overwrite, max_row, node_list, (int)c->N, 256, rows_grid_cap);
 }

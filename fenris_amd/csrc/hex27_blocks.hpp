@@ -92,7 +92,12 @@ __global__ void __launch_bounds__(256, 4) k_hex27_dense_blocks(const KArgs a, do
     };
     const long long Gs = gridDim.x;
     auto elem_of = [&](long long w) { const long long wc = min(w, a.work_end - 1); return a.labels ? (long long)a.labels[wc] : wc; };
-    auto node_at = [&](const Roles& r, long long e) { return a.conn[(size_t)e * N + r.ri / 3]; };
+    // (the connectivity and the gradient tables come with the nodes in lexicographic order of their reference positions -- engine_two_pass.hip --,
+    // geometry vertex g sits at place (vtx_pack >> 5 g) & 31)
+    auto node_at = [&](const Roles& r, long long e) {
+        const int nd = r.ri / 3;
+        return a.conn[(size_t)e * N + (r.xrole ? (int)((a.vtx_pack >> (5 * nd)) & 31ull) : nd)];
+    };
     auto value_at = [&](const Roles& r, int node) { return r.src[(size_t)node * 3 + r.ri % 3]; };
     const long long w0 = a.work_begin + blockIdx.x;
     if (w0 >= a.work_end) return;

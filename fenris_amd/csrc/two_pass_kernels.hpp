@@ -33,6 +33,20 @@ __global__ void __launch_bounds__(256) k_entry_positions(long long total, int n,
     pos[it] = (PT)find_col(ncols + r0, (int)(noff[i + 1] - r0), (unsigned)conn[(size_t)(ent / (unsigned)n) * n + J]);
     (void)adj_off;
 }
+// triangle layout: the connectivity with the columns of every element permuted (conn_p[e][perm[n]] = conn[e][n]) and the (node, element) entries with
+// the permuted local index
+static __global__ void __launch_bounds__(256) k_permute_conn27(long long total, const int* conn, const int* perm, int* conn_p) {
+    const long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= total) return;
+    const long long e = it / 27;
+    conn_p[e * 27 + perm[(int)(it - e * 27)]] = conn[it];
+}
+static __global__ void __launch_bounds__(256) k_permute_entries27(long long entries, const unsigned* adj, const int* perm, unsigned* adj_p) {
+    const long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= entries) return;
+    const unsigned ent = adj[it], e = ent / 27u;
+    adj_p[it] = e * 27u + (unsigned)perm[ent - e * 27u];
+}
 static __global__ void __launch_bounds__(256) k_entry_nodes(int num_nodes, const unsigned* adj_off, int* entry_node) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_nodes) return;
@@ -202,7 +216,7 @@ __global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, con
         const int per = 8 * xcw, full = ((int)gridDim.x / per) * per;
         if (vb < full) { const int xcd = vb & 7, k = vb >> 3; vb = ((k / xcw) * 8 + xcd) * xcw + k % xcw; }
     }
-    int it = (vb * wpb + wave) * npw;
+    int it = (vb * wpb + wave) * npw;   // (the four wavefronts on interleaved nodes instead: level)
     node_count = min(node_count, it + npw);
     if (it >= node_count) return;
     auto load_desc = [&](int itx) {

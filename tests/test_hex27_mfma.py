@@ -181,6 +181,19 @@ def test_roles_rotate_and_triangles_are_symmetric(oracle, op, per_point):
         assert eng.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
         assert np.abs(k3.values - k.values).max() <= 1e-12 * np.abs(vals).max()
         eng.set_option("FENRIS_HIP_NO_MFMA", None)
+        # the two passes work on the element's nodes in lexicographic order of their reference positions (engine_two_pass.hip); on the element's
+        # own order (the A/B switch) the sum of grad u runs over the nodes in another order: the same matrix to rounding, symmetric bit for bit,
+        # and the tables of either order are rebuilt when the switch changes inside one context
+        eng.set_option("FENRIS_HIP_HEX27_NO_LEX", 1)
+        k4 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert eng.last_kernel_name() in HEX27_TWO_PASS
+        assert np.abs(k4.values - vals).max() <= 1e-12 * np.abs(vals).max()
+        assert np.abs(k4.values - k.values).max() <= 1e-13 * np.abs(vals).max()
+        d4 = (k4.to_scipy() - k4.to_scipy().T).tocoo()
+        assert d4.nnz == 0 or not np.any(d4.data != 0.0)
+        eng.set_option("FENRIS_HIP_HEX27_NO_LEX", None)
+        k5 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert np.array_equal(k5.values, k.values)
         if op == "NEO_HOOKEAN" and not per_point:
             mesh = _mesh(7)
             u = 0.002 * np.random.default_rng(8).standard_normal(3 * mesh.num_nodes())

@@ -223,3 +223,34 @@ def test_large_deformation_keeps_the_tolerance(engine, oracle):
     vals = oracle.assemble(ref)[4]
     assert not np.isnan(vals).any()
     assert np.abs(k.values - vals).max() <= 1e-11 * np.abs(vals).max()
+
+
+@pytest.mark.parametrize("k,layers", [(5, 2), (12, 2), (18, 2)])
+def test_hex27_fans_through_the_triangle_gather(oracle, k, layers):
+    """Hex27 elements around an axis (tests/test_high_valence.py's hexahedron fan, refined): the axis nodes belong to up to 2 k elements and their rows hold
+    up to ~550 node blocks -- 16-bit column slots in the second pass (k >= 12), rows of very different lengths next to each other, several groups of
+    entries per node -- against the oracle, symmetric bit for bit, the same bits twice, with few and with many nodes per wavefront."""
+    from test_high_valence import hex_fan
+    mesh = fa.hex27_mesh_from_hex8(hex_fan(k, layers))
+    u = 0.01 * np.random.default_rng(k).standard_normal(3 * mesh.num_nodes())
+    eng = fa.Engine(0)
+    try:
+        asm, ref = _build(eng, oracle, mesh, "NEO_HOOKEAN", u)
+        k1 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert eng.last_kernel_name() in HEX27_TWO_PASS
+        st, _, ro, ci, vals = oracle.assemble(ref)
+        assert st == 0 and np.array_equal(k1.row_offsets, ro) and np.array_equal(k1.col_indices, ci)
+        assert np.abs(k1.values - vals).max() <= 1e-12 * np.abs(vals).max()
+        d = (k1.to_scipy() - k1.to_scipy().T).tocoo()
+        assert d.nnz == 0 or not np.any(d.data != 0.0)
+        for grid in (1, 7):
+            eng.set_option("FENRIS_HIP_TWO_PASS_ROWS_GRID", grid)
+            k2 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert np.array_equal(k2.values, k1.values)
+        eng.set_option("FENRIS_HIP_TWO_PASS_ROWS_GRID", None)
+        eng.set_option("FENRIS_HIP_TWO_PASS_XCD_CHUNK", 8)
+        eng.set_option("FENRIS_HIP_TWO_PASS_NODES_PER_WAVE", 1)
+        k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+        assert np.array_equal(k3.values, k1.values)
+    finally:
+        eng.close()

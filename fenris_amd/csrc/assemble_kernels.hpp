@@ -966,7 +966,18 @@ __global__ void __launch_bounds__(256) k_assemble_matrix(const KArgs a) {
                     continue;
                 }
             }
-            if (MODE == MODE_DUMP) {
+            if (MODE == MODE_DUMP && S == 3 && a.ke_tri) {
+                // the lower node-block triangle, row-major: block (J, I), I <= J, at place J (J + 1) / 2 + I -- the pair index this thread unpacked, so
+                // consecutive threads write consecutive runs of 72 bytes and nothing is written twice (the full column-major matrix below leaves in
+                // 24-byte pieces, both triangles: the pass was bound by those stores).  K[(J, r), (I, c)] = K[(I, c), (J, r)] = blk[c][r].
+                typedef double f64x2_u8 __attribute__((ext_vector_type(2), aligned(8)));
+                double* kb = a.ke_out + ((size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * NP + (size_t)(it % NP)) * 9;
+                const double v[9] = {blk[0][0], blk[1 % S][0], blk[2 % S][0], blk[0][1 % S], blk[1 % S][1 % S], blk[2 % S][1 % S],
+                                     blk[0][2 % S], blk[1 % S][2 % S], blk[2 % S][2 % S]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { f64x2_u8 p2; p2.x = v[2 * k]; p2.y = v[2 * k + 1]; reinterpret_cast<f64x2_u8*>(kb)[k] = p2; }
+                kb[8] = v[8];
+            } else if (MODE == MODE_DUMP) {
                 // K_e column-major (s n) x (s n), both triangles
                 double* ke = a.ke_out + (size_t)(a.ke_by_elem ? (long long)lds_i[L.o_uniq + u] : (w0 - a.work_begin + u)) * (S * N) * (S * N);
                 // runs of S contiguous values: column (J, j) rows (I, 0..S), and column (I, i) rows (J, 0..S)

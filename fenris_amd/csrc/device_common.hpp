@@ -119,6 +119,7 @@ struct KArgs {
     double* scalar_out;
     double* ke_out;
     int ke_by_elem;          // MODE_DUMP: index ke_out by element id instead of by work position
+    int ke_tri;              // MODE_DUMP (two-pass assembly, s = 3): the LOWER node-block triangle, row-major, block (J, I <= J) = 9 contiguous doubles
     int overwrite;
     DevStatus* status;
     unsigned long long* trace;  // profiling only: 7 counters (6 phase cycle sums over waves, wave count) or null

@@ -265,6 +265,7 @@ void fill_common(fh_ctx* c, KArgs& a) {
     a.gref = c->gref.p;
     a.gref_t = c->gref_t.p;
     a.vtx_pack = 0;
+    a.ke_tri = 0;
     a.ggeom = c->ggeom.p;
     a.phiref = c->phiref.p;
     // (the all-affine instantiations of the element pass drop the mixed coefficients of the geometry map for the residual and the energy of EVERY

@@ -515,7 +515,7 @@ int read_status(fh_ctx* c, uint64_t* failed);
 int choose_epb(fh_ctx* c, int what);
 int build_partition(fh_ctx* c);
 size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0, int nc_row = 0);
-int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem);
+int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem, bool tri = false);
 int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite);
 size_t two_pass_dense_doubles(fh_ctx* c);   // doubles of the element-matrix buffer between the two passes (depends on the first pass's layout)
 int hex8_tune_lanes_now(fh_ctx* c);

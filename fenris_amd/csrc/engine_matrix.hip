@@ -211,11 +211,12 @@ int launch_affine(fh_ctx* c, KArgs& a) {
 }
 
 // dense element matrices of the elements [first, first + count) into device memory (no status read-back)
-int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem) {
+int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem, bool tri) {
     KArgs a;
     fill_common(c, a);
     a.ke_out = ke_dev;
     a.ke_by_elem = by_elem ? 1 : 0;
+    a.ke_tri = tri ? 1 : 0;
     if (by_elem && (a.nonsym & 1)) a.nonsym |= 2;   // two-pass assembly of a non-symmetric operator: K_e transposed (the gather reads columns as rows)
     a.labels = (by_elem && c->has_mask) ? c->active_list.p : nullptr;  // two-pass assembly: the active elements only
     a.work_begin = (long long)first;

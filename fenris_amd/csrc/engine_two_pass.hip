@@ -48,10 +48,19 @@ int launch_rows_t(fh_ctx* c, int layout, hipStream_t st, const PT* pos, const un
     if (count <= 0) return FH_OK;
     const int wpb = threads / 64;
     const size_t lds = (size_t)wpb * sizeof(double) * SS * SS * max_row;
-    if (layout == 2) {   // upper node-block triangles (Hex27 from hex27_blocks.hpp)
-        if (SS != 3 || c->ei.n != 27) return c->fail(FH_HIP_ERROR, "two-pass gather: triangle layout is for Hex27, s = 3");
+    if (layout != 0) {   // node-block triangles: 2 = upper (Hex27 from hex27_blocks.hpp), 1 = lower (the generic first pass with ke_tri)
+        if (SS != 3) return c->fail(FH_HIP_ERROR, "two-pass gather: the triangle layouts are for s = 3");
         const int abl = c->env_int("FENRIS_HIP_ABLATE", 0) >> 8;   // (profiling, timing only: bits 8.. = no stores / no value loads / no LDS adds / no clearing in the second pass)
-        auto kt = abl ? k_rows_from_tri<PT, true> : k_rows_from_tri<PT, false>;
+        typedef void (*tri_kernel)(const unsigned*, const unsigned*, const unsigned*, const PT*, const double*, double*, int, int, const int*, int, int, int);
+        tri_kernel kt = nullptr;
+        const int n = (int)c->ei.n;
+        if (layout == 2 && n == 27) kt = abl ? k_rows_from_tri<27, false, PT, true> : k_rows_from_tri<27, false, PT, false>;
+        else if (layout == 1 && n == 27) kt = k_rows_from_tri<27, true, PT>;
+        else if (layout == 1 && n == 20) kt = k_rows_from_tri<20, true, PT>;
+        else if (layout == 1 && n == 10) kt = k_rows_from_tri<10, true, PT>;
+        else if (layout == 1 && n == 8) kt = k_rows_from_tri<8, true, PT>;
+        else if (layout == 1 && n == 4) kt = k_rows_from_tri<4, true, PT>;
+        if (!kt) return c->fail(FH_HIP_ERROR, "two-pass gather: no triangle kernel for this element");
         overwrite = (overwrite ? 1 : 0) | (abl << 8);
         if (lds > 48 * 1024) HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // consecutive nodes per wavefront: 4, more when the grid would pass its cap (small grids in the tests: FENRIS_HIP_TWO_PASS_GRID);
@@ -66,7 +75,7 @@ int launch_rows_t(fh_ctx* c, int layout, hipStream_t st, const PT* pos, const un
     }
     void (*kern)(int, int, const unsigned*, const unsigned*, const unsigned*, const PT*, const double*, double*, int, int, const int*, int) =
         k_rows_from_dense<SS, PT>;
-    if (!c->env("FENRIS_HIP_NO_ROWS_SMALL")) {
+    {
         const int ld_ = SS * (int)c->ei.n;
         if (ld_ <= 8) kern = k_rows_from_dense_small<SS, PT, 8>;
         else if (ld_ <= 16) kern = k_rows_from_dense_small<SS, PT, 16>;
@@ -97,15 +106,20 @@ int launch_rows(fh_ctx* c, int layout, hipStream_t st, const unsigned* adj_off, 
 }  // namespace
 
 // layout of the element matrices between the passes: 0 column-major full matrices (generic first pass), 2 upper node-block triangles
-// (hex27_blocks.hpp: Hex27 LinearElastic / NeoHookean with a uniform table of 27 points run on the matrix cores)
+// (hex27_blocks.hpp: Hex27 LinearElastic / NeoHookean with a uniform table of 27 points run on the matrix cores), 1 lower node-block triangles
+// (generic first pass, s = 3 on the 3D elements, symmetric operators: half the bytes between the passes, written as runs of 72 bytes)
 static int two_pass_layout(fh_ctx* c) {
     const bool mfma = c->elem_kind == FH_HEX27 && (c->op == FH_LINEAR_ELASTIC || c->op == FH_NEO_HOOKEAN) && !c->has_rules &&
                       c->nq == 27 && c->has_params && c->gref_t.p != nullptr && c->has_hex27_perm && !c->env("FENRIS_HIP_NO_MFMA");
-    return mfma ? 2 : 0;
+    if (mfma) return 2;
+    const int n = (int)c->ei.n;
+    const bool tri = c->S() == 3 && c->ei.d == 3 && !c->ragged && (n == 4 || n == 8 || n == 10 || n == 20 || n == 27) &&
+                     !(c->op == FH_TENSOR && !c->tensor_sym) && !c->env("FENRIS_HIP_TWO_PASS_FULL");
+    return tri ? 1 : 0;
 }
 size_t two_pass_dense_doubles(fh_ctx* c) {
     const size_t ld = (size_t)c->S() * c->ei.n;
-    return two_pass_layout(c) == 2 ? (size_t)Hex27BlkLds::KE_TRI * c->E : ld * ld * c->E;
+    return two_pass_layout(c) != 0 ? (size_t)(c->ei.n * (c->ei.n + 1) / 2) * 9 * c->E : ld * ld * c->E;
 }
 
 // Owner-computes for high-order elements (n > 8), two passes: dense element matrices (element-parallel, every K_e
@@ -114,7 +128,7 @@ size_t two_pass_dense_doubles(fh_ctx* c) {
 int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     const int S = c->S();
     const int layout = two_pass_layout(c);
-    const bool mfma = layout != 0;
+    const bool mfma = layout == 2;
     const size_t ke_doubles = two_pass_dense_doubles(c);
     if (c->ke_dense.n < ke_doubles) HIP_TRY(c, c->ke_dense.alloc(ke_doubles));
     const unsigned max_row = c->max_row;  // longest node row, cached with the pattern (no O(N) host scan per assembly)
@@ -174,14 +188,14 @@ int assemble_two_pass(fh_ctx* c, double* values_dev, int overwrite) {
     // CU: 7.4 / 4.5 / 3.4 / ~3.25 ms), which registers and the LDS rows of the longest node row hold at 16.)
     const int* node_list = nullptr;
     const int rows_grid_cap = c->env_int("FENRIS_HIP_TWO_PASS_ROWS_GRID", c->env_int("FENRIS_HIP_TWO_PASS_GRID", 1 << 17));   // (C4: 2^17 workgroups 8.33 ms, one per four nodes (410 k) 8.42, 2^13 8.45, 2^11 8.68)
-    c->last_kernel = mfma ? "k_hex27_dense_blocks + k_rows_from_tri" : "k_assemble_matrix<dump> + k_rows_from_dense";
+    c->last_kernel = mfma ? "k_hex27_dense_blocks + k_rows_from_tri" : layout == 1 ? "k_assemble_matrix<dump> + k_rows_from_tri" : "k_assemble_matrix<dump> + k_rows_from_dense";
 
     // ---- serial form: all element matrices, then all rows
     if (mfma) {
         const int r1 = launch_hex27_blocks(c, 0, (long long)(c->has_mask ? c->num_active : c->E), c->stream);
         if (r1) return r1;
     } else {
-        const int r1 = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true);
+        const int r1 = element_matrices_enqueue(c, 0, c->has_mask ? c->num_active : c->E, c->ke_dense.p, true, layout == 1);
         if (r1) return r1;
     }
     return launch_rows(c, layout, c->stream, adj_off, lex ? c->tp_adj.p : adj, values_dev, overwrite, max_row, node_list, (int)c->N, 256, rows_grid_cap);

@@ -166,23 +166,25 @@ __global__ void __launch_bounds__(256) k_rows_from_dense(int num_nodes, int n, c
 }
 
 
-// Second pass for the Hex27 matrix-core first pass (hex27_blocks.hpp): the element matrices are stored as their UPPER NODE-BLOCK TRIANGLE,
-// ke[e][tri(I, J)][i][j] with tri(I, J) = I (53 - I) / 2 + J for I <= J (378 blocks of 3 x 3 = 3 402 doubles instead of 6 561).  The rows of local
-// node a of element e are the blocks (a, J), J >= a -- one contiguous run -- and, by symmetry (K_e[(a, r), (J, c)] = K_e[(J, c), (a, r)]), the
-// TRANSPOSED blocks (J, a), J < a: a 72-byte piece each.  A lane takes the entries idx = lane + 64 h, h < 4, of the entry's 243 values in the
-// order (J, r, c).  Both halves of a symmetric pair of the global matrix are sums of the SAME stored doubles in the same (ascending element)
-// order: the assembled matrix is symmetric bit for bit.
-template <typename PT, bool ABL = false>
+// Second pass over element matrices stored as a NODE-BLOCK TRIANGLE (s = 3: blocks of 3 x 3 = 9 contiguous doubles; n (n + 1) / 2 blocks instead of n^2):
+//   UPPER (LOWER = false; hex27_blocks.hpp, n = 27):  ke[e][tri(I, J)][i][j], tri(I, J) = I (2 n - 1 - I) / 2 + J for I <= J.  The rows of local node a
+//     are the blocks (a, J), J >= a -- one contiguous run -- and, by symmetry (K_e[(a, r), (J, c)] = K_e[(J, c), (a, r)]), the TRANSPOSED blocks (J, a),
+//     J < a: a 72-byte piece each.
+//   LOWER (the generic first pass, k_assemble_matrix<MODE_DUMP> with ke_tri):  ke[e][J (J + 1) / 2 + I][r][c] = K_e[(J, r), (I, c)], I <= J.  The run is
+//     (a, J), J <= a, the transposed pieces are (J, a), J > a.
+// A lane takes the entries idx = lane + 64 h of the entry's 9 n values in the order (J, r, c).  Both halves of a symmetric pair of the global matrix
+// are sums of the SAME stored doubles in the same (ascending element) order: the assembled matrix is symmetric bit for bit.
+template <int n, bool LOWER, typename PT, bool ABL = false>
 __global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, const unsigned* adj_off, const unsigned* adj, const PT* pos_tab,
                                                        const double* ke, double* vals, int overwrite, int max_cnt, const int* node_list,
                                                        int node_count, int npw, int xcw) {
-    constexpr int S = 3, n = 27, TRI = (n * (n + 1) / 2) * 9, EB = 4, HR = 4;
+    constexpr int S = 3, TRI = (n * (n + 1) / 2) * 9, EB = 4, HR = (S * S * n + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)(blockDim.x >> 6);
     double* acc = reinterpret_cast<double*>(smem) + (size_t)wave * S * S * max_cnt;
-    // the lane's four places inside an entry (the last round is partly empty: 243 = 3 x 64 + 51), as byte offsets into the element's triangle:
-    //   direct[h] + 72 row(a)        the block (a, J), J >= a         (row(a) = a (53 - a) / 2: scalar)
-    //   mirror[h] + 72 a             the transposed block (J, a), J < a
+    // the lane's HR places inside an entry (the last round is partly empty; n = 27: 243 = 3 x 64 + 51), as byte offsets into the element's triangle:
+    //   direct[h] + 72 row(a)        the block (a, J) of the run      (UPPER: row(a) = a (2 n - 1 - a) / 2, LOWER: a (a + 1) / 2: scalar)
+    //   mirror[h] + 72 a             the transposed block (J, a) outside it
     // and the lane of the entry's position load (one load per entry: lane J holds the column slot of local node J; the four places fetch
     // theirs with ds_bpermute) and the place of the value in the staged rows (row r of the node, column c of the block).
     unsigned direct[HR], mirror[HR];
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, con
         const int J = idx / 9, rc = idx - 9 * J;
         Jl[h] = J;
         direct[h] = 8u * (unsigned)idx;
-        mirror[h] = 8u * (unsigned)(((J * (53 - J)) / 2) * 9 + (rc % 3) * 3 + rc / 3);
+        mirror[h] = 8u * (unsigned)((LOWER ? (J * (J + 1)) / 2 : (J * (2 * n - 1 - J)) / 2) * 9 + (rc % 3) * 3 + rc / 3);
         rowoff[h] = rc / 3;
         colc[h] = rc % 3;
     }
@@ -261,11 +263,11 @@ __global__ void __launch_bounds__(256) k_rows_from_tri(const unsigned* noff, con
                     // registers that earlier loads of the group still target, and waits for those loads first)
                     if constexpr (sizeof(PT) == 1) pl[k] = (int)__builtin_amdgcn_raw_buffer_load_b8(pos_rsrc, poff, (int)((tk - t0) * (unsigned)n), 0);
                     else pl[k] = (int)__builtin_amdgcn_raw_buffer_load_b16(pos_rsrc, poff, (int)((tk - t0) * (unsigned)(2 * n)), 0);
-                    const unsigned sd = 72u * ((a * (53u - a)) >> 1), sm = 72u * a;
+                    const unsigned sd = 72u * (LOWER ? (a * (a + 1u)) >> 1 : (a * ((unsigned)(2 * n - 1) - a)) >> 1), sm = 72u * a;
 #pragma unroll
                     for (int h = 0; h < HR; ++h) {
-                        unsigned off = (unsigned)Jl[h] >= a ? direct[h] + sd : mirror[h] + sm;
-                        if (ABL && (overwrite & 0x1000)) off = direct[h] + 1944u * (a % 13u);   // (timing only: the entry's 243 values as ONE contiguous run)
+                        unsigned off = (LOWER ? (unsigned)Jl[h] <= a : (unsigned)Jl[h] >= a) ? direct[h] + sd : mirror[h] + sm;
+                        if (ABL && (overwrite & 0x1000)) off = direct[h] + (unsigned)(72 * n) * (a % (unsigned)((n + 1) / 2));   // (timing only: the entry's 243 values as ONE contiguous run)
                         // (the partly empty last round: loaded under the same condition as it is used -- an unconditional load with a conditional
                         // use is moved down to the use by the compiler, behind the wait for everything else)
                         if (ABL && (overwrite & 0x200)) v[k][h] = 1.0;

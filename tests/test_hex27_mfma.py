@@ -66,7 +66,7 @@ def test_generic_first_pass_for_other_operators(engine, oracle):
     u = 0.01 * np.random.default_rng(4).standard_normal(3 * mesh.num_nodes())
     asm, ref = _build(engine, oracle, mesh, "STVK", u)
     k = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-    assert engine.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
+    assert engine.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_tri"
     vals = oracle.assemble(ref)[4]
     assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
 
@@ -178,7 +178,7 @@ def test_roles_rotate_and_triangles_are_symmetric(oracle, op, per_point):
         assert np.array_equal(k.values, k2.values)
         eng.set_option("FENRIS_HIP_NO_MFMA", 1)
         k3 = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
-        assert eng.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
+        assert eng.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_tri"
         assert np.abs(k3.values - k.values).max() <= 1e-12 * np.abs(vals).max()
         eng.set_option("FENRIS_HIP_NO_MFMA", None)
         # the two passes work on the element's nodes in lexicographic order of their reference positions (engine_two_pass.hip); on the element's

@@ -10,6 +10,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
 
 TWO_PASS_GENERIC = "k_assemble_matrix<dump> + k_rows_from_dense"
+TWO_PASS_TRI = "k_assemble_matrix<dump> + k_rows_from_tri"   # the same first pass writing the lower node-block triangle: 3 x 3 blocks on the 3D elements
 TWO_PASS_MFMA = "k_hex27_dense_blocks + k_rows_from_tri"
 
 
@@ -17,9 +18,12 @@ def expected(mesh, rule, op, data, mask):
     """the selection rules (mask: no influence on the choice -- every owner-computes kernel has its masked instantiation)"""
     if mesh == "hex27":
         # more than 8 nodes: always two passes; the first one on the matrix cores for LinearElastic / NeoHookean with a 27-point rule
-        return TWO_PASS_MFMA if op in ("LinearElastic", "NeoHookean") and rule == "gauss3" else TWO_PASS_GENERIC
+        if op in ("LinearElastic", "NeoHookean") and rule == "gauss3":
+            return TWO_PASS_MFMA
+        return TWO_PASS_GENERIC if op == "Laplace" else TWO_PASS_TRI
     if op in ("NeoHookean", "StVK"):
-        return TWO_PASS_GENERIC                      # nonlinear materials: recomputing the prologue per owner block costs more than the round trip
+        # nonlinear materials: recomputing the prologue per owner block costs more than the round trip; triangles where the blocks are 3 x 3
+        return TWO_PASS_TRI if mesh in ("hex8 affine", "hex8 general", "tet4") else TWO_PASS_GENERIC
     if data == "per-point":
         if mesh == "tet4" and rule == "strength1":
             return "k_gather_rows"                   # one point: "per point" is "per rule", the row-owner kernel takes it
@@ -43,4 +47,4 @@ def test_kernel_selection_table():
     assert not wrong, wrong[:5]
     # every kernel family of the gather mode appears
     assert {r[5] for r in rows} == {"k_affine_rows", "k_hex8_rows", "k_gather_pipelined", "k_gather_rows", "k_assemble_matrix<gather>",
-                                     TWO_PASS_GENERIC, TWO_PASS_MFMA}
+                                     TWO_PASS_GENERIC, TWO_PASS_TRI, TWO_PASS_MFMA}

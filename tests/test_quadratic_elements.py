@@ -254,6 +254,27 @@ def test_matrix_vector_scalar_match_oracle(engine, oracle, kind, op):
         k = fa.CsrAssembler(scatter).assemble(asm)
         assert np.array_equal(k.row_offsets, ro) and np.array_equal(k.col_indices, ci)
         assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max(), (scatter, engine.last_kernel_name())
+    # the gather runs as two passes on these elements; between them the element matrices are lower node-block triangles where the blocks are 3 x 3
+    # (3D elasticity family) and full column-major matrices otherwise (and under FENRIS_HIP_TWO_PASS_FULL): same matrix to rounding, and the
+    # triangle form adds the same stored doubles to (I, J) and (J, I): symmetric bit for bit
+    kg = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+    tri = op != "LAPLACE" and d == 3
+    two_pass = engine.last_kernel_name().startswith("k_assemble_matrix<dump>")     # (Tri6 with a linear operator: six nodes, one pass)
+    assert two_pass or kind == "TRI6"
+    if two_pass:
+        assert engine.last_kernel_name() == "k_assemble_matrix<dump> + " + ("k_rows_from_tri" if tri else "k_rows_from_dense")
+    if tri:
+        a = kg.to_scipy()
+        dd = (a - a.T).tocoo()
+        assert dd.nnz == 0 or not np.any(dd.data != 0.0)
+        engine.set_option("FENRIS_HIP_TWO_PASS_FULL", 1)
+        try:
+            kf = fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm)
+            assert engine.last_kernel_name() == "k_assemble_matrix<dump> + k_rows_from_dense"
+        finally:
+            engine.set_option("FENRIS_HIP_TWO_PASS_FULL", None)
+        assert np.abs(kf.values - kg.values).max() <= 1e-13 * np.abs(vals).max()
+        assert np.array_equal(fa.CsrAssembler(fa.SCATTER_GATHER).assemble(asm).values, kg.values)
     k = fa.CsrParAssembler().assemble(fa.color_nodes(asm), asm)
     assert np.abs(k.values - vals).max() <= 1e-12 * np.abs(vals).max()
     f = fa.VectorAssembler().assemble_vector(asm)

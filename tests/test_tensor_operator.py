@@ -125,7 +125,7 @@ def test_device_tensor_operator_matches_the_oracle(oracle, case, symmetric):
             want = ref.element_matrix(e)[1]
             assert np.abs(ke[e] - want).max() <= 1e-12 * np.abs(want).max()      # [e][row][col]
         if case == "tet10":
-            assert any("k_rows_from_dense" in s for s in seen), seen     # ten nodes: the two-pass form, K_e transposed for the gather
+            assert any(("k_rows_from_dense" if not symmetric else "k_rows_from_tri") in s for s in seen), seen     # ten nodes: the two-pass form (K_e in full and transposed for the non-symmetric tensor, its triangle for the symmetric one)
     finally:
         eng.close()
 

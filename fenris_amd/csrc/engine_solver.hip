@@ -70,28 +70,41 @@ static int sum_partials(fh_ctx* c, const double* dev, int blocks, int K, double*
     return FH_OK;
 }
 
-static int spmv_launch(fh_ctx* c, const double* vals, const double* x, double* y, double* partial, int grid) {
+// y = A x (+ the partial sums of x . y, `partials` of them, when `partial` is given).  ONE trip per wavefront: as many short-lived workgroups as the rows need,
+// dispatched in order, instead of a resident grid striding over the rows -- the rows in flight stay one compact window of the value array (Hex8
+// elasticity 216^3, 19.7 GB of values: 4 096 striding workgroups 5.34 ms, 32 768: 4.99, one trip each (636 k): 4.65; 1 280 = exactly the resident
+// ones: 6.7).  The per-workgroup partials of x . y go to `scratch` and are summed over `partials` contiguous ranges in a fixed order.
+static int spmv_launch(fh_ctx* c, const double* vals, const double* x, double* y, double* partial, int partials, DevBuf<double>* scratch) {
     const int N = (int)c->N;
-    if (c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE")) {   // half a wavefront per node, one lane per column block
+    const bool half = c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE");   // half a wavefront per node, one lane per column block
+    const int grid = std::max(1, half ? (N + 15) / 16 : (N + 3) / 4);
+    double* wg_partial = nullptr;
+    if (partial) {
+        if (scratch->n < (size_t)grid) HIP_TRY(c, scratch->alloc((size_t)grid));
+        wg_partial = scratch->p;
+    }
+    if (half) {
         switch (c->S()) {
-            case 1: hipLaunchKernelGGL((k_spmv_blocked_half<1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
-            case 2: hipLaunchKernelGGL((k_spmv_blocked_half<2>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
+            case 1: hipLaunchKernelGGL((k_spmv_blocked_half<1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial); break;
+            case 2: hipLaunchKernelGGL((k_spmv_blocked_half<2>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial); break;
             default:
-                hipLaunchKernelGGL((k_spmv_blocked_half<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial);
+                hipLaunchKernelGGL((k_spmv_blocked_half<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial);
                 break;
         }
-        HIP_TRY(c, hipGetLastError());
-        return FH_OK;
-    }
-    switch (c->S()) {
-        case 1: hipLaunchKernelGGL((k_spmv_blocked<1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
-        case 2: hipLaunchKernelGGL((k_spmv_blocked<2>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
-        default: hipLaunchKernelGGL((k_spmv_blocked<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, partial); break;
+    } else {
+        switch (c->S()) {
+            case 1: hipLaunchKernelGGL((k_spmv_blocked<1>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial); break;
+            case 2: hipLaunchKernelGGL((k_spmv_blocked<2>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial); break;
+            default: hipLaunchKernelGGL((k_spmv_blocked<3>), dim3(grid), dim3(256), 0, c->stream, N, c->noff.p, c->ncols.p, vals, x, y, wg_partial); break;
+        }
     }
     HIP_TRY(c, hipGetLastError());
+    if (partial) {
+        hipLaunchKernelGGL(k_sum_partial_ranges<1>, dim3(partials), dim3(256), 0, c->stream, wg_partial, (long long)grid, partial);
+        HIP_TRY(c, hipGetLastError());
+    }
     return FH_OK;
 }
-
 static int matrix_ready(fh_ctx* c, const char* who) {
     if (!c->has_pattern) return c->fail(FH_INVALID_STATE, std::string(who) + ": call fh_pattern first");
     if (c->S() < 1 || c->S() > 3) return c->fail(FH_UNSUPPORTED, std::string(who) + ": solution dim must be 1..3");
@@ -105,9 +118,8 @@ int fh_spmv_dev(fh_ctx* c, const double* values_dev, const double* x_dev, double
     if (rc) return rc;
     if (!values_dev || !x_dev || !y_dev) return c->fail(FH_BAD_ARGUMENT, "fh_spmv: null argument");
     if (c->N == 0) return FH_OK;
-    const int grid = (int)std::min<uint64_t>(4096, (c->N + 3) / 4);
     c->last_kernel = (c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE")) ? "k_spmv_blocked_half" : "k_spmv_blocked";
-    return spmv_launch(c, values_dev, x_dev, y_dev, nullptr, grid);
+    return spmv_launch(c, values_dev, x_dev, y_dev, nullptr, 0, nullptr);
 }
 
 int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, double* x_dev, int preconditioner, double rel_tol,
@@ -123,14 +135,16 @@ int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, do
     const int S = c->S();
     const int n = S * (int)c->N;
     if (n == 0) return FH_OK;
-    const int gv = std::min(1024, (n + 255) / 256);                               // vector kernels
-    const int gs = (int)std::min<uint64_t>(2048, (c->N + 3) / 4);                  // SpMV: one wavefront per node
-    DevBuf<double> r, z, p, Ap, dinv, partial;
+    const int gv = std::min(1024, (n + 255) / 256);                               // vector kernels: ranges of their per-workgroup partials
+    const int gvb = std::max(1, (n + 255) / 256);                                 // ... and their workgroups: one entry per thread, short-lived (see spmv_launch)
+    const int gs = (int)std::min<uint64_t>(2048, (c->N + 3) / 4);                  // SpMV: ranges of its per-workgroup partials
+    DevBuf<double> r, z, p, Ap, dinv, partial, wg_partial;
     HIP_TRY(c, r.alloc(n));
     HIP_TRY(c, z.alloc(n));
     HIP_TRY(c, p.alloc(n));
     HIP_TRY(c, Ap.alloc(n));
     HIP_TRY(c, partial.alloc((size_t)3 * std::max(gv, gs)));
+    HIP_TRY(c, wg_partial.alloc((size_t)3 * gvb));
     if (preconditioner == FH_PRECOND_JACOBI) {
         HIP_TRY(c, dinv.alloc(n));
         const int g = (n + 255) / 256;
@@ -143,9 +157,10 @@ int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, do
     }
     c->last_kernel = (c->max_row <= 32 && !c->env("FENRIS_HIP_SPMV_WAVE_PER_NODE")) ? "k_spmv_blocked_half" : "k_spmv_blocked";
     // r = b - A x;  z = P r;  p = z   (cg.rs:388-404)
-    rc = spmv_launch(c, values_dev, x_dev, r.p, nullptr, gs);
+    rc = spmv_launch(c, values_dev, x_dev, r.p, nullptr, 0, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, n, b_dev, dinv.p, r.p, z.p, p.p, partial.p);
+    hipLaunchKernelGGL(k_cg_init, dim3(gvb), dim3(256), 0, c->stream, n, b_dev, dinv.p, r.p, z.p, p.p, wg_partial.p);
+    hipLaunchKernelGGL(k_sum_partial_ranges<3>, dim3(gv), dim3(256), 0, c->stream, wg_partial.p, (long long)gvb, partial.p);
     HIP_TRY(c, hipGetLastError());
     double s3[3];
     rc = sum_partials(c, partial.p, gv, 3, s3);
@@ -164,14 +179,15 @@ int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, do
         if (r_norm <= rel_tol * b_norm) break;  // RelativeResidualCriterion, cg.rs:108-124
         if (max_iter && it >= max_iter) { status = FH_CG_MAX_ITERATIONS; break; }
         double pAp;
-        rc = spmv_launch(c, values_dev, p.p, Ap.p, partial.p, gs);
+        rc = spmv_launch(c, values_dev, p.p, Ap.p, partial.p, gs, &wg_partial);
         if (rc) return rc;
         rc = sum_partials(c, partial.p, gs, 1, &pAp);
         if (rc) return rc;
         if (pAp <= 0.0) { status = FH_CG_INDEFINITE_OPERATOR; break; }
         if (zTr <= 0.0) { status = FH_CG_INDEFINITE_PRECONDITIONER; break; }
         const double alpha = zTr / pAp;
-        hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, n, alpha, p.p, Ap.p, dinv.p, x_dev, r.p, z.p, partial.p);
+        hipLaunchKernelGGL(k_cg_update, dim3(gvb), dim3(256), 0, c->stream, n, alpha, p.p, Ap.p, dinv.p, x_dev, r.p, z.p, wg_partial.p);
+        hipLaunchKernelGGL(k_sum_partial_ranges<2>, dim3(gv), dim3(256), 0, c->stream, wg_partial.p, (long long)gvb, partial.p);
         HIP_TRY(c, hipGetLastError());
         ++it;
         double s2[2];
@@ -179,7 +195,7 @@ int fh_cg_solve_dev(fh_ctx* c, const double* values_dev, const double* b_dev, do
         if (rc) return rc;
         const double beta = s2[0] / zTr;
         r_norm = std::sqrt(s2[1]);
-        hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, n, beta, z.p, p.p);
+        hipLaunchKernelGGL(k_cg_direction, dim3(gvb), dim3(256), 0, c->stream, n, beta, z.p, p.p);
         HIP_TRY(c, hipGetLastError());
         zTr = s2[0];
     }

@@ -34,6 +34,21 @@ __device__ __forceinline__ void block_sum_store(double (&v)[K], double* out) {
         for (int k = 0; k < K; ++k) out[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
 }
 
+// `count` groups of K partials -> gridDim.x groups of K sums, each over one contiguous part of them, in a fixed order: the SpMV and the vector kernels of
+// the CG loop launch short-lived workgroups (see spmv_launch) and leave K partials per workgroup; the host sums what this kernel leaves
+template <int K>
+static __global__ void __launch_bounds__(256) k_sum_partial_ranges(const double* in, long long count, double* out) {
+    const long long per = (count + gridDim.x - 1) / gridDim.x;
+    const long long lo = per * blockIdx.x, hi = min(count, lo + per);
+    double s[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) s[j] = 0.0;
+    for (long long k = lo + threadIdx.x; k < hi; k += 256)
+#pragma unroll
+        for (int j = 0; j < K; ++j) s[j] += in[K * k + j];
+    block_sum_store<K>(s, out + K * blockIdx.x);
+}
+
 // y = A x on the node-blocked CSR: the S rows of node i are contiguous, each S * cnt long, and share the
 // node-level column list (global.rs:100-118).  One wavefront per node (grid-stride); lanes stride over the
 // row entries, S row sums per lane, butterfly reduction.  Optionally the partial of  x . y  per workgroup.

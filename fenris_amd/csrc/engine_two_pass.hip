@@ -32,7 +32,9 @@ int launch_hex27_blocks(fh_ctx* c, long long w0, long long w1, hipStream_t st) {
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
     // (FENRIS_HIP_TWO_PASS_GRID: tests force many elements / nodes per workgroup on small meshes)
-    const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", wgs_default)))));
+    // eight times the resident workgroups, dispatched in order (each strides over ~24 elements on C4): 1 / 2 / 4 / 16 x the resident ones 6.15 / 6.08 /
+    // 6.04 / 6.03 ms, one element per workgroup 6.54 (the tables a workgroup stages once)
+    const int grid1 = std::max(1, (int)std::min<long long>(w1 - w0, c->env_int("FENRIS_HIP_TWO_PASS_GRID", 8 * dev_cus * std::max(1, c->env_int("FENRIS_HIP_HEX27_WGS_PER_CU", wgs_default)))));
     void (*kern)(const KArgs, double, double);
     if (a.trace) kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_blocks<FH_NEO_HOOKEAN, true> : k_hex27_dense_blocks<FH_LINEAR_ELASTIC, true>;   // FENRIS_HIP_TRACE: per-phase cycles
     else kern = c->op == FH_NEO_HOOKEAN ? k_hex27_dense_blocks<FH_NEO_HOOKEAN> : k_hex27_dense_blocks<FH_LINEAR_ELASTIC>;

@@ -97,7 +97,7 @@ enum { FH_ASSEMBLE_OVERWRITE = 0x100 };
  * reference's coloured loop (global.rs:322-373: every entry is a sum in a fixed order).  The row-owner kernels (affine and general Hex8 with the
  * eight-point rule, Tet4) and the two-pass form (Hex27, NeoHookean, StVK) already are; the configurations whose one-pass kernel accumulates with
  * LDS atomics in hardware order (Quad4 / Tri3, Hex8 with other rules or per-point parameters) take the two-pass form instead -- slower, and the
- * dense element matrices need E (s n)^2 doubles; FH_UNSUPPORTED under a row range.  FH_SCATTER_COLORED is reproducible as it is;
+ * dense element matrices need E (s n)^2 doubles (9 E n (n + 1) / 2 for 3 x 3 blocks on the 3D elements: node-block triangles); FH_UNSUPPORTED under a row range.  FH_SCATTER_COLORED is reproducible as it is;
  * FH_SCATTER_ATOMIC never is (FH_BAD_ARGUMENT with this flag). */
 enum { FH_ASSEMBLE_REPRODUCIBLE = 0x200 };
 

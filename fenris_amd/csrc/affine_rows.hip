@@ -373,8 +373,12 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             const int grp = (int)((x >> 24) & 3u);
             const bool stores = ((x >> 28) & 1u) != 0u;
             const unsigned yoff = y & 0xffffu;
+            // (the scalar unit is what this loop is short of -- profiles/r06_c2_lds_bound.txt: sixteen more scalar instructions per position cost 12 %,
+            // sixteen vector ones 1 % -- so the two buffer offsets toggle by one xor each and the DPP sums add a selected zero instead of branching)
+            const unsigned js_stride = (unsigned)(T.us * GW * 8), out_stride = (unsigned)(accp * 8);
+            unsigned js_cur = par ? js_stride : 0u, out_cur = par ? out_stride : 0u;
             for (;;) {
-                const char* js = reinterpret_cast<const char*>(JS + (size_t)par * T.us * GW);
+                const char* js = reinterpret_cast<const char*>(JS) + js_cur;
                 const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
                 const f64x2* m1 = reinterpret_cast<const f64x2*>(js + oR1);
                 const f64x2 u0 = m0[0], u1 = m0[1], u2 = m0[2], w0 = m1[0], w1 = m1[1], w2 = m1[2];
@@ -382,13 +386,15 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
                 sm = fma(a0.y, u0.y, sm); sm = fma(a1.x, u1.x, sm); sm = fma(a1.y, u1.y, sm); sm = fma(a2.x, u2.x, sm); sm = fma(a2.y, u2.y, sm);
                 sm = fma(b0.x, w0.x, sm); sm = fma(b0.y, w0.y, sm); sm = fma(b1.x, w1.x, sm); sm = fma(b1.y, w1.y, sm); sm = fma(b2.x, w2.x, sm);
                 sm = fma(b2.y, w2.y, sm);
-                if (grp >= 1) sm += dpp_quad_full<0xB1>(sm);
-                if (grp >= 2) sm += dpp_quad_full<0x4E>(sm);
+                { const double t = dpp_quad_full<0xB1>(sm); sm += (grp >= 1) ? t : 0.0; }
+                { const double t = dpp_quad_full<0x4E>(sm); sm += (grp >= 2) ? t : 0.0; }
                 if constexpr (MASKED) { if (anyz && zl) sm = 0.0; }
-                if (stores) *reinterpret_cast<double*>(reinterpret_cast<char*>(OUT + (size_t)par * accp) + 8 * head + yoff) = sm;
+                if (stores) *reinterpret_cast<double*>(reinterpret_cast<char*>(OUT) + out_cur + 8 * head + yoff) = sm;
                 tr_barrier();
                 ++p;
                 par ^= 1;
+                js_cur ^= js_stride;
+                out_cur ^= out_stride;
                 if (p >= p_end) break;
                 read_hdr();
                 if (z & 4) break;   // the lane table changes with this position

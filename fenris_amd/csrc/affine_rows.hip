@@ -47,7 +47,7 @@ constexpr unsigned AR_ZERO_G = 64u;
 size_t affine_rows_lds_bytes(int op, int us, int acc_max) {
     const int gw = (op == FH_LAPLACE) ? AFFINE_ROWS_GW_LAP : AFFINE_ROWS_GW_LE;
     const size_t accp = (size_t)((acc_max + 16 + 1) & ~1);
-    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2);
+    return sizeof(double) * ((size_t)65 * gw + (size_t)2 * us * gw + 2 * accp) + 4 * sizeof(int4) + 2 * 256 * sizeof(uint2) + 64;   // (+ 64: where the lanes without a block write)
 }
 
 template <int OP, bool OVERWRITE, bool DBG, int DEPTH, int NSTORE, bool MASKED>
@@ -68,6 +68,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
                                                     // flags | table slot << 1 | table changed << 2 | table id << 8, head}:
                                                     // written by the loader wave two positions ahead, read by every wave
     uint2* LT = reinterpret_cast<uint2*>(HDR + 4);  // [2][256] lane tables: the one in use and the one that comes next
+    double* DUMP = reinterpret_cast<double*>(LT + 2 * 256);   // [8] Laplace row loop: the lanes that own no block write here instead of branching around the store
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,9 +228,10 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         };
         auto load_tab = [&](int id, int half) { return reinterpret_cast<const uint4*>(T.lanes)[(size_t)(unsigned)id * 128u + 64u * half + lane]; };
         auto park_tab = [&](int slot, int half, uint4 v) { reinterpret_cast<uint4*>(LT + 256 * slot)[64 * half + lane] = v; };
-        auto ring_entry = [&](int4 hq, int slot, bool changed) {
+        // (.z bit 4: the position lies behind this workgroup's range -- the Laplace row loop leaves on it instead of counting positions)
+        auto ring_entry = [&](int4 hq, int slot, bool changed, bool beyond) {
             int4 o = with_head(hq);
-            o.z = (hq.z & 9) | (slot << 1) | (changed ? 4 : 0) | (hq.z & ~0xff);
+            o.z = (hq.z & 9) | (slot << 1) | (changed ? 4 : 0) | (beyond ? 16 : 0) | (hq.z & ~0xff);
             return o;
         };
         // prologue: ring entries, lane tables and records of p_begin (and what p_begin + 1 needs), fetches for the next ones
@@ -241,7 +243,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             park_tab(0, 0, t0); park_tab(0, 1, t1);
             const bool ch1 = (hq1.z >> 8) != id_prev;
             if (ch1) { const uint4 u0 = load_tab(hq1.z >> 8, 0), u1 = load_tab(hq1.z >> 8, 1); park_tab(1, 0, u0); park_tab(1, 1, u1); slot_cur = 1; }
-            if (lane == 0) { HDR[p_begin & 3] = ring_entry(hq0, 0, true); HDR[(p_begin + 1) & 3] = ring_entry(hq1, slot_cur, ch1); }
+            if (lane == 0) { HDR[p_begin & 3] = ring_entry(hq0, 0, true, false); HDR[(p_begin + 1) & 3] = ring_entry(hq1, slot_cur, ch1, p_begin + 1 >= p_end); }
             id_prev = hq1.z >> 8;
         }
         // Requests run DEPTH positions ahead of their use (memory answers in 1 - 2 us while the stores of every workgroup are
@@ -300,7 +302,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             const int id2 = __builtin_amdgcn_readfirstlane(h_nxt[k].z) >> 8;                                                  \
             const bool ch2 = id2 != id_prev;                                                                                  \
             const int slot2 = ch2 ? (slot_cur ^ 1) : slot_cur;                                                                \
-            if (lane == 0) HDR[((p) + 2) & 3] = ring_entry(h_nxt[k], slot2, ch2);                                             \
+            if (lane == 0) HDR[((p) + 2) & 3] = ring_entry(h_nxt[k], slot2, ch2, (p) + 2 >= p_end);                           \
             if (ch2) { tab0 = load_tab(id2, 0); tab1 = load_tab(id2, 1); tab_pending = true; slot_pending = slot2; }          \
             slot_cur = slot2;                                                                                                 \
             id_prev = id2;                                                                                                    \
@@ -338,15 +340,22 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
         // everything derived from the lane record (the reference blocks of the lane's two terms, the record offsets, the place of the
         // block in the staged rows) lives in fixed registers: as ONE loop with a reload under `if (table changed)` the compiler carried
         // thirteen register pairs through two copies per position, a quarter of this wave's ~100 instructions (round 4, C2).
-        int p = p_begin, z = 0, head = 0;
+        // The scalar unit is what this loop is short of (profiles/r06_c2_lds_bound.txt: sixteen more scalar instructions per position cost 12 %,
+        // sixteen vector ones 1 %): the buffer offsets and the ring offset move by one scalar instruction each, the DPP sums add a selected zero
+        // and the lanes without a block store to a dump slot instead of branching, and the loop ends on ONE bit of the header (table changed | behind
+        // the range, the second set by the loader) instead of counting positions.
+        int z = 0, head = 0;
+        unsigned hoff = 16u * (unsigned)(p_begin & 3);
+        const unsigned js_stride = (unsigned)(T.us * GW * 8), out_stride = (unsigned)(accp * 8);
+        unsigned js_cur = 0u, out_cur = 0u;
         auto read_hdr = [&]() {
             int zw[2];
-            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + 16u * (unsigned)(p & 3)) : "memory");
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(*reinterpret_cast<long long*>(zw)) : "v"(hdr_addr + hoff) : "memory");
             z = __builtin_amdgcn_readfirstlane(zw[0]);
             head = zw[1] & 15;
-            if (MASKED && !(z & 1)) {   // an incomplete position: its row lanes clear the extent first (see the general loop below)
+            if (MASKED && !(z & 17)) {   // an incomplete position (of this range): its row lanes clear the extent first (see the general loop below)
                 const int ext = __builtin_amdgcn_readfirstlane(zw[1]) >> 4;
-                double* buf = OUT + (size_t)par * accp;
+                double* buf = reinterpret_cast<double*>(reinterpret_cast<char*>(OUT) + out_cur);
                 if (!(ablate_arg & AFFINE_ROWS_NO_CLEAR)) {
                     const int lo = head, hi = head + ext, k0 = (lo + 1) >> 1, k1 = hi >> 1;
                     const f64x2 z2 = {0.0, 0.0};
@@ -358,7 +367,8 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             }
         };
         read_hdr();
-        while (p < p_end) {
+        const unsigned out_base = (unsigned)(unsigned long long)OUT, dump_addr = (unsigned)(unsigned long long)DUMP + 8u * (unsigned)(tid & 7);
+        while (!(z & 16)) {
             const uint2 lc = LT[256 * ((z >> 1) & 1) + tid];
             const unsigned x = lc.x, y = lc.y;
             bool zl = false, anyz = false;
@@ -372,11 +382,7 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
             const unsigned oR0 = (x & 31u) * (GW * 8), oR1 = ((x >> 12) & 31u) * (GW * 8);
             const int grp = (int)((x >> 24) & 3u);
             const bool stores = ((x >> 28) & 1u) != 0u;
-            const unsigned yoff = y & 0xffffu;
-            // (the scalar unit is what this loop is short of -- profiles/r06_c2_lds_bound.txt: sixteen more scalar instructions per position cost 12 %,
-            // sixteen vector ones 1 % -- so the two buffer offsets toggle by one xor each and the DPP sums add a selected zero instead of branching)
-            const unsigned js_stride = (unsigned)(T.us * GW * 8), out_stride = (unsigned)(accp * 8);
-            unsigned js_cur = par ? js_stride : 0u, out_cur = par ? out_stride : 0u;
+            const unsigned yoff = out_base + (y & 0xffffu);
             for (;;) {
                 const char* js = reinterpret_cast<const char*>(JS) + js_cur;
                 const f64x2* m0 = reinterpret_cast<const f64x2*>(js + oR0);
@@ -389,15 +395,16 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
                 { const double t = dpp_quad_full<0xB1>(sm); sm += (grp >= 1) ? t : 0.0; }
                 { const double t = dpp_quad_full<0x4E>(sm); sm += (grp >= 2) ? t : 0.0; }
                 if constexpr (MASKED) { if (anyz && zl) sm = 0.0; }
-                if (stores) *reinterpret_cast<double*>(reinterpret_cast<char*>(OUT) + out_cur + 8 * head + yoff) = sm;
+                {
+                    const unsigned dst = stores ? yoff + out_cur + 8u * (unsigned)head : dump_addr;
+                    asm volatile("ds_write_b64 %0, %1" : : "v"(dst), "v"(sm) : "memory");
+                }
                 tr_barrier();
-                ++p;
-                par ^= 1;
+                hoff = (hoff + 16u) & 48u;
                 js_cur ^= js_stride;
                 out_cur ^= out_stride;
-                if (p >= p_end) break;
                 read_hdr();
-                if (z & 4) break;   // the lane table changes with this position
+                if (z & 20) break;   // the lane table changes with this position, or the range is done
             }
         }
         if (wave == 0) tr_report(0);

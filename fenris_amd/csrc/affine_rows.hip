@@ -164,6 +164,65 @@ k_affine_rows(const KArgs a, const AffineRowTables T, const int ablate_arg) {
                 }
             }
         };
+        if constexpr (LAP && !DBG && NSTORE == 1) {
+            // Laplace / mass: a position's rows are at most a few hundred doubles, and what a position costs is the CU's ONE scalar unit
+            // (profiles/r06_c2_lds_bound.txt: a scalar instruction costs ten vector ones here; the loop above runs ~110 of them per position).  The same
+            // stream with everything that is uniform kept in VECTOR registers -- no readfirstlane, the ranges as per-lane predicates -- and the two
+            // buffers addressed by one xor-toggled offset: ~25 scalar instructions per position.  Non-temporal stores always (see put).
+            const int small_trips = (accp / 2 + 63) / 64;
+            // (what a header holds is uniform, and the compiler knows: it would move every line below to the scalar unit -- `vec` hides that from it)
+            auto vec = [](int4 h) { asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w)); return h; };
+            auto stream_small = [&](const int4 hv, unsigned buf_off, unsigned other_off, int cin, int cout) {
+                const int head = hv.w & 15, hi = head + hv.y, lo = cin ? 0 : head;
+                const int L = cout ? (hi & ~15) : hi;                  // stored now: [lo, L); carried: [L, hi)
+                const int k0 = (lo + 1) >> 1, k1 = L >> 1;              // whole 16-byte pieces [k0, k1)
+                double* line0 = a.vals + ((long long)hv.x - (long long)head);
+                const char* bufc = reinterpret_cast<const char*>(OUT) + buf_off;
+#pragma nounroll
+                for (int j = 0; j < small_trips; ++j) {
+                    const int idx = k0 + lane + 64 * j;
+                    if (idx < k1) {
+                        const f64x2 v = reinterpret_cast<const f64x2*>(bufc)[idx];
+                        f64x2* dst = reinterpret_cast<f64x2*>(line0) + idx;
+                        if constexpr (OVERWRITE) __builtin_nontemporal_store(v, dst);
+                        else { const f64x2 o = *dst; f64x2 r; r.x = o.x + v.x; r.y = o.y + v.y; *dst = r; }
+                    }
+                }
+                // the ends of a run of positions are single doubles: lane 0 the lower, lane 1 the upper one
+                const int e = lane == 0 ? (((lo & 1) && lo < L) ? lo : -1) : (((L & 1) && L - 1 >= lo) ? L - 1 : -1);
+                if (lane < 2 && e >= 0) {
+                    const double v = reinterpret_cast<const double*>(bufc)[e];
+                    if constexpr (OVERWRITE) __builtin_nontemporal_store(v, line0 + e); else line0[e] += v;
+                }
+                if (cout && lane < hi - L) reinterpret_cast<double*>(reinterpret_cast<char*>(OUT) + other_off)[lane] = reinterpret_cast<const double*>(bufc)[L + lane];
+            };
+            const unsigned out_stride = (unsigned)(accp * 8);
+            lds_barrier();  // B0
+            tr_start();
+            int cin = 0;
+            unsigned cur = 0u;                       // byte offset of the buffer the row waves fill during this position
+            int4 h_prev = vec(HDR[p_begin & 3]);
+            if constexpr (MASKED) { if (!(rfl(h_prev.z) & 1)) tr_barrier(); }
+            tr_barrier();
+            cur ^= out_stride;
+            for (int p = p_begin + 1; p < p_end; ++p) {
+                const int4 h_cur = vec(HDR[p & 3]);
+                if constexpr (MASKED) { if (!(rfl(h_cur.z) & 1)) tr_barrier(); }   // an incomplete position: the row waves clear their buffer first (see there)
+                int cout = (h_cur.x == h_prev.x + h_prev.y && !(ablate_arg & AFFINE_ROWS_NO_CARRY)) ? 1 : 0;
+                {   // a position of less than two lines that ends before the first line boundary behind its start stores its own piece (see below)
+                    const int head_p = h_prev.w & 15, lo_p = cin ? 0 : head_p, hi_p = head_p + h_prev.y;
+                    if ((h_prev.z & 8) && (hi_p & ~15) < lo_p) cout = 0;
+                }
+                stream_small(h_prev, cur ^ out_stride, cur, cin, cout);
+                cin = cout;
+                h_prev = h_cur;
+                tr_barrier();
+                cur ^= out_stride;
+            }
+            stream_small(h_prev, cur ^ out_stride, cur, cin, 0);
+            if (wave == 5) tr_report(2);
+            return;
+        }
         lds_barrier();  // B0
         tr_start();
         bool carry_in = false;

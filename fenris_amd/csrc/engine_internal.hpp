@@ -512,7 +512,7 @@ int check_ready(fh_ctx* c, const char* who, bool need_pattern);
 void fill_common(fh_ctx* c, KArgs& a);
 int reset_status(fh_ctx* c);
 int read_status(fh_ctx* c, uint64_t* failed);
-int choose_epb(fh_ctx* c, int what);
+int choose_epb(fh_ctx* c, int what, size_t lds_target = LDS_TARGET);
 int build_partition(fh_ctx* c);
 size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int nb, bool gather, int mb = 0, int fast = 0, int nc_row = 0);
 int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* ke_dev, bool by_elem, bool tri = false);

@@ -44,11 +44,11 @@ size_t layout_bytes_dyn(int ek, int op, int what, int nq, int ub, int acc, int n
 }
 
 
-int choose_epb(fh_ctx* c, int what) {
+int choose_epb(fh_ctx* c, int what, size_t lds_target) {
     int best = 1;
     for (int epb = 1; epb <= 64; ++epb) {
         const size_t b = layout_bytes_dyn(c->elem_kind, c->op, what, c->nq, epb, 0, 0, false, 0, generic_fast(c));
-        if (b <= LDS_TARGET) best = epb; else break;
+        if (b <= lds_target) best = epb; else break;
     }
     return best;
 }
@@ -221,7 +221,9 @@ int element_matrices_enqueue(fh_ctx* c, uint64_t first, uint64_t count, double* 
     a.labels = (by_elem && c->has_mask) ? c->active_list.p : nullptr;  // two-pass assembly: the active elements only
     a.work_begin = (long long)first;
     a.work_end = (long long)(first + count);
-    a.epb = choose_epb(c, WHAT_MATRIX);
+    // elements per workgroup by an LDS budget of 52 KB = THREE workgroups per CU (the other generic kernels: 64 KB, two): Hex8 NeoHookean 128^3 6.24 -> 5.66 ms,
+    // StVK 7.31 -> 6.64, Tet10 / Tet4 level; 39 KB (four) is level or worse (profiles/r06_two_pass_triangles_generic.txt)
+    a.epb = choose_epb(c, WHAT_MATRIX, (size_t)52 * 1024);
     a.ub = a.epb;
     const size_t lds = layout_bytes_dyn(c->elem_kind, c->op, WHAT_MATRIX, c->nq, a.ub, 0, 0, false, 0, a.fast);
     if (lds > LDS_LIMIT) return c->fail(FH_UNSUPPORTED, "quadrature rule too large for LDS staging");

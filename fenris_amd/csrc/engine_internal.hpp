@@ -346,7 +346,7 @@ struct fh_ctx {
     DevBuf<int> r_rec;          // row-owner kernel (rows_kernel.hpp): shared part of the records
     bool part_perm = false;     // the blocks were formed in a locality order of the nodes (row-owner Tet4 kernel only)
     bool part_rows_only = false;  // tables that only the row-owner Tet4 kernel can use (locality order and / or larger blocks)
-    int rows_try = 0;           // block sizes tried for them: 0 = nine nodes / 256 entries, 1 = seven / 224, then the standard form
+    int rows_try = 0;           // block sizes tried for them: 13 nodes / 352 entries, 11 / 288, 9 / 256, 7 / 224, then the standard form
     DevBuf<unsigned> r_lanes4;  //                                     lanes per position (Tet4): three words each
     DevBuf<int> r_vconn;        //                                     unique vertices + slot words per position (Tet4)
     int r_rw = 0, r_ls = 256, r_vn = 256;   // (r_vn: vertices per position in r_vconn)

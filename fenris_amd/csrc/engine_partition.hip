@@ -321,13 +321,16 @@ int build_partition(fh_ctx* c) {
     // Hex8 Laplace / LinearElastic without a mask: the general positions run on k_hex8_rows (36 row lanes per node as well)
     const bool hrows_cand = c->elem_kind == FH_HEX8 && (c->op == FH_LAPLACE || c->op == FH_LINEAR_ELASTIC) && !c->has_rules &&
                             !c->env("FENRIS_HIP_NO_HEX8_ROWS");
-    const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", rows_special ? (c->rows_try == 0 ? 9 : 7)
+    // (row-owner Tet4 tables, by attempt: 13 nodes / 352 entries, 11 / 288, 9 / 256, 7 / 224 -- whatever the lane format takes: 256 lanes, 252 slots,
+    // 256 distinct vertices per position; round 6: a position's cost is mostly cost per POSITION, C3 0.456 ms at 9 nodes, 0.394 at 12 - 13)
+    static const int rows_nb[4] = {13, 11, 9, 7}, rows_mb[4] = {352, 288, 256, 224};
+    const int nb_target = std::max(1, std::min(64, c->env_int("FENRIS_HIP_GATHER_NB", rows_special ? rows_nb[std::min(c->rows_try, 3)]
                                                                                                      : (S == 1 && !aff_cand && !hrows_cand) ? 8 : 7)));  // < 256: packed in 8 bits
     // Tables for the row-owner Tet4 kernel alone may hold more entries per block than the pipelined kernel's lane mapping takes
     // and more nodes (the lane word has four bits for the node): nine nodes / 256 entries first (C3: 98 k positions of ~170 lanes
     // instead of 171 k of ~90, 0.80 -> 0.64 ms), seven / 224 when that cannot be expressed (0.67 ms), then the standard form
     c->part_rows_only = rows_special;
-    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? (c->rows_try == 0 ? 256 : 224) : 128)));
+    const int mb = std::max(16, std::min(1024, c->env_int("FENRIS_HIP_GATHER_MB", rows_special ? rows_mb[std::min(c->rows_try, 3)] : 128)));
     const size_t lds_target = (size_t)c->env_int("FENRIS_HIP_GATHER_LDS_KB", 52) * 1024;
     // accumulators: nb_target typical rows, but at least the largest single row block
     unsigned noff_ends[2] = {0, 0};   // (telescoping sum of the row lengths; two values of the device array: the host copy may not exist)
@@ -566,8 +569,8 @@ int build_partition(fh_ctx* c) {
         if (jt != 1 && jt != 2 && jt != 4 && jt != n) jt = 1;
         if (n % jt != 0) jt = 1;
         c->p_jt = jt;
-        if (us * c->ei.ng <= (rows_special ? 1024 : 512) && us <= 252 && ms <= 256 && (rows_special || (ms * (n / jt) <= 256 && ms * n / 4 <= 256)) && ms <= mb &&
-            nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= 512 &&
+        if (us * c->ei.ng <= (rows_special ? 1024 : 512) && us <= 252 && ms <= (rows_special ? 352 : 256) && (rows_special || (ms * (n / jt) <= 256 && ms * n / 4 <= 256)) && ms <= mb &&
+            nb_target <= 254 && pipe_record_words(us, ms, n, nb_target) <= (rows_special ? 1024 : 512) &&
             (c->fast_ok || (c->op == FH_MASS_SCALAR && c->elem_kind == FH_HEX8))) {   // (the mass tables take densities that differ from point to point)
             const int nblk = c->nblk;
             mark("headers to the host, staging sizes");
@@ -838,7 +841,7 @@ int build_partition(fh_ctx* c) {
         }
     }
     if (c->part_rows_only && !c->has_rows) {  // these tables serve the row-owner kernel only: smaller blocks, then the standard form
-        if (++c->rows_try >= 2) c->perm_failed = true;
+        if (++c->rows_try >= 4) c->perm_failed = true;
         c->part_perm = false;
         c->part_rows_only = false;
         return build_partition(c);

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256, 3) k_gather_rows_tet4(const KArgs a, cons
 static __global__ void __launch_bounds__(64) k_build_row_lanes_tet4(const int* p_rec, int rw_old, int us, int ms, int nbs, int npos, int rw_new,
                                                              int* rec_new, unsigned* lanes, int ls, int* status, const unsigned* row_real,
                                                              int count_only) {
-    constexpr int N = 4, NKEY = 16 * 128, TMAX = 48, TL = 6, MAXTERMS = 1024;   // up to 16 nodes per block
+    constexpr int N = 4, NKEY = 16 * 128, TMAX = 48, TL = 6, MAXTERMS = 1408;   // up to 16 nodes and 352 (node, element) entries per block
     __shared__ int cnt[NKEY], off[NKEY], fill[NKEY];
     __shared__ unsigned short terms[MAXTERMS];
     __shared__ unsigned lw[256][4];
